@@ -1,0 +1,156 @@
+/*
+ * hydra_mi.h -- C-ABI of libhydra_mi.so, the MI355X (gfx950) implementation of
+ * HydraGL's per-frame hot loop: Brox optical flow followed by the EKF
+ * measurement update of a textured triangle mesh.
+ *
+ * Every entry point is what the reference's binding for this path would call
+ * through ctypes; the reference interface each one replaces is cited as
+ * reference file:line.  Conventions:
+ *   - plain pointers and sizes only; all host arrays are C-contiguous and owned
+ *     by the caller, the library copies in/out; device buffers are owned by the
+ *     handle and freed by *_destroy;
+ *   - every call returns 0 on success and a negative code on error; the text of
+ *     the last error of the calling thread is hm_last_error();
+ *   - one handle <-> one HIP stream <-> one host thread; the host-pointer calls
+ *     are synchronous at return (the reference synchronises after every launch,
+ *     cuda_multi.py:793,804,1083); the *_dev calls enqueue on the handle's
+ *     stream and return, hm_*_sync waits.
+ */
+#ifndef HYDRA_MI_H
+#define HYDRA_MI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HM_OK 0
+#define HM_ERR_ARG (-1)     /* bad argument (reference: Python exception / assert) */
+#define HM_ERR_HIP (-2)     /* HIP runtime failure, including "no GPU" */
+#define HM_ERR_STATE (-3)   /* call sequence error, e.g. jz before initjacobian (cuda_multi.py:611) */
+
+const char *hm_last_error(void);
+const char *hm_version(void);
+/* number of visible HIP devices, or a negative error code */
+int hm_device_count(void);
+
+/* ------------------------------------------------------------------------
+ * Brox optical flow.  Replaces cv::cuda::BroxOpticalFlow as used by
+ * processflow_gpu (src/optical_flow_ext.cpp:294-331).
+ * ---------------------------------------------------------------------- */
+typedef struct hm_brox *hm_brox_t;
+
+/* cuda::BroxOpticalFlow::create(alpha, gamma, scale_factor, inner, outer, solver)
+ * (src/optical_flow_ext.cpp:310; parameter meaning :300-308; defaults :453-488).
+ * max_batch = number of frame pairs one calc_batch call may carry. */
+int hm_brox_create(int device, int width, int height, int max_batch,
+                   float alpha, float gamma, float scale_factor,
+                   int inner_iterations, int outer_iterations, int solver_iterations,
+                   hm_brox_t *out);
+int hm_brox_destroy(hm_brox_t h);
+
+/* brox->calc(frame0f, frame1f, flow) + split + download
+ * (src/optical_flow_ext.cpp:314-328): two 8-bit gray frames in, flowx / flowy
+ * (row-major f32, width*height each) out.  Host pointers. */
+int hm_brox_calc(hm_brox_t h, const uint8_t *frame0, const uint8_t *frame1,
+                 float *flowx, float *flowy);
+/* n independent pairs, pair i at offset i*width*height in each array
+ * (the loop of process(), src/optical_flow_ext.cpp:361-412, turned into a batch). */
+int hm_brox_calc_batch(hm_brox_t h, int n, const uint8_t *frame0, const uint8_t *frame1,
+                       float *flowx, float *flowy);
+/* same, all four pointers in device memory; asynchronous on the handle's stream */
+int hm_brox_calc_dev(hm_brox_t h, int n, const uint8_t *d_frame0, const uint8_t *d_frame1,
+                     float *d_flowx, float *d_flowy);
+int hm_brox_sync(hm_brox_t h);
+/* the hipStream_t of the handle (so a caller can order its own work against it) */
+void *hm_brox_stream(hm_brox_t h);
+/* pyramid geometry: returns the number of levels, fills widths/heights (cap entries) */
+int hm_brox_levels(hm_brox_t h, int *widths, int *heights, int cap);
+/* SOR relaxation factor (default 1.99) */
+int hm_brox_set_omega(hm_brox_t h, float omega);
+/* launch tuning, never changes results: "sor_fuse" = red-black iterations fused
+ * per SOR launch (0 = choose per level, else a divisor of solver_iterations),
+ * "sor_threads" = 256 or 512 threads per SOR workgroup */
+int hm_brox_tune(hm_brox_t h, const char *key, int value);
+
+/* HIP-event timing of the SOR launches of subsequent calc calls.
+ * read: total milliseconds, launches, and pixel-iterations (sum over launches of
+ * pixels * red-black iterations) since profiling was switched on or last read. */
+int hm_brox_profile(hm_brox_t h, int enable);
+int hm_brox_profile_read(hm_brox_t h, double *sor_ms, long long *sor_launches,
+                         double *sor_pixel_iterations);
+
+/* Single operators on host arrays, for parity tests against the oracle.
+ * Each allocates scratch, runs the same kernel calc uses, and copies back. */
+int hm_op_blur(const float *src, int w, int h, float scale_factor, float *dst);
+int hm_op_resample(const float *src, int ws, int hs, float *dst, int wd, int hd, float mul);
+int hm_op_deriv(const float *src, int w, int h, float *dx, float *dy);
+/* in: I0,Ix0,Iy0,I1,I1x,I1y,I1xx,I1xy,I1yy,u,v   out: Iz,Ix,Iy,Ixz,Iyz,Ixx,Ixy,Iyy */
+int hm_op_warp(const float *const in[11], int w, int h, float *const out[8]);
+/* in: u,v,du,dv + the 8 warped fields   out: nu,nv,a12,idu,idv,sx,sy */
+int hm_op_prepare(const float *const in[12], int w, int h, float alpha, float gamma,
+                  float *const out[7]);
+/* du,dv updated in place; coef = nu,nv,a12,idu,idv,sx,sy; fuse = sor_fuse (+100 selects
+ * 512-thread workgroups) */
+int hm_op_sor(float *du, float *dv, const float *const coef[7], int w, int h,
+              int iterations, int fuse, float omega);
+
+/* ------------------------------------------------------------------------
+ * EKF measurement model.  Replaces Renderer (renderer.py:197-737, the OpenGL
+ * rasteriser) and CUDAGL / CUDAGL_multi (cuda.py, cuda_multi.py: the reduction
+ * kernels and their PBO plumbing).
+ * ---------------------------------------------------------------------- */
+typedef struct hm_ctx *hm_ctx_t;
+
+/* Renderer.__init__ + loadMesh (renderer.py:199-295, 560-654) and the
+ * CUDAGL_multi constructor (cuda_multi.py:24-71): mesh topology, texture
+ * coordinates (= initial vertex positions in pixels, renderer.py:579) and the
+ * measurement-noise scales that the reference bakes into its kernels
+ * (cuda_multi.py:420).  tri: T*3 int32 vertex ids; uv: N*2 float pixels. */
+int hm_ctx_create(int device, int width, int height, int n_vertices, int n_triangles,
+                  const int32_t *tri, const float *uv,
+                  float eps_Z, float eps_J, float eps_M, hm_ctx_t *out);
+int hm_ctx_destroy(hm_ctx_t h);
+/* gloo.Texture2D(im1) bound as init_texture (renderer.py:222-223,232): W*H u8 */
+int hm_set_texture(hm_ctx_t h, const uint8_t *tex);
+/* the observed frame of compute()/initjacobian (kalman.py:676-700,
+ * renderer.py:674-679): y_im u8, y_flow x/y f32, y_m u8 in {0,1} */
+int hm_set_observation(hm_ctx_t h, const uint8_t *y_im, const float *y_fx,
+                       const float *y_fy, const uint8_t *y_m);
+/* device-resident variant (flow straight from hm_brox_calc_dev) */
+int hm_set_observation_dev(hm_ctx_t h, const uint8_t *d_y_im, const float *d_y_fx,
+                           const float *d_y_fy, const uint8_t *d_y_m);
+
+/* Renderer.render() of state X (renderer.py:310-325 after update_vertex_buffer
+ * :503-524).  X = 4N doubles [x0,y0,..,vx0,vy0,..] (kalman.py:178).  Any output
+ * pointer may be NULL.  im u8, fx/fy f32, m u8 (255 where covered), all W*H. */
+int hm_render(hm_ctx_t h, const double *X, uint8_t *im, float *fx, float *fy, uint8_t *m);
+/* initjacobian (cuda.py:940-950): render X and keep it as the reference render */
+int hm_initjacobian(hm_ctx_t h, const double *X);
+/* jz (cuda.py:972-980): render Xp, return sum and the 4 component sums */
+int hm_jz(hm_ctx_t h, const double *Xp, double *jz, double jzc[4]);
+/* j (cuda.py:982-1010): renders X + dX e_i and X + dX e_j around the state given
+ * to initjacobian */
+int hm_j(hm_ctx_t h, const double *X, double deltaX, int i, int j, double *out);
+/* Renderer.error (renderer.py:485-501): SSE per channel, with the 8-bit
+ * wrap-around the reference's uint8 arithmetic has for the image and mask terms.
+ * err = e_im, e_fx, e_fy, e_m; fx/fy (may be NULL) receive the rendered flow */
+int hm_error(hm_ctx_t h, const double *X, const uint8_t *y_im, const float *y_fx,
+             const float *y_fy, const uint8_t *y_m, double err[4], float *fx, float *fy);
+
+/* KFState.update (kalman.py:437-449) in one call, single-perturbation
+ * semantics (_jacobian :491-518, _hessian_sparse :583-606, deltaX = 2): renders
+ * X once, then evaluates every +-deltaX perturbation only inside the bounding
+ * box of the triangles it moves.  Hz[4N], Hzc[4N*4], HTH[4N*4N] (dense, symmetric,
+ * zero outside the J pattern kalman.py:202-205).  sparse = 0 selects _hessian
+ * (:521-536), which has the same value. */
+int hm_measure(hm_ctx_t h, const double *X, double deltaX,
+               double *Hz, double *Hzc, double *HTH);
+int hm_ctx_sync(hm_ctx_t h);
+void *hm_ctx_stream(hm_ctx_t h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYDRA_MI_H */

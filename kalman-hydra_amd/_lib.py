@@ -1,0 +1,114 @@
+"""ctypes binding of libhydra_mi.so (declared in include/hydra_mi.h).
+
+There is no CPU fallback: if the library has not been built (``python
+__graft_entry__.py build``) importing a compute entry point raises, and on a
+machine without a GPU every compute call returns HM_ERR_HIP, which surfaces
+here as RuntimeError.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libhydra_mi.so")
+
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_vp = ctypes.c_void_p
+
+#: every symbol include/hydra_mi.h declares -> (restype, argtypes)
+SIGNATURES = {
+    "hm_last_error": (ctypes.c_char_p, []),
+    "hm_version": (ctypes.c_char_p, []),
+    "hm_device_count": (ctypes.c_int, []),
+    "hm_brox_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                      ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      ctypes.POINTER(c_vp)]),
+    "hm_brox_destroy": (ctypes.c_int, [c_vp]),
+    "hm_brox_calc": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "hm_brox_calc_batch": (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_vp, c_vp, c_vp]),
+    "hm_brox_calc_dev": (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_vp, c_vp, c_vp]),
+    "hm_brox_sync": (ctypes.c_int, [c_vp]),
+    "hm_brox_stream": (c_vp, [c_vp]),
+    "hm_brox_levels": (ctypes.c_int, [c_vp, c_i32p, c_i32p, ctypes.c_int]),
+    "hm_brox_set_omega": (ctypes.c_int, [c_vp, ctypes.c_float]),
+    "hm_brox_tune": (ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int]),
+    "hm_brox_profile": (ctypes.c_int, [c_vp, ctypes.c_int]),
+    "hm_brox_profile_read": (ctypes.c_int, [c_vp, c_f64p, ctypes.POINTER(ctypes.c_longlong), c_f64p]),
+    "hm_op_blur": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, c_vp]),
+    "hm_op_resample": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_float]),
+    "hm_op_deriv": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
+    "hm_op_warp": (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_vp)]),
+    "hm_op_prepare": (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                     ctypes.c_float, ctypes.POINTER(c_vp)]),
+    "hm_op_sor": (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                 ctypes.c_int, ctypes.c_float]),
+    "hm_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp,
+                                     c_vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.POINTER(c_vp)]),
+    "hm_ctx_destroy": (ctypes.c_int, [c_vp]),
+    "hm_set_texture": (ctypes.c_int, [c_vp, c_vp]),
+    "hm_set_observation": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "hm_set_observation_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "hm_render": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "hm_initjacobian": (ctypes.c_int, [c_vp, c_vp]),
+    "hm_jz": (ctypes.c_int, [c_vp, c_vp, c_f64p, c_f64p]),
+    "hm_j": (ctypes.c_int, [c_vp, c_vp, ctypes.c_double, ctypes.c_int, ctypes.c_int, c_f64p]),
+    "hm_error": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f64p, c_vp, c_vp]),
+    "hm_measure": (ctypes.c_int, [c_vp, c_vp, ctypes.c_double, c_vp, c_vp, c_vp]),
+    "hm_ctx_sync": (ctypes.c_int, [c_vp]),
+    "hm_ctx_stream": (c_vp, [c_vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if it was never built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                "%s is missing: the HIP extension has not been built "
+                "(run `python __graft_entry__.py build`); there is no CPU fallback" % SO_PATH)
+        L = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name, None)
+            if fn is None:                 # calling it later raises AttributeError -- loudly
+                continue
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def missing_symbols():
+    """Declared in include/hydra_mi.h but absent from the built library (must be empty)."""
+    L = lib()
+    return [name for name in SIGNATURES if getattr(L, name, None) is None]
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().hm_last_error()
+        raise RuntimeError("%s failed (code %d): %s" % (what or "libhydra_mi call", rc,
+                                                         msg.decode() if msg else "?"))
+
+
+def ptr(a):
+    """void* of a C-contiguous numpy array (None -> NULL)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_vp)
+
+
+def ptr_array(arrs):
+    return (c_vp * len(arrs))(*[a.ctypes.data for a in arrs])
+
+
+def as_c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)

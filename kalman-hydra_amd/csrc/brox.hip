@@ -1,0 +1,583 @@
+// Brox optical flow on MI355X: host orchestration and C-ABI (include/hydra_mi.h).
+// Replaces cv::cuda::BroxOpticalFlow as called by processflow_gpu
+// (reference src/optical_flow_ext.cpp:294-331).
+#include "hm_common.h"
+#include "brox_kernels.h"
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+// ---- error plumbing (shared by the whole library) --------------------------------
+static thread_local char g_err[512] = "";
+void hm_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *hm_last_error(void) { return g_err; }
+extern "C" const char *hm_version(void) { return "hydra_mi 0.1 (gfx950)"; }
+extern "C" int hm_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        hm_set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return HM_ERR_HIP;
+    }
+    return n;
+}
+
+// ---- geometry -----------------------------------------------------------------------
+static Geo make_geo(int w, int h)
+{
+    Geo g;
+    g.w = w; g.h = h;
+    g.pitch = (w + 15) / 16 * 16;
+    g.plane = (g.pitch * h + 63) / 64 * 64;
+    return g;
+}
+
+// level k is ceil(W s^k) x ceil(H s^k) (s accumulated in float); levels are added while
+// the previous one exceeds 15 px on both sides and fewer than `outer` exist
+static int make_levels(int W, int H, float scale, int outer, std::vector<Geo> &out)
+{
+    out.clear();
+    out.push_back(make_geo(W, H));
+    float sc = 1.0f;
+    while (out.back().w > 15 && out.back().h > 15 && (int)out.size() < outer && out.size() < 128) {
+        sc = sc * scale;
+        int w = (int)ceilf((float)W * sc), h = (int)ceilf((float)H * sc);
+        if (w < 1) w = 1;
+        if (h < 1) h = 1;
+        out.push_back(make_geo(w, h));
+    }
+    return (int)out.size();
+}
+
+// sigma = 0.6 sqrt(1/s^2 - 1), R = ceil(3 sigma) >= 1, taps normalised in double
+static Taps make_taps(float scale)
+{
+    Taps t;
+    double sigma = 0.6 * sqrt(1.0 / ((double)scale * (double)scale) - 1.0);
+    int R = (int)ceil(3.0 * sigma);
+    if (R < 1) R = 1;
+    if (R > (BROX_MAX_TAPS - 1) / 2) R = (BROX_MAX_TAPS - 1) / 2;
+    double tmp[BROX_MAX_TAPS], sum = 0.0;
+    for (int i = -R; i <= R; i++) {
+        tmp[i + R] = exp(-(double)(i * i) / (2.0 * sigma * sigma));
+        sum += tmp[i + R];
+    }
+    memset(t.g, 0, sizeof t.g);
+    for (int i = 0; i <= 2 * R; i++) t.g[i] = (float)(tmp[i] / sum);
+    t.R = R;
+    return t;
+}
+
+static dim3 grid2d(const Geo &g, int n) { return dim3(hm_cdiv(g.w, 64), hm_cdiv(g.h, 4), n); }
+static const dim3 kBlock2d(64, 4, 1);
+
+// ---- SOR launch ------------------------------------------------------------------------
+#define SOR_TW 64
+#define SOR_TH 64
+
+struct SorPlan {
+    int K;                      // iterations per launch
+    int threads;                // 256 (8 rows per thread) or 512 (4 rows per thread)
+    int tiles_x, tiles_y, step_x, step_y, halo_x, halo_y;
+};
+
+// iterations fused per launch: everything when the level fits one tile (no halo
+// needed); otherwise the largest divisor of `solver` up to 5 (halo 2K = 10 px of a
+// 64-px tile is where redundant work starts to outweigh the saved traffic)
+static SorPlan sor_plan(const Geo &g, int solver, int fuse, int threads)
+{
+    SorPlan p;
+    p.threads = threads;
+    bool fitx = g.w <= SOR_TW, fity = g.h <= SOR_TH;
+    int K;
+    if (fuse > 0) K = fuse;
+    else if (fitx && fity) K = solver;
+    else {
+        K = 1;
+        for (int d = 1; d <= 5 && d <= solver; d++)
+            if (solver % d == 0) K = d;
+    }
+    p.K = K;
+    p.halo_x = fitx ? 0 : 2 * K;
+    p.halo_y = fity ? 0 : 2 * K;
+    p.step_x = SOR_TW - 2 * p.halo_x;
+    p.step_y = SOR_TH - 2 * p.halo_y;
+    p.tiles_x = fitx ? 1 : hm_cdiv(g.w, p.step_x);
+    p.tiles_y = fity ? 1 : hm_cdiv(g.h, p.step_y);
+    return p;
+}
+
+static void sor_launch(const SorPlan &p, SorArgs a, int n, hipStream_t s)
+{
+    a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y;
+    a.step_x = p.step_x; a.step_y = p.step_y;
+    a.halo_x = p.halo_x; a.halo_y = p.halo_y;
+    dim3 grid(p.tiles_x * p.tiles_y, 1, n);
+    if (p.threads == 512)
+        hipLaunchKernelGGL((k_sor<SOR_TW, SOR_TH, 512>), grid, dim3(512), 0, s, a, p.K);
+    else
+        hipLaunchKernelGGL((k_sor<SOR_TW, SOR_TH, 256>), grid, dim3(256), 0, s, a, p.K);
+}
+
+// ---- handle ------------------------------------------------------------------------------
+struct hm_brox {
+    int device, W, H, B;
+    float alpha, gamma, scale, omega;
+    int inner, outer, solver, fuse, sor_threads;
+    std::vector<Geo> geo;
+    Taps taps;
+    hipStream_t stream;
+    float *arena;
+    size_t arena_floats;
+    std::vector<float *> pyr0, pyr1;
+    float *tmpA, *tmpB;
+    float *Ix0, *Iy0, *I1x, *I1y, *I1xx, *I1xy, *I1yy;
+    float *Iz, *Ix, *Iy, *Ixz, *Iyz, *Ixx, *Ixy, *Iyy;
+    float *nu, *nv, *a12, *idu, *idv, *sx, *sy;
+    float *u, *v, *u2, *v2, *du[2], *dv[2];
+    uint8_t *d_f0, *d_f1;        // staging of host frames
+    float *d_ox, *d_oy;          // staging of the host-bound result (tight W*H per pair)
+    // profiling
+    bool prof;
+    std::vector<hipEvent_t> ev;  // start/stop pairs
+    size_t ev_used;
+    double prof_ms, prof_pxit;
+    long long prof_launches;
+    std::vector<double> ev_pxit;
+};
+
+static int brox_free(hm_brox *h)
+{
+    if (!h) return HM_OK;
+    hipSetDevice(h->device);
+    for (hipEvent_t e : h->ev) hipEventDestroy(e);
+    if (h->arena) hipFree(h->arena);
+    if (h->d_f0) hipFree(h->d_f0);
+    if (h->d_f1) hipFree(h->d_f1);
+    if (h->d_ox) hipFree(h->d_ox);
+    if (h->d_oy) hipFree(h->d_oy);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return HM_OK;
+}
+
+extern "C" int hm_brox_create(int device, int W, int H, int max_batch, float alpha, float gamma,
+                              float scale, int inner, int outer, int solver, hm_brox_t *out)
+{
+    HM_ARG(out != nullptr, "hm_brox_create: out is NULL");
+    *out = nullptr;
+    HM_ARG(W >= 1 && H >= 1 && W <= 16384 && H <= 16384, "hm_brox_create: bad size %dx%d", W, H);
+    HM_ARG(max_batch >= 1 && max_batch <= 4096, "hm_brox_create: bad max_batch %d", max_batch);
+    HM_ARG(scale > 0.0f && scale < 1.0f, "hm_brox_create: scale_factor must be in (0,1), got %g", scale);
+    HM_ARG(inner >= 1 && outer >= 1 && solver >= 1, "hm_brox_create: iteration counts must be >= 1");
+    HM_ARG(alpha > 0.0f && gamma >= 0.0f, "hm_brox_create: alpha must be > 0 and gamma >= 0");
+    HM_HIP(hipSetDevice(device));
+    hm_brox *h = new hm_brox();
+    h->device = device; h->W = W; h->H = H; h->B = max_batch;
+    h->alpha = alpha; h->gamma = gamma; h->scale = scale; h->omega = 1.99f;
+    h->inner = inner; h->outer = outer; h->solver = solver; h->fuse = 0; h->sor_threads = 256;
+    h->arena = nullptr; h->d_f0 = h->d_f1 = nullptr; h->d_ox = h->d_oy = nullptr; h->stream = nullptr;
+    h->prof = false; h->ev_used = 0; h->prof_ms = 0; h->prof_pxit = 0; h->prof_launches = 0;
+    make_levels(W, H, scale, outer, h->geo);
+    h->taps = make_taps(scale);
+
+    const size_t B = (size_t)max_batch;
+    const size_t plane0 = (size_t)h->geo[0].plane;
+    size_t pyr_floats = 0;
+    for (const Geo &g : h->geo) pyr_floats += (size_t)g.plane * B;
+    const int nfields = 2 + 7 + 8 + 7 + 4 + 4;
+    h->arena_floats = 2 * pyr_floats + (size_t)nfields * plane0 * B;
+    hipError_t e = hipMalloc((void **)&h->arena, h->arena_floats * sizeof(float));
+    if (e != hipSuccess) {
+        hm_set_error("hm_brox_create: hipMalloc of %zu MiB failed: %s", h->arena_floats * 4 >> 20, hipGetErrorString(e));
+        brox_free(h);
+        return HM_ERR_HIP;
+    }
+    // padding columns are read (never used) by float2 loads: keep them finite
+    e = hipMemset(h->arena, 0, h->arena_floats * sizeof(float));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_f0, B * W * H);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_f1, B * W * H);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_ox, B * W * H * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_oy, B * W * H * sizeof(float));
+    if (e != hipSuccess) {
+        hm_set_error("hm_brox_create: device setup failed: %s", hipGetErrorString(e));
+        brox_free(h);
+        return HM_ERR_HIP;
+    }
+    float *p = h->arena;
+    auto take = [&](size_t n) { float *r = p; p += n; return r; };
+    for (const Geo &g : h->geo) h->pyr0.push_back(take((size_t)g.plane * B));
+    for (const Geo &g : h->geo) h->pyr1.push_back(take((size_t)g.plane * B));
+    float **fields[] = {&h->tmpA, &h->tmpB, &h->Ix0, &h->Iy0, &h->I1x, &h->I1y, &h->I1xx, &h->I1xy, &h->I1yy,
+                        &h->Iz, &h->Ix, &h->Iy, &h->Ixz, &h->Iyz, &h->Ixx, &h->Ixy, &h->Iyy,
+                        &h->nu, &h->nv, &h->a12, &h->idu, &h->idv, &h->sx, &h->sy,
+                        &h->u, &h->v, &h->u2, &h->v2, &h->du[0], &h->du[1], &h->dv[0], &h->dv[1]};
+    static_assert(sizeof(fields) / sizeof(fields[0]) == 32, "field count");
+    for (float **f : fields) *f = take(plane0 * B);
+    *out = h;
+    return HM_OK;
+}
+
+extern "C" int hm_brox_destroy(hm_brox_t h) { return brox_free(h); }
+
+extern "C" int hm_brox_levels(hm_brox_t h, int *ws, int *hs, int cap)
+{
+    HM_ARG(h != nullptr, "hm_brox_levels: NULL handle");
+    int n = (int)h->geo.size();
+    for (int i = 0; i < n && i < cap; i++) {
+        if (ws) ws[i] = h->geo[i].w;
+        if (hs) hs[i] = h->geo[i].h;
+    }
+    return n;
+}
+
+extern "C" int hm_brox_set_omega(hm_brox_t h, float omega)
+{
+    HM_ARG(h != nullptr, "hm_brox_set_omega: NULL handle");
+    HM_ARG(omega > 0.0f && omega < 2.0f, "hm_brox_set_omega: omega must be in (0,2), got %g", omega);
+    h->omega = omega;
+    return HM_OK;
+}
+
+extern "C" int hm_brox_tune(hm_brox_t h, const char *key, int value)
+{
+    HM_ARG(h != nullptr && key != nullptr, "hm_brox_tune: NULL argument");
+    if (!strcmp(key, "sor_fuse")) {
+        HM_ARG(value == 0 || (value >= 1 && value <= 7 && h->solver % value == 0),
+               "hm_brox_tune: sor_fuse=%d must be 0 or a divisor of solver_iterations (%d) not above 7", value, h->solver);
+        h->fuse = value;
+    } else if (!strcmp(key, "sor_threads")) {
+        HM_ARG(value == 256 || value == 512, "hm_brox_tune: sor_threads must be 256 or 512");
+        h->sor_threads = value;
+    } else {
+        hm_set_error("hm_brox_tune: unknown key '%s'", key);
+        return HM_ERR_ARG;
+    }
+    return HM_OK;
+}
+
+extern "C" void *hm_brox_stream(hm_brox_t h) { return h ? (void *)h->stream : nullptr; }
+
+extern "C" int hm_brox_sync(hm_brox_t h)
+{
+    HM_ARG(h != nullptr, "hm_brox_sync: NULL handle");
+    HM_HIP(hipSetDevice(h->device));
+    HM_HIP(hipStreamSynchronize(h->stream));
+    return HM_OK;
+}
+
+extern "C" int hm_brox_profile(hm_brox_t h, int enable)
+{
+    HM_ARG(h != nullptr, "hm_brox_profile: NULL handle");
+    HM_HIP(hipSetDevice(h->device));
+    h->prof = enable != 0;
+    h->ev_used = 0; h->prof_ms = 0; h->prof_pxit = 0; h->prof_launches = 0;
+    h->ev_pxit.clear();
+    return HM_OK;
+}
+
+// fold the recorded event pairs into the running totals (stream must be idle)
+static int prof_collect(hm_brox *h)
+{
+    for (size_t i = 0; i < h->ev_used; i += 2) {
+        float ms = 0.0f;
+        HM_HIP(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+        h->prof_ms += ms;
+        h->prof_pxit += h->ev_pxit[i / 2];
+        h->prof_launches++;
+    }
+    h->ev_used = 0;
+    h->ev_pxit.clear();
+    return HM_OK;
+}
+
+extern "C" int hm_brox_profile_read(hm_brox_t h, double *ms, long long *launches, double *pxit)
+{
+    HM_ARG(h != nullptr, "hm_brox_profile_read: NULL handle");
+    HM_HIP(hipSetDevice(h->device));
+    HM_HIP(hipStreamSynchronize(h->stream));
+    int rc = prof_collect(h);
+    if (rc) return rc;
+    if (ms) *ms = h->prof_ms;
+    if (launches) *launches = h->prof_launches;
+    if (pxit) *pxit = h->prof_pxit;
+    h->prof_ms = 0; h->prof_pxit = 0; h->prof_launches = 0;
+    return HM_OK;
+}
+
+// ---- the pipeline ---------------------------------------------------------------------------
+static int brox_run(hm_brox *h, int n, const uint8_t *d_f0, const uint8_t *d_f1, float *d_ox, float *d_oy)
+{
+    hipStream_t s = h->stream;
+    const int L = (int)h->geo.size();
+    const Geo &g0 = h->geo[0];
+    hipLaunchKernelGGL(k_u8_to_f32, grid2d(g0, n), kBlock2d, 0, s, d_f0, h->W, h->W * h->H, h->pyr0[0], g0);
+    hipLaunchKernelGGL(k_u8_to_f32, grid2d(g0, n), kBlock2d, 0, s, d_f1, h->W, h->W * h->H, h->pyr1[0], g0);
+    for (int k = 1; k < L; k++) {
+        const Geo &gs = h->geo[k - 1], &gd = h->geo[k];
+        for (int im = 0; im < 2; im++) {
+            float *src = im ? h->pyr1[k - 1] : h->pyr0[k - 1];
+            float *dst = im ? h->pyr1[k] : h->pyr0[k];
+            hipLaunchKernelGGL((k_blur<false>), grid2d(gs, n), kBlock2d, 0, s, src, h->tmpA, gs, h->taps);
+            hipLaunchKernelGGL((k_blur<true>), grid2d(gs, n), kBlock2d, 0, s, h->tmpA, h->tmpB, gs, h->taps);
+            hipLaunchKernelGGL(k_resample, grid2d(gd, n), kBlock2d, 0, s, h->tmpB, gs, dst, gd, 1.0f);
+        }
+    }
+    float *u = h->u, *v = h->v, *u2 = h->u2, *v2 = h->v2;
+    {
+        const Geo &gc = h->geo[L - 1];
+        HM_HIP(hipMemsetAsync(u, 0, (size_t)gc.plane * n * sizeof(float), s));
+        HM_HIP(hipMemsetAsync(v, 0, (size_t)gc.plane * n * sizeof(float), s));
+    }
+    for (int k = L - 1; k >= 0; k--) {
+        const Geo &g = h->geo[k];
+        const dim3 gr = grid2d(g, n);
+        hipLaunchKernelGGL(k_deriv, gr, kBlock2d, 0, s, h->pyr0[k], h->Ix0, h->Iy0, g);
+        hipLaunchKernelGGL(k_deriv, gr, kBlock2d, 0, s, h->pyr1[k], h->I1x, h->I1y, g);
+        hipLaunchKernelGGL(k_deriv, gr, kBlock2d, 0, s, h->I1x, h->I1xx, h->I1xy, g);
+        hipLaunchKernelGGL(k_deriv, gr, kBlock2d, 0, s, h->I1y, (float *)nullptr, h->I1yy, g);
+        WarpIn wi = {h->pyr0[k], h->Ix0, h->Iy0, h->pyr1[k], h->I1x, h->I1y, h->I1xx, h->I1xy, h->I1yy, u, v};
+        WarpOut wo = {h->Iz, h->Ix, h->Iy, h->Ixz, h->Iyz, h->Ixx, h->Ixy, h->Iyy};
+        hipLaunchKernelGGL(k_warp, gr, kBlock2d, 0, s, wi, wo, g);
+        int cur = 0;
+        HM_HIP(hipMemsetAsync(h->du[0], 0, (size_t)g.plane * n * sizeof(float), s));
+        HM_HIP(hipMemsetAsync(h->dv[0], 0, (size_t)g.plane * n * sizeof(float), s));
+        const SorPlan plan = sor_plan(g, h->solver, h->fuse, h->sor_threads);
+        Coef co = {h->nu, h->nv, h->a12, h->idu, h->idv, h->sx, h->sy};
+        for (int it = 0; it < h->inner; it++) {
+            PrepIn pi = {u, v, h->du[cur], h->dv[cur], h->Iz, h->Ix, h->Iy, h->Ixz, h->Iyz, h->Ixx, h->Ixy, h->Iyy};
+            hipLaunchKernelGGL(k_diffusivity, dim3(hm_cdiv(g.w, DIFF_BX), hm_cdiv(g.h, DIFF_BY), n),
+                               dim3(DIFF_BX, DIFF_BY), 0, s, pi, co, g, h->alpha);
+            hipLaunchKernelGGL(k_system, gr, kBlock2d, 0, s, pi, co, g, h->gamma);
+            for (int done = 0; done < h->solver; done += plan.K) {
+                SorArgs a;
+                a.du_in = h->du[cur]; a.dv_in = h->dv[cur];
+                a.du_out = h->du[cur ^ 1]; a.dv_out = h->dv[cur ^ 1];
+                a.nu = h->nu; a.nv = h->nv; a.a12 = h->a12; a.idu = h->idu; a.idv = h->idv;
+                a.sx = h->sx; a.sy = h->sy;
+                a.g = g;
+                a.om = h->omega; a.om1 = 1.0f - h->omega;
+                bool rec = h->prof;
+                if (rec) {
+                    if (h->ev_used + 2 > h->ev.size()) {
+                        hipEvent_t e0, e1;
+                        HM_HIP(hipEventCreate(&e0));
+                        HM_HIP(hipEventCreate(&e1));
+                        h->ev.push_back(e0);
+                        h->ev.push_back(e1);
+                    }
+                    HM_HIP(hipEventRecord(h->ev[h->ev_used], s));
+                }
+                sor_launch(plan, a, n, s);
+                if (rec) {
+                    HM_HIP(hipEventRecord(h->ev[h->ev_used + 1], s));
+                    h->ev_used += 2;
+                    h->ev_pxit.push_back((double)g.w * g.h * n * plan.K);
+                }
+                cur ^= 1;
+            }
+        }
+        hipLaunchKernelGGL(k_add, gr, kBlock2d, 0, s, u, v, h->du[cur], h->dv[cur], g);
+        if (k > 0) {
+            const Geo &gf = h->geo[k - 1];
+            const dim3 grf = grid2d(gf, n);
+            hipLaunchKernelGGL(k_resample, grf, kBlock2d, 0, s, u, g, u2, gf, (float)gf.w / (float)g.w);
+            hipLaunchKernelGGL(k_resample, grf, kBlock2d, 0, s, v, g, v2, gf, (float)gf.h / (float)g.h);
+            float *t = u; u = u2; u2 = t;
+            t = v; v = v2; v2 = t;
+        }
+    }
+    // level-0 planes are pitched; the caller's arrays are tight
+    for (int b = 0; b < n; b++) {
+        HM_HIP(hipMemcpy2DAsync(d_ox + (size_t)b * h->W * h->H, h->W * sizeof(float), u + (size_t)b * g0.plane,
+                                g0.pitch * sizeof(float), h->W * sizeof(float), h->H, hipMemcpyDeviceToDevice, s));
+        HM_HIP(hipMemcpy2DAsync(d_oy + (size_t)b * h->W * h->H, h->W * sizeof(float), v + (size_t)b * g0.plane,
+                                g0.pitch * sizeof(float), h->W * sizeof(float), h->H, hipMemcpyDeviceToDevice, s));
+    }
+    HM_HIP(hipGetLastError());
+    return HM_OK;
+}
+
+extern "C" int hm_brox_calc_dev(hm_brox_t h, int n, const uint8_t *d_f0, const uint8_t *d_f1, float *d_ox, float *d_oy)
+{
+    HM_ARG(h != nullptr, "hm_brox_calc_dev: NULL handle");
+    HM_ARG(n >= 1 && n <= h->B, "hm_brox_calc_dev: n=%d outside 1..max_batch=%d", n, h->B);
+    HM_ARG(d_f0 && d_f1 && d_ox && d_oy, "hm_brox_calc_dev: NULL pointer");
+    HM_HIP(hipSetDevice(h->device));
+    return brox_run(h, n, d_f0, d_f1, d_ox, d_oy);
+}
+
+extern "C" int hm_brox_calc_batch(hm_brox_t h, int n, const uint8_t *f0, const uint8_t *f1, float *ox, float *oy)
+{
+    HM_ARG(h != nullptr, "hm_brox_calc_batch: NULL handle");
+    HM_ARG(n >= 1 && n <= h->B, "hm_brox_calc_batch: n=%d outside 1..max_batch=%d", n, h->B);
+    HM_ARG(f0 && f1 && ox && oy, "hm_brox_calc_batch: NULL pointer");
+    HM_HIP(hipSetDevice(h->device));
+    const size_t px = (size_t)h->W * h->H * n;
+    HM_HIP(hipMemcpyAsync(h->d_f0, f0, px, hipMemcpyHostToDevice, h->stream));
+    HM_HIP(hipMemcpyAsync(h->d_f1, f1, px, hipMemcpyHostToDevice, h->stream));
+    int rc = hm_brox_calc_dev(h, n, h->d_f0, h->d_f1, h->d_ox, h->d_oy);
+    if (rc) return rc;
+    HM_HIP(hipMemcpyAsync(ox, h->d_ox, px * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HM_HIP(hipMemcpyAsync(oy, h->d_oy, px * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HM_HIP(hipStreamSynchronize(h->stream));
+    return HM_OK;
+}
+
+extern "C" int hm_brox_calc(hm_brox_t h, const uint8_t *f0, const uint8_t *f1, float *ox, float *oy)
+{
+    return hm_brox_calc_batch(h, 1, f0, f1, ox, oy);
+}
+
+// ---- single operators on host arrays (parity tests) ---------------------------------------------
+namespace {
+struct Scratch {      // pitched device planes with tight host I/O
+    std::vector<float *> bufs;
+    ~Scratch() { for (float *b : bufs) hipFree(b); }
+    float *plane(const Geo &g)
+    {
+        float *p = nullptr;
+        if (hipMalloc((void **)&p, (size_t)g.plane * sizeof(float)) != hipSuccess) return nullptr;
+        hipMemset(p, 0, (size_t)g.plane * sizeof(float));
+        bufs.push_back(p);
+        return p;
+    }
+    float *up(const Geo &g, const float *host)
+    {
+        float *p = plane(g);
+        if (p && hipMemcpy2D(p, g.pitch * sizeof(float), host, g.w * sizeof(float), g.w * sizeof(float), g.h,
+                             hipMemcpyHostToDevice) != hipSuccess)
+            return nullptr;
+        return p;
+    }
+    static bool down(const Geo &g, const float *dev, float *host)
+    {
+        return hipMemcpy2D(host, g.w * sizeof(float), dev, g.pitch * sizeof(float), g.w * sizeof(float), g.h,
+                           hipMemcpyDeviceToHost) == hipSuccess;
+    }
+};
+}  // namespace
+
+#define OP_CHECK(p)                                                              \
+    do {                                                                         \
+        if (!(p)) {                                                              \
+            hm_set_error("hm_op: device allocation or copy failed: %s",          \
+                         hipGetErrorString(hipGetLastError()));                  \
+            return HM_ERR_HIP;                                                   \
+        }                                                                        \
+    } while (0)
+
+extern "C" int hm_op_blur(const float *src, int w, int h, float scale, float *dst)
+{
+    HM_ARG(src && dst && w >= 1 && h >= 1 && scale > 0.0f && scale < 1.0f, "hm_op_blur: bad argument");
+    Geo g = make_geo(w, h);
+    Taps t = make_taps(scale);
+    Scratch sc;
+    float *a = sc.up(g, src), *b = sc.plane(g), *c = sc.plane(g);
+    OP_CHECK(a && b && c);
+    hipLaunchKernelGGL((k_blur<false>), grid2d(g, 1), kBlock2d, 0, 0, a, b, g, t);
+    hipLaunchKernelGGL((k_blur<true>), grid2d(g, 1), kBlock2d, 0, 0, b, c, g, t);
+    HM_HIP(hipDeviceSynchronize());
+    OP_CHECK(Scratch::down(g, c, dst));
+    return HM_OK;
+}
+
+extern "C" int hm_op_resample(const float *src, int ws, int hs, float *dst, int wd, int hd, float mul)
+{
+    HM_ARG(src && dst && ws >= 1 && hs >= 1 && wd >= 1 && hd >= 1, "hm_op_resample: bad argument");
+    Geo gs = make_geo(ws, hs), gd = make_geo(wd, hd);
+    Scratch sc;
+    float *a = sc.up(gs, src), *b = sc.plane(gd);
+    OP_CHECK(a && b);
+    hipLaunchKernelGGL(k_resample, grid2d(gd, 1), kBlock2d, 0, 0, a, gs, b, gd, mul);
+    HM_HIP(hipDeviceSynchronize());
+    OP_CHECK(Scratch::down(gd, b, dst));
+    return HM_OK;
+}
+
+extern "C" int hm_op_deriv(const float *src, int w, int h, float *dx, float *dy)
+{
+    HM_ARG(src && dx && dy && w >= 1 && h >= 1, "hm_op_deriv: bad argument");
+    Geo g = make_geo(w, h);
+    Scratch sc;
+    float *a = sc.up(g, src), *b = sc.plane(g), *c = sc.plane(g);
+    OP_CHECK(a && b && c);
+    hipLaunchKernelGGL(k_deriv, grid2d(g, 1), kBlock2d, 0, 0, a, b, c, g);
+    HM_HIP(hipDeviceSynchronize());
+    OP_CHECK(Scratch::down(g, b, dx) && Scratch::down(g, c, dy));
+    return HM_OK;
+}
+
+extern "C" int hm_op_warp(const float *const in[11], int w, int h, float *const out[8])
+{
+    HM_ARG(in && out && w >= 1 && h >= 1, "hm_op_warp: bad argument");
+    Geo g = make_geo(w, h);
+    Scratch sc;
+    const float *d[11];
+    float *o[8];
+    for (int i = 0; i < 11; i++) { d[i] = sc.up(g, in[i]); OP_CHECK(d[i]); }
+    for (int i = 0; i < 8; i++) { o[i] = sc.plane(g); OP_CHECK(o[i]); }
+    WarpIn wi = {d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10]};
+    WarpOut wo = {o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]};
+    hipLaunchKernelGGL(k_warp, grid2d(g, 1), kBlock2d, 0, 0, wi, wo, g);
+    HM_HIP(hipDeviceSynchronize());
+    for (int i = 0; i < 8; i++) OP_CHECK(Scratch::down(g, o[i], out[i]));
+    return HM_OK;
+}
+
+extern "C" int hm_op_prepare(const float *const in[12], int w, int h, float alpha, float gamma, float *const out[7])
+{
+    HM_ARG(in && out && w >= 1 && h >= 1, "hm_op_prepare: bad argument");
+    Geo g = make_geo(w, h);
+    Scratch sc;
+    const float *d[12];
+    float *o[7];
+    for (int i = 0; i < 12; i++) { d[i] = sc.up(g, in[i]); OP_CHECK(d[i]); }
+    for (int i = 0; i < 7; i++) { o[i] = sc.plane(g); OP_CHECK(o[i]); }
+    PrepIn pi = {d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10], d[11]};
+    Coef co = {o[0], o[1], o[2], o[3], o[4], o[5], o[6]};
+    hipLaunchKernelGGL(k_diffusivity, dim3(hm_cdiv(w, DIFF_BX), hm_cdiv(h, DIFF_BY), 1), dim3(DIFF_BX, DIFF_BY), 0, 0,
+                       pi, co, g, alpha);
+    hipLaunchKernelGGL(k_system, grid2d(g, 1), kBlock2d, 0, 0, pi, co, g, gamma);
+    HM_HIP(hipDeviceSynchronize());
+    for (int i = 0; i < 7; i++) OP_CHECK(Scratch::down(g, o[i], out[i]));
+    return HM_OK;
+}
+
+extern "C" int hm_op_sor(float *du, float *dv, const float *const coef[7], int w, int h, int iterations, int fuse,
+                         float omega)
+{
+    HM_ARG(du && dv && coef && w >= 1 && h >= 1 && iterations >= 1, "hm_op_sor: bad argument");
+    HM_ARG(fuse % 100 == 0 || (fuse % 100 >= 1 && fuse % 100 <= 7 && iterations % (fuse % 100) == 0),
+           "hm_op_sor: fuse=%d must be 0 or a divisor of iterations=%d not above 7", fuse % 100, iterations);
+    Geo g = make_geo(w, h);
+    Scratch sc;
+    const float *c[7];
+    for (int i = 0; i < 7; i++) { c[i] = sc.up(g, coef[i]); OP_CHECK(c[i]); }
+    float *b[4] = {sc.up(g, du), sc.up(g, dv), sc.plane(g), sc.plane(g)};
+    OP_CHECK(b[0] && b[1] && b[2] && b[3]);
+    SorPlan plan = sor_plan(g, iterations, fuse % 100, fuse >= 100 ? 512 : 256);
+    int cur = 0;
+    for (int done = 0; done < iterations; done += plan.K) {
+        SorArgs a;
+        a.du_in = b[cur ? 2 : 0]; a.dv_in = b[cur ? 3 : 1];
+        a.du_out = b[cur ? 0 : 2]; a.dv_out = b[cur ? 1 : 3];
+        a.nu = c[0]; a.nv = c[1]; a.a12 = c[2]; a.idu = c[3]; a.idv = c[4]; a.sx = c[5]; a.sy = c[6];
+        a.g = g;
+        a.om = omega; a.om1 = 1.0f - omega;
+        sor_launch(plan, a, 1, 0);
+        cur ^= 1;
+    }
+    HM_HIP(hipDeviceSynchronize());
+    OP_CHECK(Scratch::down(g, b[cur ? 2 : 0], du) && Scratch::down(g, b[cur ? 3 : 1], dv));
+    return HM_OK;
+}

@@ -1,0 +1,429 @@
+// Device kernels of the Brox optical-flow path (gfx950).  All arithmetic is
+// binary32 in a fixed order with contraction off (-ffp-contract=off) and
+// correctly rounded sqrt / divide, so results are reproducible bit for bit.
+//
+// Layout: every field of one pyramid level is a pitched plane, `pitch` floats
+// per row (multiple of 16, so rows start 64-byte aligned and pixel pairs can be
+// moved as float2), `plane` floats per batch item; blockIdx.z = batch item.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BROX_EPS2 1e-6f
+#define BROX_MAX_TAPS 33
+
+struct Geo {      // one pyramid level
+    int w, h, pitch, plane;
+};
+
+struct Taps {
+    float g[BROX_MAX_TAPS];
+    int R;
+};
+
+__device__ __forceinline__ int d_mirror(int i, int n)
+{
+    while (i < 0 || i >= n) {
+        if (i < 0) i = -i - 1;
+        else i = 2 * n - i - 1;
+    }
+    return i;
+}
+
+__device__ __forceinline__ int d_clampi(int i, int lo, int hi) { return i < lo ? lo : (i > hi ? hi : i); }
+
+// ---- frame conversion: x * (1/255), as the reference does before calc() -----
+__global__ void k_u8_to_f32(const uint8_t *__restrict__ src, int src_pitch, int src_plane,
+                            float *__restrict__ dst, Geo g)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    const uint8_t *s = src + (size_t)blockIdx.z * src_plane;
+    float *d = dst + (size_t)blockIdx.z * g.plane;
+    d[y * g.pitch + x] = (float)s[y * src_pitch + x] * (1.0f / 255.0f);
+}
+
+// ---- separable Gaussian, mirrored border ---------------------------------------
+template <bool VERT>
+__global__ void k_blur(const float *__restrict__ src, float *__restrict__ dst, Geo g, Taps t)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    const float *s = src + (size_t)blockIdx.z * g.plane;
+    float acc = 0.0f;
+    for (int i = -t.R; i <= t.R; i++) {
+        float val = VERT ? s[d_mirror(y + i, g.h) * g.pitch + x] : s[y * g.pitch + d_mirror(x + i, g.w)];
+        acc = acc + t.g[i + t.R] * val;
+    }
+    dst[(size_t)blockIdx.z * g.plane + y * g.pitch + x] = acc;
+}
+
+// ---- bilinear sampling, coordinates clamped to the image -----------------------
+__device__ __forceinline__ float d_bilin(const float *__restrict__ img, int w, int h, int pitch,
+                                         float px, float py)
+{
+    if (px < 0.0f) px = 0.0f;
+    if (py < 0.0f) py = 0.0f;
+    if (px > (float)(w - 1)) px = (float)(w - 1);
+    if (py > (float)(h - 1)) py = (float)(h - 1);
+    float fx0 = floorf(px), fy0 = floorf(py);
+    int x0 = (int)fx0, y0 = (int)fy0;
+    int x1 = x0 + 1 < w ? x0 + 1 : w - 1;
+    int y1 = y0 + 1 < h ? y0 + 1 : h - 1;
+    float ax = px - fx0, ay = py - fy0;
+    float a = img[y0 * pitch + x0], b = img[y0 * pitch + x1];
+    float c = img[y1 * pitch + x0], d = img[y1 * pitch + x1];
+    float top = (1.0f - ax) * a + ax * b;
+    float bot = (1.0f - ax) * c + ax * d;
+    return (1.0f - ay) * top + ay * bot;
+}
+
+// resample src level onto dst level, value scaled by mul (pyramid and prolongation)
+__global__ void k_resample(const float *__restrict__ src, Geo gs, float *__restrict__ dst, Geo gd, float mul)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= gd.w || y >= gd.h) return;
+    float rx = (float)gs.w / (float)gd.w, ry = (float)gs.h / (float)gd.h;
+    float sx = ((float)x + 0.5f) * rx - 0.5f;
+    float sy = ((float)y + 0.5f) * ry - 0.5f;
+    const float *s = src + (size_t)blockIdx.z * gs.plane;
+    dst[(size_t)blockIdx.z * gd.plane + y * gd.pitch + x] = d_bilin(s, gs.w, gs.h, gs.pitch, sx, sy) * mul;
+}
+
+// ---- 5-tap derivatives ------------------------------------------------------------
+__device__ __forceinline__ float d_d5(float m2, float m1, float p1, float p2)
+{
+    return (8.0f * (p1 - m1) - (p2 - m2)) * (1.0f / 12.0f);
+}
+
+// dx and/or dy of one image (either output may be null)
+__global__ void k_deriv(const float *__restrict__ src, float *__restrict__ dx, float *__restrict__ dy, Geo g)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    size_t off = (size_t)blockIdx.z * g.plane;
+    const float *s = src + off;
+    if (dx) {
+        const float *r = s + y * g.pitch;
+        dx[off + y * g.pitch + x] = d_d5(r[d_mirror(x - 2, g.w)], r[d_mirror(x - 1, g.w)],
+                                         r[d_mirror(x + 1, g.w)], r[d_mirror(x + 2, g.w)]);
+    }
+    if (dy) {
+        dy[off + y * g.pitch + x] = d_d5(s[d_mirror(y - 2, g.h) * g.pitch + x], s[d_mirror(y - 1, g.h) * g.pitch + x],
+                                         s[d_mirror(y + 1, g.h) * g.pitch + x], s[d_mirror(y + 2, g.h) * g.pitch + x]);
+    }
+}
+
+// ---- warp: frame 1 and its derivative images sampled at (x+u, y+v) ---------------
+struct WarpIn {
+    const float *I0, *Ix0, *Iy0, *I1, *I1x, *I1y, *I1xx, *I1xy, *I1yy, *u, *v;
+};
+struct WarpOut {
+    float *Iz, *Ix, *Iy, *Ixz, *Iyz, *Ixx, *Ixy, *Iyy;
+};
+
+__global__ void k_warp(WarpIn in, WarpOut out, Geo g)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    size_t off = (size_t)blockIdx.z * g.plane;
+    size_t p = off + y * g.pitch + x;
+    int w = g.w, h = g.h, pitch = g.pitch;
+    float px = (float)x + in.u[p], py = (float)y + in.v[p];
+    if (px < 0.0f || py < 0.0f || px > (float)(w - 1) || py > (float)(h - 1)) {
+        out.Iz[p] = 0.0f; out.Ix[p] = 0.0f; out.Iy[p] = 0.0f; out.Ixz[p] = 0.0f; out.Iyz[p] = 0.0f;
+        out.Ixx[p] = 0.0f; out.Ixy[p] = 0.0f; out.Iyy[p] = 0.0f;
+        return;
+    }
+    float i1 = d_bilin(in.I1 + off, w, h, pitch, px, py);
+    float ix = d_bilin(in.I1x + off, w, h, pitch, px, py);
+    float iy = d_bilin(in.I1y + off, w, h, pitch, px, py);
+    out.Iz[p] = i1 - in.I0[p];
+    out.Ix[p] = ix;
+    out.Iy[p] = iy;
+    if (x < 2 || y < 2 || x > w - 3 || y > h - 3 ||
+        px < 2.0f || py < 2.0f || px > (float)(w - 4) || py > (float)(h - 4)) {
+        out.Ixz[p] = 0.0f; out.Iyz[p] = 0.0f; out.Ixx[p] = 0.0f; out.Ixy[p] = 0.0f; out.Iyy[p] = 0.0f;
+        return;
+    }
+    out.Ixz[p] = ix - in.Ix0[p];
+    out.Iyz[p] = iy - in.Iy0[p];
+    out.Ixx[p] = d_bilin(in.I1xx + off, w, h, pitch, px, py);
+    out.Ixy[p] = d_bilin(in.I1xy + off, w, h, pitch, px, py);
+    out.Iyy[p] = d_bilin(in.I1yy + off, w, h, pitch, px, py);
+}
+
+// ---- linear system of one lagged-nonlinearity step ---------------------------------
+__device__ __forceinline__ float d_psi(float s2) { return 0.5f / sqrtf(s2 + BROX_EPS2); }
+
+struct PrepIn {
+    const float *u, *v, *du, *dv, *Iz, *Ix, *Iy, *Ixz, *Iyz, *Ixx, *Ixy, *Iyy;
+};
+struct Coef {
+    float *nu, *nv, *a12, *idu, *idv, *sx, *sy;
+};
+
+// Stage 1: edge diffusivities of the smoothness term at the current u+du, v+dv.
+// One 64x4 block; U = u+du and V = v+dv of the block plus a 1-px ring are staged
+// in LDS once (every pixel is needed by up to 8 neighbouring edges).
+#define DIFF_BX 64
+#define DIFF_BY 4
+__global__ __launch_bounds__(DIFF_BX * DIFF_BY) void k_diffusivity(PrepIn in, Coef c, Geo g, float alpha)
+{
+    __shared__ float sU[DIFF_BY + 2][DIFF_BX + 2];
+    __shared__ float sV[DIFF_BY + 2][DIFF_BX + 2];
+    const int w = g.w, h = g.h, pitch = g.pitch;
+    const size_t off = (size_t)blockIdx.z * g.plane;
+    const int bx0 = blockIdx.x * DIFF_BX, by0 = blockIdx.y * DIFF_BY;
+    const int tid = threadIdx.y * DIFF_BX + threadIdx.x;
+    for (int i = tid; i < (DIFF_BY + 2) * (DIFF_BX + 2); i += DIFF_BX * DIFF_BY) {
+        int ly = i / (DIFF_BX + 2), lx = i - ly * (DIFF_BX + 2);
+        int gx = d_clampi(bx0 + lx - 1, 0, w - 1), gy = d_clampi(by0 + ly - 1, 0, h - 1);
+        size_t p = off + gy * pitch + gx;
+        sU[ly][lx] = in.u[p] + in.du[p];
+        sV[ly][lx] = in.v[p] + in.dv[p];
+    }
+    __syncthreads();
+    int x = bx0 + threadIdx.x, y = by0 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    // LDS coordinates of (x,y); clamped neighbours coincide with the ring because the
+    // ring itself was filled with clamped reads
+    int lx = threadIdx.x + 1, ly = threadIdx.y + 1;
+    size_t p = off + y * pitch + x;
+    float rsx = 0.0f, rsy = 0.0f;
+    if (x + 1 < w) {
+        float ux = sU[ly][lx + 1] - sU[ly][lx];
+        float vx = sV[ly][lx + 1] - sV[ly][lx];
+        float uy = 0.25f * ((sU[ly + 1][lx] - sU[ly - 1][lx]) + (sU[ly + 1][lx + 1] - sU[ly - 1][lx + 1]));
+        float vy = 0.25f * ((sV[ly + 1][lx] - sV[ly - 1][lx]) + (sV[ly + 1][lx + 1] - sV[ly - 1][lx + 1]));
+        rsx = alpha * d_psi(((ux * ux + uy * uy) + vx * vx) + vy * vy);
+    }
+    if (y + 1 < h) {
+        float uy = sU[ly + 1][lx] - sU[ly][lx];
+        float vy = sV[ly + 1][lx] - sV[ly][lx];
+        float ux = 0.25f * ((sU[ly][lx + 1] - sU[ly][lx - 1]) + (sU[ly + 1][lx + 1] - sU[ly + 1][lx - 1]));
+        float vx = 0.25f * ((sV[ly][lx + 1] - sV[ly][lx - 1]) + (sV[ly + 1][lx + 1] - sV[ly + 1][lx - 1]));
+        rsy = alpha * d_psi(((ux * ux + uy * uy) + vx * vx) + vy * vy);
+    }
+    c.sx[p] = rsx;
+    c.sy[p] = rsy;
+}
+
+// Stage 2: data and gradient-constancy terms and the assembled 2x2-block system.
+__global__ void k_system(PrepIn in, Coef c, Geo g, float gamma)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    const int w = g.w, h = g.h, pitch = g.pitch;
+    const size_t off = (size_t)blockIdx.z * g.plane;
+    const size_t p = off + y * pitch + x;
+    float ddu = in.du[p], ddv = in.dv[p];
+    float ix = in.Ix[p], iy = in.Iy[p], iz = in.Iz[p];
+    float ixx = in.Ixx[p], ixy = in.Ixy[p], iyy = in.Iyy[p], ixz = in.Ixz[p], iyz = in.Iyz[p];
+    float q0 = (iz + ix * ddu) + iy * ddv;
+    float pd = d_psi(q0 * q0);
+    float q1 = (ixz + ixx * ddu) + ixy * ddv;
+    float q2 = (iyz + ixy * ddu) + iyy * ddv;
+    float pg = gamma * d_psi(q1 * q1 + q2 * q2);
+    float A11 = pd * (ix * ix) + pg * (ixx * ixx + ixy * ixy);
+    float A12 = pd * (ix * iy) + pg * (ixx * ixy + ixy * iyy);
+    float A22 = pd * (iy * iy) + pg * (ixy * ixy + iyy * iyy);
+    float b1 = -(pd * (ix * iz) + pg * (ixx * ixz + ixy * iyz));
+    float b2 = -(pd * (iy * iz) + pg * (ixy * ixz + iyy * iyz));
+    float sl = x > 0 ? c.sx[p - 1] : 0.0f, sr = c.sx[p];
+    float st = y > 0 ? c.sy[p - pitch] : 0.0f, sb = c.sy[p];
+    size_t pl = x > 0 ? p - 1 : p, pr = x + 1 < w ? p + 1 : p;
+    size_t pt = y > 0 ? p - pitch : p, pb = y + 1 < h ? p + pitch : p;
+    float uc = in.u[p], vc = in.v[p];
+    float su = ((sl * (in.u[pl] - uc) + sr * (in.u[pr] - uc)) + st * (in.u[pt] - uc)) + sb * (in.u[pb] - uc);
+    float sv = ((sl * (in.v[pl] - vc) + sr * (in.v[pr] - vc)) + st * (in.v[pt] - vc)) + sb * (in.v[pb] - vc);
+    float ssum = ((sl + sr) + st) + sb;
+    c.nu[p] = b1 + su;
+    c.nv[p] = b2 + sv;
+    c.a12[p] = A12;
+    c.idu[p] = 1.0f / (A11 + ssum);
+    c.idv[p] = 1.0f / (A22 + ssum);
+}
+
+// ---- u += du, v += dv ------------------------------------------------------------------
+__global__ void k_add(float *__restrict__ u, float *__restrict__ v, const float *__restrict__ du,
+                      const float *__restrict__ dv, Geo g)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    size_t p = (size_t)blockIdx.z * g.plane + y * g.pitch + x;
+    u[p] = u[p] + du[p];
+    v[p] = v[p] + dv[p];
+}
+
+// ---- red-black SOR, K iterations per launch (K is a launch argument) -----------------------------------------------
+// One workgroup relaxes a TW x TH tile K times without going back to memory
+// (overlapped temporal tiling: the tile carries a halo of 2K pixels per side,
+// one ring of which becomes stale per half-sweep; only the interior is written
+// back).  Red-black relaxation does not depend on the visiting order inside a
+// colour, so the result is bit-identical to a whole-image sweep.
+//
+//  * the seven coefficient fields of a thread's pixels live in registers for all K
+//    iterations (loaded once, coalesced float2 per pixel pair);
+//  * du / dv live in LDS in a checkerboard-compressed layout -- in each row the
+//    pixels of colour 0 come first, then colour 1 -- so every access of a
+//    half-sweep (own pixel and its four neighbours, which all have the other
+//    colour) is unit-stride across lanes: no bank conflicts, all lanes active;
+//  * du / dv are double-buffered in memory (a neighbouring tile reads the halo
+//    this tile would otherwise overwrite).
+struct SorArgs {
+    const float *du_in, *dv_in;
+    float *du_out, *dv_out;
+    const float *nu, *nv, *a12, *idu, *idv, *sx, *sy;
+    Geo g;
+    int tiles_x, tiles_y;   // tile grid
+    int step_x, step_y;     // interior size of a tile
+    int halo_x, halo_y;     // 2K, or 0 when the image fits the tile on that axis
+    float om, om1;          // omega, 1 - omega
+};
+
+template <int TW, int TH, int NT>
+__global__ __launch_bounds__(NT) void k_sor(SorArgs a, int K)
+{
+    constexpr int HALF = TW / 2;             // pixels of one colour per row
+    constexpr int NG = NT / HALF;            // lane groups, each owns whole rows
+    constexpr int RPT = TH / NG;             // rows per thread
+    static_assert(TH % NG == 0 && RPT % 2 == 0, "rows per thread must be even");
+    __shared__ float s_du[TH * TW];
+    __shared__ float s_dv[TH * TW];
+
+    // XCD-aware tile order: consecutive workgroup ids land on different XCDs, so
+    // give each XCD a contiguous run of tiles (neighbouring tiles share halo lines
+    // in that XCD's L2).  Speed only.
+    const int nt = a.tiles_x * a.tiles_y;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, k = bid >> 3, q = nt >> 3, rem = nt & 7;
+        bid = xcd * q + (xcd < rem ? xcd : rem) + k;   // bijection on [0, nt)
+    }
+    const int ty = bid / a.tiles_x, tx = bid - ty * a.tiles_x;
+    const int w = a.g.w, h = a.g.h, pitch = a.g.pitch;
+    const size_t off = (size_t)blockIdx.z * a.g.plane;
+    const int gx0 = tx * a.step_x - a.halo_x;      // even
+    const int gy0 = ty * a.step_y - a.halo_y;      // even
+
+    const int grp = threadIdx.x / HALF, i = threadIdx.x - grp * HALF;
+    const int r0 = grp * RPT;                      // even
+    const int gxa = gx0 + 2 * i;                   // global x of the even pixel of the pair
+
+    // registers: [row][pixel of the pair].  The weight towards the upper neighbour
+    // is the lower weight of the row above (own register except for the first
+    // row), the weight towards the left neighbour of the odd pixel is the right
+    // weight of the even one.
+    float nu[RPT][2], nv[RPT][2], a12[RPT][2], idu[RPT][2], idv[RPT][2];
+    float sr[RPT][2], sb[RPT][2], sl0[RPT], st0[2];
+    st0[0] = 0.0f; st0[1] = 0.0f;
+
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+        const int r = r0 + j, gy = gy0 + r;
+        const bool rowok = gy >= 0 && gy < h;
+        const bool ok0 = rowok && gxa >= 0 && gxa < w;      // gxa is even: ok1 implies ok0
+        const bool ok1 = rowok && gxa + 1 >= 0 && gxa + 1 < w;
+        float2 z = make_float2(0.0f, 0.0f);
+        float2 f_nu = z, f_nv = z, f_a = z, f_iu = z, f_iv = z, f_sx = z, f_sy = z, f_du = z, f_dv = z;
+        float f_sl = 0.0f;
+        if (ok0) {   // gxa even, pitch even: the pair is 8-byte aligned and inside the row's pitch
+            const size_t p = off + (size_t)gy * pitch + gxa;
+            f_nu = *(const float2 *)(a.nu + p);
+            f_nv = *(const float2 *)(a.nv + p);
+            f_a = *(const float2 *)(a.a12 + p);
+            f_iu = *(const float2 *)(a.idu + p);
+            f_iv = *(const float2 *)(a.idv + p);
+            f_sx = *(const float2 *)(a.sx + p);
+            f_sy = *(const float2 *)(a.sy + p);
+            f_du = *(const float2 *)(a.du_in + p);
+            f_dv = *(const float2 *)(a.dv_in + p);
+            if (gxa > 0) f_sl = a.sx[p - 1];
+            if (j == 0 && gy > 0) {
+                float2 t = *(const float2 *)(a.sy + p - pitch);
+                st0[0] = t.x;
+                st0[1] = ok1 ? t.y : 0.0f;
+            }
+        }
+        // a pixel outside the image gets an all-zero system: it stays finite and is never used
+        nu[j][0] = f_nu.x; nv[j][0] = f_nv.x; a12[j][0] = f_a.x; idu[j][0] = f_iu.x; idv[j][0] = f_iv.x;
+        sr[j][0] = f_sx.x; sb[j][0] = f_sy.x; sl0[j] = f_sl;
+        nu[j][1] = ok1 ? f_nu.y : 0.0f; nv[j][1] = ok1 ? f_nv.y : 0.0f; a12[j][1] = ok1 ? f_a.y : 0.0f;
+        idu[j][1] = ok1 ? f_iu.y : 0.0f; idv[j][1] = ok1 ? f_iv.y : 0.0f;
+        sr[j][1] = ok1 ? f_sx.y : 0.0f; sb[j][1] = ok1 ? f_sy.y : 0.0f;
+        // checkerboard-compressed LDS row: colour of the even pixel is (r & 1) == (j & 1)
+        const int c0 = j & 1;
+        s_du[r * TW + c0 * HALF + i] = f_du.x;
+        s_dv[r * TW + c0 * HALF + i] = f_dv.x;
+        s_du[r * TW + (1 - c0) * HALF + i] = ok1 ? f_du.y : 0.0f;
+        s_dv[r * TW + (1 - c0) * HALF + i] = ok1 ? f_dv.y : 0.0f;
+    }
+    __syncthreads();
+
+    const float om = a.om, om1 = a.om1;
+#pragma unroll 1
+    for (int it = 0; it < K; it++) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+#pragma unroll
+            for (int j = 0; j < RPT; j++) {
+                // colour c in row r: pixel x = 2i + q with q = (r + c) & 1 = (j + c) & 1
+                const int q = (j + c) & 1;
+                const int r = r0 + j, gy = gy0 + r, gx = gxa + q;
+                const int oc = (1 - c) * HALF;           // neighbours have the other colour
+                // slots of the left / right neighbours inside their row
+                int il = q ? i : i - 1, ir = q ? i + 1 : i;
+                il = il < 0 ? 0 : il;
+                ir = ir > HALF - 1 ? HALF - 1 : ir;
+                const int ru = r > 0 ? r - 1 : 0, rd = r < TH - 1 ? r + 1 : TH - 1;
+                const float cu = s_du[r * TW + c * HALF + i], cv = s_dv[r * TW + c * HALF + i];
+                float ul = s_du[r * TW + oc + il], ur = s_du[r * TW + oc + ir];
+                float ut = s_du[ru * TW + oc + i], ub = s_du[rd * TW + oc + i];
+                float vl = s_dv[r * TW + oc + il], vr = s_dv[r * TW + oc + ir];
+                float vt = s_dv[ru * TW + oc + i], vb = s_dv[rd * TW + oc + i];
+                // at the image border the oracle pairs the (zero) weight with the pixel itself
+                if (gx <= 0) { ul = cu; vl = cv; }
+                if (gx >= w - 1) { ur = cu; vr = cv; }
+                if (gy <= 0) { ut = cu; vt = cv; }
+                if (gy >= h - 1) { ub = cu; vb = cv; }
+                const float wl = q ? sr[j][0] : sl0[j];
+                const float wt = j > 0 ? sb[j > 0 ? j - 1 : 0][q] : st0[q];
+                const float su = ((wl * ul + sr[j][q] * ur) + wt * ut) + sb[j][q] * ub;
+                const float sv = ((wl * vl + sr[j][q] * vr) + wt * vt) + sb[j][q] * vb;
+                const float dun = om1 * cu + om * (((nu[j][q] - a12[j][q] * cv) + su) * idu[j][q]);
+                const float dvn = om1 * cv + om * (((nv[j][q] - a12[j][q] * dun) + sv) * idv[j][q]);
+                s_du[r * TW + c * HALF + i] = dun;
+                s_dv[r * TW + c * HALF + i] = dvn;
+            }
+            __syncthreads();
+        }
+    }
+
+    // write back the interior
+    const int lx = 2 * i;
+    const bool colin = lx >= a.halo_x && lx < a.halo_x + a.step_x;
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+        const int r = r0 + j, gy = gy0 + r;
+        if (!colin || r < a.halo_y || r >= a.halo_y + a.step_y || gy >= h || gxa >= w) continue;
+        const size_t p = off + (size_t)gy * pitch + gxa;
+        const int c0 = j & 1;
+        const float u0 = s_du[r * TW + c0 * HALF + i], u1 = s_du[r * TW + (1 - c0) * HALF + i];
+        const float v0 = s_dv[r * TW + c0 * HALF + i], v1 = s_dv[r * TW + (1 - c0) * HALF + i];
+        if (gxa + 1 < w) {
+            *(float2 *)(a.du_out + p) = make_float2(u0, u1);
+            *(float2 *)(a.dv_out + p) = make_float2(v0, v1);
+        } else {
+            a.du_out[p] = u0;
+            a.dv_out[p] = v0;
+        }
+    }
+}

@@ -1,0 +1,158 @@
+"""GPU parity of the Brox path: every HIP kernel and the whole pipeline against
+oracle/brox_ref.c on the same seeded inputs, through the C-ABI.
+
+The oracle and the kernels use the same binary32 operation order with FMA
+contraction off, so the bar is BIT-EXACT equality (np.array_equal; it treats
++0 and -0 as equal), well inside the 1e-4 end-point-error tolerance the
+build contract allows.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(16, 16), (37, 29), (64, 64), (65, 64), (100, 77), (200, 150), (131, 259)]
+
+
+def _rand(shape, seed, lo=-1.0, hi=1.0):
+    rng = np.random.default_rng(seed)
+    return rng.uniform(lo, hi, shape).astype(np.float32)
+
+
+def _smooth(shape, seed):
+    from scipy import ndimage
+    rng = np.random.default_rng(seed)
+    return ndimage.gaussian_filter(rng.random(shape), 2.0).astype(np.float32)
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+def test_blur_resample_deriv(hm, oracle_brox, w, h):
+    from hydra_mi import brox
+    img = _smooth((h, w), 1)
+    assert np.array_equal(brox.op_blur(img, 0.8), oracle_brox.blur(img, 0.8))
+    assert np.array_equal(brox.op_blur(img, 0.5), oracle_brox.blur(img, 0.5))
+    wd, hd = int(np.ceil(w * 0.8)), int(np.ceil(h * 0.8))
+    assert np.array_equal(brox.op_resample(img, wd, hd, 1.0), oracle_brox.resample(img, wd, hd, 1.0))
+    up = brox.op_resample(img, w + 13, h + 7, 1.25)
+    assert np.array_equal(up, oracle_brox.resample(img, w + 13, h + 7, 1.25))
+    dx, dy = brox.op_deriv(img)
+    rx, ry = oracle_brox.deriv(img)
+    assert np.array_equal(dx, rx) and np.array_equal(dy, ry)
+
+
+def _level_fields(oracle_brox, w, h, seed):
+    I0 = _smooth((h, w), seed)
+    I1 = _smooth((h, w), seed + 1)
+    Ix0, Iy0 = oracle_brox.deriv(I0)
+    I1x, I1y = oracle_brox.deriv(I1)
+    I1xx, I1xy = oracle_brox.deriv(I1x)
+    _, I1yy = oracle_brox.deriv(I1y)
+    u = _rand((h, w), seed + 2, -3, 3)
+    v = _rand((h, w), seed + 3, -3, 3)
+    return (I0, Ix0, Iy0, I1, I1x, I1y, I1xx, I1xy, I1yy, u, v)
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+def test_warp_prepare(hm, oracle_brox, w, h):
+    from hydra_mi import brox
+    f = _level_fields(oracle_brox, w, h, 10)
+    got = brox.op_warp(*f)
+    ref = oracle_brox.warp(*f)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g, r)
+    u, v = f[9], f[10]
+    du = _rand((h, w), 20, -0.5, 0.5)
+    dv = _rand((h, w), 21, -0.5, 0.5)
+    got = brox.op_prepare(u, v, du, dv, ref, 0.197, 50.0)
+    exp = oracle_brox.prepare(u, v, du, dv, ref, 0.197, 50.0)
+    for name, g, r in zip("nu nv a12 idu idv sx sy".split(), got, exp):
+        assert np.array_equal(g, r), name
+
+
+@pytest.mark.parametrize("w,h", SIZES + [(300, 300)])
+@pytest.mark.parametrize("fuse", [0, 1, 2, 5, 105])
+def test_sor(hm, oracle_brox, w, h, fuse):
+    from hydra_mi import brox
+    f = _level_fields(oracle_brox, w, h, 30)
+    warped = oracle_brox.warp(*f)
+    du = _rand((h, w), 40, -0.5, 0.5)
+    dv = _rand((h, w), 41, -0.5, 0.5)
+    coef = oracle_brox.prepare(f[9], f[10], du, dv, warped, 0.197, 50.0)
+    gdu, gdv = brox.op_sor(du, dv, coef, 10, fuse=fuse)
+    rdu, rdv = oracle_brox.sor(du, dv, coef, 10)
+    assert np.array_equal(gdu, rdu) and np.array_equal(gdv, rdv)
+
+
+def _pair(hm, n, name, seed=0):
+    from hydra_mi import synth
+    f0, f1, tu, tv = synth.warp_pair(n, name, seed)
+    return f0, f1, tu, tv
+
+
+@pytest.mark.parametrize("n,name", [(64, "warp"), (128, "translate_leftup"), (200, "rotate"),
+                                    (256, "translate_leftup_stretch")])
+def test_calc_matches_oracle(hm, oracle_brox, n, name):
+    from hydra_mi import brox
+    f0, f1, tu, tv = _pair(hm, n, name)
+    bf = brox.BroxOpticalFlow(n, n)
+    assert bf.levels() == oracle_brox.levels(n, n)
+    u, v = bf.calc(f0, f1)
+    ru, rv = oracle_brox.calc(f0, f1)
+    epe = np.sqrt((u - ru) ** 2 + (v - rv) ** 2)
+    assert epe.max() <= 1e-4, epe.max()           # the contract's tolerance
+    assert np.array_equal(u, ru) and np.array_equal(v, rv)   # what is actually achieved
+    # and the flow is a sensible estimate of the analytic field (informational bound)
+    b = n // 8
+    err = np.sqrt((u - tu) ** 2 + (v - tv) ** 2)[b:-b, b:-b]
+    assert err.mean() < 0.25
+
+
+def test_calc_nonsquare_and_params(hm, oracle_brox):
+    from hydra_mi import brox, synth
+    f0, f1, _, _ = synth.warp_pair(160, "warp", 3)
+    f0, f1 = np.ascontiguousarray(f0[:100, :150]), np.ascontiguousarray(f1[:100, :150])
+    for kw, okw in [(dict(alpha=0.4, gamma=25.0, inner_iterations=5, solver_iterations=5),
+                     dict(alpha=0.4, gamma=25.0, inner=5, solver=5)),
+                    (dict(scale_factor=0.5, outer_iterations=3), dict(scale=0.5, outer=3)),
+                    (dict(outer_iterations=1, solver_iterations=7), dict(outer=1, solver=7))]:
+        bf = brox.BroxOpticalFlow(150, 100, **kw)
+        u, v = bf.calc(f0, f1)
+        ru, rv = oracle_brox.calc(f0, f1, **okw)
+        assert np.array_equal(u, ru) and np.array_equal(v, rv), kw
+
+
+def test_calc_batch_and_tuning_do_not_change_results(hm, oracle_brox):
+    from hydra_mi import brox, synth
+    n = 96
+    pairs = [synth.warp_pair(n, name, seed) for seed, name in enumerate(["warp", "rotate", "translate_leftup"])]
+    F0 = np.stack([p[0] for p in pairs])
+    F1 = np.stack([p[1] for p in pairs])
+    bf = brox.BroxOpticalFlow(n, n, max_batch=3)
+    U, V = bf.calc_batch(F0, F1)
+    for i in range(3):
+        ru, rv = oracle_brox.calc(F0[i], F1[i])
+        assert np.array_equal(U[i], ru) and np.array_equal(V[i], rv)
+    for key, val in [("sor_fuse", 1), ("sor_fuse", 2), ("sor_threads", 512), ("sor_fuse", 0)]:
+        bf.tune(key, val)
+        U2, V2 = bf.calc_batch(F0, F1)
+        assert np.array_equal(U, U2) and np.array_equal(V, V2), (key, val)
+
+
+def test_identical_frames_give_zero_flow(hm):
+    from hydra_mi import brox, synth
+    f0 = synth.warp_pair(64, "warp")[0]
+    u, v = brox.BroxOpticalFlow(64, 64).calc(f0, f0)
+    assert np.abs(u).max() == 0.0 and np.abs(v).max() == 0.0
+
+
+def test_errors_are_loud(hm):
+    from hydra_mi import brox
+    with pytest.raises(RuntimeError):
+        brox.BroxOpticalFlow(64, 64, scale_factor=1.5)
+    bf = brox.BroxOpticalFlow(64, 64)
+    with pytest.raises(ValueError):
+        bf.calc(np.zeros((32, 32), np.uint8), np.zeros((32, 32), np.uint8))
+    with pytest.raises(TypeError):
+        bf.calc(np.zeros((64, 64), np.float32), np.zeros((64, 64), np.float32))
+    with pytest.raises(RuntimeError):
+        bf.tune("sor_fuse", 3)        # 3 does not divide solver_iterations = 10

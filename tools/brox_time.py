@@ -1,0 +1,43 @@
+"""Ad-hoc timing of the Brox pipeline variants on one GPU (development aid, not the bench)."""
+import sys, os, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import hydra_mi
+from hydra_mi import brox, synth
+
+def run(n, batch, reps, tunes):
+    f0, f1, _, _ = synth.warp_pair(n, "translate_leftup_stretch", 0)
+    F0 = torch.from_numpy(np.stack([f0] * batch)).cuda()
+    F1 = torch.from_numpy(np.stack([f1] * batch)).cuda()
+    U = torch.empty((batch, n, n), dtype=torch.float32, device="cuda")
+    V = torch.empty_like(U)
+    torch.cuda.synchronize()
+    bf = brox.BroxOpticalFlow(n, n, max_batch=batch)
+    for tune in tunes:
+        for k, v in tune.items():
+            bf.tune(k, v)
+        for _ in range(2):
+            bf.calc_dev(batch, F0.data_ptr(), F1.data_ptr(), U.data_ptr(), V.data_ptr())
+        bf.sync()
+        t = time.perf_counter()
+        for _ in range(reps):
+            bf.calc_dev(batch, F0.data_ptr(), F1.data_ptr(), U.data_ptr(), V.data_ptr())
+        bf.sync()
+        dt = (time.perf_counter() - t) / reps
+        bf.profile(True)
+        for _ in range(reps):
+            bf.calc_dev(batch, F0.data_ptr(), F1.data_ptr(), U.data_ptr(), V.data_ptr())
+        ms, launches, pxit = bf.profile_read()
+        bf.profile(False)
+        print(json.dumps(dict(n=n, batch=batch, tune=tune, ms_per_call=dt * 1e3, pairs_per_s=batch / dt,
+                              sor_ms_per_call=ms / reps, sor_launches=launches // reps,
+                              sor_GBps_alg=52.0 * pxit / (ms * 1e-3) / 1e9 if ms else None)), flush=True)
+
+if __name__ == "__main__":
+    tunes = [dict(sor_fuse=0, sor_threads=256), dict(sor_fuse=0, sor_threads=512),
+             dict(sor_fuse=1, sor_threads=256), dict(sor_fuse=1, sor_threads=512),
+             dict(sor_fuse=2, sor_threads=256), dict(sor_fuse=2, sor_threads=512)]
+    run(512, 1, 5, tunes)
+    run(1024, 1, 5, tunes)
+    run(1024, 8, 3, tunes[:2])
