@@ -1,0 +1,193 @@
+"""bench.py -- frames/sec of the hot path (Brox flow + EKF update) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one video frame: Brox optical flow of the frame pair (k, k+1), both frames
+already resident in HBM, followed by IteratedMSKalmanFilter.compute on frame k+1 with
+that flow (predict, mask projection, iterated measurement update), flow handed over in
+device memory.  Workload at every N: BASELINE.json config "1024x1024 video, ~200-vertex
+mesh" -- a textured disk advected by an analytic field, synthetic, one independent video
+per GPU (weak scaling: the EKF is a recurrence over the frames of one video, videos are
+the shardable unit; the only collective is the final gather of the tracked states).
+
+Prints ONE JSON line (rank 0).  `roofline` is the SOR kernel: HIP-event time of every
+SOR launch inside the timed region against 52 B per pixel per red-black iteration
+(SURVEY.md 8d).  `cpu_baseline` is the oracle (NumPy/C restatement of the reference's
+CPU path) timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SOR_BYTES_PER_PIXEL_ITERATION = 52.0      # 11 f32 fields read + 2 written
+HBM_PEAK_GBPS = 8000.0                    # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def make_video(n, frames, seed):
+    from hydra_mi import synth
+    video, masks, centre, radius = synth.disk_video(n, frames, "translate_leftup", seed)
+    return video, masks, centre, radius
+
+
+def cpu_baseline(n, video, masks, dm, iters_per_frame, budget_s=25.0):
+    """Oracle on the host cores: one Brox pair + a timed sample of EKF perturbation evaluations,
+    scaled to the evaluations one frame needs (2*4N jz + nzj j per IEKF iteration, kalman.py:397,498-515,595-598)."""
+    from oracle import brox_oracle, ekf_ref
+    threads = max(1, min(16, os.cpu_count() or 1))
+    brox_oracle.set_threads(threads)
+    t0 = time.perf_counter()
+    u, v = brox_oracle.calc(video[0], video[1])
+    t_brox = time.perf_counter() - t0
+    brox_oracle.set_threads(1)
+    N = dm.size()
+    meas = ekf_ref.Measurement(N, dm.t, dm.p, video[0], 1e-3, 1.0, 1.0)
+    X = np.concatenate((dm.p.reshape(-1), np.zeros(2 * N)))
+    flow = np.dstack((u, v)).astype(np.float32)
+    t0 = time.perf_counter()
+    meas.initjacobian(X, video[1], flow, masks[1])
+    t_init = time.perf_counter() - t0
+    n_jz = n_j = 0
+    t_jz = t_j = 0.0
+    k = 0
+    while t_jz + t_j < budget_s and k < 4 * N:
+        Xp = X.copy()
+        Xp[k] += 2.0
+        t0 = time.perf_counter(); meas.jz(Xp); t_jz += time.perf_counter() - t0; n_jz += 1
+        t0 = time.perf_counter(); meas.j(2.0, k, k); t_j += time.perf_counter() - t0; n_j += 1
+        k += max(1, (4 * N) // 8)
+    _, J = ekf_ref.adjacency(N, dm.t)
+    nzj = float(np.sum(np.triu(J)))
+    per_iter = t_init + 2 * 4 * N * (t_jz / n_jz) + nzj * (t_j / n_j)
+    t_frame = t_brox + iters_per_frame * per_iter
+    return {"value": 1.0 / t_frame, "unit": "frames/sec", "cores": threads, "kind": "port",
+            "sample": "oracle Brox on 1 pair (%d OpenMP threads, %.2f s) + %d jz and %d j evaluations of the NumPy "
+                      "EKF twin (1 thread) scaled to 2*4N=%d jz + %d j per IEKF iteration x %.1f iterations/frame"
+                      % (threads, t_brox, n_jz, n_j, 8 * N, int(nzj), iters_per_frame)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--h0", type=float, default=0.047, help="mesh edge length as a fraction of the frame size")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+
+    import torch
+    import torch.distributed as dist
+    import hydra_mi  # noqa: F401
+    from hydra_mi import brox, kalman, mesh
+    from hydra_mi.renderer import DeviceObservation
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n = args.size
+    K, Wm = args.steps, args.warmup
+    frames = K + Wm + 1
+    video, masks, centre, radius = make_video(n, frames, seed=rank)
+    dm = mesh.disk_mesh(centre[0], centre[1], radius - 1.0, args.h0 * n)
+    d_video = torch.from_numpy(video).cuda()
+    d_masks = torch.from_numpy(masks).cuda()
+    d_u = torch.empty((n, n), dtype=torch.float32, device="cuda")
+    d_v = torch.empty_like(d_u)
+    torch.cuda.synchronize()
+
+    bf = brox.BroxOpticalFlow(n, n, device=local_rank)
+    bf.tune("sor_threads", 512)
+    flow0 = np.zeros((n, n, 2), np.float32)
+    kf = kalman.IteratedMSKalmanFilter(dm, video[0], flow0, True)
+    N = kf.N
+
+    t_flow = t_ekf = 0.0
+    iters = 0
+
+    def step(k):
+        nonlocal t_flow, t_ekf, iters
+        t0 = time.perf_counter()
+        bf.calc_dev(1, d_video[k].data_ptr(), d_video[k + 1].data_ptr(), d_u.data_ptr(), d_v.data_ptr())
+        bf.sync()
+        t1 = time.perf_counter()
+        obs = DeviceObservation(d_video[k + 1].data_ptr(), d_u.data_ptr(), d_v.data_ptr(), d_masks[k + 1].data_ptr(),
+                                y_m_host=masks[k + 1])
+        kf.compute(obs, None, None)
+        t2 = time.perf_counter()
+        t_flow += t1 - t0
+        t_ekf += t2 - t1
+        iters += kf.niter
+
+    bf.profile(True)
+    for k in range(Wm):
+        step(k)
+    bf.profile_read()
+    t_flow = t_ekf = 0.0
+    iters = 0
+    kf.predtime = kf.updatetime = kf.projecttime = 0.0
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(Wm, Wm + K):
+        step(k)
+    state = torch.from_numpy(kf.state.X.reshape(-1).copy()).cuda()
+    if world > 1:                       # the batch path's only exchange: gather the tracked states
+        gathered = [torch.empty_like(state) for _ in range(world)]
+        dist.all_gather(gathered, state)
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    sor_ms, sor_launches, sor_pxit = bf.profile_read()
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        achieved = SOR_BYTES_PER_PIXEL_ITERATION * sor_pxit / (sor_ms * 1e-3) / 1e9 if sor_ms > 0 else 0.0
+        out = {
+            "metric": "frames/sec (Brox flow + EKF update) at 1024^2" if n == 1024 else
+                      "frames/sec (Brox flow + EKF update) at %d^2" % n,
+            "value": world * K / elapsed, "unit": "frames/sec", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (flow, renders) / f64 (EKF sums and state)", "data": "synthetic",
+            "config": {"workload": "%dx%d video, %d-vertex mesh (%d triangles), one video per GPU; Brox defaults "
+                                   "alpha .197 gamma 50 scale .8 inner 10 outer 77 solver 10; IteratedMSKalmanFilter "
+                                   "defaults" % (n, n, N, kf.state.NT), "frames_per_gpu": K, "parallelism": "videos x%d" % world},
+            "breakdown_ms_per_step": {"brox_flow": 1e3 * t_flow / K, "ekf_compute": 1e3 * t_ekf / K,
+                                      "ekf_predict": 1e3 * kf.predtime / K, "ekf_update": 1e3 * kf.updatetime / K,
+                                      "iekf_iterations": iters / K},
+            "roofline": {"bound": "hbm", "kernel": "k_sor", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "launches_per_step": sor_launches / K, "avg_launch_us": 1e3 * sor_ms / max(1, sor_launches),
+                         "bytes_per_pixel_iteration": SOR_BYTES_PER_PIXEL_ITERATION},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, video, masks, dm, max(1.0, iters / K))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -110,7 +110,7 @@ typedef struct hm_ctx *hm_ctx_t;
  * (cuda_multi.py:420).  tri: T*3 int32 vertex ids; uv: N*2 float pixels. */
 int hm_ctx_create(int device, int width, int height, int n_vertices, int n_triangles,
                   const int32_t *tri, const float *uv,
-                  float eps_Z, float eps_J, float eps_M, hm_ctx_t *out);
+                  double eps_Z, double eps_J, double eps_M, hm_ctx_t *out);
 int hm_ctx_destroy(hm_ctx_t h);
 /* gloo.Texture2D(im1) bound as init_texture (renderer.py:222-223,232): W*H u8 */
 int hm_set_texture(hm_ctx_t h, const uint8_t *tex);
@@ -126,26 +126,34 @@ int hm_set_observation_dev(hm_ctx_t h, const uint8_t *d_y_im, const float *d_y_f
  * :503-524).  X = 4N doubles [x0,y0,..,vx0,vy0,..] (kalman.py:178).  Any output
  * pointer may be NULL.  im u8, fx/fy f32, m u8 (255 where covered), all W*H. */
 int hm_render(hm_ctx_t h, const double *X, uint8_t *im, float *fx, float *fy, uint8_t *m);
+
+/* In the calls below `masked` selects which observed flow the residuals use:
+ * 0 = the flow as given to hm_set_observation, 1 = that flow multiplied by y_m
+ * (what compute() hands to update(), kalman.py:679-687; error() gets the raw
+ * flow, :700). */
+
 /* initjacobian (cuda.py:940-950): render X and keep it as the reference render */
-int hm_initjacobian(hm_ctx_t h, const double *X);
-/* jz (cuda.py:972-980): render Xp, return sum and the 4 component sums */
-int hm_jz(hm_ctx_t h, const double *Xp, double *jz, double jzc[4]);
-/* j (cuda.py:982-1010): renders X + dX e_i and X + dX e_j around the state given
- * to initjacobian */
+int hm_initjacobian(hm_ctx_t h, const double *X, int masked);
+/* jz (cuda.py:972-980): render Xp, return the sum and its 4 components
+ * (image, flow x, flow y, mask) against the reference render */
+int hm_jz(hm_ctx_t h, const double *Xp, int masked, double *jz, double jzc[4]);
+/* j (cuda.py:982-1010): renders X + dX e_i and X + dX e_j and reduces the products
+ * of their differences to the reference render */
 int hm_j(hm_ctx_t h, const double *X, double deltaX, int i, int j, double *out);
-/* Renderer.error (renderer.py:485-501): SSE per channel, with the 8-bit
- * wrap-around the reference's uint8 arithmetic has for the image and mask terms.
- * err = e_im, e_fx, e_fy, e_m; fx/fy (may be NULL) receive the rendered flow */
-int hm_error(hm_ctx_t h, const double *X, const uint8_t *y_im, const float *y_fx,
-             const float *y_fy, const uint8_t *y_m, double err[4], float *fx, float *fy);
+/* Renderer.error (renderer.py:485-501): SSE per channel of render(X) against the
+ * observation, with the 8-bit wrap-around the reference's uint8 arithmetic has
+ * for the image and mask terms.  err = e_im, e_fx, e_fy, e_m; fx/fy (may be NULL)
+ * receive the rendered flow planes */
+int hm_error(hm_ctx_t h, const double *X, int masked, double err[4], float *fx, float *fy);
 
 /* KFState.update (kalman.py:437-449) in one call, single-perturbation
- * semantics (_jacobian :491-518, _hessian_sparse :583-606, deltaX = 2): renders
- * X once, then evaluates every +-deltaX perturbation only inside the bounding
- * box of the triangles it moves.  Hz[4N], Hzc[4N*4], HTH[4N*4N] (dense, symmetric,
- * zero outside the J pattern kalman.py:202-205).  sparse = 0 selects _hessian
- * (:521-536), which has the same value. */
-int hm_measure(hm_ctx_t h, const double *X, double deltaX,
+ * semantics (_jacobian :491-518, _hessian_sparse :583-606; deltaX = 2 there):
+ * renders X once, then evaluates every +-deltaX perturbation only inside the
+ * bounding box of the triangles it moves, one workgroup per vertex / per mesh
+ * edge.  Hz[4N], Hzc[4N*4] (may be NULL), HTH[4N*4N] (dense, symmetric, zero
+ * outside the J pattern kalman.py:202-205; _hessian :521-536 has the same
+ * value because non-adjacent vertices have disjoint supports). */
+int hm_measure(hm_ctx_t h, const double *X, double deltaX, int masked,
                double *Hz, double *Hzc, double *HTH);
 int hm_ctx_sync(hm_ctx_t h);
 void *hm_ctx_stream(hm_ctx_t h);

@@ -48,17 +48,17 @@ SIGNATURES = {
     "hm_op_sor": (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                  ctypes.c_int, ctypes.c_float]),
     "hm_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp,
-                                     c_vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.POINTER(c_vp)]),
+                                     c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.POINTER(c_vp)]),
     "hm_ctx_destroy": (ctypes.c_int, [c_vp]),
     "hm_set_texture": (ctypes.c_int, [c_vp, c_vp]),
     "hm_set_observation": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     "hm_set_observation_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     "hm_render": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "hm_initjacobian": (ctypes.c_int, [c_vp, c_vp]),
-    "hm_jz": (ctypes.c_int, [c_vp, c_vp, c_f64p, c_f64p]),
+    "hm_initjacobian": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int]),
+    "hm_jz": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_f64p, c_f64p]),
     "hm_j": (ctypes.c_int, [c_vp, c_vp, ctypes.c_double, ctypes.c_int, ctypes.c_int, c_f64p]),
-    "hm_error": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f64p, c_vp, c_vp]),
-    "hm_measure": (ctypes.c_int, [c_vp, c_vp, ctypes.c_double, c_vp, c_vp, c_vp]),
+    "hm_error": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_f64p, c_vp, c_vp]),
+    "hm_measure": (ctypes.c_int, [c_vp, c_vp, ctypes.c_double, ctypes.c_int, c_vp, c_vp, c_vp]),
     "hm_ctx_sync": (ctypes.c_int, [c_vp]),
     "hm_ctx_stream": (c_vp, [c_vp]),
 }

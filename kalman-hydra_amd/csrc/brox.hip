@@ -201,9 +201,12 @@ extern "C" int hm_brox_create(int device, int W, int H, int max_batch, float alp
         brox_free(h);
         return HM_ERR_HIP;
     }
-    // padding columns are read (never used) by float2 loads: keep them finite
-    e = hipMemset(h->arena, 0, h->arena_floats * sizeof(float));
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    // padding columns are read (never used) by float2 loads: keep them finite.  The fill
+    // goes on the handle's own stream: that stream is non-blocking, so a fill issued on the
+    // null stream could still be running when the first calc starts.
+    e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMemsetAsync(h->arena, 0, h->arena_floats * sizeof(float), h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_f0, B * W * H);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_f1, B * W * H);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_ox, B * W * H * sizeof(float));

@@ -1,0 +1,429 @@
+// EKF measurement model on MI355X: host orchestration and C-ABI (include/hydra_mi.h).
+// Replaces reference renderer.py (OpenGL rasteriser), cuda.py and cuda_multi.py
+// (reduction kernels + PBO plumbing).
+#include "hm_common.h"
+#include "ekf_kernels.h"
+#include <algorithm>
+#include <cstring>
+#include <set>
+#include <utility>
+#include <vector>
+
+struct hm_ctx {
+    int device, W, H, N, T, E, njobs;
+    double eps_Z, eps_J, eps_M;
+    hipStream_t stream;
+    // mesh
+    int *d_tri, *d_star_off, *d_star_tri, *d_edges;
+    float *d_uv;
+    uint8_t *d_tex;
+    std::vector<int> edges;          // host copy, E*2
+    // observation
+    uint8_t *d_yim, *d_ym;
+    float *d_yfx, *d_yfy, *d_yfxm, *d_yfym;
+    bool obs_owned;                  // false when set_observation_dev aliases caller memory
+    const uint8_t *o_yim, *o_ym;     // pointers in use (owned or caller's)
+    const float *o_yfx, *o_yfy;
+    bool have_tex, have_obs, have_ref;
+    // renders
+    Targets ref, P, Q;
+    TriSetup *d_setup;
+    double *d_X, *d_out, *d_partial;
+    uint8_t *d_im8, *d_m8;
+    std::vector<double> X0;          // state of the reference render
+    std::vector<double> h_out, h_partial;
+    int red_blocks;
+};
+
+static int alloc_targets(Targets &t, size_t n)
+{
+    HM_HIP(hipMalloc((void **)&t.acc, n * sizeof(int)));
+    HM_HIP(hipMalloc((void **)&t.fx, n * sizeof(float)));
+    HM_HIP(hipMalloc((void **)&t.fy, n * sizeof(float)));
+    HM_HIP(hipMalloc((void **)&t.cnt, n * sizeof(int)));
+    return HM_OK;
+}
+static void free_targets(Targets &t)
+{
+    if (t.acc) (void)hipFree(t.acc);
+    if (t.fx) (void)hipFree(t.fx);
+    if (t.fy) (void)hipFree(t.fy);
+    if (t.cnt) (void)hipFree(t.cnt);
+}
+
+static int ctx_free(hm_ctx *h)
+{
+    if (!h) return HM_OK;
+    (void)hipSetDevice(h->device);
+    void *ptrs[] = {h->d_tri, h->d_star_off, h->d_star_tri, h->d_edges, h->d_uv, h->d_tex, h->d_yim, h->d_ym, h->d_yfx,
+                    h->d_yfy, h->d_yfxm, h->d_yfym, h->d_setup, h->d_X, h->d_out, h->d_partial, h->d_im8, h->d_m8};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    free_targets(h->ref);
+    free_targets(h->P);
+    free_targets(h->Q);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return HM_OK;
+}
+
+template <typename T>
+static int upload(T **dst, const T *src, size_t n)
+{
+    HM_HIP(hipMalloc((void **)dst, (n ? n : 1) * sizeof(T)));
+    if (n) HM_HIP(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return HM_OK;
+}
+
+extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32_t *tri, const float *uv, double eps_Z,
+                             double eps_J, double eps_M, hm_ctx_t *out)
+{
+    HM_ARG(out != nullptr, "hm_ctx_create: out is NULL");
+    *out = nullptr;
+    HM_ARG(W >= 1 && H >= 1 && W <= 4096 && H <= 4096, "hm_ctx_create: frame size %dx%d outside 1..4096", W, H);
+    HM_ARG(N >= 3 && T >= 1 && T <= EKF_MAX_TRI, "hm_ctx_create: need N >= 3 vertices and 1..%d triangles (N=%d, T=%d)",
+           EKF_MAX_TRI, N, T);
+    HM_ARG(tri && uv, "hm_ctx_create: NULL mesh arrays");
+    HM_ARG(eps_Z > 0 && eps_J > 0 && eps_M > 0, "hm_ctx_create: eps_Z, eps_J, eps_M must be positive");
+    std::vector<std::vector<int>> star(N);
+    std::set<std::pair<int, int>> eset;
+    for (int t = 0; t < T; t++) {
+        int v[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+        for (int k = 0; k < 3; k++) {
+            HM_ARG(v[k] >= 0 && v[k] < N, "hm_ctx_create: triangle %d refers to vertex %d (N=%d)", t, v[k], N);
+            star[v[k]].push_back(t);
+            int a = v[k], b = v[(k + 1) % 3];
+            if (a != b) eset.insert(std::make_pair(std::min(a, b), std::max(a, b)));
+        }
+    }
+    std::vector<int> off(N + 1, 0), flat;
+    for (int v = 0; v < N; v++) {
+        // a vertex listed twice in one (degenerate) triangle would be listed twice here
+        std::sort(star[v].begin(), star[v].end());
+        star[v].erase(std::unique(star[v].begin(), star[v].end()), star[v].end());
+        HM_ARG((int)star[v].size() <= EKF_MAX_STAR, "hm_ctx_create: vertex %d has %d triangles, limit %d", v,
+               (int)star[v].size(), EKF_MAX_STAR);
+        off[v + 1] = off[v] + (int)star[v].size();
+        flat.insert(flat.end(), star[v].begin(), star[v].end());
+    }
+    HM_HIP(hipSetDevice(device));
+    hm_ctx *h = new hm_ctx();
+    h->device = device; h->W = W; h->H = H; h->N = N; h->T = T;
+    h->eps_Z = eps_Z; h->eps_J = eps_J; h->eps_M = eps_M;
+    h->obs_owned = true; h->have_tex = h->have_obs = h->have_ref = false;
+    h->o_yim = h->o_ym = nullptr; h->o_yfx = h->o_yfy = nullptr;
+    h->d_yim = h->d_ym = nullptr; h->d_yfx = h->d_yfy = h->d_yfxm = h->d_yfym = nullptr;
+    h->ref = Targets{nullptr, nullptr, nullptr, nullptr}; h->P = h->ref; h->Q = h->ref;
+    h->d_setup = nullptr; h->d_X = h->d_out = h->d_partial = nullptr; h->d_im8 = h->d_m8 = nullptr;
+    for (const auto &e : eset) { h->edges.push_back(e.first); h->edges.push_back(e.second); }
+    h->E = (int)eset.size();
+    h->njobs = N + h->E;
+    h->red_blocks = 512;
+    const size_t n = (size_t)W * H;
+    int rc = HM_OK;
+    auto step = [&](int r) { if (rc == HM_OK) rc = r; };
+    step(upload(&h->d_tri, tri, (size_t)3 * T));
+    step(upload(&h->d_uv, uv, (size_t)2 * N));
+    step(upload(&h->d_star_off, off.data(), off.size()));
+    step(upload(&h->d_star_tri, flat.data(), flat.size()));
+    step(upload(&h->d_edges, h->edges.data(), h->edges.size()));
+    if (rc == HM_OK) {
+        hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_tex, n);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_yim, n);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_ym, n);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_yfx, n * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_yfy, n * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_yfxm, n * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_yfym, n * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_setup, (size_t)T * sizeof(TriSetup));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_X, (size_t)4 * N * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_out, (size_t)h->njobs * MEAS_OUT * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_partial, (size_t)h->red_blocks * 4 * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_im8, n);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_m8, n);
+        if (e != hipSuccess) {
+            hm_set_error("hm_ctx_create: device allocation failed: %s", hipGetErrorString(e));
+            rc = HM_ERR_HIP;
+        }
+    }
+    step(alloc_targets(h->ref, n));
+    step(alloc_targets(h->P, n));
+    step(alloc_targets(h->Q, n));
+    if (rc != HM_OK) {
+        ctx_free(h);
+        return rc;
+    }
+    h->h_out.resize((size_t)h->njobs * MEAS_OUT);
+    h->h_partial.resize((size_t)h->red_blocks * 4);
+    *out = h;
+    return HM_OK;
+}
+
+extern "C" int hm_ctx_destroy(hm_ctx_t h) { return ctx_free(h); }
+extern "C" void *hm_ctx_stream(hm_ctx_t h) { return h ? (void *)h->stream : nullptr; }
+extern "C" int hm_ctx_sync(hm_ctx_t h)
+{
+    HM_ARG(h != nullptr, "hm_ctx_sync: NULL handle");
+    HM_HIP(hipSetDevice(h->device));
+    HM_HIP(hipStreamSynchronize(h->stream));
+    return HM_OK;
+}
+
+extern "C" int hm_set_texture(hm_ctx_t h, const uint8_t *tex)
+{
+    HM_ARG(h && tex, "hm_set_texture: NULL argument");
+    HM_HIP(hipSetDevice(h->device));
+    HM_HIP(hipMemcpyAsync(h->d_tex, tex, (size_t)h->W * h->H, hipMemcpyHostToDevice, h->stream));
+    HM_HIP(hipStreamSynchronize(h->stream));
+    h->have_tex = true;
+    return HM_OK;
+}
+
+static int finish_observation(hm_ctx *h)
+{
+    const int n = h->W * h->H;
+    hipLaunchKernelGGL(k_mask_flow, dim3(hm_cdiv(n, 256)), dim3(256), 0, h->stream, h->o_ym, h->o_yfx, h->o_yfy,
+                       h->d_yfxm, h->d_yfym, n);
+    HM_HIP(hipGetLastError());
+    h->have_obs = true;
+    return HM_OK;
+}
+
+extern "C" int hm_set_observation(hm_ctx_t h, const uint8_t *y_im, const float *y_fx, const float *y_fy,
+                                  const uint8_t *y_m)
+{
+    HM_ARG(h && y_im && y_fx && y_fy && y_m, "hm_set_observation: NULL argument");
+    HM_HIP(hipSetDevice(h->device));
+    const size_t n = (size_t)h->W * h->H;
+    HM_HIP(hipMemcpyAsync(h->d_yim, y_im, n, hipMemcpyHostToDevice, h->stream));
+    HM_HIP(hipMemcpyAsync(h->d_ym, y_m, n, hipMemcpyHostToDevice, h->stream));
+    HM_HIP(hipMemcpyAsync(h->d_yfx, y_fx, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HM_HIP(hipMemcpyAsync(h->d_yfy, y_fy, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    h->o_yim = h->d_yim; h->o_ym = h->d_ym; h->o_yfx = h->d_yfx; h->o_yfy = h->d_yfy;
+    int rc = finish_observation(h);
+    if (rc) return rc;
+    HM_HIP(hipStreamSynchronize(h->stream));
+    return HM_OK;
+}
+
+extern "C" int hm_set_observation_dev(hm_ctx_t h, const uint8_t *d_y_im, const float *d_y_fx, const float *d_y_fy,
+                                      const uint8_t *d_y_m)
+{
+    HM_ARG(h && d_y_im && d_y_fx && d_y_fy && d_y_m, "hm_set_observation_dev: NULL argument");
+    HM_HIP(hipSetDevice(h->device));
+    h->o_yim = d_y_im; h->o_ym = d_y_m; h->o_yfx = d_y_fx; h->o_yfy = d_y_fy;
+    return finish_observation(h);
+}
+
+// render state X (host, 4N doubles) into target t on the handle's stream
+static int render_into(hm_ctx *h, const double *X, Targets t)
+{
+    HM_HIP(hipMemcpyAsync(h->d_X, X, (size_t)4 * h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    Mesh m = {h->W, h->H, h->N, h->T, h->d_tri, h->d_uv, h->d_tex};
+    hipLaunchKernelGGL(k_setup_all, dim3(hm_cdiv(h->T, 64)), dim3(64), 0, h->stream, m, h->d_X, h->d_setup);
+    hipLaunchKernelGGL(k_render, dim3(hm_cdiv(h->W, EKF_TILE), hm_cdiv(h->H, EKF_TILE)), dim3(EKF_TILE, EKF_TILE), 0,
+                       h->stream, m, h->d_X, h->d_setup, t);
+    HM_HIP(hipGetLastError());
+    return HM_OK;
+}
+
+#define NEED_TEX(h, who) \
+    if (!(h)->have_tex) { hm_set_error(who ": hm_set_texture has not been called"); return HM_ERR_STATE; }
+#define NEED_OBS(h, who) \
+    if (!(h)->have_obs) { hm_set_error(who ": hm_set_observation has not been called"); return HM_ERR_STATE; }
+#define NEED_REF(h, who) \
+    if (!(h)->have_ref) { hm_set_error(who ": hm_initjacobian has not been called"); return HM_ERR_STATE; }
+
+extern "C" int hm_render(hm_ctx_t h, const double *X, uint8_t *im, float *fx, float *fy, uint8_t *mk)
+{
+    HM_ARG(h && X, "hm_render: NULL argument");
+    NEED_TEX(h, "hm_render");
+    HM_HIP(hipSetDevice(h->device));
+    int rc = render_into(h, X, h->P);
+    if (rc) return rc;
+    const int n = h->W * h->H;
+    hipLaunchKernelGGL(k_resolve, dim3(hm_cdiv(n, 256)), dim3(256), 0, h->stream, h->P, h->d_im8, h->d_m8, n);
+    if (im) HM_HIP(hipMemcpyAsync(im, h->d_im8, n, hipMemcpyDeviceToHost, h->stream));
+    if (mk) HM_HIP(hipMemcpyAsync(mk, h->d_m8, n, hipMemcpyDeviceToHost, h->stream));
+    if (fx) HM_HIP(hipMemcpyAsync(fx, h->P.fx, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (fy) HM_HIP(hipMemcpyAsync(fy, h->P.fy, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HM_HIP(hipStreamSynchronize(h->stream));
+    return HM_OK;
+}
+
+static Obs obs_of(hm_ctx *h, int masked)
+{
+    Obs o = {h->o_yim, masked ? h->d_yfxm : h->o_yfx, masked ? h->d_yfym : h->o_yfy, h->o_ym};
+    return o;
+}
+
+extern "C" int hm_initjacobian(hm_ctx_t h, const double *X, int masked)
+{
+    HM_ARG(h && X, "hm_initjacobian: NULL argument");
+    (void)masked;
+    NEED_TEX(h, "hm_initjacobian");
+    NEED_OBS(h, "hm_initjacobian");
+    HM_HIP(hipSetDevice(h->device));
+    int rc = render_into(h, X, h->ref);
+    if (rc) return rc;
+    HM_HIP(hipStreamSynchronize(h->stream));
+    h->X0.assign(X, X + 4 * h->N);
+    h->have_ref = true;
+    return HM_OK;
+}
+
+// sum the per-workgroup partials in index order
+static int collect4(hm_ctx *h, double s[4])
+{
+    HM_HIP(hipMemcpyAsync(h->h_partial.data(), h->d_partial, (size_t)h->red_blocks * 4 * sizeof(double),
+                          hipMemcpyDeviceToHost, h->stream));
+    HM_HIP(hipStreamSynchronize(h->stream));
+    for (int k = 0; k < 4; k++) s[k] = 0.0;
+    for (int b = 0; b < h->red_blocks; b++)
+        for (int k = 0; k < 4; k++) s[k] += h->h_partial[(size_t)4 * b + k];
+    return HM_OK;
+}
+
+extern "C" int hm_jz(hm_ctx_t h, const double *Xp, int masked, double *jz, double jzc[4])
+{
+    HM_ARG(h && Xp, "hm_jz: NULL argument");
+    NEED_REF(h, "hm_jz");
+    HM_HIP(hipSetDevice(h->device));
+    int rc = render_into(h, Xp, h->P);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_jz, dim3(h->red_blocks), dim3(RED_NT), 0, h->stream, h->ref, h->P, obs_of(h, masked),
+                       h->W * h->H, h->d_partial);
+    double s[4];
+    rc = collect4(h, s);
+    if (rc) return rc;
+    double c[4] = {s[0] / h->eps_Z, s[1] / h->eps_J, -s[2] / h->eps_J, s[3] / h->eps_M};
+    if (jzc) for (int k = 0; k < 4; k++) jzc[k] = c[k];
+    if (jz) *jz = ((c[0] + c[1]) + c[2]) + c[3];
+    return HM_OK;
+}
+
+extern "C" int hm_j(hm_ctx_t h, const double *X, double deltaX, int i, int j, double *out)
+{
+    HM_ARG(h && X && out, "hm_j: NULL argument");
+    HM_ARG(i >= 0 && i < 4 * h->N && j >= 0 && j < 4 * h->N, "hm_j: state index outside 0..%d", 4 * h->N - 1);
+    NEED_REF(h, "hm_j");
+    HM_HIP(hipSetDevice(h->device));
+    std::vector<double> Xp(X, X + 4 * h->N), Xq(X, X + 4 * h->N);
+    Xp[i] += deltaX;
+    Xq[j] += deltaX;
+    int rc = render_into(h, Xp.data(), h->P);
+    if (rc) return rc;
+    HM_HIP(hipStreamSynchronize(h->stream));     // d_X is reused by the second render
+    rc = render_into(h, Xq.data(), h->Q);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_j, dim3(h->red_blocks), dim3(RED_NT), 0, h->stream, h->ref, h->P, h->Q, h->W * h->H,
+                       h->d_partial);
+    double s[4];
+    rc = collect4(h, s);
+    if (rc) return rc;
+    *out = ((s[0] / h->eps_Z + s[1] / h->eps_J) + s[2] / h->eps_J) + s[3] / h->eps_M;
+    return HM_OK;
+}
+
+extern "C" int hm_error(hm_ctx_t h, const double *X, int masked, double err[4], float *fx, float *fy)
+{
+    HM_ARG(h && X && err, "hm_error: NULL argument");
+    NEED_TEX(h, "hm_error");
+    NEED_OBS(h, "hm_error");
+    HM_HIP(hipSetDevice(h->device));
+    int rc = render_into(h, X, h->P);
+    if (rc) return rc;
+    const int n = h->W * h->H;
+    hipLaunchKernelGGL(k_error, dim3(h->red_blocks), dim3(RED_NT), 0, h->stream, h->P, obs_of(h, masked), n,
+                       h->d_partial);
+    if (fx) HM_HIP(hipMemcpyAsync(fx, h->P.fx, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (fy) HM_HIP(hipMemcpyAsync(fy, h->P.fy, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    return collect4(h, err);
+}
+
+extern "C" int hm_measure(hm_ctx_t h, const double *X, double deltaX, int masked, double *Hz, double *Hzc, double *HTH)
+{
+    HM_ARG(h && X && Hz && HTH, "hm_measure: NULL argument");
+    HM_ARG(deltaX > 0, "hm_measure: deltaX must be positive");
+    NEED_TEX(h, "hm_measure");
+    NEED_OBS(h, "hm_measure");
+    HM_HIP(hipSetDevice(h->device));
+    int rc = render_into(h, X, h->ref);
+    if (rc) return rc;
+    h->X0.assign(X, X + 4 * h->N);
+    h->have_ref = true;
+    MeasureArgs a;
+    a.m = Mesh{h->W, h->H, h->N, h->T, h->d_tri, h->d_uv, h->d_tex};
+    a.topo = StarTopo{h->d_star_off, h->d_star_tri, h->d_edges, h->E};
+    a.ref = h->ref;
+    a.obs = obs_of(h, masked);
+    a.X = h->d_X;
+    a.delta = deltaX;
+    a.out = h->d_out;
+    hipLaunchKernelGGL(k_measure, dim3(h->njobs), dim3(MEAS_NT), 0, h->stream, a);
+    HM_HIP(hipGetLastError());
+    HM_HIP(hipMemcpyAsync(h->h_out.data(), h->d_out, h->h_out.size() * sizeof(double), hipMemcpyDeviceToHost,
+                          h->stream));
+    HM_HIP(hipStreamSynchronize(h->stream));
+
+    const int N = h->N, n4 = 4 * N;
+    const double eZ = h->eps_Z, eJ = h->eps_J, eM = h->eps_M, d = deltaX;
+    memset(HTH, 0, (size_t)n4 * n4 * sizeof(double));
+    auto put = [&](int p, int q, double val) {
+        HTH[(size_t)p * n4 + q] = val / d / d;
+        HTH[(size_t)q * n4 + p] = val / d / d;
+    };
+    auto sum4 = [&](const double *s) { return ((s[0] / eZ + s[1] / eJ) + s[2] / eJ) + s[3] / eM; };
+    for (int v = 0; v < N; v++) {
+        const double *o = &h->h_out[(size_t)v * MEAS_OUT];
+        const int ix = 2 * v, iy = 2 * v + 1, ivx = 2 * N + 2 * v, ivy = 2 * N + 2 * v + 1;
+        // central differences of jz (kalman.py:499-515): component sums carry the sign of jz_CPU
+        const int idx[4] = {ix, iy, ivx, ivy};
+        double cp[4][4] = {{o[A_XP] / eZ, o[A_XP + 1] / eJ, -o[A_XP + 2] / eJ, o[A_XP + 3] / eM},
+                           {o[A_YP] / eZ, o[A_YP + 1] / eJ, -o[A_YP + 2] / eJ, o[A_YP + 3] / eM},
+                           {0, o[A_VXP] / eJ, 0, 0},
+                           {0, 0, -o[A_VYP] / eJ, 0}};
+        double cm[4][4] = {{o[A_XM] / eZ, o[A_XM + 1] / eJ, -o[A_XM + 2] / eJ, o[A_XM + 3] / eM},
+                           {o[A_YM] / eZ, o[A_YM + 1] / eJ, -o[A_YM + 2] / eJ, o[A_YM + 3] / eM},
+                           {0, o[A_VXM] / eJ, 0, 0},
+                           {0, 0, -o[A_VYM] / eJ, 0}};
+        for (int k = 0; k < 4; k++) {
+            double hp = ((cp[k][0] + cp[k][1]) + cp[k][2]) + cp[k][3];
+            double hm_ = ((cm[k][0] + cm[k][1]) + cm[k][2]) + cm[k][3];
+            Hz[idx[k]] = (hp / d - hm_ / d) / 2;
+            if (Hzc)
+                for (int ch = 0; ch < 4; ch++) Hzc[(size_t)idx[k] * 4 + ch] = (cp[k][ch] / d - cm[k][ch] / d) / 2;
+        }
+        put(ix, ix, sum4(o + A_XX));
+        put(ix, iy, sum4(o + A_XY));
+        put(iy, iy, sum4(o + A_YY));
+        put(ix, ivx, o[A_XVX] / eJ);
+        put(iy, ivx, o[A_YVX] / eJ);
+        put(ix, ivy, o[A_XVY] / eJ);
+        put(iy, ivy, o[A_YVY] / eJ);
+        put(ivx, ivx, o[A_VXVX] / eJ);
+        put(ivy, ivy, o[A_VYVY] / eJ);
+    }
+    for (int e = 0; e < h->E; e++) {
+        const double *o = &h->h_out[(size_t)(N + e) * MEAS_OUT];
+        const int v = h->edges[2 * e], w = h->edges[2 * e + 1];
+        const int vx_ = 2 * v, vy_ = 2 * v + 1, vvx = 2 * N + 2 * v, vvy = 2 * N + 2 * v + 1;
+        const int wx_ = 2 * w, wy_ = 2 * w + 1, wvx = 2 * N + 2 * w, wvy = 2 * N + 2 * w + 1;
+        put(vx_, wx_, sum4(o + B_XX));
+        put(vx_, wy_, sum4(o + B_XY));
+        put(vy_, wx_, sum4(o + B_YX));
+        put(vy_, wy_, sum4(o + B_YY));
+        put(vx_, wvx, o[B_XVX] / eJ);
+        put(vy_, wvx, o[B_YVX] / eJ);
+        put(vvx, wx_, o[B_VXX] / eJ);
+        put(vvx, wy_, o[B_VXY] / eJ);
+        put(vvx, wvx, o[B_VXVX] / eJ);
+        put(vx_, wvy, o[B_XVY] / eJ);
+        put(vy_, wvy, o[B_YVY] / eJ);
+        put(vvy, wx_, o[B_VYX] / eJ);
+        put(vvy, wy_, o[B_VYY] / eJ);
+        put(vvy, wvy, o[B_VYVY] / eJ);
+    }
+    return HM_OK;
+}

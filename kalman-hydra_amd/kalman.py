@@ -1,0 +1,569 @@
+"""Extended / iterated Kalman filter of the mesh tracker -- the reference's filter API.
+
+Drop-in for the classes of reference kalman.py on the hot path: ``KFState``
+(:106-624), ``KalmanFilter`` (:626-765), ``IteratedKalmanFilter`` (:767-831),
+``IteratedMSKalmanFilter`` (:834-960) and the module-level ``stats`` (:25-104).
+Constructor arguments, defaults, method names, the state layout
+``X = [x0,y0,...,vx0,vy0,...]`` (:178) and the return value of ``compute`` are the
+reference's.  What changes is where the work is done:
+
+* ``KFState.update`` (:437-449) is one call into libhydra_mi.so
+  (``Renderer.measure`` -> ``hm_measure``): the mesh is rasterised and every
+  finite-difference perturbation of kalman.py:491-518 / :583-606 is evaluated and
+  reduced on the GPU, inside the bounding box of the triangles it moves.  The
+  result has the single-perturbation semantics of the reference
+  (``multi=False``); ``multi=True`` -- the reference's way of batching several
+  perturbations into one render -- is accepted and gives the same numbers.
+* the dense algebra of the update uses one LU factorisation per IEKF iteration
+  instead of an explicit inverse per iteration; the covariance is formed once,
+  for the state that is kept.  Same mathematics, rounding-level differences.
+* the mass-spring predict uses the sparsity of the incidence matrix.
+
+There is no CPU measurement path: ``cuda=False`` raises.
+"""
+import sys
+import time
+
+import numpy as np
+import scipy.linalg as sla
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from .renderer import Renderer, MaskedFlow, DeviceObservation
+
+
+class Statistics:
+    """reference kalman.py:25-62: counters the timing study reads (timing_synthetic.py:60-90)."""
+
+    _scalars = ("niter", "meshpts", "gridsize", "jacobianpartitions", "hessianpartitions", "nzj")
+    _lists = dict(jacobianrenderstc=2, hessianrenderstc=2, renders=1, statepredtime=1, stateupdatetc=2,
+                  hessinc=1, jacinc=1, hessincsparse=1)
+
+    def __init__(self):
+        for k in self._scalars:
+            setattr(self, k, 0)
+        for k, n in self._lists.items():
+            setattr(self, k, [0] * n)
+
+    def reset(self):
+        for k in self._scalars:
+            setattr(self, k, 0)
+        for k, n in self._lists.items():
+            getattr(self, k)[:] = [0] * n
+
+
+stats = Statistics()
+
+
+def _log(msg):
+    sys.stdout.write(msg + "\n")
+
+
+def _rows_unique(a):
+    return np.unique(np.asarray(a), axis=0)
+
+
+class KFState:
+    def __init__(self, distmesh, im, flow, cuda, eps_F=1, eps_Z=1e-3, eps_J=1e-3, eps_M=1e-3, vel=None,
+                 sparse=True, multi=True, verbose=False, renderer=None):
+        self.multi = multi
+        self.sparse = sparse
+        self.verbose = verbose
+        self._ver = np.array(distmesh.p, np.float32)
+        self._vel = np.zeros(self._ver.shape, np.float32) if vel is None else np.asarray(vel).reshape(self._ver.shape)
+        self.tex = im
+        self.nx, self.ny = im.shape[0], im.shape[1]
+        self.M = self.nx * self.ny
+        self.NZ = self.M
+        self.eps_F, self.eps_Z, self.eps_J, self.eps_M = eps_F, eps_Z, eps_J, eps_M
+        self.N = distmesh.size()
+        self.u = self._ver
+
+        # orientation of the faces and removal of slivers, |sin(angle at vertex 0)| <= 0.06 (:148-161)
+        tri = np.asarray(distmesh.t)
+        a = self._ver[tri[:, 1]] - self._ver[tri[:, 0]]
+        b = self._ver[tri[:, 2]] - self._ver[tri[:, 0]]
+        cr = a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]
+        sine = cr / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+        keep = np.abs(sine) > 0.06
+        if verbose:
+            _log("Removing %d faces for being too flat" % int(np.sum(~keep)))
+        self.sineface = sine[keep]
+        self.ori = np.sign(cr)[keep]
+        self.tri = tri[keep]
+        distmesh.t = self.tri
+        self.NT = self.tri.shape[0]
+
+        # bars that no remaining face uses are dropped (:163-175)
+        t = self.tri
+        allbars = np.vstack((t[:, [0, 1]], t[:, [1, 2]], t[:, [0, 2]]))
+        allbars = _rows_unique(np.sort(allbars, axis=1))
+        have = set(map(tuple, allbars))
+        sel = np.array([tuple(bar) in have for bar in np.asarray(distmesh.bars)], bool)
+        distmesh.bars = np.asarray(distmesh.bars)[sel]
+        distmesh.L = np.asarray(distmesh.L)[sel]
+
+        # state, transition and covariances (:178-186)
+        N = self.N
+        self.X = np.vstack((self._ver.reshape(-1, 1), self._vel.reshape(-1, 1))).astype(np.float64)
+        e = np.eye(2 * N)
+        z = np.zeros((2 * N, 2 * N))
+        self.F = np.block([[e, e], [z, e]])
+        self.Weps = eps_F * np.block([[e / 4, e / 2], [e / 2, e]])
+        self.W = np.block([[1e-2 * e, z], [z, e]])
+
+        # vertex adjacency and the sparsity pattern of HTH (:189-205)
+        Jv = np.eye(N)
+        for k in range(3):
+            for l in range(3):
+                Jv[t[:, k], t[:, l]] = 1
+        self.Jv = Jv
+        self.J = np.kron(np.ones((2, 2)), np.kron(Jv, np.ones((2, 2))))
+
+        # spring incidence and rest lengths (:206-218)
+        bars = distmesh.bars
+        self.I = bars.shape[0]
+        Kp = np.zeros((N, self.I))
+        Kp[bars[:, 0], np.arange(self.I)] = 1
+        Kp[bars[:, 1], np.arange(self.I)] = -1
+        self.Kp = Kp
+        self.K = np.kron(Kp, np.eye(2))
+        self.Ks = sp.csr_matrix(self.K)
+        self.l0 = self.lengths()
+        self.L = self.lengths()
+
+        # perturbation partitions of the reference's multi-render scheme (:223-389); kept as
+        # attributes for API compatibility, the native path does not need them
+        self.E, self.labels = self._vertex_partitions()
+        self.Q, self.E_hessian, self.E_hessian_idx, self.labels_hess = self._pair_partitions()
+
+        # `renderer` lets a caller supply the measurement object (tests of the host logic do);
+        # by default it is the HIP one -- there is no CPU implementation in this package
+        self.renderer = renderer if renderer is not None else Renderer(
+            distmesh, self._vel, flow, self.nx, im, cuda, eps_Z, eps_J, eps_M, self.labels, self.labels_hess,
+            self.Q, showtracking=False)
+
+        stats.meshpts = self.N
+        stats.gridsize = getattr(distmesh, "h0", 0)
+        stats.nzj = np.sum(self.J) / 2 + (self.N * 4) / 2
+        stats.hessinc[0] = 2 + (stats.meshpts * 4) * (stats.meshpts * 4)
+        stats.jacinc[0] = 2 + stats.meshpts * 4 * 2
+        stats.hessincsparse[0] = 2 + stats.nzj * 2
+        stats.jacobianpartitions = len(self.E)
+        stats.hessianpartitions = len(self.E_hessian)
+
+    # -- partitions ---------------------------------------------------------------------------
+    def _vertex_partitions(self):
+        """Greedy classes of mutually non-adjacent vertices (:223-255) and, per class, the vertex
+        each triangle is attributed to, -1 if none (:263-272)."""
+        nbr = [set(np.nonzero(self.Jv[q])[0]) - {q} for q in range(self.N)]
+        free = set(range(self.N))
+        queue = list(range(self.N))
+        classes = []
+        while queue:
+            later = set()
+            members = []
+            while queue:
+                q = queue[0]
+                members.append(q)
+                later = (later | nbr[q]) & free
+                free.discard(q)
+                queue = [x for x in queue if x != q and x not in nbr[q]]
+            queue = sorted(later)
+            classes.append(members)
+        labels = -np.ones((len(self.tri), len(classes)))
+        for k, members in enumerate(classes):
+            for node in members:                       # later members overwrite earlier ones, as in the reference
+                labels[np.any(self.tri == node, axis=1), k] = node
+        return classes, labels
+
+    def _pair_partitions(self):
+        """Same idea for the vertex pairs Q = {(i,j): i<=j adjacent} of the sparse Hessian (:305-389)."""
+        N = self.N
+        Q = np.array([[i, j] for i in range(N) for j in range(i, N) if self.Jv[i, j]])
+        nbr = [set(np.nonzero(self.Jv[q])[0]) for q in range(N)]
+        diag = {int(q[0]): k for k, q in enumerate(Q) if q[0] == q[1]}
+        free = set(range(len(Q)))
+        queue = list(range(len(Q)))
+        classes, classes_idx = [], []
+        while queue:
+            later = set()
+            members = []
+            while queue:
+                qi = queue[0]
+                a, b = int(Q[qi][0]), int(Q[qi][1])
+                near = (nbr[a] | nbr[b]) - {a, b}
+                clash = {k for k in queue if int(Q[k][0]) in near or int(Q[k][1]) in near}
+                clash |= {diag[a], diag[b]} & set(queue)
+                members.append(qi)
+                free.discard(qi)
+                later = (later | clash) & free
+                queue = [k for k in queue if k != qi and k not in clash]
+            queue = sorted(later)
+            idx = np.array(sorted(members), float)
+            classes_idx.append(idx)
+            classes.append(Q[idx.astype(int)].reshape(-1, 2))
+        labels = -np.ones((len(self.tri), len(classes)))
+        for k, pairs in enumerate(classes):
+            for i, (n1, n2) in enumerate(pairs):
+                hit = np.any(self.tri == n1, axis=1) | np.any(self.tri == n2, axis=1)
+                labels[hit, k] = classes_idx[k][i]
+        return Q, classes, classes_idx, labels
+
+    # -- geometry -------------------------------------------------------------------------------
+    def vertices(self):
+        return self.X[0:2 * self.N].reshape((-1, 2))
+
+    def velocities(self):
+        return self.X[2 * self.N:].reshape((-1, 2))
+
+    def lengths(self):
+        d = self.Ks.T.dot(self.vertices().reshape(-1, 1)).reshape(-1, 2)
+        return np.sqrt((d * d).sum(axis=1)).reshape(-1, 1)
+
+    def update_orientation(self):
+        ver = self.vertices()
+        a = ver[self.tri[:, 1]] - ver[self.tri[:, 0]]
+        b = ver[self.tri[:, 2]] - ver[self.tri[:, 0]]
+        cr = a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]
+        self.ori = np.sign(cr)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            self.sineface = cr / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+
+    def size(self):
+        return self.X.shape[0]
+
+    def setforce(self, f):
+        self.renderer.force = f
+
+    def get_flow(self):
+        return self.renderer.get_flow()
+
+    def refresh(self, multi_idx=-1, hess=False):
+        self.renderer.update_vertex_buffer(self.vertices(), self.velocities(), multi_idx, hess)
+
+    def render(self):
+        stats.renders[0] += 1
+        return self.renderer.render()
+
+    # -- linearisation of the measurement ------------------------------------------------------------
+    def update(self, y_im, y_flow, y_m):
+        """(Hz, HTH, Hz_components) at the current state -- reference kalman.py:437-449."""
+        t0 = time.time()
+        Hz, HTH, Hzc = self.renderer.measure(self, y_im, y_flow, y_m)
+        dt = time.time() - t0
+        stats.stateupdatetc[0] += dt
+        stats.stateupdatetc[1] += 1
+        # the reference splits this time between its Jacobian and Hessian passes; here it is one launch
+        stats.jacobianrenderstc[0] += dt / 2
+        stats.jacobianrenderstc[1] += stats.jacinc[0]
+        stats.hessianrenderstc[0] += dt / 2
+        stats.hessianrenderstc[1] += stats.hessincsparse[0] if self.sparse else stats.hessinc[0]
+        return Hz, HTH, Hzc
+
+    # one perturbation per render, through the fine-grained operators (slow; used by the parity tests)
+    def _jacobian(self, y_im, y_flow, y_m, deltaX=2):
+        n = self.size()
+        Hz = np.zeros((n, 1))
+        Hzc = np.zeros((n, 4))
+        self.refresh()
+        self.renderer.initjacobian(y_im, y_flow, y_m)
+        for idx in range(n):
+            for sign in (+1, -1):
+                self.X[idx, 0] += sign * deltaX
+                hz, hzc = self.renderer.jz(self)
+                self.X[idx, 0] -= sign * deltaX
+                Hz[idx, 0] += sign * hz / deltaX
+                Hzc[idx, :] += sign * hzc / deltaX
+            Hz[idx, 0] /= 2
+            Hzc[idx, :] /= 2
+        return Hz, Hzc
+
+    _jacobian_multi = _jacobian
+
+    def _hessian_sparse(self, y_im, y_flow, y_m, deltaX=2, pattern=None):
+        n = self.size()
+        HTH = np.zeros((n, n))
+        self.refresh()
+        self.renderer.initjacobian(y_im, y_flow, y_m)
+        for i in range(n):
+            for j in range(i, n):
+                if pattern is None or pattern[i, j] == 1:
+                    HTH[i, j] = self.renderer.j(self, deltaX, i, j) / deltaX / deltaX
+                    HTH[j, i] = HTH[i, j]
+        return HTH
+
+    def _hessian_sparse_multi(self, y_im, y_flow, y_m, deltaX=2):
+        return self._hessian_sparse(y_im, y_flow, y_m, deltaX, self.J)
+
+    def _hessian(self, y_im, y_flow, y_m, deltaX=2):
+        return self._hessian_sparse(y_im, y_flow, y_m, deltaX, None)
+
+
+class KalmanFilter:
+    def __init__(self, distmesh, im, flow, cuda, vel=None, sparse=True, multi=True, eps_F=1, eps_Z=1e-3,
+                 eps_J=1e-3, eps_M=1e-3, verbose=False, renderer=None):
+        self.distmesh = distmesh
+        self.N = distmesh.size()
+        self.verbose = verbose
+        self.state = KFState(distmesh, im, flow, cuda, vel=vel, sparse=sparse, multi=multi, eps_F=eps_F,
+                             eps_Z=eps_Z, eps_J=eps_J, eps_M=eps_M, verbose=verbose, renderer=renderer)
+        self.predtime = 0
+        self.updatetime = 0
+        self.projecttime = 0
+
+    def size(self):
+        return self.N * 4
+
+    def _say(self, msg):
+        if self.verbose:
+            _log(msg)
+
+    def compute(self, y_im, y_flow, y_m, maskflow=True, imageoutput=None):
+        """One frame: predict, project onto the mask, update; returns the error tuple (:676-700).
+
+        ``y_im`` may be a renderer.DeviceObservation (frame, flow and mask already in device
+        memory, e.g. the flow straight from hm_brox_calc_dev); y_flow / y_m are then ignored."""
+        if isinstance(y_im, DeviceObservation):
+            obs = y_im
+            self.state.renderer.set_observation_dev(obs)
+            y_flow, y_m, mask_host = obs.raw, obs, obs.y_m_host
+            y_flow_mask = obs.masked if maskflow is True else obs.raw
+        else:
+            self.state.renderer.update_frame(y_im, y_flow, y_m)
+            y_flow_mask = MaskedFlow(y_flow, y_m) if maskflow is True else y_flow
+            mask_host = y_m
+        t0 = time.time()
+        self.predict()
+        t1 = time.time()
+        self.projectmask(mask_host)
+        t2 = time.time()
+        self.update(y_im, y_flow_mask, y_m)
+        t3 = time.time()
+        self.predtime += t1 - t0
+        self.projecttime += t2 - t1
+        self.updatetime += t3 - t2
+        self._say("Prediction time: %g\nProjection time: %g\nUpdate time: %g" % (t1 - t0, t2 - t1, t3 - t2))
+        if imageoutput is not None:
+            self._say("imageoutput=%r ignored: screenshots are not part of this path" % (imageoutput,))
+        return self.error(y_im, y_flow, y_m)
+
+    def predict(self):
+        """Constant-velocity prediction (:703-718)."""
+        t0 = time.time()
+        st = self.state
+        self.orig_x = st.X.copy()
+        st.X = st.F.dot(st.X)
+        self.pred_x = st.X.copy()
+        st.W = st.F.dot(st.W.dot(st.F.T)) + st.Weps
+        stats.statepredtime[0] += time.time() - t0
+
+    def projectmask(self, y_m):
+        """Vertices more than 1 px outside the object are pulled back onto its outline (:724-742).
+
+        The reference takes the signed distance from OpenCV contours (imgproc.py:175-248,
+        outside this path); here it is the Euclidean distance transform of the mask, sampled
+        bilinearly.  Steps, step size and the stale d / index set follow the reference."""
+        p = self.state.vertices()
+        if y_m is None or _all_inside(y_m, p):
+            return                        # every vertex is inside the object: d <= 0, nothing to project
+        fd = _mask_distance(y_m)
+        ddeps = 1e-1
+        p_orig = p.copy()
+        d = fd(p)
+        ix = d > 1
+        for _ in range(10):
+            if ix.any():
+                gx = (fd(p[ix] + [ddeps, 0]) - d[ix]) / ddeps
+                gy = (fd(p[ix] + [0, ddeps]) - d[ix]) / ddeps
+                g2 = gx ** 2 + gy ** 2
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    step = np.where(g2 > 0, d[ix] / g2, 0.0)
+                p[ix] -= (step * np.vstack((gx, gy))).T
+        self.state.X[0:2 * self.N] = p.reshape(-1, 1)
+        self.state.X[2 * self.N:] += (p - p_orig).reshape(-1, 1)
+
+    def update(self, y_im, y_flow, y_m):
+        """Single EKF step in information form (:745-761)."""
+        st = self.state
+        X, W = st.X, st.W
+        Hz, HTH, Hzc = st.update(y_im, y_flow, y_m)
+        Wn = np.linalg.inv(np.linalg.inv(W) + HTH)
+        st.X = X + Wn.dot(Hz)
+        st.W = Wn
+        self.tv = Wn.dot(Hzc[:, 0])
+        self.fv = Wn.dot(Hzc[:, 1] + Hzc[:, 2])
+        self.mv = Wn.dot(Hzc[:, 3])
+
+    def error(self, y_im, y_flow, y_m):
+        return self.state.renderer.error(self.state, y_im, y_flow, y_m)
+
+
+class IteratedKalmanFilter(KalmanFilter):
+    def __init__(self, distmesh, im, flow, cuda, sparse=True, multi=True, nI=10, eps_F=1e-3, eps_Z=1e-3,
+                 eps_J=1e-3, eps_M=1e10, **kw):
+        KalmanFilter.__init__(self, distmesh, im, flow, cuda, sparse=sparse, multi=multi, eps_F=eps_F, eps_Z=eps_Z,
+                              eps_J=eps_J, eps_M=eps_M, **kw)
+        self.nI = nI
+        self.reltol = 1e-4
+
+    def update(self, y_im, y_flow, y_m):
+        """Iterated EKF in information form (:774-831).
+
+        Per iteration the reference forms W = inv(invW0 + HTH) and
+        X = X0 + W Hz - W HTH (X0 - X).  Only W (Hz - HTH (X0 - X)) is needed to move the
+        state, so each iteration factorises invW0 + HTH once and solves; the covariance is
+        formed for the state that is kept (the last accepted one)."""
+        st = self.state
+        X = st.X
+        X_orig, X_old = X.copy(), X.copy()
+        W_old = st.W
+        invW_orig = np.linalg.inv(st.W)
+        A_old = None                     # information matrix of X_old; None = still the prior
+        eold = 0.0
+        conv = False
+        reverted = False
+        A = None
+        Hzc = np.zeros((st.size(), 4))
+        self.niter = 0
+        for i in range(self.nI):
+            self._say("   IEKF K = %d" % i)
+            Hz, HTH, Hzc = st.update(y_im, y_flow, y_m)
+            A = invW_orig + HTH
+            lu = sla.lu_factor(A, check_finite=False)
+            X = X_orig + sla.lu_solve(lu, Hz - HTH.dot(X_orig - X), check_finite=False)
+            st.X = X
+            self.niter += 1
+            st.update_orientation()
+            if np.any(st.ori < 0):
+                st.X = X_old
+                A = A_old
+                reverted = True
+                self._say("** Mesh inconsistent ** Reverting to last good state and continuing")
+                break
+            e_im, e_fx, e_fy, e_m, _, _ = self.error(y_im, y_flow, y_m)
+            enew = float(np.sqrt(float(e_im) ** 2 + e_fx ** 2 + e_fy ** 2 + float(e_m) ** 2))
+            self._say("-- e_im: %d, e_fx: %d, e_fy: %d, e_m: %d" % (e_im, e_fx, e_fy, e_m))
+            if abs(enew - eold) / enew < self.reltol:
+                conv = True
+                break
+            eold = enew
+            X_old = X.copy()
+            A_old = A
+        stats.niter += self.niter
+        st.W = W_old if A is None else np.linalg.inv(A)
+        self.reverted = reverted
+        Wd = st.W
+        self.tv = Wd.dot(Hzc[:, 0])
+        self.fv = Wd.dot(Hzc[:, 1] + Hzc[:, 2])
+        self.mv = Wd.dot(Hzc[:, 3])
+        self.converged = conv
+
+
+class IteratedMSKalmanFilter(IteratedKalmanFilter):
+    """Iterated filter with mass-spring dynamics (:834-960)."""
+
+    def __init__(self, distmesh, im, flow, cuda, sparse=True, multi=True, nI=10, eps_F=1e-1, eps_Z=1e-3,
+                 eps_J=1, eps_M=1, **kw):
+        IteratedKalmanFilter.__init__(self, distmesh, im, flow, cuda, sparse=sparse, multi=multi, eps_F=eps_F,
+                                      eps_Z=eps_Z, eps_J=eps_J, eps_M=eps_M, nI=nI, **kw)
+        self.M = 1
+        self.kappa = -1
+        self.deltat = 0.05
+        self.maxiter = 1000
+        self.tol = 1e-4
+        self.force = lambda l1, l2: -self.kappa * (l1 - l2)
+        self.state.setforce(self.force)
+
+    def _jacobian(self):
+        """d f / d y of the spring force at the current vertices (:865-902), sparse.
+
+        dfdy = -K [diag(kappa (1 - l0/l)) x I2] K^T - K diag(d) [dk x 1_2],
+        dk_i = kappa l0_i / l_i^3 * d_i^T (K^T)_i,   d = K^T y."""
+        st = self.state
+        K = st.Ks
+        y = st.vertices().reshape(-1, 1)
+        d = K.T.dot(y)
+        l = st.lengths()[:, 0]
+        l0 = st.l0[:, 0]
+        k = np.repeat(self.kappa * (1 - l0 / l), 2)
+        c = np.repeat(self.kappa * l0 / l ** 3, 2)
+        KT = K.T.tocsr()
+        rows = sp.diags(d[:, 0]).dot(KT)                         # row 2i+a: d_{i,a} (K^T)_{2i+a}
+        I2 = sp.kron(sp.eye(st.I), np.ones((2, 2)), format="csr")  # sums and repeats the two rows of a bar
+        dk_rep = sp.diags(c).dot(I2.dot(rows))
+        dfdy = -(K.dot(sp.diags(k)).dot(KT)) - K.dot(sp.diags(d[:, 0]).dot(dk_rep))
+        return dfdy.tocsr()
+
+    def _dfdx(self):
+        n2 = 2 * self.state.N
+        e = sp.eye(n2, format="csr")
+        A = self._jacobian() * (self.deltat / self.M)
+        return sp.bmat([[e, self.deltat * e], [A, e]], format="csr")
+
+    def _dgdx(self):
+        n2 = 2 * self.state.N
+        e = sp.eye(n2, format="csr")
+        A = self._jacobian() * (self.deltat / self.M)
+        return sp.bmat([[e, -self.deltat * e], [-A, e]], format="csc")
+
+    def predict(self):
+        t0 = time.time()
+        st = self.state
+        self.orig_x = st.X.copy()
+        F = self._dfdx()                  # linearised at the state before the step (:856)
+        self._newton()
+        self.pred_x = st.X.copy()
+        FW = F.dot(st.W)
+        st.W = F.dot(FW.T) + st.Weps      # F (F W)^T = F W F^T for symmetric W, with F sparse
+        stats.statepredtime[0] += time.time() - t0
+
+    def _newton(self):
+        """20 implicit-Euler sub-steps, each solved by Newton's method (:923-960)."""
+        st = self.state
+        dt, M = self.deltat, self.M
+        K = st.Ks
+        l0 = st.l0[:, 0]
+        for _ in range(int(np.ceil(1 / dt))):
+            x = st.X.copy()
+            xp = x.copy()
+            xo = np.zeros_like(x)
+            n = 0
+            while n < self.maxiter and np.linalg.norm(xo - xp) > self.tol * np.linalg.norm(xp):
+                xo = xp.copy()
+                v = st.velocities().reshape(-1, 1)
+                y = st.vertices().reshape(-1, 1)
+                d = K.T.dot(y)
+                l = st.lengths()[:, 0]
+                k = np.repeat(self.kappa * (1 - l0 / l), 2).reshape(-1, 1)
+                f = K.dot(k * d)
+                g = xp - x - dt * np.vstack((v, f / M))
+                xp = xp - spla.spsolve(self._dgdx(), g).reshape(-1, 1)
+                st.X = xp
+                n += 1
+
+
+def _all_inside(y_m, p):
+    """True if the four pixels around every vertex belong to the mask (then its distance is <= 0)."""
+    m = np.asarray(y_m)
+    H, W = m.shape
+    x0 = np.floor(p[:, 0]).astype(int)
+    y0 = np.floor(p[:, 1]).astype(int)
+    if x0.min() < 0 or y0.min() < 0 or x0.max() + 1 >= W or y0.max() + 1 >= H:
+        return False
+    return bool(np.all(m[y0, x0] > 0.5) and np.all(m[y0, x0 + 1] > 0.5) and np.all(m[y0 + 1, x0] > 0.5)
+                and np.all(m[y0 + 1, x0 + 1] > 0.5))
+
+
+def _mask_distance(y_m):
+    """Signed distance to the object outline: positive outside the mask, negative inside."""
+    from scipy import ndimage
+    m = np.asarray(y_m) > 0.5
+    if not m.any():
+        return lambda p: np.zeros(len(np.atleast_2d(p)))
+    dist = ndimage.distance_transform_edt(~m) - ndimage.distance_transform_edt(m)
+
+    def fd(p):
+        p = np.atleast_2d(p)
+        return ndimage.map_coordinates(dist, [p[:, 1], p[:, 0]], order=1, mode="nearest")
+    return fd

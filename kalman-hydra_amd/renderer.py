@@ -1,0 +1,258 @@
+"""Measurement model of the mesh tracker on MI355X.
+
+Host mirror of the reference's ``renderer.Renderer`` (reference
+renderer.py:197-737) for the part that is on the hot path: the four off-screen
+renders of the textured mesh and the reductions against the observed frame
+that the reference splits between OpenGL (renderer.py:310-325) and the CUDA
+kernels of ``CUDAGL`` / ``CUDAGL_multi`` (cuda.py, cuda_multi.py).  Here both
+live in libhydra_mi.so (csrc/ekf.hip): a software rasteriser and fused
+perturb-and-reduce kernels; nothing is rendered on a CPU and there is no
+fallback.  The on-screen views, screenshots and key bindings of the reference
+canvas are visualisation and are not part of this path.
+
+Same method names and argument meaning as the reference:
+``update_vertex_buffer``, ``render``, ``initjacobian``, ``jz``, ``jz_multi``,
+``j``, ``j_multi``, ``error``, ``update_frame``, ``get_flow``; plus ``measure``,
+the fused form of ``KFState.update`` (kalman.py:437-449).
+
+``FlowStream`` reads the ``<path>_%03d_x.mat`` / ``_y.mat`` files the flow tool
+writes (reference renderer.py:807-874).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _lib
+from . import matio
+
+
+class Renderer:
+    def __init__(self, distmesh, vel, flow, nx, im1, cuda, eps_Z, eps_J, eps_M, labels=None, labels_hess=None,
+                 Q=None, showtracking=False, force=None, multi=True, device=0):
+        if not cuda:
+            raise NotImplementedError(
+                "cuda=False: this build has no CPU measurement path (the reference's NumPy twin, "
+                "cuda.py:929-1010, is restated under oracle/ as test infrastructure only)")
+        self._h = None
+        self.Q = Q
+        self.cuda = cuda
+        self.force = force
+        self.labels, self.labels_hess = labels, labels_hess
+        self.tri = np.ascontiguousarray(distmesh.t, np.int32)
+        self.n = int(distmesh.p.shape[0])
+        im1 = np.asarray(im1)
+        tex = im1 if im1.ndim == 2 else im1[:, :, 0]      # the r8 target keeps channel 0 (cuda.py:931)
+        self.ny, self.nx = int(tex.shape[0]), int(tex.shape[1])
+        if int(nx) != self.ny:
+            raise ValueError("nx=%d does not match the frame (%d rows)" % (nx, self.ny))
+        uv = np.ascontiguousarray(distmesh.p, np.float32)  # texture coordinates = initial vertices (renderer.py:579)
+        L = _lib.lib()
+        h = _lib.c_vp()
+        _lib.check(L.hm_ctx_create(int(device), self.nx, self.ny, self.n, int(self.tri.shape[0]), _lib.ptr(self.tri),
+                                   _lib.ptr(uv), eps_Z, eps_J, eps_M, ctypes.byref(h)), "hm_ctx_create")
+        self._h = h
+        _lib.check(L.hm_set_texture(self._h, _lib.ptr(np.ascontiguousarray(tex, np.uint8))), "hm_set_texture")
+        self.vertices = np.array(distmesh.p, np.float64)
+        self.velocities = np.array(vel, np.float64).reshape(self.vertices.shape)
+        self._obs = None
+        self.current_frame = tex
+        self.current_flowx, self.current_flowy = flow[:, :, 0], flow[:, :, 1]
+
+    # -- lifetime -------------------------------------------------------------------------
+    def close(self):
+        if self._h is not None:
+            _lib.lib().hm_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- state ----------------------------------------------------------------------------
+    def update_vertex_buffer(self, vertices, velocities, multi_idx=-1, hess=False):
+        """reference renderer.py:503-556.  The label palettes selected by multi_idx / hess
+        only exist for the reference's multi-perturbation trick and have no effect here."""
+        self.vertices = np.asarray(vertices, np.float64).reshape(-1, 2)
+        self.velocities = np.asarray(velocities, np.float64).reshape(-1, 2)
+
+    def _X(self, state=None):
+        if state is not None:
+            return np.ascontiguousarray(np.asarray(state.X, np.float64).reshape(-1))
+        return np.ascontiguousarray(np.concatenate((self.vertices.reshape(-1), self.velocities.reshape(-1))))
+
+    def render(self):
+        """The four renders of the current vertex buffer -> (im u8, fx f32, fy f32, m u8)."""
+        n = self.nx * self.ny
+        im = np.empty((self.ny, self.nx), np.uint8)
+        m = np.empty_like(im)
+        fx = np.empty((self.ny, self.nx), np.float32)
+        fy = np.empty_like(fx)
+        _lib.check(_lib.lib().hm_render(self._h, _lib.ptr(self._X()), _lib.ptr(im), _lib.ptr(fx), _lib.ptr(fy),
+                                        _lib.ptr(m)), "hm_render")
+        self.last_render = (im, fx, fy, m)
+        return self.last_render
+
+    def get_flow(self):
+        """reference renderer.py:666-672."""
+        _, fx, fy, _ = self.render()
+        return fx, fy
+
+    # -- observation ------------------------------------------------------------------------
+    def update_frame(self, y_im, y_flow, y_m):
+        """reference renderer.py:656-664: the frame compute() works on.  Uploaded once."""
+        self.set_observation(y_im, y_flow, y_m)
+
+    def set_observation(self, y_im, y_flow, y_m):
+        y_im = np.asarray(y_im)
+        if y_im.ndim == 3:
+            y_im = y_im[:, :, 0]
+        a = np.ascontiguousarray(y_im, np.uint8)
+        fx = np.ascontiguousarray(y_flow[:, :, 0], np.float32)
+        fy = np.ascontiguousarray(y_flow[:, :, 1], np.float32)
+        m = np.ascontiguousarray(y_m, np.uint8)
+        if a.shape != (self.ny, self.nx) or fx.shape != a.shape or m.shape != a.shape:
+            raise ValueError("observation arrays must be %dx%d" % (self.ny, self.nx))
+        _lib.check(_lib.lib().hm_set_observation(self._h, _lib.ptr(a), _lib.ptr(fx), _lib.ptr(fy), _lib.ptr(m)),
+                   "hm_set_observation")
+        self._obs = (y_im, y_flow, y_m)
+
+    def set_observation_dev(self, obs):
+        """A DeviceObservation: frame, flow planes (e.g. what hm_brox_calc_dev just wrote) and mask
+        already in device memory.  The caller keeps them alive and ordered before this call."""
+        _lib.check(_lib.lib().hm_set_observation_dev(self._h, int(obs.d_y_im), int(obs.d_flowx), int(obs.d_flowy),
+                                                     int(obs.d_y_m)), "hm_set_observation_dev")
+        self._obs = obs
+
+    def _masked_flag(self, y_im, y_flow, y_m):
+        """0/1 if the arrays are the uploaded observation (raw or mask-multiplied), else upload them."""
+        o = self._obs
+        if isinstance(y_im, DeviceObservation):
+            if o is not y_im:
+                self.set_observation_dev(y_im)
+            return 1 if y_flow is y_im.masked else 0
+        if o is not None and len(o) == 3 and y_im is o[0] and y_m is o[2]:
+            if y_flow is o[1]:
+                return 0
+            if getattr(y_flow, "_hm_masked_from", None) is o[1]:
+                return 1
+        self.set_observation(y_im, y_flow, y_m)
+        return 0
+
+    # -- the reference's operator interface ---------------------------------------------------
+    def initjacobian(self, y_im, y_flow, y_m):
+        """reference renderer.py:674-679 / cuda.py:940-950: current render becomes the reference."""
+        self._masked = self._masked_flag(y_im, y_flow, y_m)
+        _lib.check(_lib.lib().hm_initjacobian(self._h, _lib.ptr(self._X()), self._masked), "hm_initjacobian")
+
+    def jz(self, state=None):
+        """reference renderer.py:681-694 / cuda.py:972-980 -> (jz, [im, fx, fy, m] components)."""
+        out = ctypes.c_double()
+        comp = (ctypes.c_double * 4)()
+        _lib.check(_lib.lib().hm_jz(self._h, _lib.ptr(self._X(state)), getattr(self, "_masked", 0),
+                                    ctypes.byref(out), comp), "hm_jz")
+        return out.value, np.array(comp[:])
+
+    def jz_multi(self, state):
+        """reference renderer.py:696-709.  The label-segmented sums of the reference equal the
+        single-perturbation sums for every perturbed vertex; evaluate those directly."""
+        raise NotImplementedError("use Renderer.measure(): it returns Hz for all vertices in one launch")
+
+    def j(self, state, deltaX, i, j):
+        """reference renderer.py:711-721 / cuda.py:982-1010."""
+        out = ctypes.c_double()
+        _lib.check(_lib.lib().hm_j(self._h, _lib.ptr(self._X(state)), float(deltaX), int(i), int(j),
+                                   ctypes.byref(out)), "hm_j")
+        return out.value
+
+    def j_multi(self, state, deltaX, ee, labelidx, ee_idx):
+        """reference renderer.py:723-737 (CPU branch): one j per listed pair -> (h, h_hist)."""
+        nq = len(self.Q)
+        h = np.zeros((nq, 1))
+        hist = np.zeros((nq, 1))
+        for idx, eidx in enumerate(ee_idx):
+            e = ee[idx]
+            h[int(eidx)] = self.j(state, deltaX, int(e[0]), int(e[1]))
+            hist[int(eidx)] = 1
+        return h, hist
+
+    def measure(self, state, y_im, y_flow, y_m, deltaX=2.0):
+        """KFState.update (kalman.py:437-449) fused: -> (Hz [4N,1], HTH [4N,4N], Hz_components [4N,4])."""
+        masked = self._masked_flag(y_im, y_flow, y_m)
+        n4 = 4 * self.n
+        Hz = np.empty(n4)
+        Hzc = np.empty((n4, 4))
+        HTH = np.empty((n4, n4))
+        _lib.check(_lib.lib().hm_measure(self._h, _lib.ptr(self._X(state)), float(deltaX), masked, _lib.ptr(Hz),
+                                         _lib.ptr(Hzc), _lib.ptr(HTH)), "hm_measure")
+        return Hz.reshape(-1, 1), HTH, Hzc
+
+    def error(self, state, y_im, y_flow, y_m):
+        """reference renderer.py:485-501 -> (e_im, e_fx, e_fy, e_m, fx, fy)."""
+        masked = self._masked_flag(y_im, y_flow, y_m)
+        err = (ctypes.c_double * 4)()
+        fx = np.empty((self.ny, self.nx), np.float32)
+        fy = np.empty_like(fx)
+        _lib.check(_lib.lib().hm_error(self._h, _lib.ptr(self._X(state)), masked, err, _lib.ptr(fx), _lib.ptr(fy)),
+                   "hm_error")
+        # the reference returns read_pixels arrays of shape (ny, nx, 1)
+        return int(err[0]), err[1], err[2], int(err[3]), fx[:, :, None], fy[:, :, None]
+
+
+class DeviceObservation:
+    """One observed frame held in device memory (addresses as integers): u8 frame, f32 flow x / y,
+    u8 mask in {0,1}, all W*H row-major.  ``raw`` and ``masked`` are the tokens to pass as y_flow."""
+
+    class _Token:
+        def __init__(self, name):
+            self.name = name
+
+    def __init__(self, d_y_im, d_flowx, d_flowy, d_y_m, y_m_host=None):
+        self.d_y_im, self.d_flowx, self.d_flowy, self.d_y_m = d_y_im, d_flowx, d_flowy, d_y_m
+        self.y_m_host = y_m_host
+        self.raw = DeviceObservation._Token("raw")
+        self.masked = DeviceObservation._Token("masked")
+
+
+class MaskedFlow(np.ndarray):
+    """y_m * y_flow (kalman.py:679-682) that remembers the raw flow it was made from, so the
+    renderer can use the device-side product instead of uploading the frame a second time."""
+
+    def __new__(cls, y_flow, y_m):
+        out = np.dstack((y_m * y_flow[:, :, 0], y_m * y_flow[:, :, 1])).astype(np.float32).view(cls)
+        out._hm_masked_from = y_flow
+        return out
+
+    def __array_finalize__(self, obj):
+        self._hm_masked_from = getattr(obj, "_hm_masked_from", None)
+
+
+class FlowStream:
+    """reference renderer.py:807-874: flow frames <path>_%03d_x.mat / _y.mat."""
+
+    def __init__(self, path):
+        self.path = path
+        self.frame = 0
+
+    def _names(self):
+        return (self.path + "_%03d_x.mat" % self.frame, self.path + "_%03d_y.mat" % self.frame)
+
+    def peek(self):
+        fn_x, fn_y = self._names()
+        try:
+            self.flowx = matio.read_mat(fn_x)
+            self.flowy = matio.read_mat(fn_y)
+        except IOError:
+            return False, None
+        return True, np.dstack((self.flowx, self.flowy)).astype(np.float32)
+
+    def read(self):
+        ret, flow = self.peek()
+        self.frame += 1
+        return ret, flow
+
+    def isOpened(self):
+        fn_x, fn_y = self._names()
+        return os.path.isfile(fn_x) and os.path.isfile(fn_y)

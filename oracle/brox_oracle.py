@@ -39,6 +39,10 @@ def lib():
         _lib.brox_ref_calc_u8.restype = ctypes.c_int
         _lib.brox_ref_levels.restype = ctypes.c_int
         _lib.brox_ref_gauss.restype = ctypes.c_int
+        # one thread unless a caller asks for more: the OpenMP loops are there for the
+        # timed CPU baseline, and a default-sized team on a many-core host with a small
+        # CPU quota (the GPU box) is orders of magnitude slower than one thread
+        _lib.brox_ref_set_threads(ctypes.c_int(1))
     return _lib
 
 

@@ -1,0 +1,429 @@
+"""oracle/ekf_ref.py -- CPU restatement of the reference's EKF measurement path.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg, never by the product package.
+
+What it restates (reference file:line):
+  * the measurement model = four off-screen renders of the textured mesh
+    (renderer.py:310-325; shaders :22-48,70-113; vertex mapping :503-524;
+    texture coordinates :579) -- here a software rasteriser, see `render`;
+  * the NumPy "CPU path" of the reduction kernels, which is the semantic
+    reference for them: initjacobian_CPU (cuda.py:940-950), jz_CPU (:972-980),
+    j_CPU (:982-1010);
+  * finite-difference assembly: _jacobian (kalman.py:491-518), _hessian_sparse
+    (:583-606), i.e. multi=False, sparse=True, cuda=False -- the only CPU
+    configuration of the reference that is not broken;
+  * Renderer.error (renderer.py:485-501) including its uint8 wrap-around;
+  * the filter: state / covariances (kalman.py:178-186), spring incidence
+    (:209-217), predict (:703-718 and :850-960), IEKF update (:774-831),
+    non-iterated update (:745-761), compute (:676-700).
+
+Pinning: the reference's own known-answer test for this path
+(test/test_cuda.py:198-266, the "ones" case) is reproduced in
+tests/test_oracle_ekf.py; its pickled fixture is missing from the reference
+(.MISSING_LARGE_BLOBS), so the inputs are regenerated from
+test/createtestdata_kalmanfilter.py:37-54.
+
+Raster semantics that OpenGL leaves to the driver are fixed here, and the HIP
+rasteriser follows them exactly:
+  * vertex positions are snapped to 1/256 pixel (8 sub-pixel bits, what GPUs do)
+    and coverage is decided by exact integer edge functions with a top-left
+    tie-break, so a pixel centre on a shared edge belongs to exactly one triangle;
+  * pixel (row r, col c) is covered iff its centre (c+.5, r+.5) is inside
+    (NDC mapping renderer.py:509-510 + read_pixels' vertical flip cuda.py:929-938);
+  * attributes are interpolated in binary32 in plane-equation form
+    a0 + l1 (a1 - a0) + l2 (a2 - a0), l_i = E_i / (2 area), which returns a
+    constant attribute exactly (test/test_cuda.py:256-266 relies on that);
+  * the texture is sampled at the nearest texel of the INITIAL frame (vispy
+    Texture2D default filter) at the interpolated initial vertex position;
+  * blending is additive (gloo.set_state('additive'), renderer.py:346, stays on
+    for the FBO passes): overlapping triangles add, 8-bit targets saturate;
+  * both triangle orientations are drawn (face culling is off).
+"""
+import numpy as np
+
+SUB = 256          # sub-pixel grid
+
+
+def snap(P):
+    """(N,2) float64 pixel coordinates -> int64 on the 1/256 grid (round half to even)."""
+    return np.rint(np.asarray(P, np.float64) * SUB).astype(np.int64)
+
+
+def _topleft(dx, dy):
+    return (dy > 0) | ((dy == 0) & (dx < 0))
+
+
+def render(X, N, tri, uv, tex, W, H):
+    """Render state X -> (im u8, fx f32, fy f32, m u8), each HxW.
+
+    X: 4N doubles [x0,y0,...,vx0,vy0,...] (kalman.py:178).  fy is the render of
+    -v_y (renderer.py:513).  m is 255 where any triangle covers the pixel.
+    """
+    X = np.asarray(X, np.float64).reshape(-1)
+    P = snap(X[:2 * N].reshape(N, 2))
+    vel = X[2 * N:].reshape(N, 2)
+    ax = vel[:, 0].astype(np.float32)
+    ay = (-vel[:, 1]).astype(np.float32)
+    uvf = np.asarray(uv, np.float32)
+    acc_im = np.zeros((H, W), np.int64)
+    fx = np.zeros((H, W), np.float32)
+    fy = np.zeros((H, W), np.float32)
+    cnt = np.zeros((H, W), np.int64)
+    for t in np.asarray(tri):
+        i0, i1, i2 = int(t[0]), int(t[1]), int(t[2])
+        (x0, y0), (x1, y1), (x2, y2) = P[i0], P[i1], P[i2]
+        area = (x1 - x0) * (y2 - y0) - (y1 - y0) * (x2 - x0)
+        if area == 0:
+            continue
+        if area < 0:
+            i1, i2 = i2, i1
+            (x1, y1), (x2, y2) = (x2, y2), (x1, y1)
+            area = -area
+        c_lo = max(0, int((min(x0, x1, x2) - 128) // SUB))
+        c_hi = min(W - 1, int((max(x0, x1, x2) - 128) // SUB) + 1)
+        r_lo = max(0, int((min(y0, y1, y2) - 128) // SUB))
+        r_hi = min(H - 1, int((max(y0, y1, y2) - 128) // SUB) + 1)
+        if c_lo > c_hi or r_lo > r_hi:
+            continue
+        px = (np.arange(c_lo, c_hi + 1, dtype=np.int64) * SUB + 128)[None, :]
+        py = (np.arange(r_lo, r_hi + 1, dtype=np.int64) * SUB + 128)[:, None]
+        e0 = (x2 - x1) * (py - y1) - (y2 - y1) * (px - x1)
+        e1 = (x0 - x2) * (py - y2) - (y0 - y2) * (px - x2)
+        e2 = (x1 - x0) * (py - y0) - (y1 - y0) * (px - x0)
+        ins = ((e0 > 0) | ((e0 == 0) & _topleft(x2 - x1, y2 - y1))) & \
+              ((e1 > 0) | ((e1 == 0) & _topleft(x0 - x2, y0 - y2))) & \
+              ((e2 > 0) | ((e2 == 0) & _topleft(x1 - x0, y1 - y0)))
+        if not ins.any():
+            continue
+        inv = np.float32(1.0) / np.float32(area)
+        l1 = e1.astype(np.float32) * inv
+        l2 = e2.astype(np.float32) * inv
+
+        def lerp(a):        # plane-equation form: a constant attribute is reproduced exactly
+            return (a[i0] + l1 * (a[i1] - a[i0])) + l2 * (a[i2] - a[i0])
+
+        tx = np.clip(np.floor(lerp(uvf[:, 0])).astype(np.int64), 0, W - 1)
+        ty = np.clip(np.floor(lerp(uvf[:, 1])).astype(np.int64), 0, H - 1)
+        sl = (slice(r_lo, r_hi + 1), slice(c_lo, c_hi + 1))
+        acc_im[sl] += np.where(ins, tex[ty, tx].astype(np.int64), 0)
+        fx[sl] = np.where(ins, fx[sl] + lerp(ax), fx[sl])
+        fy[sl] = np.where(ins, fy[sl] + lerp(ay), fy[sl])
+        cnt[sl] += ins
+    im = np.minimum(acc_im, 255).astype(np.uint8)
+    m = np.where(cnt > 0, 255, 0).astype(np.uint8)
+    return im, fx, fy, m
+
+
+class Measurement:
+    """The CPU twin of CUDAGL (cuda.py:929-1010) on top of `render`."""
+
+    def __init__(self, N, tri, uv, tex, eps_Z, eps_J, eps_M):
+        self.N = int(N)
+        self.tri = np.asarray(tri, np.int64)
+        self.uv = np.asarray(uv, np.float32)
+        tex = np.asarray(tex)
+        self.tex = tex if tex.ndim == 2 else tex[:, :, 0]     # read_pixels()[:,:,0]
+        self.H, self.W = self.tex.shape
+        self.eps_Z, self.eps_J, self.eps_M = float(eps_Z), float(eps_J), float(eps_M)
+
+    def render(self, X):
+        return render(X, self.N, self.tri, self.uv, self.tex, self.W, self.H)
+
+    def initjacobian(self, X, y_im, y_flow, y_m):
+        """cuda.py:940-950 (called with 255*y_m, renderer.py:679)."""
+        yt, yfx, yfy, ym = self.render(X)
+        self.X0 = np.array(X, np.float64).reshape(-1)
+        self.ref = (yt, yfx, yfy, ym)
+        self.z = (np.asarray(y_im, np.float64) - yt.astype(np.float64)) / 255.0
+        self.zfx = np.asarray(y_flow[:, :, 0], np.float32) - yfx
+        self.zfy = np.asarray(y_flow[:, :, 1], np.float32) + yfy
+        self.zm = (255.0 * np.asarray(y_m, np.float64) - ym.astype(np.float64)) / 255.0
+
+    def _diff(self, Xp):
+        yt, yfx, yfy, ym = self.ref
+        pt, pfx, pfy, pm = self.render(Xp)
+        return ((pt.astype(np.float64) - yt.astype(np.float64)) / 255.0, pfx - yfx, pfy - yfy,
+                (pm.astype(np.float64) - ym.astype(np.float64)) / 255.0)
+
+    def jz(self, Xp):
+        """cuda.py:972-980 -> (total, [im, fx, fy, m])."""
+        d, dfx, dfy, dm = self._diff(Xp)
+        c = np.array([np.sum(d * self.z) / self.eps_Z,
+                      np.sum(dfx.astype(np.float64) * self.zfx.astype(np.float64)) / self.eps_J,
+                      -np.sum(dfy.astype(np.float64) * self.zfy.astype(np.float64)) / self.eps_J,
+                      np.sum(dm * self.zm) / self.eps_M])
+        return c.sum(), c
+
+    def j(self, deltaX, i, jdx):
+        """cuda.py:982-1010: perturbations of the initjacobian state."""
+        Xp = self.X0.copy(); Xp[i] += deltaX
+        Xq = self.X0.copy(); Xq[jdx] += deltaX
+        a = self._diff(Xp)
+        b = self._diff(Xq)
+        return (np.sum(a[0] * b[0]) / self.eps_Z
+                + np.sum(a[1].astype(np.float64) * b[1].astype(np.float64)) / self.eps_J
+                + np.sum(a[2].astype(np.float64) * b[2].astype(np.float64)) / self.eps_J
+                + np.sum(a[3] * b[3]) / self.eps_M)
+
+    def error(self, X, y_im, y_flow, y_m):
+        """renderer.py:485-501.  y_im / y_m / the renders are uint8 there, so the
+        image and mask differences and their squares wrap modulo 256 before the sum."""
+        pt, pfx, pfy, pm = self.render(X)
+        y_im = np.asarray(y_im)
+        y_m = np.asarray(y_m)
+        if y_im.dtype == np.uint8:
+            d = (y_im - pt).astype(np.uint8)
+            e_im = int(np.sum((d * d).astype(np.uint8), dtype=np.uint64))
+        else:
+            d = y_im.astype(np.float64) - pt
+            e_im = float(np.sum(d * d))
+        if y_m.dtype == np.uint8:
+            d = ((255 * y_m.astype(np.int64)).astype(np.uint8) - pm).astype(np.uint8)
+            e_m = int(np.sum((d * d).astype(np.uint8), dtype=np.uint64))
+        else:
+            d = 255.0 * y_m.astype(np.float64) - pm
+            e_m = float(np.sum(d * d))
+        dfx = np.asarray(y_flow[:, :, 0], np.float32) - pfx
+        dfy = np.asarray(y_flow[:, :, 1], np.float32) + pfy
+        e_fx = float(np.sum(dfx.astype(np.float64) ** 2))
+        e_fy = float(np.sum(dfy.astype(np.float64) ** 2))
+        return e_im, e_fx, e_fy, e_m, pfx, pfy
+
+
+def adjacency(N, tri):
+    """Jv (kalman.py:189-198) and the 4N x 4N pattern J = kron(ones(2,2), kron(Jv, ones(2,2))) (:202-205)."""
+    Jv = np.eye(N)
+    for t in tri:
+        for a in t:
+            for b in t:
+                Jv[a, b] = 1
+    J = np.kron(np.ones((2, 2)), np.kron(Jv, np.ones((2, 2))))
+    return Jv, J
+
+
+def jacobian(meas, X, y_im, y_flow, y_m, deltaX=2.0):
+    """_jacobian, kalman.py:491-518: central differences of jz."""
+    n = X.size
+    X = np.array(X, np.float64).reshape(-1)
+    meas.initjacobian(X, y_im, y_flow, y_m)
+    Hz = np.zeros((n, 1))
+    Hzc = np.zeros((n, 4))
+    for k in range(n):
+        Xp = X.copy(); Xp[k] += deltaX
+        hp, cp = meas.jz(Xp)
+        Xm = X.copy(); Xm[k] -= deltaX
+        hm_, cm = meas.jz(Xm)
+        Hz[k, 0] = (hp / deltaX - hm_ / deltaX) / 2
+        Hzc[k] = (cp / deltaX - cm / deltaX) / 2
+    return Hz, Hzc
+
+
+def hessian_sparse(meas, X, J, deltaX=2.0):
+    """_hessian_sparse, kalman.py:583-606 (initjacobian must have been called at X)."""
+    n = X.size
+    HTH = np.zeros((n, n))
+    for i in range(n):
+        for k in range(i, n):
+            if J[i, k] == 1:
+                HTH[i, k] = meas.j(deltaX, i, k) / deltaX / deltaX
+                HTH[k, i] = HTH[i, k]
+    return HTH
+
+
+# ---------------------------------------------------------------------------------
+# the filter (host algebra), restated for the oracle
+# ---------------------------------------------------------------------------------
+def initial_covariances(N, eps_F):
+    """kalman.py:179-186."""
+    e = np.eye(2 * N)
+    z = np.zeros((2 * N, 2 * N))
+    F = np.block([[e, e], [z, e]])
+    Weps = eps_F * np.block([[e / 4, e / 2], [e / 2, e]])
+    W = np.block([[1e-2 * e, z], [z, e]])
+    return F, Weps, W
+
+
+def incidence(N, bars):
+    """K = kron(Kp, I2), kalman.py:209-214."""
+    Kp = np.zeros((N, len(bars)))
+    for idx, (i1, i2) in enumerate(bars):
+        Kp[i1, idx] = 1
+        Kp[i2, idx] = -1
+    return np.kron(Kp, np.eye(2))
+
+
+def bar_lengths(K, y):
+    d = (K.T @ y.reshape(-1, 1)).reshape(-1, 2)
+    return np.sqrt((d * d).sum(1))
+
+
+def ms_dfdy(K, l0, y, kappa):
+    """IteratedMSKalmanFilter._jacobian, kalman.py:865-902."""
+    y = y.reshape(-1, 1)
+    I = l0.size
+    d = K.T @ y
+    l = bar_lengths(K, y)
+    k = np.kron(np.diag(kappa * (1 - l0 / l)), np.eye(2))
+    dk = np.zeros((I, y.size))
+    for i in range(I):
+        KTi = K.T[2 * i:2 * i + 2, :]
+        dk[i, :] = kappa * l0[i] / l[i] ** 3 * (y.T @ (KTi.T @ KTi))
+    dk = np.kron(dk, np.ones((2, 1)))
+    return -K @ (k @ K.T) - K @ (np.diagflat(d) @ dk)
+
+
+def ms_predict(X, W, Weps, K, l0, kappa=-1.0, M=1.0, deltat=0.05, maxiter=1000, tol=1e-4):
+    """IteratedMSKalmanFilter.predict, kalman.py:850-863 with _dfdx :904-912 and _newton :923-960."""
+    X = np.array(X, np.float64).reshape(-1, 1)
+    n2 = X.size // 2
+    e = np.eye(n2)
+    dfdy = ms_dfdy(K, l0, X[:n2], kappa)
+    F = np.block([[e, deltat * e], [deltat * dfdy / M, e]])
+    for _ in range(int(np.ceil(1 / deltat))):
+        x = X.copy()
+        xp = x.copy()
+        xo = np.zeros_like(x)
+        it = 0
+        while it < maxiter and np.linalg.norm(xo - xp) > tol * np.linalg.norm(xp):
+            xo = xp.copy()
+            v = X[n2:]
+            y = X[:n2]
+            d = K.T @ y
+            l = bar_lengths(K, y)
+            k = np.kron(np.diag(kappa * (1 - l0 / l)), np.eye(2))
+            f = K @ (k @ d)
+            g = xp - x - deltat * np.vstack((v, f / M))
+            dfdy_k = ms_dfdy(K, l0, y, kappa)
+            G = np.block([[e, -deltat * e], [-deltat * dfdy_k / M, e]])
+            xp = xp - np.linalg.inv(G) @ g
+            X = xp
+            it += 1
+    Wn = F @ (W @ F.T) + Weps
+    return X, Wn
+
+
+def orientation(X, N, tri):
+    """update_orientation, kalman.py:410-414."""
+    ver = X[:2 * N].reshape(-1, 2)
+    a = ver[tri[:, 1]] - ver[tri[:, 0]]
+    b = ver[tri[:, 2]] - ver[tri[:, 0]]
+    return np.sign(a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0])
+
+
+def iekf_update(meas, X, W, J, tri, y_im, y_flow, y_m, nI=10, reltol=1e-4, deltaX=2.0):
+    """IteratedKalmanFilter.update, kalman.py:774-831.  Returns (X, W, iterations, trace)."""
+    N = X.size // 4
+    X = np.array(X, np.float64).reshape(-1, 1)
+    X_orig, X_old = X.copy(), X.copy()
+    W = np.array(W, np.float64)
+    W_old = W.copy()
+    invW_orig = np.linalg.inv(W)
+    eold = 0.0
+    trace = []
+    for it in range(nI):
+        Hz, Hzc = jacobian(meas, X.reshape(-1), y_im, y_flow, y_m, deltaX)
+        HTH = hessian_sparse(meas, X.reshape(-1), J, deltaX)
+        W = np.linalg.inv(invW_orig + HTH)
+        X = X_orig + W @ Hz - W @ (HTH @ (X_orig - X))
+        if np.any(orientation(X.reshape(-1), N, tri) < 0):
+            X, W = X_old, W_old
+            trace.append(("reverted",))
+            break
+        e_im, e_fx, e_fy, e_m, _, _ = meas.error(X.reshape(-1), y_im, y_flow, y_m)
+        enew = float(np.sqrt(float(e_im) ** 2 + e_fx ** 2 + e_fy ** 2 + float(e_m) ** 2))
+        trace.append((e_im, e_fx, e_fy, e_m))
+        if abs(enew - eold) / enew < reltol:
+            break
+        eold = enew
+        X_old, W_old = X.copy(), W.copy()
+    return X, W, len(trace), trace
+
+
+def kf_update(meas, X, W, J, y_im, y_flow, y_m, deltaX=2.0):
+    """KalmanFilter.update, kalman.py:745-761."""
+    X = np.array(X, np.float64).reshape(-1, 1)
+    Hz, Hzc = jacobian(meas, X.reshape(-1), y_im, y_flow, y_m, deltaX)
+    HTH = hessian_sparse(meas, X.reshape(-1), J, deltaX)
+    Wn = np.linalg.inv(np.linalg.inv(W) + HTH)
+    return X + Wn @ Hz, Wn
+
+
+def mask_flow(y_flow, y_m):
+    """compute(): the observed flow is multiplied by the mask first, kalman.py:679-682."""
+    return np.dstack((y_m * y_flow[:, :, 0], y_m * y_flow[:, :, 1])).astype(np.float32)
+
+
+def project_mask(X, N, y_m, steps=10, ddeps=1e-1):
+    """KalmanFilter.projectmask, kalman.py:724-742.  The reference's distance function comes
+    from OpenCV contours (imgproc.py:175-248, outside the hot path and not available here);
+    as in the product, it is replaced by the Euclidean distance transform of the mask sampled
+    bilinearly.  Loop structure (10 steps, forward difference 0.1, d and the index set not
+    refreshed inside the loop, displacement also added to the velocities) follows the reference."""
+    from scipy import ndimage
+    X = np.array(X, np.float64).reshape(-1, 1)
+    m = np.asarray(y_m) > 0.5
+    if not m.any():
+        return X
+    dist = ndimage.distance_transform_edt(~m) - ndimage.distance_transform_edt(m)
+    fd = lambda q: ndimage.map_coordinates(dist, [q[:, 1], q[:, 0]], order=1, mode="nearest")
+    p = X[:2 * N].reshape(-1, 2).copy()
+    p0 = p.copy()
+    d = fd(p)
+    ix = d > 1
+    for _ in range(steps):
+        if ix.any():
+            gx = (fd(p[ix] + [ddeps, 0]) - d[ix]) / ddeps
+            gy = (fd(p[ix] + [0, ddeps]) - d[ix]) / ddeps
+            g2 = gx ** 2 + gy ** 2
+            with np.errstate(divide="ignore", invalid="ignore"):
+                s = np.where(g2 > 0, d[ix] / g2, 0.0)
+            p[ix] -= (s * np.vstack((gx, gy))).T
+    X[:2 * N] = p.reshape(-1, 1)
+    X[2 * N:] += (p - p0).reshape(-1, 1)
+    return X
+
+
+def remove_flat_faces(p, t, bars, L):
+    """KFState.__init__, kalman.py:148-175: drop faces with |sin| <= 0.06 and orphaned bars."""
+    p = np.asarray(p, np.float32)
+    a = p[t[:, 1]] - p[t[:, 0]]
+    b = p[t[:, 2]] - p[t[:, 0]]
+    cr = a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]
+    keep = np.abs(cr / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))) > 0.06
+    t = t[keep]
+    used = set()
+    for v1, v2, v3 in t:
+        used |= {(min(v1, v2), max(v1, v2)), (min(v2, v3), max(v2, v3)), (min(v1, v3), max(v1, v3))}
+    sel = np.array([(int(b0), int(b1)) in used for b0, b1 in bars], bool)
+    return t, bars[sel], L[sel]
+
+
+class Tracker:
+    """IteratedMSKalmanFilter driven frame by frame (kalman.py:676-700 + :834-960), oracle side."""
+
+    def __init__(self, p, t, bars, L, im, eps_F=1e-1, eps_Z=1e-3, eps_J=1.0, eps_M=1.0, nI=10, vel=None):
+        t, bars, L = remove_flat_faces(p, np.asarray(t), np.asarray(bars), np.asarray(L))
+        self.N = len(p)
+        self.tri = t
+        ver = np.asarray(p, np.float32).astype(np.float64)       # KFState keeps float32 vertices (:112)
+        v0 = np.zeros_like(ver) if vel is None else np.asarray(vel, np.float64).reshape(ver.shape)
+        self.X = np.concatenate((ver.reshape(-1), v0.reshape(-1))).reshape(-1, 1)
+        self.F, self.Weps, self.W = initial_covariances(self.N, eps_F)
+        self.Jv, self.J = adjacency(self.N, t)
+        self.K = incidence(self.N, bars)
+        self.l0 = bar_lengths(self.K, self.X[:2 * self.N])
+        self.meas = Measurement(self.N, t, ver, im, eps_Z, eps_J, eps_M)
+        self.nI = nI
+
+    def compute(self, y_im, y_flow, y_m, dynamics="ms"):
+        if dynamics == "ms":
+            self.X, self.W = ms_predict(self.X, self.W, self.Weps, self.K, self.l0)
+        else:                                                     # KalmanFilter.predict, kalman.py:703-718
+            self.X = self.F @ self.X
+            self.W = self.F @ (self.W @ self.F.T) + self.Weps
+        self.X = project_mask(self.X, self.N, y_m)
+        fm = mask_flow(y_flow, y_m)
+        self.X, self.W, self.niter, self.trace = iekf_update(self.meas, self.X, self.W, self.J, self.tri, y_im, fm,
+                                                             y_m, nI=self.nI)
+        return self.meas.error(self.X.reshape(-1), y_im, y_flow, y_m)
