@@ -2,7 +2,7 @@
 
 The build contract fixes the directory name, which is not a valid Python
 identifier; ``import hydra_mi`` (or ``importlib.import_module("kalman-hydra_amd")``)
-gives the same module object.
+gives the same module objects, including for ``from hydra_mi.<sub> import ...``.
 """
 import importlib
 import os
@@ -12,4 +12,6 @@ _root = os.path.dirname(os.path.abspath(__file__))
 if _root not in sys.path:
     sys.path.insert(0, _root)
 _pkg = importlib.import_module("kalman-hydra_amd")
+for _sub in ("_lib", "matio", "synth", "mesh", "brox", "renderer", "kalman"):
+    sys.modules[__name__ + "." + _sub] = importlib.import_module("kalman-hydra_amd." + _sub)
 sys.modules[__name__] = _pkg

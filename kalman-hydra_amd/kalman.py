@@ -21,6 +21,7 @@ reference's.  What changes is where the work is done:
 
 There is no CPU measurement path: ``cuda=False`` raises.
 """
+import os
 import sys
 import time
 
@@ -53,6 +54,56 @@ class Statistics:
 
 
 stats = Statistics()
+
+# The dense update runs on host BLAS.  A default-sized BLAS thread team on a many-core host
+# with a small CPU quota (a container, the GPU box) is slower than a handful of threads by
+# orders of magnitude, so the team is capped (HYDRA_MI_BLAS_THREADS overrides the cap).
+try:
+    from threadpoolctl import threadpool_limits as _threadpool_limits
+except ImportError:                                   # pragma: no cover
+    _threadpool_limits = None
+_BLAS_THREADS = int(os.environ.get("HYDRA_MI_BLAS_THREADS", "8"))
+
+
+def _spd_factor(A):
+    """Cholesky factor of the information matrix, or an LU factor if it is not positive definite
+    (the finite-difference HTH is symmetric but only approximately positive semi-definite)."""
+    try:
+        return ("cho", sla.cho_factor(A, lower=True, check_finite=False))
+    except np.linalg.LinAlgError:
+        return ("lu", sla.lu_factor(A, check_finite=False))
+
+
+def _factor_solve(fac, b):
+    kind, f = fac
+    if kind == "cho":
+        return sla.cho_solve(f, b, check_finite=False)
+    return sla.lu_solve(f, b, check_finite=False)
+
+
+def _spd_inverse(A):
+    """inv(A) for a symmetric matrix: through the Cholesky factor when A is positive definite."""
+    try:
+        c, info = sla.lapack.dpotrf(A, lower=1, clean=0, overwrite_a=0)
+        if info == 0:
+            inv, info = sla.lapack.dpotri(c, lower=1, overwrite_c=1)
+            if info == 0:
+                low = np.tril(inv)
+                return low + np.tril(inv, -1).T
+    except Exception:
+        pass
+    return np.linalg.inv(A)
+
+
+class _blas_cap:
+    def __enter__(self):
+        self._ctx = _threadpool_limits(limits=_BLAS_THREADS) if _threadpool_limits is not None else None
+        if self._ctx is not None:
+            self._ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self._ctx is not None:
+            self._ctx.__exit__(*a)
 
 
 def _log(msg):
@@ -333,13 +384,14 @@ class KalmanFilter:
             self.state.renderer.update_frame(y_im, y_flow, y_m)
             y_flow_mask = MaskedFlow(y_flow, y_m) if maskflow is True else y_flow
             mask_host = y_m
-        t0 = time.time()
-        self.predict()
-        t1 = time.time()
-        self.projectmask(mask_host)
-        t2 = time.time()
-        self.update(y_im, y_flow_mask, y_m)
-        t3 = time.time()
+        with _blas_cap():
+            t0 = time.time()
+            self.predict()
+            t1 = time.time()
+            self.projectmask(mask_host)
+            t2 = time.time()
+            self.update(y_im, y_flow_mask, y_m)
+            t3 = time.time()
         self.predtime += t1 - t0
         self.projecttime += t2 - t1
         self.updatetime += t3 - t2
@@ -418,7 +470,7 @@ class IteratedKalmanFilter(KalmanFilter):
         X = st.X
         X_orig, X_old = X.copy(), X.copy()
         W_old = st.W
-        invW_orig = np.linalg.inv(st.W)
+        invW_orig = _spd_inverse(st.W)
         A_old = None                     # information matrix of X_old; None = still the prior
         eold = 0.0
         conv = False
@@ -430,8 +482,7 @@ class IteratedKalmanFilter(KalmanFilter):
             self._say("   IEKF K = %d" % i)
             Hz, HTH, Hzc = st.update(y_im, y_flow, y_m)
             A = invW_orig + HTH
-            lu = sla.lu_factor(A, check_finite=False)
-            X = X_orig + sla.lu_solve(lu, Hz - HTH.dot(X_orig - X), check_finite=False)
+            X = X_orig + _factor_solve(_spd_factor(A), Hz - HTH.dot(X_orig - X))
             st.X = X
             self.niter += 1
             st.update_orientation()
@@ -441,7 +492,7 @@ class IteratedKalmanFilter(KalmanFilter):
                 reverted = True
                 self._say("** Mesh inconsistent ** Reverting to last good state and continuing")
                 break
-            e_im, e_fx, e_fy, e_m, _, _ = self.error(y_im, y_flow, y_m)
+            e_im, e_fx, e_fy, e_m, _, _ = st.renderer.error(st, y_im, y_flow, y_m, want_flow=False)
             enew = float(np.sqrt(float(e_im) ** 2 + e_fx ** 2 + e_fy ** 2 + float(e_m) ** 2))
             self._say("-- e_im: %d, e_fx: %d, e_fy: %d, e_m: %d" % (e_im, e_fx, e_fy, e_m))
             if abs(enew - eold) / enew < self.reltol:
@@ -451,7 +502,7 @@ class IteratedKalmanFilter(KalmanFilter):
             X_old = X.copy()
             A_old = A
         stats.niter += self.niter
-        st.W = W_old if A is None else np.linalg.inv(A)
+        st.W = W_old if A is None else _spd_inverse(A)
         self.reverted = reverted
         Wd = st.W
         self.tv = Wd.dot(Hzc[:, 0])
@@ -474,26 +525,43 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
         self.tol = 1e-4
         self.force = lambda l1, l2: -self.kappa * (l1 - l2)
         self.state.setforce(self.force)
+        self._bar_pattern()
 
     def _jacobian(self):
         """d f / d y of the spring force at the current vertices (:865-902), sparse.
 
-        dfdy = -K [diag(kappa (1 - l0/l)) x I2] K^T - K diag(d) [dk x 1_2],
-        dk_i = kappa l0_i / l_i^3 * d_i^T (K^T)_i,   d = K^T y."""
+        The reference forms  -K [diag(kappa (1 - l0/l)) x I2] K^T - K diag(d) [dk x 1_2]  with
+        dk_i = kappa l0_i / l_i^3 * d_i^T (K^T)_i and d = K^T y, as dense products.  Bar i between
+        vertices a and b contributes the 2x2 block  B_i = k_i I + c_i d_i d_i^T  (k_i = kappa (1 - l0_i/l_i),
+        c_i = kappa l0_i / l_i^3) with sign - on (a,a), (b,b) and + on (a,b), (b,a); assembled here
+        directly from those blocks."""
         st = self.state
-        K = st.Ks
-        y = st.vertices().reshape(-1, 1)
-        d = K.T.dot(y)
-        l = st.lengths()[:, 0]
+        bars = self._bars
+        y = st.vertices()
+        d = y[bars[:, 0]] - y[bars[:, 1]]
+        l = np.sqrt((d * d).sum(axis=1))
         l0 = st.l0[:, 0]
-        k = np.repeat(self.kappa * (1 - l0 / l), 2)
-        c = np.repeat(self.kappa * l0 / l ** 3, 2)
-        KT = K.T.tocsr()
-        rows = sp.diags(d[:, 0]).dot(KT)                         # row 2i+a: d_{i,a} (K^T)_{2i+a}
-        I2 = sp.kron(sp.eye(st.I), np.ones((2, 2)), format="csr")  # sums and repeats the two rows of a bar
-        dk_rep = sp.diags(c).dot(I2.dot(rows))
-        dfdy = -(K.dot(sp.diags(k)).dot(KT)) - K.dot(sp.diags(d[:, 0]).dot(dk_rep))
-        return dfdy.tocsr()
+        k = self.kappa * (1 - l0 / l)
+        c = self.kappa * l0 / l ** 3
+        Bm = c[:, None, None] * (d[:, :, None] * d[:, None, :])
+        Bm[:, 0, 0] += k
+        Bm[:, 1, 1] += k
+        vals = np.concatenate((-Bm, -Bm, Bm, Bm)).reshape(-1)
+        n2 = 2 * st.N
+        return sp.csr_matrix((vals, (self._jrows, self._jcols)), shape=(n2, n2))
+
+    def _bar_pattern(self):
+        """Row / column indices of the four 2x2 blocks every bar contributes to dfdy."""
+        bars = np.asarray(self.distmesh.bars, np.int64)
+        self._bars = bars
+        a, b = bars[:, 0], bars[:, 1]
+        al = np.arange(2)
+        rows, cols = [], []
+        for (p, q) in ((a, a), (b, b), (a, b), (b, a)):
+            rows.append((2 * p[:, None, None] + al[None, :, None]) + 0 * al[None, None, :])
+            cols.append((2 * q[:, None, None] + al[None, None, :]) + 0 * al[None, :, None])
+        self._jrows = np.concatenate(rows).reshape(-1)
+        self._jcols = np.concatenate(cols).reshape(-1)
 
     def _dfdx(self):
         n2 = 2 * self.state.N
@@ -511,19 +579,24 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
         t0 = time.time()
         st = self.state
         self.orig_x = st.X.copy()
-        F = self._dfdx()                  # linearised at the state before the step (:856)
+        A = self._jacobian() * (self.deltat / self.M)     # F = [[I, dt I], [A, I]] at the state before the step (:856)
         self._newton()
         self.pred_x = st.X.copy()
-        FW = F.dot(st.W)
-        st.W = F.dot(FW.T) + st.Weps      # F (F W)^T = F W F^T for symmetric W, with F sparse
+        st.W = _fwft(A, self.deltat, st.W) + st.Weps
         stats.statepredtime[0] += time.time() - t0
 
     def _newton(self):
-        """20 implicit-Euler sub-steps, each solved by Newton's method (:923-960)."""
+        """20 implicit-Euler sub-steps, each solved by Newton's method (:923-960).
+
+        The reference inverts the 4N x 4N matrix G = [[I, -dt I], [-A, I]], A = dt dfdy / M, in every
+        Newton iteration.  Eliminating the first block row leaves the 2N x 2N system
+        (I - dt A) s1 = g1 + dt g2,  s2 = g2 + A s1, solved sparse."""
         st = self.state
         dt, M = self.deltat, self.M
-        K = st.Ks
+        bars = self._bars
         l0 = st.l0[:, 0]
+        n2 = 2 * st.N
+        eye = sp.eye(n2, format="csc")
         for _ in range(int(np.ceil(1 / dt))):
             x = st.X.copy()
             xp = x.copy()
@@ -532,15 +605,37 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
             while n < self.maxiter and np.linalg.norm(xo - xp) > self.tol * np.linalg.norm(xp):
                 xo = xp.copy()
                 v = st.velocities().reshape(-1, 1)
-                y = st.vertices().reshape(-1, 1)
-                d = K.T.dot(y)
-                l = st.lengths()[:, 0]
-                k = np.repeat(self.kappa * (1 - l0 / l), 2).reshape(-1, 1)
-                f = K.dot(k * d)
-                g = xp - x - dt * np.vstack((v, f / M))
-                xp = xp - spla.spsolve(self._dgdx(), g).reshape(-1, 1)
+                y = st.vertices()
+                d = y[bars[:, 0]] - y[bars[:, 1]]
+                l = np.sqrt((d * d).sum(axis=1))
+                L = (self.kappa * (1 - l0 / l))[:, None] * d          # spring force along each bar
+                f = np.zeros((st.N, 2))
+                np.add.at(f, bars[:, 0], L)
+                np.add.at(f, bars[:, 1], -L)
+                g = xp - x - dt * np.vstack((v, f.reshape(-1, 1) / M))
+                A = self._jacobian() * (dt / M)
+                g1, g2 = g[:n2], g[n2:]
+                s1 = spla.spsolve((eye - dt * A).tocsc(), g1 + dt * g2).reshape(-1, 1)
+                s2 = g2 + A.dot(s1)
+                xp = xp - np.vstack((s1, s2))
                 st.X = xp
                 n += 1
+
+
+def _fwft(A, a, W):
+    """F W F^T for F = [[I, a I], [A, I]] with A sparse (2N x 2N), by blocks."""
+    n2 = A.shape[0]
+    W11, W12, W21, W22 = W[:n2, :n2], W[:n2, n2:], W[n2:, :n2], W[n2:, n2:]
+    P11 = W11 + a * W21
+    P12 = W12 + a * W22
+    P21 = A.dot(np.ascontiguousarray(W11)) + W21
+    P22 = A.dot(np.ascontiguousarray(W12)) + W22
+    out = np.empty_like(W)
+    out[:n2, :n2] = P11 + a * P12
+    out[:n2, n2:] = A.dot(np.ascontiguousarray(P11.T)).T + P12
+    out[n2:, :n2] = P21 + a * P22
+    out[n2:, n2:] = A.dot(np.ascontiguousarray(P21.T)).T + P22
+    return out
 
 
 def _all_inside(y_m, p):

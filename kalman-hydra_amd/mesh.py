@@ -87,3 +87,26 @@ def square4_mesh(start, end):
     p = np.array([[start, start], [end, start], [start, end], [end, end]], np.float64)
     t = np.array([[0, 1, 2], [1, 3, 2]], np.int64)
     return Mesh(p, t, float(end - start))
+
+
+def mask_mesh(mask, h0):
+    """Mesh of an arbitrary object mask: hex grid points inside the mask (eroded by h0/4) plus
+    Delaunay, triangles with centroid outside dropped.  A stand-in for the DistMesh initialisation
+    of the reference CLI (run_kalmanfilter.py:58-63), which is outside the hot path."""
+    from scipy import ndimage
+    m = np.asarray(mask) > 0
+    ys, xs = np.nonzero(m)
+    if len(xs) == 0:
+        raise ValueError("empty object mask")
+    dist = ndimage.distance_transform_edt(m)
+    pts = _hexgrid(xs.min(), ys.min(), xs.max(), ys.max(), h0)
+    inside_px = lambda q: ndimage.map_coordinates(dist, [q[:, 1], q[:, 0]], order=1, mode="constant", cval=0.0)
+    pts = pts[inside_px(pts) > 0.25 * h0]
+    # boundary points: contour pixels thinned to spacing ~h0
+    edge = np.column_stack(np.nonzero(m & (dist <= 1.0)))[:, ::-1].astype(float)
+    keep = []
+    for q in edge:
+        if all((q[0] - k[0]) ** 2 + (q[1] - k[1]) ** 2 >= (0.8 * h0) ** 2 for k in keep):
+            keep.append(q)
+    pts = np.vstack((np.array(keep).reshape(-1, 2), pts))
+    return _triangulate(pts, lambda c: inside_px(c) > 0.0, h0)

@@ -189,16 +189,22 @@ class Renderer:
                                          _lib.ptr(Hzc), _lib.ptr(HTH)), "hm_measure")
         return Hz.reshape(-1, 1), HTH, Hzc
 
-    def error(self, state, y_im, y_flow, y_m):
-        """reference renderer.py:485-501 -> (e_im, e_fx, e_fy, e_m, fx, fy)."""
+    def error(self, state, y_im, y_flow, y_m, want_flow=True):
+        """reference renderer.py:485-501 -> (e_im, e_fx, e_fy, e_m, fx, fy).
+
+        want_flow=False skips the device-to-host copy of the two rendered flow planes (the IEKF
+        loop only looks at the four sums); fx, fy are then None."""
         masked = self._masked_flag(y_im, y_flow, y_m)
         err = (ctypes.c_double * 4)()
-        fx = np.empty((self.ny, self.nx), np.float32)
-        fy = np.empty_like(fx)
+        fx = fy = None
+        if want_flow:
+            fx = np.empty((self.ny, self.nx), np.float32)
+            fy = np.empty_like(fx)
         _lib.check(_lib.lib().hm_error(self._h, _lib.ptr(self._X(state)), masked, err, _lib.ptr(fx), _lib.ptr(fy)),
                    "hm_error")
-        # the reference returns read_pixels arrays of shape (ny, nx, 1)
-        return int(err[0]), err[1], err[2], int(err[3]), fx[:, :, None], fy[:, :, None]
+        if want_flow:      # the reference returns read_pixels arrays of shape (ny, nx, 1)
+            fx, fy = fx[:, :, None], fy[:, :, None]
+        return int(err[0]), err[1], err[2], int(err[3]), fx, fy
 
 
 class DeviceObservation:

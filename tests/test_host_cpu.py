@@ -1,0 +1,271 @@
+"""Host logic of the product on the CPU: file format, input generators, meshes, filter
+algebra (with the measurement supplied by the oracle), sharding over two gloo ranks."""
+import os
+import struct
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import ekf_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- .mat wire format (reference src/optical_flow_ext.cpp:47-170) -----------------------
+def test_mat_format_bytes(hm, tmp_path):
+    from hydra_mi import matio
+    a = np.arange(12, dtype=np.float32).reshape(3, 4)
+    fn = str(tmp_path / "f_000_x.mat")
+    matio.write_mat(fn, a)
+    raw = open(fn, "rb").read()
+    assert struct.unpack("<iii", raw[:12]) == (5, 4, 3)          # CV_32FC1, width, height
+    assert raw[12:] == a.tobytes()
+    assert np.array_equal(matio.read_mat(fn), a)
+    d = np.arange(6, dtype=np.float64).reshape(2, 3)
+    fn2 = str(tmp_path / "d.mat")
+    matio.write_mat(fn2, d)
+    assert struct.unpack("<iii", open(fn2, "rb").read(12)) == (6, 3, 2)
+    assert np.array_equal(matio.read_mat(fn2), d)
+    with pytest.raises(ValueError):
+        matio.write_mat(fn2, np.zeros((2, 2), np.int32))
+    with pytest.raises(IOError):
+        matio.read_mat(str(tmp_path / "missing.mat"))
+
+
+def test_flowstream_reads_tool_output(hm, tmp_path):
+    from hydra_mi import matio
+    from hydra_mi.renderer import FlowStream
+    prefix = str(tmp_path / "flow")
+    for k in range(2):
+        matio.write_flow(prefix, k, np.full((4, 5), k + 0.5, np.float32), np.full((4, 5), -k, np.float32))
+    fs = FlowStream(prefix)
+    assert fs.isOpened()
+    ok, peeked = fs.peek()
+    ok, f0 = fs.read()
+    ok1, f1 = fs.read()
+    ok2, f2 = fs.read()
+    assert ok and ok1 and not ok2 and f2 is None
+    assert f0.shape == (4, 5, 2) and f0.dtype == np.float32 and np.array_equal(peeked, f0)
+    assert np.all(f1[:, :, 0] == 1.5) and np.all(f1[:, :, 1] == -1)
+
+
+# ---- input generators ---------------------------------------------------------------------
+def test_synth_test_data_matches_reference_layout(hm):
+    """reference synth.py:10-42 including its quirk: box rows [43,86) (flipped), flow rows [42,85)."""
+    from hydra_mi import synth
+    video, flow = synth.test_data(128, 128)
+    assert video.shape == (128, 128, 10) and flow.shape == (128, 128, 2, 10)
+    rows = np.nonzero(video[:, :, 0].any(axis=1))[0]
+    cols = np.nonzero(video[:, :, 0].any(axis=0))[0]
+    assert (rows.min(), rows.max(), cols.min(), cols.max()) == (43, 85, 42, 84)
+    assert set(np.unique(video[:, :, 0])) == {0, 128, 255}
+    f = np.nonzero(flow[:, :, 0, 0])
+    assert (f[0].min(), f[0].max(), f[1].min(), f[1].max()) == (42, 84, 42, 84)
+    assert np.all(flow[42:85, 42:85, :, 0] == -3)
+    # frame k is frame 0 moved up-left by 3k
+    assert np.array_equal(video[:-9, :-9, 3], video[9:, 9:, 0])
+    assert np.all(flow[33:76, 33:76, :, 3] == -3) and flow[:, :, :, 3].sum() == -3 * 2 * 43 * 43
+
+
+def test_flowfields_values(hm):
+    from hydra_mi import synth
+    assert synth.flowfields["translate_leftup"]((10.0, 20.0), 0) == (-1.5, -1.5)
+    assert synth.flowfields["rotate"]((300.0, 325.0), 0) == (-1.0, 0.0)
+    assert synth.flowfields["translate_leftup_stretch"]((600.0, 0.0), 0) == (1.0, -1.0)
+    vx, vy = synth.flowfields["warp"]((150.0, 450.0), 0)
+    assert abs(vx - (-(0.5 - 1) * 150 * (150 / 800. - 1) / 250.)) < 1e-12
+    f0, f1, tu, tv = synth.warp_pair(48, "translate_leftup", 0)
+    assert f0.dtype == np.uint8 and np.allclose(tu, -1.5 * 48 / 600)
+
+
+# ---- filter host logic with the oracle as measurement backend ---------------------------------
+class OracleRenderer:
+    """Duck-type of renderer.Renderer on top of oracle/ekf_ref (tests only)."""
+
+    def __init__(self, dm, tex, eps):
+        self.meas = ekf_ref.Measurement(dm.size(), dm.t, dm.p, tex, *eps)
+        self.force = None
+        self.J = ekf_ref.adjacency(dm.size(), dm.t)[1]
+
+    def setforce(self, f):
+        self.force = f
+
+    def update_frame(self, *a):
+        pass
+
+    def measure(self, state, y_im, y_flow, y_m, deltaX=2.0):
+        X = state.X.reshape(-1)
+        Hz, Hzc = ekf_ref.jacobian(self.meas, X, y_im, np.asarray(y_flow), y_m, deltaX)
+        return Hz, ekf_ref.hessian_sparse(self.meas, X, self.J, deltaX), Hzc
+
+    def error(self, state, y_im, y_flow, y_m, want_flow=True):
+        return self.meas.error(state.X.reshape(-1), y_im, np.asarray(y_flow), y_m)
+
+
+def _tiny_case(hm):
+    from hydra_mi import mesh, synth
+    video, flow = synth.test_data(48, 48)
+    dm = mesh.box_mesh(16.0, 17.0, 31.0, 32.0, 8.0)
+    return video, flow, dm
+
+
+def test_filter_host_logic_matches_oracle_tracker(hm):
+    from hydra_mi import kalman, mesh
+    video, flow, dm = _tiny_case(hm)
+    eps = (1e-3, 1.0, 1.0)
+    dm2 = mesh.Mesh(dm.p, dm.t, dm.h0)
+    kf = kalman.IteratedMSKalmanFilter(dm, video[:, :, 0], flow[:, :, :, 0], True, nI=2,
+                                       renderer=OracleRenderer(dm, video[:, :, 0], eps))
+    tr = ekf_ref.Tracker(dm2.p, dm2.t, dm2.bars, dm2.L, video[:, :, 0], nI=2)
+    assert kf.size() == 4 * dm.size() and kf.state.X.shape == (kf.size(), 1)
+    for k in (1, 2):
+        frame = video[:, :, k]
+        mask = (frame > 0).astype(np.uint8)
+        e = kf.compute(frame, flow[:, :, :, k], mask)
+        r = tr.compute(frame, flow[:, :, :, k], mask)
+        X, Xr = kf.state.X.reshape(-1), tr.X.reshape(-1)
+        assert np.linalg.norm(X - Xr) / np.linalg.norm(Xr) < 1e-9
+        assert np.linalg.norm(kf.state.W - tr.W) / np.linalg.norm(tr.W) < 1e-7
+        assert e[0] == r[0] and e[3] == r[3] and abs(e[1] - r[1]) < 1e-6 * max(1.0, r[1])
+        assert kf.niter == tr.niter
+
+
+def test_plain_and_iterated_filters(hm):
+    """KalmanFilter (:626-765) and IteratedKalmanFilter (:767-831) defaults and one step each."""
+    from hydra_mi import kalman
+    video, flow, dm = _tiny_case(hm)
+    frame, mask = video[:, :, 1], (video[:, :, 1] > 0).astype(np.uint8)
+    kf = kalman.KalmanFilter(dm, video[:, :, 0], flow[:, :, :, 0], True,
+                             renderer=OracleRenderer(dm, video[:, :, 0], (1e-3, 1e-3, 1e-3)))
+    assert (kf.state.eps_F, kf.state.eps_Z, kf.state.eps_J, kf.state.eps_M) == (1, 1e-3, 1e-3, 1e-3)
+    N = kf.N
+    X0, W0 = kf.state.X.copy(), kf.state.W.copy()
+    kf.predict()
+    F, Weps, _ = ekf_ref.initial_covariances(N, 1)
+    assert np.allclose(kf.state.X, F @ X0) and np.allclose(kf.state.W, F @ W0 @ F.T + Weps)
+    Xp, Wp = kf.state.X.copy(), kf.state.W.copy()
+    kf.update(frame, ekf_ref.mask_flow(flow[:, :, :, 1], mask), mask)
+    Xr, Wr = ekf_ref.kf_update(kf.state.renderer.meas, Xp, Wp, kf.state.J, frame,
+                               ekf_ref.mask_flow(flow[:, :, :, 1], mask), mask)
+    assert np.allclose(kf.state.X, Xr, rtol=1e-9, atol=1e-9) and np.allclose(kf.state.W, Wr, rtol=1e-7, atol=1e-12)
+    ikf = kalman.IteratedKalmanFilter(dm, video[:, :, 0], flow[:, :, :, 0], True,
+                                      renderer=OracleRenderer(dm, video[:, :, 0], (1e-3, 1e-3, 1e10)))
+    assert (ikf.nI, ikf.reltol, ikf.state.eps_F, ikf.state.eps_M) == (10, 1e-4, 1e-3, 1e10)
+    ms = kalman.IteratedMSKalmanFilter(dm, video[:, :, 0], flow[:, :, :, 0], True,
+                                       renderer=OracleRenderer(dm, video[:, :, 0], (1e-3, 1, 1)))
+    assert (ms.state.eps_F, ms.state.eps_J, ms.state.eps_M, ms.kappa, ms.deltat, ms.tol) == (1e-1, 1, 1, -1, 0.05, 1e-4)
+
+
+def test_mesh_inversion_rolls_back(hm):
+    """kalman.py:806-811: a step that flips a triangle is discarded, the last good state kept."""
+    from hydra_mi import kalman
+    video, flow, dm = _tiny_case(hm)
+
+    class Exploding(OracleRenderer):
+        def measure(self, state, y_im, y_flow, y_m, deltaX=2.0):
+            Hz, HTH, Hzc = OracleRenderer.measure(self, state, y_im, y_flow, y_m, deltaX)
+            Hz = Hz.copy()
+            Hz[0] = 1e9                                   # throws vertex 0 far away
+            return Hz, HTH, Hzc
+
+    kf = kalman.IteratedKalmanFilter(dm, video[:, :, 0], flow[:, :, :, 0], True,
+                                     renderer=Exploding(dm, video[:, :, 0], (1e-3, 1e-3, 1e10)))
+    X0, W0 = kf.state.X.copy(), kf.state.W.copy()
+    mask = (video[:, :, 0] > 0).astype(np.uint8)
+    kf.update(video[:, :, 0], flow[:, :, :, 0], mask)
+    assert kf.reverted and np.array_equal(kf.state.X, X0) and np.array_equal(kf.state.W, W0)
+
+
+def test_state_structure_and_partitions(hm):
+    from hydra_mi import kalman, mesh
+    dm = mesh.disk_mesh(31.5, 31.5, 22.0, 9.0)
+    tex = np.zeros((64, 64), np.uint8)
+    kf = kalman.KalmanFilter(dm, tex, np.zeros((64, 64, 2), np.float32), True,
+                             renderer=OracleRenderer(dm, tex, (1, 1, 1)))
+    st = kf.state
+    N = st.N
+    assert np.array_equal(st.vertices(), dm.p.astype(np.float32)) and np.all(st.velocities() == 0)
+    Jv, J = ekf_ref.adjacency(N, st.tri)
+    assert np.array_equal(st.Jv, Jv) and np.array_equal(st.J, J)
+    assert np.array_equal(st.K, ekf_ref.incidence(N, dm.bars))
+    assert np.all(st.ori != 0) and kalman.stats.meshpts == N
+    # every vertex in exactly one class, no two adjacent vertices share a class
+    allv = sorted(v for e in st.E for v in e)
+    assert allv == list(range(N))
+    for e in st.E:
+        for a in e:
+            for b in e:
+                assert a == b or Jv[a, b] == 0
+    assert st.labels.shape == (len(st.tri), len(st.E))
+    # pairs: Q lists every adjacent-or-equal pair once; each lands in exactly one class
+    assert len(st.Q) == int(np.triu(Jv).sum())
+    idx = sorted(int(i) for e in st.E_hessian_idx for i in e)
+    assert idx == list(range(len(st.Q)))
+    for pairs in st.E_hessian:
+        verts = [set(p) for p in pairs.tolist()]
+        for i in range(len(verts)):
+            for j in range(i + 1, len(verts)):
+                assert not any(Jv[a, b] for a in verts[i] for b in verts[j] if a != b) or verts[i] & verts[j] == set()
+
+
+def test_projectmask_pulls_outliers_back(hm):
+    from hydra_mi import kalman, mesh
+    dm = mesh.square4_mesh(20, 40)
+    tex = np.zeros((64, 64), np.uint8)
+    kf = kalman.KalmanFilter(dm, tex, np.zeros((64, 64, 2), np.float32), True,
+                             renderer=OracleRenderer(dm, tex, (1, 1, 1)))
+    mask = np.zeros((64, 64), np.uint8)
+    mask[20:41, 20:41] = 1
+    X0 = kf.state.X.copy()
+    kf.projectmask(mask)                                   # all vertices within 1 px: untouched
+    assert np.array_equal(kf.state.X, X0)
+    kf.state.X[0, 0] -= 6.0                                 # vertex 0 six pixels outside
+    Xo = ekf_ref.project_mask(kf.state.X, 4, mask)
+    kf.projectmask(mask)
+    assert np.allclose(kf.state.X, Xo)
+    assert kf.state.X[0, 0] > X0[0, 0] - 1.5 and kf.state.X[8, 0] > 0     # pulled back, velocity follows
+
+
+# ---- sharding over ranks (gloo, world_size 2) ---------------------------------------------------
+def _worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import hydra_mi  # noqa: F401
+    from hydra_mi import batch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 7
+    f0 = np.arange(n * 4 * 5, dtype=np.uint8).reshape(n, 4, 5)
+    f1 = f0 + 1
+
+    def fake_flow(a, b):
+        return torch.from_numpy(a.astype(np.float32) * 2 + rank * 0), torch.from_numpy(b.astype(np.float32) - 3)
+
+    u, v = batch.flow_batch_sharded(f0, f1, fake_flow)
+    ok = bool(torch.equal(u, torch.from_numpy(f0.astype(np.float32) * 2))
+              and torch.equal(v, torch.from_numpy(f1.astype(np.float32) - 3)))
+    mine = batch.shard(n, rank, world)
+    out.put((rank, ok, list(mine)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_batch_two_ranks_gloo(hm):
+    import torch.multiprocessing as mp
+    from hydra_mi import batch
+    assert [list(batch.shard(7, r, 2)) for r in range(2)] == [[0, 1, 2, 3], [4, 5, 6]]
+    assert sum(len(batch.shard(256, r, 8)) for r in range(8)) == 256 and len(batch.shard(256, 3, 8)) == 32
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res[0][1] and res[1][1]
+    assert res[0][2] == [0, 1, 2, 3] and res[1][2] == [4, 5, 6]

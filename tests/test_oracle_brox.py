@@ -1,0 +1,62 @@
+"""CPU checks of oracle/brox_ref.c: committed golden flows (regression), and the properties that
+anchor it where the reference holds no vectors (parity with OpenCV's Brox is UNPINNED, see the
+file header): zero flow for identical frames, recovery of integer translations, the analytic-field
+RMS protocol of reference test_flow.py:120-138."""
+import os
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_oracle_reproduces_golden(oracle_brox):
+    g = np.load(os.path.join(GOLD, "brox_small.npz"))
+    for n in (64, 96, 128):
+        u, v = oracle_brox.calc(g["f0_%d" % n], g["f1_%d" % n])
+        assert np.array_equal(u, g["u_%d" % n]) and np.array_equal(v, g["v_%d" % n])
+
+
+def test_thread_count_does_not_change_results(oracle_brox):
+    g = np.load(os.path.join(GOLD, "brox_small.npz"))
+    oracle_brox.set_threads(4)
+    try:
+        u, v = oracle_brox.calc(g["f0_64"], g["f1_64"])
+    finally:
+        oracle_brox.set_threads(1)
+    assert np.array_equal(u, g["u_64"]) and np.array_equal(v, g["v_64"])
+
+
+def test_levels_and_taps(oracle_brox):
+    lv = oracle_brox.levels(1024, 1024)
+    assert lv[0] == (1024, 1024) and lv[1] == (820, 820) and lv[-1] == (15, 15) and len(lv) == 20
+    assert oracle_brox.levels(1024, 1024, outer=3) == [(1024, 1024), (820, 820), (656, 656)]
+    g = oracle_brox.gauss(0.8)
+    assert len(g) == 5 and abs(g.sum() - 1) < 1e-6 and g[2] > 0.85
+
+
+def test_identical_frames_zero_flow(hm, oracle_brox):
+    from hydra_mi import synth
+    f0 = synth.warp_pair(64, "warp")[0]
+    u, v = oracle_brox.calc(f0, f0)
+    assert np.abs(u).max() == 0 and np.abs(v).max() == 0
+
+
+def test_integer_translation_is_recovered(hm, oracle_brox):
+    from hydra_mi import synth
+    tex = (synth.noise_texture(136, 0) / 255).astype(np.float32)
+    f0 = np.ascontiguousarray(tex[4:-4, 4:-4])
+    f1 = np.ascontiguousarray(tex[4:-4, 6:134])            # frame1(x - 2, y) = frame0(x, y)
+    u, v = oracle_brox.calc(f0, f1)
+    b = 16
+    assert np.abs(u[b:-b, b:-b] + 2).mean() < 0.02 and np.abs(v[b:-b, b:-b]).mean() < 0.02
+
+
+def test_rms_against_analytic_fields(hm, oracle_brox):
+    """test_flow.py protocol: RMS of (true - computed) over the object; here the whole interior."""
+    from hydra_mi import synth
+    for name, bound in [("translate_leftup", 0.12), ("translate_leftup_stretch", 0.12), ("warp", 0.12)]:
+        f0, f1, tu, tv = synth.warp_pair(128, name, 0)
+        u, v = oracle_brox.calc(f0, f1)
+        b = 16
+        r = np.sqrt(((u - tu) ** 2 + (v - tv) ** 2)[b:-b, b:-b].mean())
+        assert r < bound, (name, r)
