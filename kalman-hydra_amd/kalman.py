@@ -417,12 +417,16 @@ class KalmanFilter:
         outside this path); here it is the Euclidean distance transform of the mask, sampled
         bilinearly.  Steps, step size and the stale d / index set follow the reference."""
         p = self.state.vertices()
-        if y_m is None or _all_inside(y_m, p):
-            return                        # every vertex is inside the object: d <= 0, nothing to project
+        if y_m is None:
+            return
+        near = ~_inside(y_m, p)           # vertices whose four surrounding pixels are not all object
+        if not near.any():
+            return                        # d <= 0 everywhere: nothing to project
         fd = _mask_distance(y_m)
         ddeps = 1e-1
         p_orig = p.copy()
-        d = fd(p)
+        d = np.zeros(len(p))              # surely-inside vertices have d <= 0: never selected below
+        d[near] = fd(p[near])
         ix = d > 1
         for _ in range(10):
             if ix.any():
@@ -638,27 +642,71 @@ def _fwft(A, a, W):
     return out
 
 
-def _all_inside(y_m, p):
-    """True if the four pixels around every vertex belong to the mask (then its distance is <= 0)."""
+def _inside(y_m, p):
+    """Per vertex: do the four pixels around it all belong to the mask (then its distance is <= 0)."""
     m = np.asarray(y_m)
     H, W = m.shape
     x0 = np.floor(p[:, 0]).astype(int)
     y0 = np.floor(p[:, 1]).astype(int)
-    if x0.min() < 0 or y0.min() < 0 or x0.max() + 1 >= W or y0.max() + 1 >= H:
-        return False
-    return bool(np.all(m[y0, x0] > 0.5) and np.all(m[y0, x0 + 1] > 0.5) and np.all(m[y0 + 1, x0] > 0.5)
-                and np.all(m[y0 + 1, x0 + 1] > 0.5))
+    ok = (x0 >= 0) & (y0 >= 0) & (x0 + 1 < W) & (y0 + 1 < H)
+    xs, ys = np.clip(x0, 0, W - 2), np.clip(y0, 0, H - 2)
+    return ok & (m[ys, xs] > 0.5) & (m[ys, xs + 1] > 0.5) & (m[ys + 1, xs] > 0.5) & (m[ys + 1, xs + 1] > 0.5)
 
 
-def _mask_distance(y_m):
-    """Signed distance to the object outline: positive outside the mask, negative inside."""
+def _mask_distance(y_m, window=12):
+    """Signed distance to the object outline: positive outside the mask, negative inside,
+    sampled bilinearly (see projectmask).
+
+    The Euclidean distance transform of a whole 1024^2 mask costs tens of milliseconds per
+    frame, and only the few vertices near the outline ever ask.  The distance of a pixel is
+    therefore taken from the transform of a (2*window+1)^2 crop around the query whenever that
+    is provably the same number (the nearest pixel of the other kind lies inside the crop, i.e.
+    |d| < distance to the crop border); otherwise from the transform of the whole mask."""
     from scipy import ndimage
     m = np.asarray(y_m) > 0.5
+    H, W = m.shape
+    full = []
+
+    def full_dist():
+        if not full:
+            full.append(ndimage.distance_transform_edt(~m) - ndimage.distance_transform_edt(m))
+        return full[0]
+
     if not m.any():
         return lambda p: np.zeros(len(np.atleast_2d(p)))
-    dist = ndimage.distance_transform_edt(~m) - ndimage.distance_transform_edt(m)
+
+    def local(px, py):
+        """Exact signed distances of the 2x2 pixels whose top-left is (px, py), or None."""
+        x0, x1 = max(0, px - window), min(W, px + 2 + window)
+        y0, y1 = max(0, py - window), min(H, py + 2 + window)
+        c = m[y0:y1, x0:x1]
+        if c.all() or not c.any():
+            return None
+        d = ndimage.distance_transform_edt(~c) - ndimage.distance_transform_edt(c)
+        out = np.empty((2, 2))
+        for j in range(2):
+            for i in range(2):
+                yy, xx = min(max(py + j, 0), H - 1), min(max(px + i, 0), W - 1)
+                v = d[yy - y0, xx - x0]
+                # distance from the pixel to the crop border, ignoring borders that are image borders
+                room = min(xx - x0 if x0 > 0 else 1e9, x1 - 1 - xx if x1 < W else 1e9,
+                           yy - y0 if y0 > 0 else 1e9, y1 - 1 - yy if y1 < H else 1e9)
+                if abs(v) >= room:
+                    return None
+                out[j, i] = v
+        return out
 
     def fd(p):
-        p = np.atleast_2d(p)
-        return ndimage.map_coordinates(dist, [p[:, 1], p[:, 0]], order=1, mode="nearest")
+        p = np.atleast_2d(np.asarray(p, np.float64))
+        out = np.empty(len(p))
+        for k, (x, y) in enumerate(p):
+            xc, yc = min(max(x, 0.0), W - 1.0), min(max(y, 0.0), H - 1.0)      # mode="nearest"
+            px, py = int(np.floor(xc)), int(np.floor(yc))
+            q = local(px, py)
+            if q is None:
+                out[k] = ndimage.map_coordinates(full_dist(), [[y], [x]], order=1, mode="nearest")[0]
+                continue
+            ax, ay = xc - px, yc - py
+            out[k] = (1 - ay) * ((1 - ax) * q[0, 0] + ax * q[0, 1]) + ay * ((1 - ax) * q[1, 0] + ax * q[1, 1])
+        return out
     return fd
