@@ -31,6 +31,17 @@ SOR_BYTES_PER_PIXEL_ITERATION = 52.0      # 11 f32 fields read +
 HBM_PEAK_GBPS = 8000.0                    # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def pmc_traffic():
+    """HBM bytes per SOR launch from the committed PMC passes (profiles/r01_sor_pmc.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of the same 8-pair 1024^2 flow batch, FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes and as the k_add calibration in that file confirms)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_sor_pmc.json")) as f:
+            return float(json.load(f)["traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def make_video(n, frames, seed):
     from hydra_mi import synth
     video, masks, centre, radius = synth.disk_video(n, frames, "translate_leftup", seed)
@@ -193,7 +204,9 @@ def main():
                                       "ekf_predict": 1e3 * kf.predtime / K, "ekf_update": 1e3 * kf.updatetime / K,
                                       "iekf_iterations": iters / K},
             "roofline": {"bound": "hbm", "kernel": "k_sor", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": pmc_traffic() if (n == 1024 and B == 8) else None,
+                         "algorithmic_bytes_per_launch": SOR_BYTES_PER_PIXEL_ITERATION * sor_pxit / max(1, sor_launches),
                          "launches": sor_launches, "profiled": "last flow batch of the timed region", "avg_launch_us": 1e3 * sor_ms / max(1, sor_launches),
                          "bytes_per_pixel_iteration": SOR_BYTES_PER_PIXEL_ITERATION},
         }

@@ -155,6 +155,18 @@ int hm_error(hm_ctx_t h, const double *X, int masked, double err[4], float *fx, 
  * value because non-adjacent vertices have disjoint supports). */
 int hm_measure(hm_ctx_t h, const double *X, double deltaX, int masked,
                double *Hz, double *Hzc, double *HTH);
+/* The dense part of the update (kalman.py:753-755, 785-799) on the device, in information form:
+ *   begin : factor the prior covariance W (4N x 4N, symmetric positive definite) and keep
+ *           inv(W) and the prior mean X0 on the device;
+ *   step  : hm_measure at X, then  step = (inv(W) + HTH)^-1 (Hz - HTH (X0 - X))  by a blocked
+ *           Cholesky factorisation (the reference forms inv(inv(W) + HTH) explicitly and
+ *           multiplies); the new iterate is X0 + step.  Hzc (4N x 4, may be NULL) as hm_measure;
+ *   cov   : (inv(W) + HTH)^-1 of the last step (which = 0) or of the one before (which = 1,
+ *           what the reference keeps as W_old for its mesh-inversion rollback, kalman.py:806-811).
+ * A non-positive-definite system shows up as NaNs in `step`. */
+int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *X0);
+int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int masked, double *step, double *Hzc);
+int hm_update_cov(hm_ctx_t h, int which, double *W_out);
 int hm_ctx_sync(hm_ctx_t h);
 void *hm_ctx_stream(hm_ctx_t h);
 

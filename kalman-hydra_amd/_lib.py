@@ -59,6 +59,9 @@ SIGNATURES = {
     "hm_j": (ctypes.c_int, [c_vp, c_vp, ctypes.c_double, ctypes.c_int, ctypes.c_int, c_f64p]),
     "hm_error": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_f64p, c_vp, c_vp]),
     "hm_measure": (ctypes.c_int, [c_vp, c_vp, ctypes.c_double, ctypes.c_int, c_vp, c_vp, c_vp]),
+    "hm_update_begin": (ctypes.c_int, [c_vp, c_vp, c_vp]),
+    "hm_update_step": (ctypes.c_int, [c_vp, c_vp, ctypes.c_double, ctypes.c_int, c_vp, c_vp]),
+    "hm_update_cov": (ctypes.c_int, [c_vp, ctypes.c_int, c_vp]),
     "hm_ctx_sync": (ctypes.c_int, [c_vp]),
     "hm_ctx_stream": (c_vp, [c_vp]),
 }

@@ -3,6 +3,7 @@
 // (reduction kernels + PBO plumbing).
 #include "hm_common.h"
 #include "ekf_kernels.h"
+#include "dense_kernels.h"
 #include <algorithm>
 #include <cstring>
 #include <set>
@@ -31,6 +32,11 @@ struct hm_ctx {
     double *d_X, *d_out, *d_partial;
     uint8_t *d_im8, *d_m8;
     std::vector<double> X0;          // state of the reference render
+    // dense update on the device (n4 = 4N)
+    double *d_H, *d_Hz, *d_Hzc, *d_invW0, *d_Af[2], *d_rhs, *d_dx, *d_Wtmp;
+    std::vector<double> upd_X0;      // prior mean given to hm_update_begin
+    int upd_last, upd_prev;          // which d_Af holds the factor of the last / previous step (-1: none)
+    bool upd_open;
     std::vector<double> h_out, h_partial;
     int red_blocks;
 };
@@ -56,7 +62,8 @@ static int ctx_free(hm_ctx *h)
     if (!h) return HM_OK;
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_tri, h->d_star_off, h->d_star_tri, h->d_edges, h->d_uv, h->d_tex, h->d_yim, h->d_ym, h->d_yfx,
-                    h->d_yfy, h->d_yfxm, h->d_yfym, h->d_setup, h->d_X, h->d_out, h->d_partial, h->d_im8, h->d_m8};
+                    h->d_yfy, h->d_yfxm, h->d_yfym, h->d_setup, h->d_X, h->d_out, h->d_partial, h->d_im8, h->d_m8,
+                    h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_rhs, h->d_dx, h->d_Wtmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     free_targets(h->ref);
@@ -115,6 +122,8 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->d_yim = h->d_ym = nullptr; h->d_yfx = h->d_yfy = h->d_yfxm = h->d_yfym = nullptr;
     h->ref = Targets{nullptr, nullptr, nullptr, nullptr}; h->P = h->ref; h->Q = h->ref;
     h->d_setup = nullptr; h->d_X = h->d_out = h->d_partial = nullptr; h->d_im8 = h->d_m8 = nullptr;
+    h->d_H = h->d_Hz = h->d_Hzc = h->d_invW0 = h->d_Af[0] = h->d_Af[1] = h->d_rhs = h->d_dx = h->d_Wtmp = nullptr;
+    h->upd_last = h->upd_prev = -1; h->upd_open = false;
     for (const auto &e : eset) { h->edges.push_back(e.first); h->edges.push_back(e.second); }
     h->E = (int)eset.size();
     h->njobs = N + h->E;
@@ -142,6 +151,16 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_partial, (size_t)h->red_blocks * 4 * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_im8, n);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_m8, n);
+        const size_t n4 = (size_t)4 * N, nn = n4 * n4 * sizeof(double);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_H, nn);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_invW0, nn);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Af[0], nn);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Af[1], nn);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Wtmp, nn);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Hz, n4 * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Hzc, n4 * 4 * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_rhs, n4 * 4 * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_dx, n4 * sizeof(double));
         if (e != hipSuccess) {
             hm_set_error("hm_ctx_create: device allocation failed: %s", hipGetErrorString(e));
             rc = HM_ERR_HIP;
@@ -342,13 +361,9 @@ extern "C" int hm_error(hm_ctx_t h, const double *X, int masked, double err[4], 
     return collect4(h, err);
 }
 
-extern "C" int hm_measure(hm_ctx_t h, const double *X, double deltaX, int masked, double *Hz, double *Hzc, double *HTH)
+// render X as the reference, run the fused perturb-and-reduce kernel, unpack into d_H / d_Hz / d_Hzc
+static int measure_on_device(hm_ctx *h, const double *X, double deltaX, int masked)
 {
-    HM_ARG(h && X && Hz && HTH, "hm_measure: NULL argument");
-    HM_ARG(deltaX > 0, "hm_measure: deltaX must be positive");
-    NEED_TEX(h, "hm_measure");
-    NEED_OBS(h, "hm_measure");
-    HM_HIP(hipSetDevice(h->device));
     int rc = render_into(h, X, h->ref);
     if (rc) return rc;
     h->X0.assign(X, X + 4 * h->N);
@@ -362,68 +377,126 @@ extern "C" int hm_measure(hm_ctx_t h, const double *X, double deltaX, int masked
     a.delta = deltaX;
     a.out = h->d_out;
     hipLaunchKernelGGL(k_measure, dim3(h->njobs), dim3(MEAS_NT), 0, h->stream, a);
+    const size_t n4 = (size_t)4 * h->N;
+    HM_HIP(hipMemsetAsync(h->d_H, 0, n4 * n4 * sizeof(double), h->stream));
+    ScatterArgs s = {h->d_out, h->d_edges, h->N, h->E, h->eps_Z, h->eps_J, h->eps_M, deltaX, h->d_H, h->d_Hz, h->d_Hzc};
+    hipLaunchKernelGGL(k_hth_scatter, dim3(hm_cdiv(h->njobs, 64)), dim3(64), 0, h->stream, s);
     HM_HIP(hipGetLastError());
-    HM_HIP(hipMemcpyAsync(h->h_out.data(), h->d_out, h->h_out.size() * sizeof(double), hipMemcpyDeviceToHost,
-                          h->stream));
-    HM_HIP(hipStreamSynchronize(h->stream));
+    return HM_OK;
+}
 
-    const int N = h->N, n4 = 4 * N;
-    const double eZ = h->eps_Z, eJ = h->eps_J, eM = h->eps_M, d = deltaX;
-    memset(HTH, 0, (size_t)n4 * n4 * sizeof(double));
-    auto put = [&](int p, int q, double val) {
-        HTH[(size_t)p * n4 + q] = val / d / d;
-        HTH[(size_t)q * n4 + p] = val / d / d;
-    };
-    auto sum4 = [&](const double *s) { return ((s[0] / eZ + s[1] / eJ) + s[2] / eJ) + s[3] / eM; };
-    for (int v = 0; v < N; v++) {
-        const double *o = &h->h_out[(size_t)v * MEAS_OUT];
-        const int ix = 2 * v, iy = 2 * v + 1, ivx = 2 * N + 2 * v, ivy = 2 * N + 2 * v + 1;
-        // central differences of jz (kalman.py:499-515): component sums carry the sign of jz_CPU
-        const int idx[4] = {ix, iy, ivx, ivy};
-        double cp[4][4] = {{o[A_XP] / eZ, o[A_XP + 1] / eJ, -o[A_XP + 2] / eJ, o[A_XP + 3] / eM},
-                           {o[A_YP] / eZ, o[A_YP + 1] / eJ, -o[A_YP + 2] / eJ, o[A_YP + 3] / eM},
-                           {0, o[A_VXP] / eJ, 0, 0},
-                           {0, 0, -o[A_VYP] / eJ, 0}};
-        double cm[4][4] = {{o[A_XM] / eZ, o[A_XM + 1] / eJ, -o[A_XM + 2] / eJ, o[A_XM + 3] / eM},
-                           {o[A_YM] / eZ, o[A_YM + 1] / eJ, -o[A_YM + 2] / eJ, o[A_YM + 3] / eM},
-                           {0, o[A_VXM] / eJ, 0, 0},
-                           {0, 0, -o[A_VYM] / eJ, 0}};
-        for (int k = 0; k < 4; k++) {
-            double hp = ((cp[k][0] + cp[k][1]) + cp[k][2]) + cp[k][3];
-            double hm_ = ((cm[k][0] + cm[k][1]) + cm[k][2]) + cm[k][3];
-            Hz[idx[k]] = (hp / d - hm_ / d) / 2;
-            if (Hzc)
-                for (int ch = 0; ch < 4; ch++) Hzc[(size_t)idx[k] * 4 + ch] = (cp[k][ch] / d - cm[k][ch] / d) / 2;
-        }
-        put(ix, ix, sum4(o + A_XX));
-        put(ix, iy, sum4(o + A_XY));
-        put(iy, iy, sum4(o + A_YY));
-        put(ix, ivx, o[A_XVX] / eJ);
-        put(iy, ivx, o[A_YVX] / eJ);
-        put(ix, ivy, o[A_XVY] / eJ);
-        put(iy, ivy, o[A_YVY] / eJ);
-        put(ivx, ivx, o[A_VXVX] / eJ);
-        put(ivy, ivy, o[A_VYVY] / eJ);
+extern "C" int hm_measure(hm_ctx_t h, const double *X, double deltaX, int masked, double *Hz, double *Hzc, double *HTH)
+{
+    HM_ARG(h && X && Hz && HTH, "hm_measure: NULL argument");
+    HM_ARG(deltaX > 0, "hm_measure: deltaX must be positive");
+    NEED_TEX(h, "hm_measure");
+    NEED_OBS(h, "hm_measure");
+    HM_HIP(hipSetDevice(h->device));
+    int rc = measure_on_device(h, X, deltaX, masked);
+    if (rc) return rc;
+    const size_t n4 = (size_t)4 * h->N;
+    HM_HIP(hipMemcpyAsync(Hz, h->d_Hz, n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (Hzc) HM_HIP(hipMemcpyAsync(Hzc, h->d_Hzc, n4 * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HM_HIP(hipMemcpyAsync(HTH, h->d_H, n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HM_HIP(hipStreamSynchronize(h->stream));
+    return HM_OK;
+}
+
+// ---- the dense part of the update on the device ----------------------------------------------------
+static void chol_factor(hm_ctx *h, double *A, int n)
+{
+    const int nb = hm_cdiv(n, DNB);
+    for (int k = 0; k < nb; k++) {
+        hipLaunchKernelGGL(k_chol_panel, dim3(nb - k), dim3(64), 0, h->stream, A, n, k);
+        const int m = nb - k - 1;
+        if (m > 0) hipLaunchKernelGGL(k_chol_update, dim3(m, m), dim3(256), 0, h->stream, A, n, k);
     }
-    for (int e = 0; e < h->E; e++) {
-        const double *o = &h->h_out[(size_t)(N + e) * MEAS_OUT];
-        const int v = h->edges[2 * e], w = h->edges[2 * e + 1];
-        const int vx_ = 2 * v, vy_ = 2 * v + 1, vvx = 2 * N + 2 * v, vvy = 2 * N + 2 * v + 1;
-        const int wx_ = 2 * w, wy_ = 2 * w + 1, wvx = 2 * N + 2 * w, wvy = 2 * N + 2 * w + 1;
-        put(vx_, wx_, sum4(o + B_XX));
-        put(vx_, wy_, sum4(o + B_XY));
-        put(vy_, wx_, sum4(o + B_YX));
-        put(vy_, wy_, sum4(o + B_YY));
-        put(vx_, wvx, o[B_XVX] / eJ);
-        put(vy_, wvx, o[B_YVX] / eJ);
-        put(vvx, wx_, o[B_VXX] / eJ);
-        put(vvx, wy_, o[B_VXY] / eJ);
-        put(vvx, wvx, o[B_VXVX] / eJ);
-        put(vx_, wvy, o[B_XVY] / eJ);
-        put(vy_, wvy, o[B_YVY] / eJ);
-        put(vvy, wx_, o[B_VYX] / eJ);
-        put(vvy, wy_, o[B_VYY] / eJ);
-        put(vvy, wvy, o[B_VYVY] / eJ);
+}
+
+#define INV_CH 16
+static void chol_inverse(hm_ctx *h, const double *L, int n, double *out)
+{
+    hipLaunchKernelGGL((k_chol_solve<INV_CH, true>), dim3(hm_cdiv(n, INV_CH)), dim3(256),
+                       (size_t)n * INV_CH * sizeof(double), h->stream, L, n, out, n, n);
+}
+
+static void chol_solve4(hm_ctx *h, const double *L, int n, double *B, int ncols)   // B: n x 4 row-major
+{
+    hipLaunchKernelGGL((k_chol_solve<4, false>), dim3(1), dim3(256), (size_t)n * 4 * sizeof(double), h->stream, L, n,
+                       B, 4, ncols);
+}
+
+extern "C" int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *X0)
+{
+    HM_ARG(h && W_prior && X0, "hm_update_begin: NULL argument");
+    HM_HIP(hipSetDevice(h->device));
+    const int n4 = 4 * h->N;
+    static bool attr_done = false;
+    if (!attr_done) {            // the inverse keeps an n x 16 slab of doubles in LDS (> 64 KiB default cap)
+        HM_HIP(hipFuncSetAttribute((const void *)k_chol_solve<INV_CH, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   120 * 1024));
+        attr_done = true;
     }
+    HM_ARG((size_t)n4 * INV_CH * sizeof(double) <= 120 * 1024, "hm_update_begin: state dimension %d too large for the "
+           "on-device inverse (limit %d)", n4, (int)(120 * 1024 / (INV_CH * sizeof(double))));
+    HM_HIP(hipMemcpyAsync(h->d_Af[0], W_prior, (size_t)n4 * n4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    chol_factor(h, h->d_Af[0], n4);
+    chol_inverse(h, h->d_Af[0], n4, h->d_invW0);
+    HM_HIP(hipGetLastError());
+    h->upd_X0.assign(X0, X0 + n4);
+    h->upd_last = h->upd_prev = -1;
+    h->upd_open = true;
+    return HM_OK;
+}
+
+extern "C" int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int masked, double *step, double *Hzc)
+{
+    HM_ARG(h && X && step, "hm_update_step: NULL argument");
+    HM_ARG(deltaX > 0, "hm_update_step: deltaX must be positive");
+    if (!h->upd_open) { hm_set_error("hm_update_step: hm_update_begin has not been called"); return HM_ERR_STATE; }
+    NEED_TEX(h, "hm_update_step");
+    NEED_OBS(h, "hm_update_step");
+    HM_HIP(hipSetDevice(h->device));
+    const int n4 = 4 * h->N;
+    int rc = measure_on_device(h, X, deltaX, masked);
+    if (rc) return rc;
+    std::vector<double> dx(n4);
+    for (int i = 0; i < n4; i++) dx[i] = h->upd_X0[i] - X[i];
+    HM_HIP(hipMemcpyAsync(h->d_dx, dx.data(), (size_t)n4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HM_HIP(hipStreamSynchronize(h->stream));        // dx is a local
+    const int slot = h->upd_last == 0 ? 1 : 0;
+    double *A = h->d_Af[slot];
+    const size_t nn = (size_t)n4 * n4;
+    hipLaunchKernelGGL(k_add_mat, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, h->d_invW0, h->d_H, A, nn);
+    // rhs column 0 = Hz - H (X0 - X); columns 1..3 unused
+    HM_HIP(hipMemsetAsync(h->d_rhs, 0, (size_t)n4 * 4 * sizeof(double), h->stream));
+    hipLaunchKernelGGL(k_rhs, dim3(n4), dim3(256), 0, h->stream, h->d_H, h->d_dx, h->d_Hz, h->d_Wtmp, n4);
+    HM_HIP(hipMemcpy2DAsync(h->d_rhs, 4 * sizeof(double), h->d_Wtmp, sizeof(double), sizeof(double), n4,
+                            hipMemcpyDeviceToDevice, h->stream));
+    chol_factor(h, A, n4);
+    chol_solve4(h, A, n4, h->d_rhs, 1);
+    HM_HIP(hipGetLastError());
+    HM_HIP(hipMemcpy2DAsync(step, sizeof(double), h->d_rhs, 4 * sizeof(double), sizeof(double), n4,
+                            hipMemcpyDeviceToHost, h->stream));
+    if (Hzc) HM_HIP(hipMemcpyAsync(Hzc, h->d_Hzc, (size_t)n4 * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HM_HIP(hipStreamSynchronize(h->stream));
+    h->upd_prev = h->upd_last;
+    h->upd_last = slot;
+    return HM_OK;
+}
+
+extern "C" int hm_update_cov(hm_ctx_t h, int which, double *W_out)
+{
+    HM_ARG(h && W_out, "hm_update_cov: NULL argument");
+    HM_ARG(which == 0 || which == 1, "hm_update_cov: which must be 0 (last step) or 1 (the step before)");
+    if (!h->upd_open) { hm_set_error("hm_update_cov: hm_update_begin has not been called"); return HM_ERR_STATE; }
+    const int slot = which == 0 ? h->upd_last : h->upd_prev;
+    if (slot < 0) { hm_set_error("hm_update_cov: no such step"); return HM_ERR_STATE; }
+    HM_HIP(hipSetDevice(h->device));
+    const int n4 = 4 * h->N;
+    chol_inverse(h, h->d_Af[slot], n4, h->d_Wtmp);
+    HM_HIP(hipGetLastError());
+    HM_HIP(hipMemcpyAsync(W_out, h->d_Wtmp, (size_t)n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HM_HIP(hipStreamSynchronize(h->stream));
     return HM_OK;
 }

@@ -537,3 +537,81 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure(MeasureArgs a)
     }
     d_block_reduce<MEAS_OUT, MEAS_NT>(acc, s_red, a.out + (size_t)job * MEAS_OUT);
 }
+
+
+// ---- job sums -> Hz, Hz components, dense HTH (device twin of the unpacking in KFState.update) -------
+// One thread per job; every entry of H is written by exactly one job (vertex jobs own the diagonal
+// 4x4 blocks, edge jobs the two mirrored off-diagonal ones), so plain stores suffice.  H must be zero.
+struct ScatterArgs {
+    const double *out;        // njobs * MEAS_OUT
+    const int *edges;
+    int N, E;
+    double eZ, eJ, eM, d;
+    double *H, *Hz, *Hzc;     // 4N x 4N, 4N, 4N x 4
+};
+
+__device__ __forceinline__ void d_put(double *H, int n4, int p, int q, double val, double d)
+{
+    const double v = val / d / d;
+    H[(size_t)p * n4 + q] = v;
+    H[(size_t)q * n4 + p] = v;
+}
+
+__global__ void k_hth_scatter(ScatterArgs a)
+{
+    const int job = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = a.N, n4 = 4 * N;
+    if (job >= N + a.E) return;
+    const double *o = a.out + (size_t)job * MEAS_OUT;
+    const double eZ = a.eZ, eJ = a.eJ, eM = a.eM, d = a.d;
+#define SUM4(s) ((((s)[0] / eZ + (s)[1] / eJ) + (s)[2] / eJ) + (s)[3] / eM)
+    if (job < N) {
+        const int v = job;
+        const int idx[4] = {2 * v, 2 * v + 1, 2 * N + 2 * v, 2 * N + 2 * v + 1};
+        // central differences of jz (kalman.py:499-515); component sums carry the sign of jz_CPU
+        const double cp[4][4] = {{o[A_XP] / eZ, o[A_XP + 1] / eJ, -o[A_XP + 2] / eJ, o[A_XP + 3] / eM},
+                                 {o[A_YP] / eZ, o[A_YP + 1] / eJ, -o[A_YP + 2] / eJ, o[A_YP + 3] / eM},
+                                 {0.0, o[A_VXP] / eJ, 0.0, 0.0},
+                                 {0.0, 0.0, -o[A_VYP] / eJ, 0.0}};
+        const double cm[4][4] = {{o[A_XM] / eZ, o[A_XM + 1] / eJ, -o[A_XM + 2] / eJ, o[A_XM + 3] / eM},
+                                 {o[A_YM] / eZ, o[A_YM + 1] / eJ, -o[A_YM + 2] / eJ, o[A_YM + 3] / eM},
+                                 {0.0, o[A_VXM] / eJ, 0.0, 0.0},
+                                 {0.0, 0.0, -o[A_VYM] / eJ, 0.0}};
+        for (int k = 0; k < 4; k++) {
+            const double hp = ((cp[k][0] + cp[k][1]) + cp[k][2]) + cp[k][3];
+            const double hm_ = ((cm[k][0] + cm[k][1]) + cm[k][2]) + cm[k][3];
+            a.Hz[idx[k]] = (hp / d - hm_ / d) / 2;
+            for (int ch = 0; ch < 4; ch++) a.Hzc[(size_t)idx[k] * 4 + ch] = (cp[k][ch] / d - cm[k][ch] / d) / 2;
+        }
+        const int ix = idx[0], iy = idx[1], ivx = idx[2], ivy = idx[3];
+        d_put(a.H, n4, ix, ix, SUM4(o + A_XX), d);
+        d_put(a.H, n4, ix, iy, SUM4(o + A_XY), d);
+        d_put(a.H, n4, iy, iy, SUM4(o + A_YY), d);
+        d_put(a.H, n4, ix, ivx, o[A_XVX] / eJ, d);
+        d_put(a.H, n4, iy, ivx, o[A_YVX] / eJ, d);
+        d_put(a.H, n4, ix, ivy, o[A_XVY] / eJ, d);
+        d_put(a.H, n4, iy, ivy, o[A_YVY] / eJ, d);
+        d_put(a.H, n4, ivx, ivx, o[A_VXVX] / eJ, d);
+        d_put(a.H, n4, ivy, ivy, o[A_VYVY] / eJ, d);
+    } else {
+        const int e = job - N;
+        const int v = a.edges[2 * e], w = a.edges[2 * e + 1];
+        const int vx_ = 2 * v, vy_ = 2 * v + 1, vvx = 2 * N + 2 * v, vvy = 2 * N + 2 * v + 1;
+        const int wx_ = 2 * w, wy_ = 2 * w + 1, wvx = 2 * N + 2 * w, wvy = 2 * N + 2 * w + 1;
+        d_put(a.H, n4, vx_, wx_, SUM4(o + B_XX), d);
+        d_put(a.H, n4, vx_, wy_, SUM4(o + B_XY), d);
+        d_put(a.H, n4, vy_, wx_, SUM4(o + B_YX), d);
+        d_put(a.H, n4, vy_, wy_, SUM4(o + B_YY), d);
+        d_put(a.H, n4, vx_, wvx, o[B_XVX] / eJ, d);
+        d_put(a.H, n4, vy_, wvx, o[B_YVX] / eJ, d);
+        d_put(a.H, n4, vvx, wx_, o[B_VXX] / eJ, d);
+        d_put(a.H, n4, vvx, wy_, o[B_VXY] / eJ, d);
+        d_put(a.H, n4, vvx, wvx, o[B_VXVX] / eJ, d);
+        d_put(a.H, n4, vx_, wvy, o[B_XVY] / eJ, d);
+        d_put(a.H, n4, vy_, wvy, o[B_YVY] / eJ, d);
+        d_put(a.H, n4, vvy, wx_, o[B_VYX] / eJ, d);
+        d_put(a.H, n4, vvy, wy_, o[B_VYY] / eJ, d);
+        d_put(a.H, n4, vvy, wvy, o[B_VYVY] / eJ, d);
+    }
+#undef SUM4
+}

@@ -440,12 +440,20 @@ class KalmanFilter:
         self.state.X[2 * self.N:] += (p - p_orig).reshape(-1, 1)
 
     def update(self, y_im, y_flow, y_m):
-        """Single EKF step in information form (:745-761)."""
+        """Single EKF step in information form (:745-761): W = inv(inv(W) + HTH), X += W Hz."""
         st = self.state
         X, W = st.X, st.W
-        Hz, HTH, Hzc = st.update(y_im, y_flow, y_m)
-        Wn = np.linalg.inv(np.linalg.inv(W) + HTH)
-        st.X = X + Wn.dot(Hz)
+        if hasattr(st.renderer, "update_step"):
+            st.renderer.update_begin(W, X)
+            step, Hzc = st.renderer.update_step(st, y_im, y_flow, y_m)     # X0 - X = 0: step = W_new Hz
+            if not np.all(np.isfinite(step)):
+                raise FloatingPointError("information matrix of the update is not positive definite")
+            Wn = st.renderer.update_cov(0)
+            st.X = X + step
+        else:
+            Hz, HTH, Hzc = st.update(y_im, y_flow, y_m)
+            Wn = _spd_inverse(_spd_inverse(W) + HTH)
+            st.X = X + Wn.dot(Hz)
         st.W = Wn
         self.tv = Wn.dot(Hzc[:, 0])
         self.fv = Wn.dot(Hzc[:, 1] + Hzc[:, 2])
@@ -467,26 +475,43 @@ class IteratedKalmanFilter(KalmanFilter):
         """Iterated EKF in information form (:774-831).
 
         Per iteration the reference forms W = inv(invW0 + HTH) and
-        X = X0 + W Hz - W HTH (X0 - X).  Only W (Hz - HTH (X0 - X)) is needed to move the
-        state, so each iteration factorises invW0 + HTH once and solves; the covariance is
-        formed for the state that is kept (the last accepted one)."""
+        X = X0 + W Hz - W HTH (X0 - X).  Only W (Hz - HTH (X0 - X)) is needed to move the state,
+        so each iteration factorises invW0 + HTH once (Cholesky) and solves; the covariance is
+        formed for the state that is kept (the last accepted one).  With the HIP renderer the
+        factorisations run on the device (hm_update_begin / _step / _cov) and only the 4N-vector
+        of the step crosses PCIe per iteration."""
         st = self.state
+        on_device = hasattr(st.renderer, "update_step")
         X = st.X
         X_orig, X_old = X.copy(), X.copy()
         W_old = st.W
-        invW_orig = _spd_inverse(st.W)
-        A_old = None                     # information matrix of X_old; None = still the prior
+        if on_device:
+            st.renderer.update_begin(st.W, X_orig)
+        else:
+            invW_orig = _spd_inverse(st.W)
+        A = A_old = None                 # host path: information matrices of X and X_old (None = the prior)
+        accepted = 0                     # iterations whose state was kept
         eold = 0.0
         conv = False
         reverted = False
-        A = None
         Hzc = np.zeros((st.size(), 4))
         self.niter = 0
         for i in range(self.nI):
             self._say("   IEKF K = %d" % i)
-            Hz, HTH, Hzc = st.update(y_im, y_flow, y_m)
-            A = invW_orig + HTH
-            X = X_orig + _factor_solve(_spd_factor(A), Hz - HTH.dot(X_orig - X))
+            t0 = time.time()
+            step = None
+            if on_device:
+                step, Hzc = st.renderer.update_step(st, y_im, y_flow, y_m)
+                if not np.all(np.isfinite(step)):
+                    raise FloatingPointError("information matrix of the update is not positive definite")
+                dt = time.time() - t0
+                stats.stateupdatetc[0] += dt
+                stats.stateupdatetc[1] += 1
+            else:
+                Hz, HTH, Hzc = st.update(y_im, y_flow, y_m)
+                A = invW_orig + HTH
+                step = _factor_solve(_spd_factor(A), Hz - HTH.dot(X_orig - X))
+            X = X_orig + step
             st.X = X
             self.niter += 1
             st.update_orientation()
@@ -499,6 +524,7 @@ class IteratedKalmanFilter(KalmanFilter):
             e_im, e_fx, e_fy, e_m, _, _ = st.renderer.error(st, y_im, y_flow, y_m, want_flow=False)
             enew = float(np.sqrt(float(e_im) ** 2 + e_fx ** 2 + e_fy ** 2 + float(e_m) ** 2))
             self._say("-- e_im: %d, e_fx: %d, e_fy: %d, e_m: %d" % (e_im, e_fx, e_fy, e_m))
+            accepted += 1
             if abs(enew - eold) / enew < self.reltol:
                 conv = True
                 break
@@ -506,7 +532,13 @@ class IteratedKalmanFilter(KalmanFilter):
             X_old = X.copy()
             A_old = A
         stats.niter += self.niter
-        st.W = W_old if A is None else _spd_inverse(A)
+        if on_device:
+            if reverted:
+                st.W = W_old if accepted == 0 else st.renderer.update_cov(1)
+            else:
+                st.W = W_old if self.niter == 0 else st.renderer.update_cov(0)
+        else:
+            st.W = W_old if A is None else _spd_inverse(A)
         self.reverted = reverted
         Wd = st.W
         self.tv = Wd.dot(Hzc[:, 0])
@@ -619,11 +651,39 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
                 g = xp - x - dt * np.vstack((v, f.reshape(-1, 1) / M))
                 A = self._jacobian() * (dt / M)
                 g1, g2 = g[:n2], g[n2:]
-                s1 = spla.spsolve((eye - dt * A).tocsc(), g1 + dt * g2).reshape(-1, 1)
+                s1 = _solve_near_identity(eye - dt * A, g1 + dt * g2)
                 s2 = g2 + A.dot(s1)
                 xp = xp - np.vstack((s1, s2))
                 st.X = xp
                 n += 1
+
+
+def _solve_near_identity(S, b):
+    """Solve S s = b for S = I - dt^2/M dfdy: symmetric, eigenvalues within a few percent of 1
+    (dt^2 = 0.0025 times a spring Jacobian of norm ~ 2 x vertex degree), so conjugate gradients
+    reach the rounding floor in about ten sparse products; a sparse direct solve takes over if
+    they do not."""
+    b = np.asarray(b, np.float64).reshape(-1)
+    bn = np.linalg.norm(b)
+    if bn == 0.0:
+        return np.zeros((b.size, 1))
+    x = b.copy()                                   # S ~ I: b is already a good guess
+    r = b - S.dot(x)
+    p = r.copy()
+    rs = float(r.dot(r))
+    for _ in range(60):
+        if np.sqrt(rs) <= 1e-15 * bn:
+            return x.reshape(-1, 1)
+        Sp = S.dot(p)
+        alpha = rs / float(p.dot(Sp))
+        x += alpha * p
+        r -= alpha * Sp
+        rs_new = float(r.dot(r))
+        p = r + (rs_new / rs) * p
+        rs = rs_new
+    if np.sqrt(rs) <= 1e-13 * bn:
+        return x.reshape(-1, 1)
+    return spla.spsolve(S.tocsc(), b).reshape(-1, 1)
 
 
 def _fwft(A, a, W):

@@ -189,6 +189,29 @@ class Renderer:
                                          _lib.ptr(Hzc), _lib.ptr(HTH)), "hm_measure")
         return Hz.reshape(-1, 1), HTH, Hzc
 
+    # -- the dense update on the device (information form) --------------------------------------
+    def update_begin(self, W_prior, X0):
+        """Factor the prior covariance on the device and keep inv(W), X0 there (hm_update_begin)."""
+        W = np.ascontiguousarray(W_prior, np.float64)
+        x0 = np.ascontiguousarray(np.asarray(X0, np.float64).reshape(-1))
+        _lib.check(_lib.lib().hm_update_begin(self._h, _lib.ptr(W), _lib.ptr(x0)), "hm_update_begin")
+
+    def update_step(self, state, y_im, y_flow, y_m, deltaX=2.0):
+        """hm_update_step: measurement at state.X and the solve, -> (step [4N,1], Hz_components [4N,4])."""
+        masked = self._masked_flag(y_im, y_flow, y_m)
+        n4 = 4 * self.n
+        step = np.empty(n4)
+        Hzc = np.empty((n4, 4))
+        _lib.check(_lib.lib().hm_update_step(self._h, _lib.ptr(self._X(state)), float(deltaX), masked,
+                                             _lib.ptr(step), _lib.ptr(Hzc)), "hm_update_step")
+        return step.reshape(-1, 1), Hzc
+
+    def update_cov(self, which=0):
+        n4 = 4 * self.n
+        W = np.empty((n4, n4))
+        _lib.check(_lib.lib().hm_update_cov(self._h, int(which), _lib.ptr(W)), "hm_update_cov")
+        return W
+
     def error(self, state, y_im, y_flow, y_m, want_flow=True):
         """reference renderer.py:485-501 -> (e_im, e_fx, e_fy, e_m, fx, fy).
 

@@ -208,3 +208,54 @@ def test_state_errors_are_loud(hm):
         renderer.Renderer(dm, np.zeros((4, 2)), np.zeros((64, 64, 2), np.float32), 64, tex, False, 1, 1, 1)
     with pytest.raises(RuntimeError):
         renderer.Renderer(dm, np.zeros((4, 2)), np.zeros((64, 64, 2), np.float32), 64, tex, True, 0.0, 1, 1)
+
+
+@pytest.mark.parametrize("n,h0", [(64, 11.0), (96, 9.0)])
+def test_device_dense_update_matches_host_algebra(hm, n, h0):
+    """hm_update_begin/_step/_cov (blocked Cholesky on the device) against numpy on the host:
+    step = (inv(W) + HTH)^-1 (Hz - HTH (X0 - X)), cov = (inv(W) + HTH)^-1."""
+    dm, N, tex, R, meas = _setup(hm, n, h0, seed=6)
+    rng = np.random.default_rng(11)
+    X = _state(dm, rng, pos_sigma=0.5)
+    X0 = X + rng.normal(0, 0.3, X.size)
+    y_im, flow, y_m = _observation(dm, meas, rng, n)
+    n4 = 4 * N
+    M = rng.normal(size=(n4, n4))
+    W = np.eye(n4) * 0.5 + 0.05 * (M @ M.T) / n4
+    st = _Flow()
+    st.X = X.reshape(-1, 1)
+    Hz, HTH, Hzc = R.measure(st, y_im, flow, y_m)
+    R.update_begin(W, X0)
+    step, Hzc2 = R.update_step(st, y_im, flow, y_m)
+    A = np.linalg.inv(W) + HTH
+    ref = np.linalg.solve(A, Hz - HTH @ (X0 - X).reshape(-1, 1))
+    assert np.array_equal(Hzc, Hzc2)
+    assert np.linalg.norm(step - ref) <= 1e-9 * np.linalg.norm(ref)
+    cov = R.update_cov(0)
+    assert np.linalg.norm(cov - np.linalg.inv(A)) <= 1e-9 * np.linalg.norm(np.linalg.inv(A))
+    # a second step keeps the first factor available as "the one before"
+    st.X = (X + 0.1).reshape(-1, 1)
+    Hz2, HTH2, _ = R.measure(st, y_im, flow, y_m)
+    step2, _ = R.update_step(st, y_im, flow, y_m)
+    A2 = np.linalg.inv(W) + HTH2
+    ref2 = np.linalg.solve(A2, Hz2 - HTH2 @ (X0 - st.X.reshape(-1)).reshape(-1, 1))
+    assert np.linalg.norm(step2 - ref2) <= 1e-9 * np.linalg.norm(ref2)
+    assert np.linalg.norm(R.update_cov(1) - np.linalg.inv(A)) <= 1e-9 * np.linalg.norm(np.linalg.inv(A))
+    assert np.linalg.norm(R.update_cov(0) - np.linalg.inv(A2)) <= 1e-9 * np.linalg.norm(np.linalg.inv(A2))
+
+
+def test_plain_kalman_filter_update_on_device(hm):
+    """KalmanFilter.update (kalman.py:745-761) through the device path against the oracle."""
+    from hydra_mi import kalman, mesh, synth
+    video, flow = synth.test_data(64, 64)
+    dm = mesh.box_mesh(21.0, 22.0, 42.0, 43.0, 10.0)
+    kf = kalman.KalmanFilter(dm, video[:, :, 0], flow[:, :, :, 0], True)
+    tr_meas = ekf_ref.Measurement(dm.size(), kf.state.tri, dm.p, video[:, :, 0], 1e-3, 1e-3, 1e-3)
+    frame, mask = video[:, :, 1], (video[:, :, 1] > 0).astype(np.uint8)
+    kf.predict()
+    Xp, Wp = kf.state.X.copy(), kf.state.W.copy()
+    fm = ekf_ref.mask_flow(flow[:, :, :, 1], mask)
+    kf.update(frame, fm, mask)
+    Xr, Wr = ekf_ref.kf_update(tr_meas, Xp, Wp, kf.state.J, frame, fm, mask)
+    assert np.linalg.norm(kf.state.X - Xr) <= 1e-8 * np.linalg.norm(Xr)
+    assert np.linalg.norm(kf.state.W - Wr) <= 1e-7 * np.linalg.norm(Wr)
