@@ -167,6 +167,11 @@ int hm_measure(hm_ctx_t h, const double *X, double deltaX, int masked,
 int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *X0);
 int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int masked, double *step, double *Hzc);
 int hm_update_cov(hm_ctx_t h, int which, double *W_out);
+/* IteratedMSKalmanFilter._newton (kalman.py:923-960): the mass-spring state prediction, ceil(1/dt)
+ * implicit-Euler sub-steps each solved by Newton's method.  Host code, no GPU involved.
+ * bars: I*2 vertex ids (distmesh.bars), l0: rest lengths; X: 4N doubles, advanced in place. */
+int hm_ms_newton(int n_vertices, int n_bars, const int32_t *bars, const double *l0, double kappa, double M,
+                 double dt, int maxiter, double tol, double *X, int *newton_iterations);
 int hm_ctx_sync(hm_ctx_t h);
 void *hm_ctx_stream(hm_ctx_t h);
 

@@ -407,7 +407,7 @@ static void chol_factor(hm_ctx *h, double *A, int n)
 {
     const int nb = hm_cdiv(n, DNB);
     for (int k = 0; k < nb; k++) {
-        hipLaunchKernelGGL(k_chol_panel, dim3(nb - k), dim3(64), 0, h->stream, A, n, k);
+        hipLaunchKernelGGL(k_chol_panel, dim3(nb - k), dim3(256), 0, h->stream, A, n, k);
         const int m = nb - k - 1;
         if (m > 0) hipLaunchKernelGGL(k_chol_update, dim3(m, m), dim3(256), 0, h->stream, A, n, k);
     }
@@ -431,14 +431,19 @@ extern "C" int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *
     HM_ARG(h && W_prior && X0, "hm_update_begin: NULL argument");
     HM_HIP(hipSetDevice(h->device));
     const int n4 = 4 * h->N;
-    static bool attr_done = false;
-    if (!attr_done) {            // the inverse keeps an n x 16 slab of doubles in LDS (> 64 KiB default cap)
+    // the inverse keeps an n x 16 slab of doubles in LDS next to its static buffers: raise the
+    // dynamic-LDS cap of that kernel to what is left of the CU's 160 KiB
+    static size_t inv_lds_cap = 0;
+    if (inv_lds_cap == 0) {
+        hipFuncAttributes fa;
+        HM_HIP(hipFuncGetAttributes(&fa, (const void *)k_chol_solve<INV_CH, true>));
+        const size_t cap = 160 * 1024 - fa.sharedSizeBytes - 1024;
         HM_HIP(hipFuncSetAttribute((const void *)k_chol_solve<INV_CH, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   120 * 1024));
-        attr_done = true;
+                                   (int)cap));
+        inv_lds_cap = cap;
     }
-    HM_ARG((size_t)n4 * INV_CH * sizeof(double) <= 120 * 1024, "hm_update_begin: state dimension %d too large for the "
-           "on-device inverse (limit %d)", n4, (int)(120 * 1024 / (INV_CH * sizeof(double))));
+    HM_ARG((size_t)n4 * INV_CH * sizeof(double) <= inv_lds_cap, "hm_update_begin: state dimension %d too large for "
+           "the on-device inverse (limit %d)", n4, (int)(inv_lds_cap / (INV_CH * sizeof(double))));
     HM_HIP(hipMemcpyAsync(h->d_Af[0], W_prior, (size_t)n4 * n4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     chol_factor(h, h->d_Af[0], n4);
     chol_inverse(h, h->d_Af[0], n4, h->d_invW0);

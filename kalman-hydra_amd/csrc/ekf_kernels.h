@@ -292,31 +292,46 @@ struct StarTopo {
 };
 
 // value of one pixel of the star of vertex `v` in one configuration: sum over the star's
-// triangles of texel / vx / -vy / coverage.  vxo, vyo override the velocity attributes of v.
+// triangles of texel / vx / -vy / coverage.
 struct StarVal {
     int acc, cnt;
     float fx, fy;
 };
 
+// In the reference configuration the four velocity perturbations of v (vx +- d, vy +- d) leave the
+// geometry alone: the same covering triangles, the same barycentrics, only the attribute of v differs.
+// They are therefore evaluated in the same pass (fxp/fxm: star sum of vx with vx_v +- d, fyp/fym
+// likewise for -vy), with the very expression a full render would use.
+struct StarVel {
+    float fxp, fxm, fyp, fym;
+};
+
+template <bool VEL>
 __device__ __forceinline__ StarVal d_star_eval(const TriSetup *__restrict__ cfg, int ns, int c, int r, const Mesh &m,
-                                               const double *__restrict__ X, int v, float vxo, float nvyo)
+                                               const double *__restrict__ X, int v, float vxp, float vxm, float nvyp,
+                                               float nvym, StarVel &vel)
 {
     StarVal s = {0, 0, 0.0f, 0.0f};
+    if (VEL) { vel.fxp = 0.0f; vel.fxm = 0.0f; vel.fyp = 0.0f; vel.fym = 0.0f; }
     const int N = m.N;
     for (int k = 0; k < ns; k++) {
         float l1, l2;
         if (!d_tri_eval(cfg[k], c, r, l1, l2)) continue;
         const TriSetup &t = cfg[k];
         s.acc += d_texel(m.tex, m.uv, t, l1, l2, m.W, m.H);
-        float a0 = t.i0 == v ? vxo : (float)X[2 * N + 2 * t.i0];
-        float a1 = t.i1 == v ? vxo : (float)X[2 * N + 2 * t.i1];
-        float a2 = t.i2 == v ? vxo : (float)X[2 * N + 2 * t.i2];
+        const float a0 = (float)X[2 * N + 2 * t.i0], a1 = (float)X[2 * N + 2 * t.i1], a2 = (float)X[2 * N + 2 * t.i2];
+        const float b0 = (float)(-X[2 * N + 2 * t.i0 + 1]), b1 = (float)(-X[2 * N + 2 * t.i1 + 1]),
+                    b2 = (float)(-X[2 * N + 2 * t.i2 + 1]);
         s.fx = s.fx + d_lerp(a0, a1, a2, l1, l2);
-        float b0 = t.i0 == v ? nvyo : (float)(-X[2 * N + 2 * t.i0 + 1]);
-        float b1 = t.i1 == v ? nvyo : (float)(-X[2 * N + 2 * t.i1 + 1]);
-        float b2 = t.i2 == v ? nvyo : (float)(-X[2 * N + 2 * t.i2 + 1]);
         s.fy = s.fy + d_lerp(b0, b1, b2, l1, l2);
         s.cnt++;
+        if (VEL) {
+            const bool v0 = t.i0 == v, v1 = t.i1 == v, v2 = t.i2 == v;
+            vel.fxp = vel.fxp + d_lerp(v0 ? vxp : a0, v1 ? vxp : a1, v2 ? vxp : a2, l1, l2);
+            vel.fxm = vel.fxm + d_lerp(v0 ? vxm : a0, v1 ? vxm : a1, v2 ? vxm : a2, l1, l2);
+            vel.fyp = vel.fyp + d_lerp(v0 ? nvyp : b0, v1 ? nvyp : b1, v2 ? nvyp : b2, l1, l2);
+            vel.fym = vel.fym + d_lerp(v0 ? nvym : b0, v1 ? nvym : b1, v2 ? nvym : b2, l1, l2);
+        }
     }
     return s;
 }
@@ -434,25 +449,21 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure(MeasureArgs a)
         }
     }
     __syncthreads();
-    // region = bounding boxes of all configurations of v (intersected with those of w)
+    // region: vertex job -- bounding boxes of the star of v in all its configurations; edge job --
+    // only the triangles that contain BOTH v and w (a product of two difference images vanishes
+    // wherever one of the stars does not reach), again in all configurations of either vertex
     int c0 = W, c1 = -1, r0 = H, r1 = -1;
     {
-        const int ncfg_v = isv ? 5 : 3;
-        for (int cfg = 0; cfg < ncfg_v; cfg++)
-            for (int k = 0; k < nsv; k++) {
+        const int ncfg = isv ? 5 : 6;
+        for (int cfg = 0; cfg < ncfg; cfg++) {
+            const int ns = (isv || cfg < 3) ? nsv : nsw;
+            const int other = isv ? -1 : (cfg < 3 ? w : v);
+            for (int k = 0; k < ns; k++) {
                 const TriSetup &s = s_cfg[cfg][k];
                 if (s.cmin > s.cmax) continue;
+                if (!isv && s.i0 != other && s.i1 != other && s.i2 != other) continue;
                 c0 = min(c0, s.cmin); c1 = max(c1, s.cmax); r0 = min(r0, s.rmin); r1 = max(r1, s.rmax);
             }
-        if (!isv) {
-            int e0 = W, e1 = -1, f0 = H, f1 = -1;
-            for (int cfg = 3; cfg < 6; cfg++)
-                for (int k = 0; k < nsw; k++) {
-                    const TriSetup &s = s_cfg[cfg][k];
-                    if (s.cmin > s.cmax) continue;
-                    e0 = min(e0, s.cmin); e1 = max(e1, s.cmax); f0 = min(f0, s.rmin); f1 = max(f1, s.rmax);
-                }
-            c0 = max(c0, e0); c1 = min(c1, e1); r0 = max(r0, f0); r1 = min(r1, f1);
         }
     }
     double acc[MEAS_OUT];
@@ -461,24 +472,24 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure(MeasureArgs a)
 
     const int rw = c1 - c0 + 1, rh = r1 - r0 + 1;
     const int npx = (rw > 0 && rh > 0) ? rw * rh : 0;
-    const float vx_v = (float)X[2 * N + 2 * v], nvy_v = (float)(-X[2 * N + 2 * v + 1]);
     for (int i = threadIdx.x; i < npx; i += MEAS_NT) {
         const int r = r0 + i / rw, c = c0 + i % rw;
         const int p = r * W + c;
         const int racc = a.ref.acc[p], rcnt = a.ref.cnt[p];
         const float rfx = a.ref.fx[p], rfy = a.ref.fy[p];
         if (isv) {
-            const StarVal sref = d_star_eval(s_cfg[0], nsv, c, r, m, X, v, vx_v, nvy_v);
-            const StarVal sxp = d_star_eval(s_cfg[1], nsv, c, r, m, X, v, vx_v, nvy_v);
-            const StarVal sxm = d_star_eval(s_cfg[2], nsv, c, r, m, X, v, vx_v, nvy_v);
-            const StarVal syp = d_star_eval(s_cfg[3], nsv, c, r, m, X, v, vx_v, nvy_v);
-            const StarVal sym = d_star_eval(s_cfg[4], nsv, c, r, m, X, v, vx_v, nvy_v);
+            StarVel vel, none;
+            const StarVal sref = d_star_eval<true>(s_cfg[0], nsv, c, r, m, X, v, (float)(X[2 * N + 2 * v] + d),
+                                                   (float)(X[2 * N + 2 * v] - d), (float)(-(X[2 * N + 2 * v + 1] + d)),
+                                                   (float)(-(X[2 * N + 2 * v + 1] - d)), vel);
+            const StarVal sxp = d_star_eval<false>(s_cfg[1], nsv, c, r, m, X, v, 0, 0, 0, 0, none);
+            const StarVal sxm = d_star_eval<false>(s_cfg[2], nsv, c, r, m, X, v, 0, 0, 0, 0, none);
+            const StarVal syp = d_star_eval<false>(s_cfg[3], nsv, c, r, m, X, v, 0, 0, 0, 0, none);
+            const StarVal sym = d_star_eval<false>(s_cfg[4], nsv, c, r, m, X, v, 0, 0, 0, 0, none);
             if (sref.cnt + sxp.cnt + sxm.cnt + syp.cnt + sym.cnt == 0) continue;
-            // velocity perturbations keep the geometry: only the attribute of v changes
-            const StarVal svxp = d_star_eval(s_cfg[0], nsv, c, r, m, X, v, (float)(X[2 * N + 2 * v] + d), nvy_v);
-            const StarVal svxm = d_star_eval(s_cfg[0], nsv, c, r, m, X, v, (float)(X[2 * N + 2 * v] - d), nvy_v);
-            const StarVal svyp = d_star_eval(s_cfg[0], nsv, c, r, m, X, v, vx_v, (float)(-(X[2 * N + 2 * v + 1] + d)));
-            const StarVal svym = d_star_eval(s_cfg[0], nsv, c, r, m, X, v, vx_v, (float)(-(X[2 * N + 2 * v + 1] - d)));
+            // velocity perturbations keep the geometry: same coverage and texels as the reference
+            const StarVal svxp = {sref.acc, sref.cnt, vel.fxp, sref.fy}, svxm = {sref.acc, sref.cnt, vel.fxm, sref.fy};
+            const StarVal svyp = {sref.acc, sref.cnt, sref.fx, vel.fyp}, svym = {sref.acc, sref.cnt, sref.fx, vel.fym};
             const Diff dxp = d_diff(racc, rcnt, rfx, rfy, sref, sxp), dxm = d_diff(racc, rcnt, rfx, rfy, sref, sxm);
             const Diff dyp = d_diff(racc, rcnt, rfx, rfy, sref, syp), dym = d_diff(racc, rcnt, rfx, rfy, sref, sym);
             const Diff dvxp = d_diff(racc, rcnt, rfx, rfy, sref, svxp), dvxm = d_diff(racc, rcnt, rfx, rfy, sref, svxm);
@@ -505,19 +516,19 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure(MeasureArgs a)
             acc[A_XVY] += (double)dxp.fy * (double)dvyp.fy; acc[A_YVY] += (double)dyp.fy * (double)dvyp.fy;
             acc[A_VXVX] += (double)dvxp.fx * (double)dvxp.fx; acc[A_VYVY] += (double)dvyp.fy * (double)dvyp.fy;
         } else {
-            const float vx_w = (float)X[2 * N + 2 * w], nvy_w = (float)(-X[2 * N + 2 * w + 1]);
-            const StarVal vref = d_star_eval(s_cfg[0], nsv, c, r, m, X, v, vx_v, nvy_v);
-            const StarVal vxp = d_star_eval(s_cfg[1], nsv, c, r, m, X, v, vx_v, nvy_v);
-            const StarVal vyp = d_star_eval(s_cfg[2], nsv, c, r, m, X, v, vx_v, nvy_v);
+            StarVel velv, velw, none;
+            const StarVal vref = d_star_eval<true>(s_cfg[0], nsv, c, r, m, X, v, (float)(X[2 * N + 2 * v] + d), 0.0f,
+                                                   (float)(-(X[2 * N + 2 * v + 1] + d)), 0.0f, velv);
+            const StarVal vxp = d_star_eval<false>(s_cfg[1], nsv, c, r, m, X, v, 0, 0, 0, 0, none);
+            const StarVal vyp = d_star_eval<false>(s_cfg[2], nsv, c, r, m, X, v, 0, 0, 0, 0, none);
             if (vref.cnt + vxp.cnt + vyp.cnt == 0) continue;
-            const StarVal wref = d_star_eval(s_cfg[3], nsw, c, r, m, X, w, vx_w, nvy_w);
-            const StarVal wxp = d_star_eval(s_cfg[4], nsw, c, r, m, X, w, vx_w, nvy_w);
-            const StarVal wyp = d_star_eval(s_cfg[5], nsw, c, r, m, X, w, vx_w, nvy_w);
+            const StarVal wref = d_star_eval<true>(s_cfg[3], nsw, c, r, m, X, w, (float)(X[2 * N + 2 * w] + d), 0.0f,
+                                                   (float)(-(X[2 * N + 2 * w + 1] + d)), 0.0f, velw);
+            const StarVal wxp = d_star_eval<false>(s_cfg[4], nsw, c, r, m, X, w, 0, 0, 0, 0, none);
+            const StarVal wyp = d_star_eval<false>(s_cfg[5], nsw, c, r, m, X, w, 0, 0, 0, 0, none);
             if (wref.cnt + wxp.cnt + wyp.cnt == 0) continue;
-            const StarVal vvx = d_star_eval(s_cfg[0], nsv, c, r, m, X, v, (float)(X[2 * N + 2 * v] + d), nvy_v);
-            const StarVal vvy = d_star_eval(s_cfg[0], nsv, c, r, m, X, v, vx_v, (float)(-(X[2 * N + 2 * v + 1] + d)));
-            const StarVal wvx = d_star_eval(s_cfg[3], nsw, c, r, m, X, w, (float)(X[2 * N + 2 * w] + d), nvy_w);
-            const StarVal wvy = d_star_eval(s_cfg[3], nsw, c, r, m, X, w, vx_w, (float)(-(X[2 * N + 2 * w + 1] + d)));
+            const StarVal vvx = {vref.acc, vref.cnt, velv.fxp, vref.fy}, vvy = {vref.acc, vref.cnt, vref.fx, velv.fyp};
+            const StarVal wvx = {wref.acc, wref.cnt, velw.fxp, wref.fy}, wvy = {wref.acc, wref.cnt, wref.fx, velw.fyp};
             const Diff ax = d_diff(racc, rcnt, rfx, rfy, vref, vxp), ay = d_diff(racc, rcnt, rfx, rfy, vref, vyp);
             const Diff avx = d_diff(racc, rcnt, rfx, rfy, vref, vvx), avy = d_diff(racc, rcnt, rfx, rfy, vref, vvy);
             const Diff bx = d_diff(racc, rcnt, rfx, rfy, wref, wxp), by = d_diff(racc, rcnt, rfx, rfy, wref, wyp);

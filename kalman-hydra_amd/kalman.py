@@ -21,6 +21,7 @@ reference's.  What changes is where the work is done:
 
 There is no CPU measurement path: ``cuda=False`` raises.
 """
+import ctypes
 import os
 import sys
 import time
@@ -30,6 +31,7 @@ import scipy.linalg as sla
 import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
+from . import _lib
 from .renderer import Renderer, MaskedFlow, DeviceObservation
 
 
@@ -622,40 +624,19 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
         stats.statepredtime[0] += time.time() - t0
 
     def _newton(self):
-        """20 implicit-Euler sub-steps, each solved by Newton's method (:923-960).
-
-        The reference inverts the 4N x 4N matrix G = [[I, -dt I], [-A, I]], A = dt dfdy / M, in every
-        Newton iteration.  Eliminating the first block row leaves the 2N x 2N system
-        (I - dt A) s1 = g1 + dt g2,  s2 = g2 + A s1, solved sparse."""
+        """20 implicit-Euler sub-steps, each solved by Newton's method (:923-960) -- native host
+        code in libhydra_mi.so (csrc/predict.cpp: block-eliminated 2N x 2N system, spring operator
+        applied bar by bar, conjugate gradients)."""
         st = self.state
-        dt, M = self.deltat, self.M
-        bars = self._bars
-        l0 = st.l0[:, 0]
-        n2 = 2 * st.N
-        eye = sp.eye(n2, format="csc")
-        for _ in range(int(np.ceil(1 / dt))):
-            x = st.X.copy()
-            xp = x.copy()
-            xo = np.zeros_like(x)
-            n = 0
-            while n < self.maxiter and np.linalg.norm(xo - xp) > self.tol * np.linalg.norm(xp):
-                xo = xp.copy()
-                v = st.velocities().reshape(-1, 1)
-                y = st.vertices()
-                d = y[bars[:, 0]] - y[bars[:, 1]]
-                l = np.sqrt((d * d).sum(axis=1))
-                L = (self.kappa * (1 - l0 / l))[:, None] * d          # spring force along each bar
-                f = np.zeros((st.N, 2))
-                np.add.at(f, bars[:, 0], L)
-                np.add.at(f, bars[:, 1], -L)
-                g = xp - x - dt * np.vstack((v, f.reshape(-1, 1) / M))
-                A = self._jacobian() * (dt / M)
-                g1, g2 = g[:n2], g[n2:]
-                s1 = _solve_near_identity(eye - dt * A, g1 + dt * g2)
-                s2 = g2 + A.dot(s1)
-                xp = xp - np.vstack((s1, s2))
-                st.X = xp
-                n += 1
+        X = np.ascontiguousarray(st.X.reshape(-1), np.float64).copy()
+        bars = np.ascontiguousarray(self._bars, np.int32)
+        l0 = np.ascontiguousarray(st.l0[:, 0], np.float64)
+        its = ctypes.c_int()
+        _lib.check(_lib.lib().hm_ms_newton(int(st.N), int(bars.shape[0]), _lib.ptr(bars), _lib.ptr(l0),
+                                           float(self.kappa), float(self.M), float(self.deltat), int(self.maxiter),
+                                           float(self.tol), _lib.ptr(X), ctypes.byref(its)), "hm_ms_newton")
+        self.newton_iterations = its.value
+        st.X = X.reshape(-1, 1)
 
 
 def _solve_near_identity(S, b):
