@@ -121,33 +121,49 @@ def main():
     d_video = torch.from_numpy(video).cuda()
     d_masks = torch.from_numpy(masks).cuda()
     B = max(1, args.flow_batch)
-    d_u = torch.empty((B, n, n), dtype=torch.float32, device="cuda")
+    d_u = torch.empty((2, B, n, n), dtype=torch.float32, device="cuda")      # double-buffered flow planes
     d_v = torch.empty_like(d_u)
     torch.cuda.synchronize()
 
     bf = brox.BroxOpticalFlow(n, n, max_batch=B, device=local_rank)
     bf.tune("sor_threads", 512)
     flow0 = np.zeros((n, n, 2), np.float32)
-    kf = kalman.IteratedMSKalmanFilter(dm, video[0], flow0, True)
+    kf = kalman.IteratedMSKalmanFilter(dm, video[0], flow0, True, device=local_rank)
     N = kf.N
 
     t_flow = t_ekf = 0.0
     iters = 0
-    chunk = [0, 0]                       # frame pairs [chunk[0], chunk[1]) have their flow in d_u / d_v
+    # frame pairs [lo, hi) of `ready` have their flow in buffer `buf`; `pending` is being computed
+    # on the flow handle's own stream while the filter works on `ready`
+    sched = {"ready": (0, 0), "buf": 0, "pending": None, "profile_from": None}
+
+    def launch(k, phase_end, buf):
+        nb = min(B, phase_end - k)
+        if sched["profile_from"] == k:
+            bf.profile(True)
+        bf.calc_dev(nb, d_video[k].data_ptr(), d_video[k + 1].data_ptr(), d_u[buf].data_ptr(), d_v[buf].data_ptr())
+        return (k, k + nb)
 
     def step(k, phase_end):
-        """Frame k+1: flow of (k, k+1) -- computed for up to B consecutive pairs per launch series,
-        they do not depend on the filter -- then the EKF on frame k+1."""
+        """Frame k+1: flow of (k, k+1) -- computed for up to B consecutive pairs per launch series (they do
+        not depend on the filter), the next series running on the GPU while the filter works through
+        this one -- then the EKF on frame k+1."""
         nonlocal t_flow, t_ekf, iters
         t0 = time.perf_counter()
-        if k >= chunk[1]:
-            nb = min(B, phase_end - k)
-            bf.calc_dev(nb, d_video[k].data_ptr(), d_video[k + 1].data_ptr(), d_u.data_ptr(), d_v.data_ptr())
+        if k >= sched["ready"][1]:
+            if sched["pending"] is not None and sched["pending"][0] == k:
+                sched["buf"] ^= 1
+            else:
+                sched["pending"] = launch(k, phase_end, sched["buf"])
             bf.sync()
-            chunk[0], chunk[1] = k, k + nb
-        i = k - chunk[0]
+            sched["ready"], sched["pending"] = sched["pending"], None
+            nxt = sched["ready"][1]
+            if nxt < phase_end:
+                sched["pending"] = launch(nxt, phase_end, sched["buf"] ^ 1)
+        i = k - sched["ready"][0]
+        cur = sched["buf"]
         t1 = time.perf_counter()
-        obs = DeviceObservation(d_video[k + 1].data_ptr(), d_u[i].data_ptr(), d_v[i].data_ptr(),
+        obs = DeviceObservation(d_video[k + 1].data_ptr(), d_u[cur, i].data_ptr(), d_v[cur, i].data_ptr(),
                                 d_masks[k + 1].data_ptr(), y_m_host=masks[k + 1])
         kf.compute(obs, None, None)
         t2 = time.perf_counter()
@@ -170,10 +186,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    last_chunk = Wm + ((K - 1) // B) * B          # first step of the last flow batch
+    sched["profile_from"] = Wm + ((K - 1) // B) * B          # first pair of the last flow batch
     for k in range(Wm, Wm + K):
-        if k == last_chunk:
-            bf.profile(True)
         step(k, Wm + K)
     state = torch.from_numpy(kf.state.X.reshape(-1).copy()).cuda()
     if world > 1:                       # the batch path's only exchange: gather the tracked states

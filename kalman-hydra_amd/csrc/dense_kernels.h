@@ -2,43 +2,70 @@
 // 4N x 4N information matrix, triangular solves, SPD inverse.  Replaces the explicit
 // numpy.linalg.inv calls of reference kalman.py:753-754, 785-786, 797-799.
 //
-// Matrices are row-major, n x n with leading dimension n; the factor L overwrites the lower
-// triangle (the strict upper triangle is left untouched and never read).
+// Matrices are row-major with leading dimension n; the factor L overwrites the lower triangle
+// (the strict upper triangle is left untouched and never read).  A matrix may carry extra rows
+// below row nb*32 (nb = ceil(n/32)): right-hand sides stored as ROWS.  The factorisation treats
+// them like any other block row, which turns them into (L^-1 b)^T -- the forward substitution of
+// a solve comes for free.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #define DNB 32          // block size
 
-// ---- potrf, step k, part 1: factor the diagonal block, solve the panel below it ---------------
-// One 256-thread workgroup per block row r >= k.  Every workgroup factors the 32x32 diagonal
-// block itself in LDS (11k flops, cheaper than a launch boundary; the rank-1 update of each of
-// the 32 steps is spread over all threads).  Workgroup r == k stores the factor; the others
-// solve X L_kk^T = A_rk for their 32 rows -- one row per thread in registers, L_kk read from
-// LDS at wave-uniform addresses (broadcast) -- and store X.
-__global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int n, int k)
+// 1/d and 1/sqrt(d) from the hardware estimates plus two Newton steps (about 1 ulp).  The
+// factorisation has a column-by-column dependency chain; a correctly rounded divide or square
+// root (a few hundred cycles each in f64) would sit on it 32 times per block.
+__device__ __forceinline__ double d_rcp(double d)
 {
-    __shared__ double D[DNB][DNB + 1];
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double d_rsqrt(double d)
+{
+    double r = __builtin_amdgcn_rsq(d);
+    r = r * fma(-0.5 * d * r, r, 1.5);
+    r = r * fma(-0.5 * d * r, r, 1.5);
+    return r;
+}
+
+// ---- potrf, step k, part 1: factor the diagonal block, solve the panel below it ---------------
+// One 256-thread workgroup per block row r >= k (rows [32 r, 32 r + 32) of an array with
+// `nrows` rows).  Every workgroup factors the 32x32 diagonal block itself in LDS (11k flops,
+// cheaper than a launch boundary; the rank-1 update of each of the 32 steps is spread over all
+// threads).  Workgroup r == k stores the factor; the others solve X L_kk^T = A_rk for their rows
+// -- 8 threads per row -- and store X.
+__global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int n, int nrows, int k)
+{
+    __shared__ double W[DNB][DNB + 1];            // working copy: column j keeps its unscaled values
+    __shared__ double D[DNB][DNB + 1];            // the factor L_kk
+    __shared__ double rD[DNB];                    // reciprocals of the diagonal of L_kk
     const int t = threadIdx.x;
     const int r = k + blockIdx.x;
     const int d0 = k * DNB;
     const int nd = min(DNB, n - d0);              // the last diagonal block may be short: pad with identity
     for (int e = t; e < DNB * DNB; e += 256) {
         int i = e / DNB, j = e % DNB;
-        D[i][j] = (i < nd && j < nd && j <= i) ? A[(size_t)(d0 + i) * n + d0 + j] : (i == j ? 1.0 : 0.0);
+        W[i][j] = (i < nd && j < nd && j <= i) ? A[(size_t)(d0 + i) * n + d0 + j] : (i == j ? 1.0 : 0.0);
+        D[i][j] = 0.0;
     }
     __syncthreads();
+    // Right-looking elimination with ONE barrier per column: the rank-1 update uses the unscaled
+    // column and 1/w_jj, so it does not wait for the scaled column, which goes to a separate array.
     const int ti = t / DNB, tc = t % DNB;         // 8 x 32 thread grid over (row, column)
     for (int j = 0; j < DNB; j++) {
-        const double piv = sqrt(D[j][j]);         // every thread reads the same word; one writes it back
-        const double rpiv = 1.0 / piv;
-        __syncthreads();
-        if (t == 0) D[j][j] = piv;
-        if (t > j && t < DNB) D[t][j] = D[t][j] * rpiv;
-        __syncthreads();
+        const double wjj = W[j][j];
+        const double rd = d_rcp(wjj);
         if (tc > j) {
-            const double lcj = D[tc][j];
+            const double wcj = W[tc][j] * rd;
             for (int i = ti; i < DNB; i += 256 / DNB)
-                if (i >= tc) D[i][tc] = D[i][tc] - D[i][j] * lcj;
+                if (i >= tc) W[i][tc] = W[i][tc] - W[i][j] * wcj;
+        }
+        if (t < DNB && t >= j) {
+            const double rs = d_rsqrt(wjj);
+            D[t][j] = (t == j) ? wjj * rs : W[t][j] * rs;
+            if (t == j) rD[j] = rs;
         }
         __syncthreads();
     }
@@ -51,12 +78,9 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int 
     }
     // rows of the panel: 8 threads per row, thread `part` keeps the entries x[c], c = part mod 8, in
     // four registers; each of the 32 substitution steps is a 4-term partial dot product per thread,
-    // a butterfly sum over the 8 threads and one divide
-    __shared__ double rD[DNB];                    // reciprocals of the diagonal of L_kk
-    if (t < DNB) rD[t] = 1.0 / D[t][t];
-    __syncthreads();
+    // a butterfly sum over the 8 threads and one multiply
     const int r0 = r * DNB;
-    const int nr = min(DNB, n - r0);
+    const int nr = min(DNB, nrows - r0);
     const int row = t / 8, part = t % 8;
     double x[4];
 #pragma unroll
@@ -89,7 +113,9 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int 
 }
 
 // ---- potrf, step k, part 2: trailing update A_rc -= L_rk L_ck^T for r >= c > k -------------------
-__global__ __launch_bounds__(256) void k_chol_update(double *__restrict__ A, int n, int k)
+// c runs over the block columns of the matrix (c < nb), r over all block rows including the
+// right-hand-side rows below the matrix.
+__global__ __launch_bounds__(256) void k_chol_update(double *__restrict__ A, int n, int nrows, int k)
 {
     const int r = k + 1 + blockIdx.y, c = k + 1 + blockIdx.x;
     if (c > r) return;
@@ -97,7 +123,7 @@ __global__ __launch_bounds__(256) void k_chol_update(double *__restrict__ A, int
     __shared__ double C[DNB][DNB + 1];
     const int t = threadIdx.x;
     const int r0 = r * DNB, c0 = c * DNB, d0 = k * DNB;
-    const int nr = min(DNB, n - r0), nc = min(DNB, n - c0);
+    const int nr = min(DNB, nrows - r0), nc = min(DNB, n - c0);
     for (int e = t; e < DNB * DNB; e += 256) {
         int i = e / DNB, j = e % DNB;
         R[i][j] = i < nr ? A[(size_t)(r0 + i) * n + d0 + j] : 0.0;
@@ -115,129 +141,180 @@ __global__ __launch_bounds__(256) void k_chol_update(double *__restrict__ A, int
     }
 }
 
-// ---- potrs: solve L L^T X = B for a slab of CH right-hand-side columns per workgroup ------------
-// B is n x ldb row-major; workgroup b handles columns [b*CH, b*CH + CH) and overwrites them with X.
-// IDENT: the right-hand side is the identity (SPD inverse) and B is only written.
-// The slab lives in LDS for the whole forward and backward substitution.  Per 32-row block:
-// (a) all 256 threads subtract the contribution of the rows already solved (a 32 x done x CH
-// product, L streamed from memory), (b) the diagonal block is staged in LDS and each wave solves
-// the 32x32 triangle for its columns, one row per lane, passing x_j between lanes by shuffle.
-template <int CH, bool IDENT>
-__global__ __launch_bounds__(256) void k_chol_solve(const double *__restrict__ L, int n, double *__restrict__ B,
-                                                    int ldb, int ncols)
+// ---- triangular solves with the factor, a slab of CH right-hand sides per workgroup --------------
+// Element (i, c) of the right-hand side / solution lives at B[i * sbi + c * sbc].
+//   FWD: L Y = B,   BWD: L^T X = Y   (both: the full solve of L L^T X = B)
+//   IDENT: the right-hand side is the identity (B is only written); with FWD alone this gives the
+//          lower-triangular inverse L^-1, whose column c is zero above row c -- the work starts there.
+// The slab lives in LDS for the whole substitution.  Per 32-row block: (a) all 256 threads subtract
+// the contribution of the rows already solved (a 32 x done x CH product, L streamed from memory),
+// (b) the diagonal block is staged in LDS and each wave solves the 32x32 triangle for its columns,
+// one row per lane, passing x_j between lanes by shuffle.  NT threads: the product of (a) is a chain
+// of memory latencies, more threads keep more loads in flight.
+template <int CH, bool IDENT, bool FWD, bool BWD, int NT>
+__global__ __launch_bounds__(NT) void k_tri_solve(const double *__restrict__ L, int n, double *__restrict__ B,
+                                                   size_t sbi, size_t sbc, int ncols)
 {
-    extern __shared__ double Y[];                 // n x CH
+    extern __shared__ double Y[];                 // n x (CH + 1): odd row stride, conflict-free column reads
+    constexpr int YS = CH + 1;
     __shared__ double T[DNB][CH + 1];
     __shared__ double Dg[DNB][DNB + 1];
     __shared__ double rDg[DNB];                   // reciprocals of the diagonal of the staged block
-    constexpr int PARTS = 256 / DNB;              // 8 partial sums per (row, column slab)
+    constexpr int PARTS = NT / DNB;               // partial sums per (row, column slab)
     __shared__ double S[PARTS][DNB][CH + 1];
     const int t = threadIdx.x;
     const int lane = t & 63, wv = t >> 6;
     const int col0 = blockIdx.x * CH;
     const int nb = (n + DNB - 1) / DNB;
-    for (int e = t; e < n * CH; e += 256) {
+    const int kb_first = (IDENT && FWD) ? col0 / DNB : 0;     // rows above are identically zero
+    const int j_first = kb_first * DNB;
+    for (int e = t; e < n * CH; e += NT) {
         int i = e / CH, c = e % CH;
         double v = 0.0;
-        if (col0 + c < ncols) v = IDENT ? (i == col0 + c ? 1.0 : 0.0) : B[(size_t)i * ldb + col0 + c];
-        Y[e] = v;
+        if (col0 + c < ncols) v = IDENT ? (i == col0 + c ? 1.0 : 0.0) : B[(size_t)i * sbi + (size_t)(col0 + c) * sbc];
+        Y[i * YS + c] = v;
     }
     __syncthreads();
-    // forward: L Y = B
-    for (int kb = 0; kb < nb; kb++) {
-        const int i0 = kb * DNB, ni = min(DNB, n - i0);
-        for (int e = t; e < DNB * DNB; e += 256) {           // stage the diagonal block (identity padded)
-            int i = e / DNB, j = e % DNB;
-            const double v = (i < ni && j <= i) ? L[(size_t)(i0 + i) * n + i0 + j] : (i == j ? 1.0 : 0.0);
-            Dg[i][j] = v;
-            if (i == j) rDg[i] = 1.0 / v;
-        }
-        {
-            const int i = t / PARTS, part = t % PARTS;        // row i of the block, every PARTS-th j
-            double acc[CH];
+    if (FWD) {
+        for (int kb = kb_first; kb < nb; kb++) {
+            const int i0 = kb * DNB, ni = min(DNB, n - i0);
+            for (int e = t; e < DNB * DNB; e += NT) {       // stage the diagonal block (identity padded)
+                int i = e / DNB, j = e % DNB;
+                const double v = (i < ni && j <= i) ? L[(size_t)(i0 + i) * n + i0 + j] : (i == j ? 1.0 : 0.0);
+                Dg[i][j] = v;
+                if (i == j) rDg[i] = 1.0 / v;
+            }
+            {
+                const int i = t / PARTS, part = t % PARTS;    // row i of the block, every PARTS-th j
+                double acc[CH];
 #pragma unroll
-            for (int c = 0; c < CH; c++) acc[c] = 0.0;
-            if (i < ni) {
-                const double *Lrow = L + (size_t)(i0 + i) * n;
+                for (int c = 0; c < CH; c++) acc[c] = 0.0;
+                if (i < ni) {
+                    const double *Lrow = L + (size_t)(i0 + i) * n;
 #pragma unroll 4
-                for (int j = part; j < i0; j += PARTS) {
-                    const double l = Lrow[j];
+                    for (int j = j_first + part; j < i0; j += PARTS) {
+                        const double l = Lrow[j];
 #pragma unroll
-                    for (int c = 0; c < CH; c++) acc[c] = acc[c] + l * Y[j * CH + c];
+                        for (int c = 0; c < CH; c++) acc[c] = acc[c] + l * Y[j * YS + c];
+                    }
                 }
-            }
 #pragma unroll
-            for (int c = 0; c < CH; c++) S[part][i][c] = acc[c];
-        }
-        __syncthreads();
-        for (int e = t; e < DNB * CH; e += 256) {             // fixed-order sum of the partials
-            int i = e / CH, c = e % CH;
-            double v = 0.0;
-            for (int q = 0; q < PARTS; q++) v += S[q][i][c];
-            T[i][c] = (i < ni ? Y[(i0 + i) * CH + c] : 0.0) - v;
-        }
-        __syncthreads();
-        for (int c = wv; c < CH; c += 4) {                    // triangle: one row per lane, x_j by shuffle
-            const int i = lane & (DNB - 1);
-            double val = T[i][c];
-            for (int j = 0; j < DNB; j++) {
-                const double xj = __shfl(val, j, 64) * rDg[j];
-                if (i == j) val = xj;
-                else if (i > j) val = val - Dg[i][j] * xj;
+                for (int c = 0; c < CH; c++) S[part][i][c] = acc[c];
             }
-            if (lane < ni) Y[(i0 + lane) * CH + c] = val;
+            __syncthreads();
+            for (int e = t; e < DNB * CH; e += NT) {         // fixed-order sum of the partials
+                int i = e / CH, c = e % CH;
+                double v = 0.0;
+                for (int q = 0; q < PARTS; q++) v += S[q][i][c];
+                T[i][c] = (i < ni ? Y[(i0 + i) * YS + c] : 0.0) - v;
+            }
+            __syncthreads();
+            for (int c = wv; c < CH; c += NT / 64) {                // triangle: one row per lane, x_j by shuffle
+                const int i = lane & (DNB - 1);
+                double val = T[i][c];
+                for (int j = 0; j < DNB; j++) {
+                    const double xj = __shfl(val, j, 64) * rDg[j];
+                    if (i == j) val = xj;
+                    else if (i > j) val = val - Dg[i][j] * xj;
+                }
+                if (lane < ni) Y[(i0 + lane) * YS + c] = val;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
-    // backward: L^T X = Y
-    for (int kb = nb - 1; kb >= 0; kb--) {
-        const int i0 = kb * DNB, ni = min(DNB, n - i0);
-        const int j0 = i0 + ni;
-        for (int e = t; e < DNB * DNB; e += 256) {
-            int i = e / DNB, j = e % DNB;
-            const double v = (i < ni && j <= i) ? L[(size_t)(i0 + i) * n + i0 + j] : (i == j ? 1.0 : 0.0);
-            Dg[i][j] = v;
-            if (i == j) rDg[i] = 1.0 / v;
-        }
-        {
-            const int i = t % DNB, part = t / DNB;            // lanes run along i: L[j][i0+i] is contiguous in i
-            double acc[CH];
+    if (BWD) {
+        for (int kb = nb - 1; kb >= 0; kb--) {
+            const int i0 = kb * DNB, ni = min(DNB, n - i0);
+            const int j0 = i0 + ni;
+            for (int e = t; e < DNB * DNB; e += NT) {
+                int i = e / DNB, j = e % DNB;
+                const double v = (i < ni && j <= i) ? L[(size_t)(i0 + i) * n + i0 + j] : (i == j ? 1.0 : 0.0);
+                Dg[i][j] = v;
+                if (i == j) rDg[i] = 1.0 / v;
+            }
+            {
+                const int i = t % DNB, part = t / DNB;        // lanes run along i: L[j][i0+i] is contiguous in i
+                double acc[CH];
 #pragma unroll
-            for (int c = 0; c < CH; c++) acc[c] = 0.0;
-            if (i < ni) {
+                for (int c = 0; c < CH; c++) acc[c] = 0.0;
+                if (i < ni) {
 #pragma unroll 4
-                for (int j = j0 + part; j < n; j += PARTS) {
-                    const double l = L[(size_t)j * n + i0 + i];
+                    for (int j = j0 + part; j < n; j += PARTS) {
+                        const double l = L[(size_t)j * n + i0 + i];
 #pragma unroll
-                    for (int c = 0; c < CH; c++) acc[c] = acc[c] + l * Y[j * CH + c];
+                        for (int c = 0; c < CH; c++) acc[c] = acc[c] + l * Y[j * YS + c];
+                    }
                 }
-            }
 #pragma unroll
-            for (int c = 0; c < CH; c++) S[part][i][c] = acc[c];
-        }
-        __syncthreads();
-        for (int e = t; e < DNB * CH; e += 256) {
-            int i = e / CH, c = e % CH;
-            double v = 0.0;
-            for (int q = 0; q < PARTS; q++) v += S[q][i][c];
-            T[i][c] = (i < ni ? Y[(i0 + i) * CH + c] : 0.0) - v;
-        }
-        __syncthreads();
-        for (int c = wv; c < CH; c += 4) {
-            const int i = lane & (DNB - 1);
-            double val = T[i][c];
-            for (int j = DNB - 1; j >= 0; j--) {
-                const double xj = __shfl(val, j, 64) * rDg[j];
-                if (i == j) val = xj;
-                else if (i < j) val = val - Dg[j][i] * xj;
+                for (int c = 0; c < CH; c++) S[part][i][c] = acc[c];
             }
-            if (lane < ni) Y[(i0 + lane) * CH + c] = val;
+            __syncthreads();
+            for (int e = t; e < DNB * CH; e += NT) {
+                int i = e / CH, c = e % CH;
+                double v = 0.0;
+                for (int q = 0; q < PARTS; q++) v += S[q][i][c];
+                T[i][c] = (i < ni ? Y[(i0 + i) * YS + c] : 0.0) - v;
+            }
+            __syncthreads();
+            for (int c = wv; c < CH; c += NT / 64) {
+                const int i = lane & (DNB - 1);
+                double val = T[i][c];
+                for (int j = DNB - 1; j >= 0; j--) {
+                    const double xj = __shfl(val, j, 64) * rDg[j];
+                    if (i == j) val = xj;
+                    else if (i < j) val = val - Dg[j][i] * xj;
+                }
+                if (lane < ni) Y[(i0 + lane) * YS + c] = val;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
-    for (int e = t; e < n * CH; e += 256) {
+    for (int e = t; e < n * CH; e += NT) {
         int i = e / CH, c = e % CH;
-        if (col0 + c < ncols) B[(size_t)i * ldb + col0 + c] = Y[e];
+        if (col0 + c < ncols) B[(size_t)i * sbi + (size_t)(col0 + c) * sbc] = Y[i * YS + c];
+    }
+}
+
+// ---- W = T^T T for lower-triangular T (= L^-1): the SPD inverse from the triangular inverse --------
+// One workgroup per 32x32 tile (I >= J) of W: W_IJ = sum over rows k >= 32 I of T[k, I-block]^T T[k, J-block].
+// Both mirror images are written (the host wants the full symmetric matrix).
+__global__ __launch_bounds__(256) void k_ttt(const double *__restrict__ Tm, int n, double *__restrict__ W)
+{
+    const int I = blockIdx.y, J = blockIdx.x;
+    if (J > I) return;
+    __shared__ double TI[DNB][DNB + 1];
+    __shared__ double TJ[DNB][DNB + 1];
+    const int t = threadIdx.x;
+    const int i0 = I * DNB, j0 = J * DNB;
+    const int ni = min(DNB, n - i0), nj = min(DNB, n - j0);
+    const int jj = t % DNB;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};         // outputs (ii = t/32 + 8 q, jj)
+    for (int k0 = i0; k0 < n; k0 += DNB) {
+        const int nk = min(DNB, n - k0);
+        for (int e = t; e < DNB * DNB; e += 256) {
+            int kk = e / DNB, c = e % DNB;
+            // T is lower triangular: entries right of the diagonal are not stored
+            TI[kk][c] = (kk < nk && c < ni && i0 + c <= k0 + kk) ? Tm[(size_t)(k0 + kk) * n + i0 + c] : 0.0;
+            TJ[kk][c] = (kk < nk && c < nj && j0 + c <= k0 + kk) ? Tm[(size_t)(k0 + kk) * n + j0 + c] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int ii = t / DNB + 8 * q;
+            double s = acc[q];
+#pragma unroll 8
+            for (int kk = 0; kk < DNB; kk++) s = s + TI[kk][ii] * TJ[kk][jj];
+            acc[q] = s;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int ii = t / DNB + 8 * q;
+        if (ii < ni && jj < nj) {
+            W[(size_t)(i0 + ii) * n + j0 + jj] = acc[q];
+            W[(size_t)(j0 + jj) * n + i0 + ii] = acc[q];
+        }
     }
 }
 

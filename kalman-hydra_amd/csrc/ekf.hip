@@ -147,15 +147,16 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_yfym, n * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_setup, (size_t)T * sizeof(TriSetup));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_X, (size_t)4 * N * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_out, (size_t)h->njobs * MEAS_OUT * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_out, (size_t)h->njobs * MEAS_VSPLIT * MEAS_OUT * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_partial, (size_t)h->red_blocks * 4 * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_im8, n);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_m8, n);
         const size_t n4 = (size_t)4 * N, nn = n4 * n4 * sizeof(double);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_H, nn);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_invW0, nn);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Af[0], nn);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Af[1], nn);
+        const size_t nn_aug = (size_t)(hm_cdiv((int)n4, DNB) * DNB + DNB) * n4 * sizeof(double);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Af[0], nn_aug);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Af[1], nn_aug);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Wtmp, nn);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Hz, n4 * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Hzc, n4 * 4 * sizeof(double));
@@ -376,7 +377,8 @@ static int measure_on_device(hm_ctx *h, const double *X, double deltaX, int mask
     a.X = h->d_X;
     a.delta = deltaX;
     a.out = h->d_out;
-    hipLaunchKernelGGL(k_measure, dim3(h->njobs), dim3(MEAS_NT), 0, h->stream, a);
+    hipLaunchKernelGGL(k_measure<true>, dim3(h->N, MEAS_VSPLIT), dim3(MEAS_NT), 0, h->stream, a);
+    if (h->E > 0) hipLaunchKernelGGL(k_measure<false>, dim3(h->E), dim3(MEAS_NT), 0, h->stream, a);
     const size_t n4 = (size_t)4 * h->N;
     HM_HIP(hipMemsetAsync(h->d_H, 0, n4 * n4 * sizeof(double), h->stream));
     ScatterArgs s = {h->d_out, h->d_edges, h->N, h->E, h->eps_Z, h->eps_J, h->eps_M, deltaX, h->d_H, h->d_Hz, h->d_Hzc};
@@ -403,27 +405,40 @@ extern "C" int hm_measure(hm_ctx_t h, const double *X, double deltaX, int masked
 }
 
 // ---- the dense part of the update on the device ----------------------------------------------------
-static void chol_factor(hm_ctx *h, double *A, int n)
+// Layout of a factor buffer d_Af[s]: n4 matrix rows, padding up to a multiple of 32 rows, then one
+// 32-row block whose first row carries the right-hand side (see dense_kernels.h).
+static int aug_rows(int n) { return hm_cdiv(n, DNB) * DNB + DNB; }
+
+// Cholesky of the n x n matrix in A; with_rhs: the right-hand-side rows go through the elimination too
+static void chol_factor(hm_ctx *h, double *A, int n, bool with_rhs)
 {
     const int nb = hm_cdiv(n, DNB);
+    const int nrows = with_rhs ? aug_rows(n) : n;
+    const int nbr = hm_cdiv(nrows, DNB);
     for (int k = 0; k < nb; k++) {
-        hipLaunchKernelGGL(k_chol_panel, dim3(nb - k), dim3(256), 0, h->stream, A, n, k);
-        const int m = nb - k - 1;
-        if (m > 0) hipLaunchKernelGGL(k_chol_update, dim3(m, m), dim3(256), 0, h->stream, A, n, k);
+        hipLaunchKernelGGL(k_chol_panel, dim3(nbr - k), dim3(256), 0, h->stream, A, n, nrows, k);
+        const int mc = nb - k - 1, mr = nbr - k - 1;
+        if (mr > 0 && mc > 0) hipLaunchKernelGGL(k_chol_update, dim3(mc, mr), dim3(256), 0, h->stream, A, n, nrows, k);
     }
 }
 
-#define INV_CH 16
-static void chol_inverse(hm_ctx *h, const double *L, int n, double *out)
+#define INV_CH 4
+// SPD inverse from the factor: T = L^-1 (forward substitution of the identity, lower triangular),
+// then inv = T^T T.  `scratch` receives T.
+static void chol_inverse(hm_ctx *h, const double *L, int n, double *scratch, double *out)
 {
-    hipLaunchKernelGGL((k_chol_solve<INV_CH, true>), dim3(hm_cdiv(n, INV_CH)), dim3(256),
-                       (size_t)n * INV_CH * sizeof(double), h->stream, L, n, out, n, n);
+    hipLaunchKernelGGL((k_tri_solve<INV_CH, true, true, false, 256>), dim3(hm_cdiv(n, INV_CH)), dim3(256),
+                       (size_t)n * (INV_CH + 1) * sizeof(double), h->stream, L, n, scratch, (size_t)n, (size_t)1, n);
+    const int nb = hm_cdiv(n, DNB);
+    hipLaunchKernelGGL(k_ttt, dim3(nb, nb), dim3(256), 0, h->stream, scratch, n, out);
 }
 
-static void chol_solve4(hm_ctx *h, const double *L, int n, double *B, int ncols)   // B: n x 4 row-major
+// backward substitution L^T x = y for the right-hand side that went through the factorisation as a row
+static void chol_backsolve_row(hm_ctx *h, double *A, int n)
 {
-    hipLaunchKernelGGL((k_chol_solve<4, false>), dim3(1), dim3(256), (size_t)n * 4 * sizeof(double), h->stream, L, n,
-                       B, 4, ncols);
+    double *row = A + (size_t)hm_cdiv(n, DNB) * DNB * n;     // y^T, overwritten by x^T
+    hipLaunchKernelGGL((k_tri_solve<4, false, false, true, 1024>), dim3(1), dim3(1024), (size_t)n * 5 * sizeof(double),
+                       h->stream, A, n, row, (size_t)1, (size_t)n, 1);
 }
 
 extern "C" int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *X0)
@@ -436,17 +451,17 @@ extern "C" int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *
     static size_t inv_lds_cap = 0;
     if (inv_lds_cap == 0) {
         hipFuncAttributes fa;
-        HM_HIP(hipFuncGetAttributes(&fa, (const void *)k_chol_solve<INV_CH, true>));
+        HM_HIP(hipFuncGetAttributes(&fa, (const void *)k_tri_solve<INV_CH, true, true, false, 256>));
         const size_t cap = 160 * 1024 - fa.sharedSizeBytes - 1024;
-        HM_HIP(hipFuncSetAttribute((const void *)k_chol_solve<INV_CH, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        HM_HIP(hipFuncSetAttribute((const void *)k_tri_solve<INV_CH, true, true, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)cap));
         inv_lds_cap = cap;
     }
-    HM_ARG((size_t)n4 * INV_CH * sizeof(double) <= inv_lds_cap, "hm_update_begin: state dimension %d too large for "
-           "the on-device inverse (limit %d)", n4, (int)(inv_lds_cap / (INV_CH * sizeof(double))));
+    HM_ARG((size_t)n4 * (INV_CH + 1) * sizeof(double) <= inv_lds_cap, "hm_update_begin: state dimension %d too large for "
+           "the on-device inverse (limit %d)", n4, (int)(inv_lds_cap / ((INV_CH + 1) * sizeof(double))));
     HM_HIP(hipMemcpyAsync(h->d_Af[0], W_prior, (size_t)n4 * n4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    chol_factor(h, h->d_Af[0], n4);
-    chol_inverse(h, h->d_Af[0], n4, h->d_invW0);
+    chol_factor(h, h->d_Af[0], n4, false);
+    chol_inverse(h, h->d_Af[0], n4, h->d_Wtmp, h->d_invW0);
     HM_HIP(hipGetLastError());
     h->upd_X0.assign(X0, X0 + n4);
     h->upd_last = h->upd_prev = -1;
@@ -473,16 +488,16 @@ extern "C" int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int ma
     double *A = h->d_Af[slot];
     const size_t nn = (size_t)n4 * n4;
     hipLaunchKernelGGL(k_add_mat, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, h->d_invW0, h->d_H, A, nn);
-    // rhs column 0 = Hz - H (X0 - X); columns 1..3 unused
-    HM_HIP(hipMemsetAsync(h->d_rhs, 0, (size_t)n4 * 4 * sizeof(double), h->stream));
-    hipLaunchKernelGGL(k_rhs, dim3(n4), dim3(256), 0, h->stream, h->d_H, h->d_dx, h->d_Hz, h->d_Wtmp, n4);
-    HM_HIP(hipMemcpy2DAsync(h->d_rhs, 4 * sizeof(double), h->d_Wtmp, sizeof(double), sizeof(double), n4,
-                            hipMemcpyDeviceToDevice, h->stream));
-    chol_factor(h, A, n4);
-    chol_solve4(h, A, n4, h->d_rhs, 1);
+    // right-hand side Hz - H (X0 - X) as the first row of the block below the matrix; the rows in
+    // between and the rest of that block stay zero
+    const size_t pad_n = (size_t)aug_rows(n4) * n4 - nn;
+    HM_HIP(hipMemsetAsync(A + nn, 0, pad_n * sizeof(double), h->stream));
+    double *rhs_row = A + (size_t)hm_cdiv(n4, DNB) * DNB * n4;
+    hipLaunchKernelGGL(k_rhs, dim3(n4), dim3(256), 0, h->stream, h->d_H, h->d_dx, h->d_Hz, rhs_row, n4);
+    chol_factor(h, A, n4, true);
+    chol_backsolve_row(h, A, n4);
     HM_HIP(hipGetLastError());
-    HM_HIP(hipMemcpy2DAsync(step, sizeof(double), h->d_rhs, 4 * sizeof(double), sizeof(double), n4,
-                            hipMemcpyDeviceToHost, h->stream));
+    HM_HIP(hipMemcpyAsync(step, rhs_row, (size_t)n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (Hzc) HM_HIP(hipMemcpyAsync(Hzc, h->d_Hzc, (size_t)n4 * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HM_HIP(hipStreamSynchronize(h->stream));
     h->upd_prev = h->upd_last;
@@ -499,9 +514,9 @@ extern "C" int hm_update_cov(hm_ctx_t h, int which, double *W_out)
     if (slot < 0) { hm_set_error("hm_update_cov: no such step"); return HM_ERR_STATE; }
     HM_HIP(hipSetDevice(h->device));
     const int n4 = 4 * h->N;
-    chol_inverse(h, h->d_Af[slot], n4, h->d_Wtmp);
+    chol_inverse(h, h->d_Af[slot], n4, h->d_Wtmp, h->d_H);      // d_H is free between steps
     HM_HIP(hipGetLastError());
-    HM_HIP(hipMemcpyAsync(W_out, h->d_Wtmp, (size_t)n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HM_HIP(hipMemcpyAsync(W_out, h->d_H, (size_t)n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HM_HIP(hipStreamSynchronize(h->stream));
     return HM_OK;
 }

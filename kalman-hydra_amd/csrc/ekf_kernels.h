@@ -389,6 +389,7 @@ struct MeasureArgs {
 
 #define MEAS_NT 256
 #define MEAS_OUT 40
+#define MEAS_VSPLIT 3          // workgroups per vertex job (their partial sums are added in order)
 // vertex job output layout (doubles):
 //   [0..15]  jz(+d) per (component x,y,vx,vy) x (channel im,fx,fy,m)        (sums, not yet / eps)
 //   [16..31] jz(-d) likewise
@@ -413,16 +414,19 @@ enum {
     B_NV = 26
 };
 
+// VERTEX selects the job kind at compile time: two kernels, each with only its own accumulators live
+// (38 / 26 doubles), so that more workgroups fit a CU.
+template <bool VERTEX>
 __global__ __launch_bounds__(MEAS_NT) void k_measure(MeasureArgs a)
 {
     __shared__ TriSetup s_cfg[6][EKF_MAX_STAR];
     __shared__ double s_red[(MEAS_NT / 64) * MEAS_OUT];
     const Mesh &m = a.m;
     const int N = m.N, W = m.W, H = m.H;
-    const int job = blockIdx.x;
+    const int job = VERTEX ? blockIdx.x : N + blockIdx.x;
     const double *X = a.X;
     const double d = a.delta;
-    const bool isv = job < N;
+    constexpr bool isv = VERTEX;
     const int v = isv ? job : a.topo.edges[2 * (job - N)];
     const int w = isv ? -1 : a.topo.edges[2 * (job - N) + 1];
     const int nsv = a.topo.star_off[v + 1] - a.topo.star_off[v];
@@ -466,13 +470,16 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure(MeasureArgs a)
             }
         }
     }
-    double acc[MEAS_OUT];
+    constexpr int NACC = VERTEX ? (int)A_NV : (int)B_NV;
+    double acc[NACC];
 #pragma unroll
-    for (int k = 0; k < MEAS_OUT; k++) acc[k] = 0.0;
+    for (int k = 0; k < NACC; k++) acc[k] = 0.0;
 
     const int rw = c1 - c0 + 1, rh = r1 - r0 + 1;
     const int npx = (rw > 0 && rh > 0) ? rw * rh : 0;
-    for (int i = threadIdx.x; i < npx; i += MEAS_NT) {
+    // a vertex job is shared by MEAS_VSPLIT workgroups (blockIdx.y), pixels dealt round-robin in chunks of 256
+    const int nsplit = VERTEX ? MEAS_VSPLIT : 1;
+    for (int i = threadIdx.x + MEAS_NT * blockIdx.y; i < npx; i += MEAS_NT * nsplit) {
         const int r = r0 + i / rw, c = c0 + i % rw;
         const int p = r * W + c;
         const int racc = a.ref.acc[p], rcnt = a.ref.cnt[p];
@@ -546,7 +553,7 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure(MeasureArgs a)
             acc[B_VYVY] += (double)avy.fy * (double)bvy.fy;
         }
     }
-    d_block_reduce<MEAS_OUT, MEAS_NT>(acc, s_red, a.out + (size_t)job * MEAS_OUT);
+    d_block_reduce<NACC, MEAS_NT>(acc, s_red, a.out + ((size_t)job * MEAS_VSPLIT + blockIdx.y) * MEAS_OUT);
 }
 
 
@@ -573,7 +580,16 @@ __global__ void k_hth_scatter(ScatterArgs a)
     const int job = blockIdx.x * blockDim.x + threadIdx.x;
     const int N = a.N, n4 = 4 * N;
     if (job >= N + a.E) return;
-    const double *o = a.out + (size_t)job * MEAS_OUT;
+    double o[MEAS_OUT];
+    {
+        const double *src = a.out + (size_t)job * MEAS_VSPLIT * MEAS_OUT;
+        const int parts = job < N ? MEAS_VSPLIT : 1;
+        for (int k = 0; k < MEAS_OUT; k++) {
+            double v = src[k];
+            for (int q = 1; q < parts; q++) v += src[q * MEAS_OUT + k];
+            o[k] = v;
+        }
+    }
     const double eZ = a.eZ, eJ = a.eJ, eM = a.eM, d = a.d;
 #define SUM4(s) ((((s)[0] / eZ + (s)[1] / eJ) + (s)[2] / eJ) + (s)[3] / eM)
     if (job < N) {

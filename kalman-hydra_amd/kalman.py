@@ -118,7 +118,7 @@ def _rows_unique(a):
 
 class KFState:
     def __init__(self, distmesh, im, flow, cuda, eps_F=1, eps_Z=1e-3, eps_J=1e-3, eps_M=1e-3, vel=None,
-                 sparse=True, multi=True, verbose=False, renderer=None):
+                 sparse=True, multi=True, verbose=False, renderer=None, device=0):
         self.multi = multi
         self.sparse = sparse
         self.verbose = verbose
@@ -194,7 +194,7 @@ class KFState:
         # by default it is the HIP one -- there is no CPU implementation in this package
         self.renderer = renderer if renderer is not None else Renderer(
             distmesh, self._vel, flow, self.nx, im, cuda, eps_Z, eps_J, eps_M, self.labels, self.labels_hess,
-            self.Q, showtracking=False)
+            self.Q, showtracking=False, device=device)
 
         stats.meshpts = self.N
         stats.gridsize = getattr(distmesh, "h0", 0)
@@ -355,12 +355,13 @@ class KFState:
 
 class KalmanFilter:
     def __init__(self, distmesh, im, flow, cuda, vel=None, sparse=True, multi=True, eps_F=1, eps_Z=1e-3,
-                 eps_J=1e-3, eps_M=1e-3, verbose=False, renderer=None):
+                 eps_J=1e-3, eps_M=1e-3, verbose=False, renderer=None, device=0):
         self.distmesh = distmesh
         self.N = distmesh.size()
         self.verbose = verbose
         self.state = KFState(distmesh, im, flow, cuda, vel=vel, sparse=sparse, multi=multi, eps_F=eps_F,
-                             eps_Z=eps_Z, eps_J=eps_J, eps_M=eps_M, verbose=verbose, renderer=renderer)
+                             eps_Z=eps_Z, eps_J=eps_J, eps_M=eps_M, verbose=verbose, renderer=renderer,
+                             device=device)
         self.predtime = 0
         self.updatetime = 0
         self.projecttime = 0
