@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--h0", type=float, default=0.047, help="mesh edge length as a fraction of the frame size")
     ap.add_argument("--flow-batch", type=int, default=8, help="consecutive frame pairs per Brox launch series")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the real run); gloo only to rehearse several ranks on one GPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -109,9 +111,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path)")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev = local_rank if args.backend == "nccl" else local_rank % max(1, ndev)
+    if dev >= ndev:
+        raise SystemExit("rank %d wants cuda:%d but only %d device(s) are visible" % (rank, dev, ndev))
+    torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo")
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     n = args.size
     K, Wm = args.steps, args.warmup
@@ -125,10 +135,10 @@ def main():
     d_v = torch.empty_like(d_u)
     torch.cuda.synchronize()
 
-    bf = brox.BroxOpticalFlow(n, n, max_batch=B, device=local_rank)
+    bf = brox.BroxOpticalFlow(n, n, max_batch=B, device=dev)
     bf.tune("sor_threads", 512)
     flow0 = np.zeros((n, n, 2), np.float32)
-    kf = kalman.IteratedMSKalmanFilter(dm, video[0], flow0, True, device=local_rank)
+    kf = kalman.IteratedMSKalmanFilter(dm, video[0], flow0, True, device=dev)
     N = kf.N
 
     t_flow = t_ekf = 0.0
@@ -189,7 +199,7 @@ def main():
     sched["profile_from"] = Wm + ((K - 1) // B) * B          # first pair of the last flow batch
     for k in range(Wm, Wm + K):
         step(k, Wm + K)
-    state = torch.from_numpy(kf.state.X.reshape(-1).copy()).cuda()
+    state = torch.from_numpy(kf.state.X.reshape(-1).copy()).to(coll_dev)
     if world > 1:                       # the batch path's only exchange: gather the tracked states
         gathered = [torch.empty_like(state) for _ in range(world)]
         dist.all_gather(gathered, state)
@@ -199,7 +209,7 @@ def main():
     sor_ms, sor_launches, sor_pxit = bf.profile_read()
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

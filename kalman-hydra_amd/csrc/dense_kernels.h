@@ -2,8 +2,9 @@
 // 4N x 4N information matrix, triangular solves, SPD inverse.  Replaces the explicit
 // numpy.linalg.inv calls of reference kalman.py:753-754, 785-786, 797-799.
 //
-// Matrices are row-major with leading dimension n; the factor L overwrites the lower triangle
-// (the strict upper triangle is left untouched and never read).  A matrix may carry extra rows
+// Matrices are row-major with leading dimension n; the factor L overwrites the blocks below the
+// block diagonal in place, its 32x32 diagonal blocks go to a side array Ld (the diagonal blocks of
+// the matrix itself stay as they were: every workgroup of a panel launch reads them).  A matrix may carry extra rows
 // below row nb*32 (nb = ceil(n/32)): right-hand sides stored as ROWS.  The factorisation treats
 // them like any other block row, which turns them into (L^-1 b)^T -- the forward substitution of
 // a solve comes for free.
@@ -36,7 +37,7 @@ __device__ __forceinline__ double d_rsqrt(double d)
 // cheaper than a launch boundary; the rank-1 update of each of the 32 steps is spread over all
 // threads).  Workgroup r == k stores the factor; the others solve X L_kk^T = A_rk for their rows
 // -- 8 threads per row -- and store X.
-__global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int n, int nrows, int k)
+__global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, double *__restrict__ Ld, int n, int nrows, int k)
 {
     __shared__ double W[DNB][DNB + 1];            // working copy: column j keeps its unscaled values
     __shared__ double D[DNB][DNB + 1];            // the factor L_kk
@@ -70,10 +71,9 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int 
         __syncthreads();
     }
     if (r == k) {
-        for (int e = t; e < DNB * DNB; e += 256) {
-            int i = e / DNB, j = e % DNB;
-            if (i < nd && j <= i) A[(size_t)(d0 + i) * n + d0 + j] = D[i][j];
-        }
+        // The factored block goes to the side array Ld, NOT back into A: the other workgroups of this
+        // launch read the unfactored block from A at their own pace.
+        for (int e = t; e < DNB * DNB; e += 256) Ld[(size_t)k * DNB * DNB + e] = D[e / DNB][e % DNB];
         return;
     }
     // rows of the panel: 8 threads per row, thread `part` keeps the entries x[c], c = part mod 8, in
@@ -152,7 +152,8 @@ __global__ __launch_bounds__(256) void k_chol_update(double *__restrict__ A, int
 // one row per lane, passing x_j between lanes by shuffle.  NT threads: the product of (a) is a chain
 // of memory latencies, more threads keep more loads in flight.
 template <int CH, bool IDENT, bool FWD, bool BWD, int NT>
-__global__ __launch_bounds__(NT) void k_tri_solve(const double *__restrict__ L, int n, double *__restrict__ B,
+__global__ __launch_bounds__(NT) void k_tri_solve(const double *__restrict__ L, const double *__restrict__ Ld, int n,
+                                                  double *__restrict__ B,
                                                    size_t sbi, size_t sbc, int ncols)
 {
     extern __shared__ double Y[];                 // n x (CH + 1): odd row stride, conflict-free column reads
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(NT) void k_tri_solve(const double *__restrict__ L, 
             const int i0 = kb * DNB, ni = min(DNB, n - i0);
             for (int e = t; e < DNB * DNB; e += NT) {       // stage the diagonal block (identity padded)
                 int i = e / DNB, j = e % DNB;
-                const double v = (i < ni && j <= i) ? L[(size_t)(i0 + i) * n + i0 + j] : (i == j ? 1.0 : 0.0);
+                const double v = Ld[(size_t)kb * DNB * DNB + e];      // diagonal blocks live in Ld (identity padded)
                 Dg[i][j] = v;
                 if (i == j) rDg[i] = 1.0 / v;
             }
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(NT) void k_tri_solve(const double *__restrict__ L, 
             const int j0 = i0 + ni;
             for (int e = t; e < DNB * DNB; e += NT) {
                 int i = e / DNB, j = e % DNB;
-                const double v = (i < ni && j <= i) ? L[(size_t)(i0 + i) * n + i0 + j] : (i == j ? 1.0 : 0.0);
+                const double v = Ld[(size_t)kb * DNB * DNB + e];      // diagonal blocks live in Ld (identity padded)
                 Dg[i][j] = v;
                 if (i == j) rDg[i] = 1.0 / v;
             }

@@ -33,7 +33,7 @@ struct hm_ctx {
     uint8_t *d_im8, *d_m8;
     std::vector<double> X0;          // state of the reference render
     // dense update on the device (n4 = 4N)
-    double *d_H, *d_Hz, *d_Hzc, *d_invW0, *d_Af[2], *d_rhs, *d_dx, *d_Wtmp;
+    double *d_H, *d_Hz, *d_Hzc, *d_invW0, *d_Af[2], *d_Ld[2], *d_rhs, *d_dx, *d_Wtmp;
     std::vector<double> upd_X0;      // prior mean given to hm_update_begin
     int upd_last, upd_prev;          // which d_Af holds the factor of the last / previous step (-1: none)
     bool upd_open;
@@ -63,7 +63,8 @@ static int ctx_free(hm_ctx *h)
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_tri, h->d_star_off, h->d_star_tri, h->d_edges, h->d_uv, h->d_tex, h->d_yim, h->d_ym, h->d_yfx,
                     h->d_yfy, h->d_yfxm, h->d_yfym, h->d_setup, h->d_X, h->d_out, h->d_partial, h->d_im8, h->d_m8,
-                    h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_rhs, h->d_dx, h->d_Wtmp};
+                    h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_Ld[0], h->d_Ld[1], h->d_rhs, h->d_dx,
+                    h->d_Wtmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     free_targets(h->ref);
@@ -123,6 +124,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->ref = Targets{nullptr, nullptr, nullptr, nullptr}; h->P = h->ref; h->Q = h->ref;
     h->d_setup = nullptr; h->d_X = h->d_out = h->d_partial = nullptr; h->d_im8 = h->d_m8 = nullptr;
     h->d_H = h->d_Hz = h->d_Hzc = h->d_invW0 = h->d_Af[0] = h->d_Af[1] = h->d_rhs = h->d_dx = h->d_Wtmp = nullptr;
+    h->d_Ld[0] = h->d_Ld[1] = nullptr;
     h->upd_last = h->upd_prev = -1; h->upd_open = false;
     for (const auto &e : eset) { h->edges.push_back(e.first); h->edges.push_back(e.second); }
     h->E = (int)eset.size();
@@ -157,6 +159,9 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         const size_t nn_aug = (size_t)(hm_cdiv((int)n4, DNB) * DNB + DNB) * n4 * sizeof(double);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Af[0], nn_aug);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Af[1], nn_aug);
+        const size_t ld_bytes = (size_t)hm_cdiv((int)n4, DNB) * DNB * DNB * sizeof(double);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Ld[0], ld_bytes);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Ld[1], ld_bytes);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Wtmp, nn);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Hz, n4 * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Hzc, n4 * 4 * sizeof(double));
@@ -410,13 +415,13 @@ extern "C" int hm_measure(hm_ctx_t h, const double *X, double deltaX, int masked
 static int aug_rows(int n) { return hm_cdiv(n, DNB) * DNB + DNB; }
 
 // Cholesky of the n x n matrix in A; with_rhs: the right-hand-side rows go through the elimination too
-static void chol_factor(hm_ctx *h, double *A, int n, bool with_rhs)
+static void chol_factor(hm_ctx *h, double *A, double *Ld, int n, bool with_rhs)
 {
     const int nb = hm_cdiv(n, DNB);
     const int nrows = with_rhs ? aug_rows(n) : n;
     const int nbr = hm_cdiv(nrows, DNB);
     for (int k = 0; k < nb; k++) {
-        hipLaunchKernelGGL(k_chol_panel, dim3(nbr - k), dim3(256), 0, h->stream, A, n, nrows, k);
+        hipLaunchKernelGGL(k_chol_panel, dim3(nbr - k), dim3(256), 0, h->stream, A, Ld, n, nrows, k);
         const int mc = nb - k - 1, mr = nbr - k - 1;
         if (mr > 0 && mc > 0) hipLaunchKernelGGL(k_chol_update, dim3(mc, mr), dim3(256), 0, h->stream, A, n, nrows, k);
     }
@@ -425,20 +430,20 @@ static void chol_factor(hm_ctx *h, double *A, int n, bool with_rhs)
 #define INV_CH 4
 // SPD inverse from the factor: T = L^-1 (forward substitution of the identity, lower triangular),
 // then inv = T^T T.  `scratch` receives T.
-static void chol_inverse(hm_ctx *h, const double *L, int n, double *scratch, double *out)
+static void chol_inverse(hm_ctx *h, const double *L, const double *Ld, int n, double *scratch, double *out)
 {
     hipLaunchKernelGGL((k_tri_solve<INV_CH, true, true, false, 256>), dim3(hm_cdiv(n, INV_CH)), dim3(256),
-                       (size_t)n * (INV_CH + 1) * sizeof(double), h->stream, L, n, scratch, (size_t)n, (size_t)1, n);
+                       (size_t)n * (INV_CH + 1) * sizeof(double), h->stream, L, Ld, n, scratch, (size_t)n, (size_t)1, n);
     const int nb = hm_cdiv(n, DNB);
     hipLaunchKernelGGL(k_ttt, dim3(nb, nb), dim3(256), 0, h->stream, scratch, n, out);
 }
 
 // backward substitution L^T x = y for the right-hand side that went through the factorisation as a row
-static void chol_backsolve_row(hm_ctx *h, double *A, int n)
+static void chol_backsolve_row(hm_ctx *h, double *A, const double *Ld, int n)
 {
     double *row = A + (size_t)hm_cdiv(n, DNB) * DNB * n;     // y^T, overwritten by x^T
     hipLaunchKernelGGL((k_tri_solve<4, false, false, true, 1024>), dim3(1), dim3(1024), (size_t)n * 5 * sizeof(double),
-                       h->stream, A, n, row, (size_t)1, (size_t)n, 1);
+                       h->stream, A, Ld, n, row, (size_t)1, (size_t)n, 1);
 }
 
 extern "C" int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *X0)
@@ -460,8 +465,8 @@ extern "C" int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *
     HM_ARG((size_t)n4 * (INV_CH + 1) * sizeof(double) <= inv_lds_cap, "hm_update_begin: state dimension %d too large for "
            "the on-device inverse (limit %d)", n4, (int)(inv_lds_cap / ((INV_CH + 1) * sizeof(double))));
     HM_HIP(hipMemcpyAsync(h->d_Af[0], W_prior, (size_t)n4 * n4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    chol_factor(h, h->d_Af[0], n4, false);
-    chol_inverse(h, h->d_Af[0], n4, h->d_Wtmp, h->d_invW0);
+    chol_factor(h, h->d_Af[0], h->d_Ld[0], n4, false);
+    chol_inverse(h, h->d_Af[0], h->d_Ld[0], n4, h->d_Wtmp, h->d_invW0);
     HM_HIP(hipGetLastError());
     h->upd_X0.assign(X0, X0 + n4);
     h->upd_last = h->upd_prev = -1;
@@ -494,8 +499,8 @@ extern "C" int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int ma
     HM_HIP(hipMemsetAsync(A + nn, 0, pad_n * sizeof(double), h->stream));
     double *rhs_row = A + (size_t)hm_cdiv(n4, DNB) * DNB * n4;
     hipLaunchKernelGGL(k_rhs, dim3(n4), dim3(256), 0, h->stream, h->d_H, h->d_dx, h->d_Hz, rhs_row, n4);
-    chol_factor(h, A, n4, true);
-    chol_backsolve_row(h, A, n4);
+    chol_factor(h, A, h->d_Ld[slot], n4, true);
+    chol_backsolve_row(h, A, h->d_Ld[slot], n4);
     HM_HIP(hipGetLastError());
     HM_HIP(hipMemcpyAsync(step, rhs_row, (size_t)n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (Hzc) HM_HIP(hipMemcpyAsync(Hzc, h->d_Hzc, (size_t)n4 * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -514,7 +519,7 @@ extern "C" int hm_update_cov(hm_ctx_t h, int which, double *W_out)
     if (slot < 0) { hm_set_error("hm_update_cov: no such step"); return HM_ERR_STATE; }
     HM_HIP(hipSetDevice(h->device));
     const int n4 = 4 * h->N;
-    chol_inverse(h, h->d_Af[slot], n4, h->d_Wtmp, h->d_H);      // d_H is free between steps
+    chol_inverse(h, h->d_Af[slot], h->d_Ld[slot], n4, h->d_Wtmp, h->d_H);      // d_H is free between steps
     HM_HIP(hipGetLastError());
     HM_HIP(hipMemcpyAsync(W_out, h->d_H, (size_t)n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HM_HIP(hipStreamSynchronize(h->stream));
