@@ -161,17 +161,27 @@ int hm_measure(hm_ctx_t h, const double *X, double deltaX, int masked,
  *   step  : hm_measure at X, then  step = (inv(W) + HTH)^-1 (Hz - HTH (X0 - X))  by a blocked
  *           Cholesky factorisation (the reference forms inv(inv(W) + HTH) explicitly and
  *           multiplies); the new iterate is X0 + step.  Hzc (4N x 4, may be NULL) as hm_measure;
+ *           err (may be NULL) receives hm_error of the new iterate X0 + step (kalman.py:813);
  *   cov   : (inv(W) + HTH)^-1 of the last step (which = 0) or of the one before (which = 1,
  *           what the reference keeps as W_old for its mesh-inversion rollback, kalman.py:806-811).
  * A non-positive-definite system shows up as NaNs in `step`. */
-int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *X0);
-int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int masked, double *step, double *Hzc);
+int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *X0);   /* W_prior NULL: the result of
+                                                                              hm_cov_predict, still on the device */
+int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int masked, double *step, double *Hzc,
+                   double err[4]);
 int hm_update_cov(hm_ctx_t h, int which, double *W_out);
 /* IteratedMSKalmanFilter._newton (kalman.py:923-960): the mass-spring state prediction, ceil(1/dt)
  * implicit-Euler sub-steps each solved by Newton's method.  Host code, no GPU involved.
  * bars: I*2 vertex ids (distmesh.bars), l0: rest lengths; X: 4N doubles, advanced in place. */
 int hm_ms_newton(int n_vertices, int n_bars, const int32_t *bars, const double *l0, double kappa, double M,
                  double dt, int maxiter, double tol, double *X, int *newton_iterations);
+/* Covariance prediction W' = F W F^T + Weps (kalman.py:717 and :863) on the device, with
+ * F = [[I, a I], [s dfdy, I]], dfdy given as one symmetric 2x2 block (Bxx, Bxy, Byy) per spring
+ * (kalman.py:865-902; n_bars = 0: the constant-velocity model), Weps = eps_F [[I/4, I/2], [I/2, I]]
+ * (:182).  W_in NULL: propagate the covariance hm_update_cov returned last (still on the device).
+ * The result is copied to W_out and kept on the device for hm_update_begin(h, NULL, X0). */
+int hm_cov_predict(hm_ctx_t h, const double *W_in, int n_bars, const int32_t *bars, const double *blocks,
+                   double a, double s, double eps_F, double *W_out);
 int hm_ctx_sync(hm_ctx_t h);
 void *hm_ctx_stream(hm_ctx_t h);
 

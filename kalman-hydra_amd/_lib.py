@@ -60,8 +60,10 @@ SIGNATURES = {
     "hm_error": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_f64p, c_vp, c_vp]),
     "hm_measure": (ctypes.c_int, [c_vp, c_vp, ctypes.c_double, ctypes.c_int, c_vp, c_vp, c_vp]),
     "hm_update_begin": (ctypes.c_int, [c_vp, c_vp, c_vp]),
-    "hm_update_step": (ctypes.c_int, [c_vp, c_vp, ctypes.c_double, ctypes.c_int, c_vp, c_vp]),
+    "hm_update_step": (ctypes.c_int, [c_vp, c_vp, ctypes.c_double, ctypes.c_int, c_vp, c_vp, c_f64p]),
     "hm_update_cov": (ctypes.c_int, [c_vp, ctypes.c_int, c_vp]),
+    "hm_cov_predict": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_vp, c_vp, ctypes.c_double, ctypes.c_double,
+                                      ctypes.c_double, c_vp]),
     "hm_ms_newton": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp, c_vp, ctypes.c_double, ctypes.c_double,
                                     ctypes.c_double, ctypes.c_int, ctypes.c_double, c_vp, ctypes.POINTER(ctypes.c_int)]),
     "hm_ctx_sync": (ctypes.c_int, [c_vp]),

@@ -327,6 +327,14 @@ __global__ void k_add_mat(const double *__restrict__ a, const double *__restrict
     if (i < n) out[i] = a[i] + b[i];
 }
 
+// out = a + s * b
+__global__ void k_vec_axpy(const double *__restrict__ a, const double *__restrict__ b, double s, double *__restrict__ out,
+                           int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + s * b[i];
+}
+
 // y = base - M x   (one workgroup per row, fixed-order reduction)
 __global__ __launch_bounds__(256) void k_rhs(const double *__restrict__ M, const double *__restrict__ x,
                                              const double *__restrict__ base, double *__restrict__ y, int n)
@@ -339,4 +347,66 @@ __global__ __launch_bounds__(256) void k_rhs(const double *__restrict__ M, const
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) y[row] = base[row] - (((s[0] + s[1]) + s[2]) + s[3]);
+}
+
+
+// ---- covariance prediction W' = F W F^T + Weps on the device -------------------------------------------
+// F = [[I, a I], [A, I]] with A = s * dfdy, dfdy assembled from one symmetric 2x2 block per spring
+// (see predict.cpp): (dfdy M)[rows of vertex v] = - sum over springs (v,u) of B (M[rows v] - M[rows u]).
+// Weps = eps * [[I/4, I/2], [I/2, I]] (reference kalman.py:182).  n2 = 2N, n4 = 4N.
+struct SpringTopo {
+    const int *off;           // N+1: springs of each vertex
+    const int *bar;           // spring id
+    const int *other;         // the vertex at the other end
+    const double *blk;        // I x 3: Bxx, Bxy, Byy
+};
+
+// P = F W, one thread per (vertex, column)
+__global__ void k_fw_rows(const double *__restrict__ W, double *__restrict__ P, int N, SpringTopo tp, double a, double s)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = blockIdx.y;
+    const int n2 = 2 * N, n4 = 4 * N;
+    if (c >= n4) return;
+    const double wx = W[(size_t)(2 * v) * n4 + c], wy = W[(size_t)(2 * v + 1) * n4 + c];
+    const double bx = W[(size_t)(n2 + 2 * v) * n4 + c], by = W[(size_t)(n2 + 2 * v + 1) * n4 + c];
+    double ax = 0.0, ay = 0.0;
+    for (int q = tp.off[v]; q < tp.off[v + 1]; q++) {
+        const int u = tp.other[q];
+        const double *B = tp.blk + 3 * tp.bar[q];
+        const double dx = wx - W[(size_t)(2 * u) * n4 + c], dy = wy - W[(size_t)(2 * u + 1) * n4 + c];
+        ax -= B[0] * dx + B[1] * dy;
+        ay -= B[1] * dx + B[2] * dy;
+    }
+    P[(size_t)(2 * v) * n4 + c] = wx + a * bx;
+    P[(size_t)(2 * v + 1) * n4 + c] = wy + a * by;
+    P[(size_t)(n2 + 2 * v) * n4 + c] = s * ax + bx;
+    P[(size_t)(n2 + 2 * v + 1) * n4 + c] = s * ay + by;
+}
+
+// W' = P F^T + Weps, one thread per (row, vertex)
+__global__ void k_pft_cols(const double *__restrict__ P, double *__restrict__ Wn, int N, SpringTopo tp, double a, double s,
+                           double eps)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = blockIdx.y;
+    const int n2 = 2 * N, n4 = 4 * N;
+    if (r >= n4) return;
+    const double *Pr = P + (size_t)r * n4;
+    const double px = Pr[2 * v], py = Pr[2 * v + 1], qx = Pr[n2 + 2 * v], qy = Pr[n2 + 2 * v + 1];
+    double ax = 0.0, ay = 0.0;
+    for (int q = tp.off[v]; q < tp.off[v + 1]; q++) {
+        const int u = tp.other[q];
+        const double *B = tp.blk + 3 * tp.bar[q];
+        const double dx = px - Pr[2 * u], dy = py - Pr[2 * u + 1];
+        ax -= dx * B[0] + dy * B[1];
+        ay -= dx * B[1] + dy * B[2];
+    }
+    double o0 = px + a * qx, o1 = py + a * qy, o2 = s * ax + qx, o3 = s * ay + qy;
+    if (r == 2 * v) { o0 += eps / 4; o2 += eps / 2; }
+    if (r == 2 * v + 1) { o1 += eps / 4; o3 += eps / 2; }
+    if (r == n2 + 2 * v) { o0 += eps / 2; o2 += eps; }
+    if (r == n2 + 2 * v + 1) { o1 += eps / 2; o3 += eps; }
+    double *Wr = Wn + (size_t)r * n4;
+    Wr[2 * v] = o0; Wr[2 * v + 1] = o1; Wr[n2 + 2 * v] = o2; Wr[n2 + 2 * v + 1] = o3;
 }

@@ -33,9 +33,14 @@ struct hm_ctx {
     uint8_t *d_im8, *d_m8;
     std::vector<double> X0;          // state of the reference render
     // dense update on the device (n4 = 4N)
-    double *d_H, *d_Hz, *d_Hzc, *d_invW0, *d_Af[2], *d_Ld[2], *d_rhs, *d_dx, *d_Wtmp;
+    double *d_H, *d_Hz, *d_Hzc, *d_invW0, *d_Af[2], *d_Ld[2], *d_rhs, *d_dx, *d_Wtmp, *d_X0, *d_Xn;
     std::vector<double> upd_X0;      // prior mean given to hm_update_begin
     int upd_last, upd_prev;          // which d_Af holds the factor of the last / previous step (-1: none)
+    bool w_post_dev;                 // d_H holds the covariance hm_update_cov returned last
+    bool w_pred_dev;                 // d_Wtmp holds the covariance hm_cov_predict returned last
+    int *d_sp_off, *d_sp_bar, *d_sp_other;
+    double *d_sp_blk;
+    size_t sp_cap;                   // capacity (springs) of the d_sp_* arrays
     bool upd_open;
     std::vector<double> h_out, h_partial;
     int red_blocks;
@@ -64,7 +69,7 @@ static int ctx_free(hm_ctx *h)
     void *ptrs[] = {h->d_tri, h->d_star_off, h->d_star_tri, h->d_edges, h->d_uv, h->d_tex, h->d_yim, h->d_ym, h->d_yfx,
                     h->d_yfy, h->d_yfxm, h->d_yfym, h->d_setup, h->d_X, h->d_out, h->d_partial, h->d_im8, h->d_m8,
                     h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_Ld[0], h->d_Ld[1], h->d_rhs, h->d_dx,
-                    h->d_Wtmp};
+                    h->d_Wtmp, h->d_X0, h->d_Xn, h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     free_targets(h->ref);
@@ -124,7 +129,9 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->ref = Targets{nullptr, nullptr, nullptr, nullptr}; h->P = h->ref; h->Q = h->ref;
     h->d_setup = nullptr; h->d_X = h->d_out = h->d_partial = nullptr; h->d_im8 = h->d_m8 = nullptr;
     h->d_H = h->d_Hz = h->d_Hzc = h->d_invW0 = h->d_Af[0] = h->d_Af[1] = h->d_rhs = h->d_dx = h->d_Wtmp = nullptr;
-    h->d_Ld[0] = h->d_Ld[1] = nullptr;
+    h->d_Ld[0] = h->d_Ld[1] = nullptr; h->d_X0 = h->d_Xn = nullptr;
+    h->w_post_dev = h->w_pred_dev = false;
+    h->d_sp_off = h->d_sp_bar = h->d_sp_other = nullptr; h->d_sp_blk = nullptr; h->sp_cap = 0;
     h->upd_last = h->upd_prev = -1; h->upd_open = false;
     for (const auto &e : eset) { h->edges.push_back(e.first); h->edges.push_back(e.second); }
     h->E = (int)eset.size();
@@ -167,6 +174,8 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Hzc, n4 * 4 * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_rhs, n4 * 4 * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_dx, n4 * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_X0, n4 * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Xn, n4 * sizeof(double));
         if (e != hipSuccess) {
             hm_set_error("hm_ctx_create: device allocation failed: %s", hipGetErrorString(e));
             rc = HM_ERR_HIP;
@@ -242,15 +251,21 @@ extern "C" int hm_set_observation_dev(hm_ctx_t h, const uint8_t *d_y_im, const f
 }
 
 // render state X (host, 4N doubles) into target t on the handle's stream
+// render the device-resident state dX into target t
+static int render_dev(hm_ctx *h, const double *dX, Targets t)
+{
+    Mesh m = {h->W, h->H, h->N, h->T, h->d_tri, h->d_uv, h->d_tex};
+    hipLaunchKernelGGL(k_setup_all, dim3(hm_cdiv(h->T, 64)), dim3(64), 0, h->stream, m, dX, h->d_setup);
+    hipLaunchKernelGGL(k_render, dim3(hm_cdiv(h->W, EKF_TILE), hm_cdiv(h->H, EKF_TILE)), dim3(EKF_TILE, EKF_TILE), 0,
+                       h->stream, m, dX, h->d_setup, t);
+    HM_HIP(hipGetLastError());
+    return HM_OK;
+}
+
 static int render_into(hm_ctx *h, const double *X, Targets t)
 {
     HM_HIP(hipMemcpyAsync(h->d_X, X, (size_t)4 * h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    Mesh m = {h->W, h->H, h->N, h->T, h->d_tri, h->d_uv, h->d_tex};
-    hipLaunchKernelGGL(k_setup_all, dim3(hm_cdiv(h->T, 64)), dim3(64), 0, h->stream, m, h->d_X, h->d_setup);
-    hipLaunchKernelGGL(k_render, dim3(hm_cdiv(h->W, EKF_TILE), hm_cdiv(h->H, EKF_TILE)), dim3(EKF_TILE, EKF_TILE), 0,
-                       h->stream, m, h->d_X, h->d_setup, t);
-    HM_HIP(hipGetLastError());
-    return HM_OK;
+    return render_dev(h, h->d_X, t);
 }
 
 #define NEED_TEX(h, who) \
@@ -385,6 +400,7 @@ static int measure_on_device(hm_ctx *h, const double *X, double deltaX, int mask
     hipLaunchKernelGGL(k_measure<true>, dim3(h->N, MEAS_VSPLIT), dim3(MEAS_NT), 0, h->stream, a);
     if (h->E > 0) hipLaunchKernelGGL(k_measure<false>, dim3(h->E), dim3(MEAS_NT), 0, h->stream, a);
     const size_t n4 = (size_t)4 * h->N;
+    h->w_post_dev = false;                       // d_H is about to be overwritten
     HM_HIP(hipMemsetAsync(h->d_H, 0, n4 * n4 * sizeof(double), h->stream));
     ScatterArgs s = {h->d_out, h->d_edges, h->N, h->E, h->eps_Z, h->eps_J, h->eps_M, deltaX, h->d_H, h->d_Hz, h->d_Hzc};
     hipLaunchKernelGGL(k_hth_scatter, dim3(hm_cdiv(h->njobs, 64)), dim3(64), 0, h->stream, s);
@@ -448,7 +464,11 @@ static void chol_backsolve_row(hm_ctx *h, double *A, const double *Ld, int n)
 
 extern "C" int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *X0)
 {
-    HM_ARG(h && W_prior && X0, "hm_update_begin: NULL argument");
+    HM_ARG(h && X0, "hm_update_begin: NULL argument");
+    if (!W_prior && !h->w_pred_dev) {
+        hm_set_error("hm_update_begin: no prior given and none resident on the device");
+        return HM_ERR_STATE;
+    }
     HM_HIP(hipSetDevice(h->device));
     const int n4 = 4 * h->N;
     // the inverse keeps an n x 16 slab of doubles in LDS next to its static buffers: raise the
@@ -464,17 +484,23 @@ extern "C" int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *
     }
     HM_ARG((size_t)n4 * (INV_CH + 1) * sizeof(double) <= inv_lds_cap, "hm_update_begin: state dimension %d too large for "
            "the on-device inverse (limit %d)", n4, (int)(inv_lds_cap / ((INV_CH + 1) * sizeof(double))));
-    HM_HIP(hipMemcpyAsync(h->d_Af[0], W_prior, (size_t)n4 * n4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (W_prior)
+        HM_HIP(hipMemcpyAsync(h->d_Af[0], W_prior, (size_t)n4 * n4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    else        // the covariance hm_cov_predict left on the device
+        HM_HIP(hipMemcpyAsync(h->d_Af[0], h->d_Wtmp, (size_t)n4 * n4 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    h->w_pred_dev = false;                       // d_Wtmp is scratch from here on
     chol_factor(h, h->d_Af[0], h->d_Ld[0], n4, false);
     chol_inverse(h, h->d_Af[0], h->d_Ld[0], n4, h->d_Wtmp, h->d_invW0);
     HM_HIP(hipGetLastError());
     h->upd_X0.assign(X0, X0 + n4);
+    HM_HIP(hipMemcpyAsync(h->d_X0, h->upd_X0.data(), (size_t)n4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     h->upd_last = h->upd_prev = -1;
     h->upd_open = true;
     return HM_OK;
 }
 
-extern "C" int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int masked, double *step, double *Hzc)
+extern "C" int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int masked, double *step, double *Hzc,
+                              double err[4])
 {
     HM_ARG(h && X && step, "hm_update_step: NULL argument");
     HM_ARG(deltaX > 0, "hm_update_step: deltaX must be positive");
@@ -483,12 +509,9 @@ extern "C" int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int ma
     NEED_OBS(h, "hm_update_step");
     HM_HIP(hipSetDevice(h->device));
     const int n4 = 4 * h->N;
-    int rc = measure_on_device(h, X, deltaX, masked);
+    int rc = measure_on_device(h, X, deltaX, masked);          // leaves X in d_X
     if (rc) return rc;
-    std::vector<double> dx(n4);
-    for (int i = 0; i < n4; i++) dx[i] = h->upd_X0[i] - X[i];
-    HM_HIP(hipMemcpyAsync(h->d_dx, dx.data(), (size_t)n4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HM_HIP(hipStreamSynchronize(h->stream));        // dx is a local
+    hipLaunchKernelGGL(k_vec_axpy, dim3(hm_cdiv(n4, 256)), dim3(256), 0, h->stream, h->d_X0, h->d_X, -1.0, h->d_dx, n4);
     const int slot = h->upd_last == 0 ? 1 : 0;
     double *A = h->d_Af[slot];
     const size_t nn = (size_t)n4 * n4;
@@ -504,7 +527,18 @@ extern "C" int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int ma
     HM_HIP(hipGetLastError());
     HM_HIP(hipMemcpyAsync(step, rhs_row, (size_t)n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (Hzc) HM_HIP(hipMemcpyAsync(Hzc, h->d_Hzc, (size_t)n4 * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HM_HIP(hipStreamSynchronize(h->stream));
+    if (err) {
+        // Renderer.error of the new iterate X0 + step, without another host round trip
+        hipLaunchKernelGGL(k_vec_axpy, dim3(hm_cdiv(n4, 256)), dim3(256), 0, h->stream, h->d_X0, rhs_row, 1.0, h->d_Xn, n4);
+        rc = render_dev(h, h->d_Xn, h->P);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_error, dim3(h->red_blocks), dim3(RED_NT), 0, h->stream, h->P, obs_of(h, masked),
+                           h->W * h->H, h->d_partial);
+        rc = collect4(h, err);                                   // synchronises the stream
+        if (rc) return rc;
+    } else {
+        HM_HIP(hipStreamSynchronize(h->stream));
+    }
     h->upd_prev = h->upd_last;
     h->upd_last = slot;
     return HM_OK;
@@ -523,5 +557,73 @@ extern "C" int hm_update_cov(hm_ctx_t h, int which, double *W_out)
     HM_HIP(hipGetLastError());
     HM_HIP(hipMemcpyAsync(W_out, h->d_H, (size_t)n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HM_HIP(hipStreamSynchronize(h->stream));
+    h->w_post_dev = true;
+    h->w_pred_dev = false;
+    return HM_OK;
+}
+
+// Covariance prediction W' = F W F^T + Weps (kalman.py:717, 863) on the device.
+//   W_in   : the covariance to propagate (host), or NULL to use the one hm_update_cov returned last,
+//            which is still on the device;
+//   bars / blocks : the springs and, per spring, the symmetric 2x2 block (Bxx, Bxy, Byy) of the force
+//            Jacobian at the state before the step; n_bars = 0 gives the constant-velocity F (A = 0);
+//   a, s   : F = [[I, a I], [s dfdy, I]];  eps_F : Weps = eps_F [[I/4, I/2], [I/2, I]].
+// The result is copied to W_out and stays on the device as the prior of the next hm_update_begin(NULL).
+extern "C" int hm_cov_predict(hm_ctx_t h, const double *W_in, int n_bars, const int32_t *bars, const double *blocks,
+                              double a, double s, double eps_F, double *W_out)
+{
+    HM_ARG(h && W_out && n_bars >= 0 && (n_bars == 0 || (bars && blocks)), "hm_cov_predict: bad argument");
+    if (!W_in && !h->w_post_dev) {
+        hm_set_error("hm_cov_predict: no covariance given and none resident on the device");
+        return HM_ERR_STATE;
+    }
+    HM_HIP(hipSetDevice(h->device));
+    const int N = h->N, n4 = 4 * N;
+    const size_t nn = (size_t)n4 * n4 * sizeof(double);
+    std::vector<int> off(N + 1, 0), bar, other;
+    for (int i = 0; i < n_bars; i++) {
+        HM_ARG(bars[2 * i] >= 0 && bars[2 * i] < N && bars[2 * i + 1] >= 0 && bars[2 * i + 1] < N,
+               "hm_cov_predict: spring %d refers to a vertex outside 0..%d", i, N - 1);
+        off[bars[2 * i] + 1]++;
+        off[bars[2 * i + 1] + 1]++;
+    }
+    for (int v = 0; v < N; v++) off[v + 1] += off[v];
+    bar.resize(2 * (size_t)n_bars); other.resize(2 * (size_t)n_bars);
+    {
+        std::vector<int> fill(off.begin(), off.end() - 1);
+        for (int i = 0; i < n_bars; i++) {
+            const int p = bars[2 * i], q = bars[2 * i + 1];
+            bar[fill[p]] = i; other[fill[p]++] = q;
+            bar[fill[q]] = i; other[fill[q]++] = p;
+        }
+    }
+    if (!h->d_sp_off) HM_HIP(hipMalloc((void **)&h->d_sp_off, (size_t)(N + 1) * sizeof(int)));
+    if ((size_t)n_bars > h->sp_cap) {
+        if (h->d_sp_bar) (void)hipFree(h->d_sp_bar);
+        if (h->d_sp_other) (void)hipFree(h->d_sp_other);
+        if (h->d_sp_blk) (void)hipFree(h->d_sp_blk);
+        h->d_sp_bar = h->d_sp_other = nullptr; h->d_sp_blk = nullptr;
+        HM_HIP(hipMalloc((void **)&h->d_sp_bar, 2 * (size_t)n_bars * sizeof(int)));
+        HM_HIP(hipMalloc((void **)&h->d_sp_other, 2 * (size_t)n_bars * sizeof(int)));
+        HM_HIP(hipMalloc((void **)&h->d_sp_blk, 3 * (size_t)n_bars * sizeof(double)));
+        h->sp_cap = n_bars;
+    }
+    HM_HIP(hipMemcpyAsync(h->d_sp_off, off.data(), (size_t)(N + 1) * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (n_bars > 0) {
+        HM_HIP(hipMemcpyAsync(h->d_sp_bar, bar.data(), bar.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HM_HIP(hipMemcpyAsync(h->d_sp_other, other.data(), other.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HM_HIP(hipMemcpyAsync(h->d_sp_blk, blocks, 3 * (size_t)n_bars * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    if (W_in) HM_HIP(hipMemcpyAsync(h->d_H, W_in, nn, hipMemcpyHostToDevice, h->stream));
+    SpringTopo tp = {h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk};
+    double *P = h->d_Af[1];                      // scratch: no factor is live between two updates
+    hipLaunchKernelGGL(k_fw_rows, dim3(hm_cdiv(n4, 256), N), dim3(256), 0, h->stream, h->d_H, P, N, tp, a, s);
+    hipLaunchKernelGGL(k_pft_cols, dim3(hm_cdiv(n4, 256), N), dim3(256), 0, h->stream, P, h->d_Wtmp, N, tp, a, s, eps_F);
+    HM_HIP(hipGetLastError());
+    HM_HIP(hipMemcpyAsync(W_out, h->d_Wtmp, nn, hipMemcpyDeviceToHost, h->stream));
+    HM_HIP(hipStreamSynchronize(h->stream));      // off / bar / other are locals
+    h->w_post_dev = false;
+    h->w_pred_dev = true;
+    h->upd_open = false;                          // the factors of the last update are gone (d_Af[1] was scratch)
     return HM_OK;
 }

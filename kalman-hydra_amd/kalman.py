@@ -404,13 +404,16 @@ class KalmanFilter:
         return self.error(y_im, y_flow, y_m)
 
     def predict(self):
-        """Constant-velocity prediction (:703-718)."""
+        """Constant-velocity prediction (:703-718): X <- F X, W <- F W F^T + Weps, F = [[I, I], [0, I]]."""
         t0 = time.time()
         st = self.state
         self.orig_x = st.X.copy()
         st.X = st.F.dot(st.X)
         self.pred_x = st.X.copy()
-        st.W = st.F.dot(st.W.dot(st.F.T)) + st.Weps
+        if hasattr(st.renderer, "cov_predict"):
+            st.W = st.renderer.cov_predict(st.W, None, None, 1.0, 0.0, st.eps_F)
+        else:
+            st.W = st.F.dot(st.W.dot(st.F.T)) + st.Weps
         stats.statepredtime[0] += time.time() - t0
 
     def projectmask(self, y_m):
@@ -448,7 +451,7 @@ class KalmanFilter:
         X, W = st.X, st.W
         if hasattr(st.renderer, "update_step"):
             st.renderer.update_begin(W, X)
-            step, Hzc = st.renderer.update_step(st, y_im, y_flow, y_m)     # X0 - X = 0: step = W_new Hz
+            step, Hzc, _ = st.renderer.update_step(st, y_im, y_flow, y_m, want_error=False)   # X0 - X = 0: step = W_new Hz
             if not np.all(np.isfinite(step)):
                 raise FloatingPointError("information matrix of the update is not positive definite")
             Wn = st.renderer.update_cov(0)
@@ -504,9 +507,12 @@ class IteratedKalmanFilter(KalmanFilter):
             t0 = time.time()
             step = None
             if on_device:
-                step, Hzc = st.renderer.update_step(st, y_im, y_flow, y_m)
+                step, Hzc, err = st.renderer.update_step(st, y_im, y_flow, y_m)
                 if not np.all(np.isfinite(step)):
-                    raise FloatingPointError("information matrix of the update is not positive definite")
+                    # inv(W) is positive definite and HTH is a Gram matrix of the difference images
+                    # (positive semi-definite), so this only happens with non-finite inputs
+                    raise FloatingPointError("the update system inv(W) + HTH is not positive definite "
+                                             "(non-finite state, covariance or observation?)")
                 dt = time.time() - t0
                 stats.stateupdatetc[0] += dt
                 stats.stateupdatetc[1] += 1
@@ -524,7 +530,10 @@ class IteratedKalmanFilter(KalmanFilter):
                 reverted = True
                 self._say("** Mesh inconsistent ** Reverting to last good state and continuing")
                 break
-            e_im, e_fx, e_fy, e_m, _, _ = st.renderer.error(st, y_im, y_flow, y_m, want_flow=False)
+            if on_device:                # error of the new iterate came back with the step
+                e_im, e_fx, e_fy, e_m = err
+            else:
+                e_im, e_fx, e_fy, e_m, _, _ = st.renderer.error(st, y_im, y_flow, y_m, want_flow=False)
             enew = float(np.sqrt(float(e_im) ** 2 + e_fx ** 2 + e_fy ** 2 + float(e_m) ** 2))
             self._say("-- e_im: %d, e_fx: %d, e_fy: %d, e_m: %d" % (e_im, e_fx, e_fy, e_m))
             accepted += 1
@@ -589,6 +598,17 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
         n2 = 2 * st.N
         return sp.csr_matrix((vals, (self._jrows, self._jcols)), shape=(n2, n2))
 
+    def _spring_blocks(self):
+        """Per spring the symmetric block (Bxx, Bxy, Byy) of dfdy at the current vertices (see _jacobian)."""
+        st = self.state
+        y = st.vertices()
+        d = y[self._bars[:, 0]] - y[self._bars[:, 1]]
+        l = np.sqrt((d * d).sum(axis=1))
+        l0 = st.l0[:, 0]
+        k = self.kappa * (1 - l0 / l)
+        c = self.kappa * l0 / l ** 3
+        return np.column_stack((k + c * d[:, 0] * d[:, 0], c * d[:, 0] * d[:, 1], k + c * d[:, 1] * d[:, 1]))
+
     def _bar_pattern(self):
         """Row / column indices of the four 2x2 blocks every bar contributes to dfdy."""
         bars = np.asarray(self.distmesh.bars, np.int64)
@@ -618,10 +638,16 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
         t0 = time.time()
         st = self.state
         self.orig_x = st.X.copy()
-        A = self._jacobian() * (self.deltat / self.M)     # F = [[I, dt I], [A, I]] at the state before the step (:856)
-        self._newton()
+        # F = [[I, dt I], [dt/M dfdy, I]] at the state before the step (:856)
+        if hasattr(st.renderer, "cov_predict"):
+            blocks = self._spring_blocks()
+            self._newton()
+            st.W = st.renderer.cov_predict(st.W, self._bars, blocks, self.deltat, self.deltat / self.M, st.eps_F)
+        else:
+            A = self._jacobian() * (self.deltat / self.M)
+            self._newton()
+            st.W = _fwft(A, self.deltat, st.W) + st.Weps
         self.pred_x = st.X.copy()
-        st.W = _fwft(A, self.deltat, st.W) + st.Weps
         stats.statepredtime[0] += time.time() - t0
 
     def _newton(self):

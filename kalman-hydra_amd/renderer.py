@@ -56,6 +56,7 @@ class Renderer:
         self.vertices = np.array(distmesh.p, np.float64)
         self.velocities = np.array(vel, np.float64).reshape(self.vertices.shape)
         self._obs = None
+        self._w_post = self._w_pred = None      # covariance arrays whose values are still on the device
         self.current_frame = tex
         self.current_flowx, self.current_flowy = flow[:, :, 0], flow[:, :, 1]
 
@@ -187,29 +188,54 @@ class Renderer:
         HTH = np.empty((n4, n4))
         _lib.check(_lib.lib().hm_measure(self._h, _lib.ptr(self._X(state)), float(deltaX), masked, _lib.ptr(Hz),
                                          _lib.ptr(Hzc), _lib.ptr(HTH)), "hm_measure")
+        self._w_post = None
         return Hz.reshape(-1, 1), HTH, Hzc
 
     # -- the dense update on the device (information form) --------------------------------------
+    def cov_predict(self, W, bars, blocks, a, s, eps_F):
+        """hm_cov_predict: F W F^T + Weps on the device.  If W is the very array update_cov returned
+        last, the copy still on the device is used instead of uploading it again."""
+        n4 = 4 * self.n
+        out = np.empty((n4, n4))
+        on_dev = W is self._w_post
+        Win = None if on_dev else np.ascontiguousarray(W, np.float64)
+        nb = 0 if bars is None else int(len(bars))
+        b = None if nb == 0 else np.ascontiguousarray(bars, np.int32)
+        blk = None if nb == 0 else np.ascontiguousarray(blocks, np.float64)
+        _lib.check(_lib.lib().hm_cov_predict(self._h, _lib.ptr(Win), nb, _lib.ptr(b), _lib.ptr(blk), float(a), float(s),
+                                             float(eps_F), _lib.ptr(out)), "hm_cov_predict")
+        self._w_post = None
+        self._w_pred = out
+        return out
+
     def update_begin(self, W_prior, X0):
-        """Factor the prior covariance on the device and keep inv(W), X0 there (hm_update_begin)."""
-        W = np.ascontiguousarray(W_prior, np.float64)
+        """Factor the prior covariance on the device and keep inv(W), X0 there (hm_update_begin).
+        The array cov_predict returned last is already on the device and is not uploaded again."""
+        on_dev = W_prior is self._w_pred
+        W = None if on_dev else np.ascontiguousarray(W_prior, np.float64)
         x0 = np.ascontiguousarray(np.asarray(X0, np.float64).reshape(-1))
         _lib.check(_lib.lib().hm_update_begin(self._h, _lib.ptr(W), _lib.ptr(x0)), "hm_update_begin")
+        self._w_pred = None
 
-    def update_step(self, state, y_im, y_flow, y_m, deltaX=2.0):
-        """hm_update_step: measurement at state.X and the solve, -> (step [4N,1], Hz_components [4N,4])."""
+    def update_step(self, state, y_im, y_flow, y_m, deltaX=2.0, want_error=True):
+        """hm_update_step: measurement at state.X, the solve and (want_error) Renderer.error of the new
+        iterate X0 + step -> (step [4N,1], Hz_components [4N,4], (e_im, e_fx, e_fy, e_m) or None)."""
         masked = self._masked_flag(y_im, y_flow, y_m)
         n4 = 4 * self.n
         step = np.empty(n4)
         Hzc = np.empty((n4, 4))
+        err = (ctypes.c_double * 4)()
         _lib.check(_lib.lib().hm_update_step(self._h, _lib.ptr(self._X(state)), float(deltaX), masked,
-                                             _lib.ptr(step), _lib.ptr(Hzc)), "hm_update_step")
-        return step.reshape(-1, 1), Hzc
+                                             _lib.ptr(step), _lib.ptr(Hzc), err if want_error else None),
+                   "hm_update_step")
+        e = (int(err[0]), err[1], err[2], int(err[3])) if want_error else None
+        return step.reshape(-1, 1), Hzc, e
 
     def update_cov(self, which=0):
         n4 = 4 * self.n
         W = np.empty((n4, n4))
         _lib.check(_lib.lib().hm_update_cov(self._h, int(which), _lib.ptr(W)), "hm_update_cov")
+        self._w_post = W
         return W
 
     def error(self, state, y_im, y_flow, y_m, want_flow=True):

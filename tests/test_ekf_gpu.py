@@ -226,7 +226,11 @@ def test_device_dense_update_matches_host_algebra(hm, n, h0):
     st.X = X.reshape(-1, 1)
     Hz, HTH, Hzc = R.measure(st, y_im, flow, y_m)
     R.update_begin(W, X0)
-    step, Hzc2 = R.update_step(st, y_im, flow, y_m)
+    step, Hzc2, err = R.update_step(st, y_im, flow, y_m)
+    st2 = _Flow()
+    st2.X = X0.reshape(-1, 1) + step
+    e_ref = R.error(st2, y_im, flow, y_m)
+    assert err[0] == e_ref[0] and err[3] == e_ref[3] and abs(err[1] - e_ref[1]) <= 1e-12 * e_ref[1]
     A = np.linalg.inv(W) + HTH
     ref = np.linalg.solve(A, Hz - HTH @ (X0 - X).reshape(-1, 1))
     assert np.array_equal(Hzc, Hzc2)
@@ -236,7 +240,7 @@ def test_device_dense_update_matches_host_algebra(hm, n, h0):
     # a second step keeps the first factor available as "the one before"
     st.X = (X + 0.1).reshape(-1, 1)
     Hz2, HTH2, _ = R.measure(st, y_im, flow, y_m)
-    step2, _ = R.update_step(st, y_im, flow, y_m)
+    step2, _, _ = R.update_step(st, y_im, flow, y_m)
     A2 = np.linalg.inv(W) + HTH2
     ref2 = np.linalg.solve(A2, Hz2 - HTH2 @ (X0 - st.X.reshape(-1)).reshape(-1, 1))
     assert np.linalg.norm(step2 - ref2) <= 1e-9 * np.linalg.norm(ref2)
@@ -259,3 +263,48 @@ def test_plain_kalman_filter_update_on_device(hm):
     Xr, Wr = ekf_ref.kf_update(tr_meas, Xp, Wp, kf.state.J, frame, fm, mask)
     assert np.linalg.norm(kf.state.X - Xr) <= 1e-8 * np.linalg.norm(Xr)
     assert np.linalg.norm(kf.state.W - Wr) <= 1e-7 * np.linalg.norm(Wr)
+
+
+def test_device_covariance_prediction(hm):
+    """hm_cov_predict against the host formula F W F^T + Weps, for both dynamics, with the covariance
+    uploaded and with the copy that update_cov leaves on the device."""
+    from hydra_mi import kalman
+    n = 64
+    dm, N, tex, R, meas = _setup(hm, n, 9.0, seed=3)
+    rng = np.random.default_rng(21)
+    n4 = 4 * N
+    M = rng.normal(size=(n4, n4))
+    W = np.eye(n4) * 0.3 + 0.02 * (M @ M.T) / n4
+    F, Weps, _ = ekf_ref.initial_covariances(N, 0.1)
+    got = R.cov_predict(W, None, None, 1.0, 0.0, 0.1)
+    assert np.linalg.norm(got - (F @ W @ F.T + Weps)) <= 1e-13 * np.linalg.norm(got)
+    # mass-spring F from the oracle's dense dfdy
+    y = dm.p.reshape(-1) + rng.normal(0, 0.5, 2 * N)
+    K = ekf_ref.incidence(N, dm.bars)
+    l0 = ekf_ref.bar_lengths(K, dm.p.reshape(-1))
+    dfdy = ekf_ref.ms_dfdy(K, l0, y, -1.0)
+    e = np.eye(2 * N)
+    Fm = np.block([[e, 0.05 * e], [0.05 * dfdy, e]])
+    d = y.reshape(-1, 2)[dm.bars[:, 0]] - y.reshape(-1, 2)[dm.bars[:, 1]]
+    l = np.sqrt((d * d).sum(1))
+    k, c = -1.0 * (1 - l0 / l), -1.0 * l0 / l ** 3
+    blocks = np.column_stack((k + c * d[:, 0] ** 2, c * d[:, 0] * d[:, 1], k + c * d[:, 1] ** 2))
+    got = R.cov_predict(W, dm.bars, blocks, 0.05, 0.05, 0.1)
+    ref = Fm @ W @ Fm.T + Weps
+    assert np.linalg.norm(got - ref) <= 1e-12 * np.linalg.norm(ref)
+    # prior straight from the device: predict -> begin(no upload) -> step -> cov -> predict(no upload)
+    X = _state(dm, rng, pos_sigma=0.4)
+    y_im, flow, y_m = _observation(dm, meas, rng, n)
+    st = _Flow()
+    st.X = X.reshape(-1, 1)
+    R.update_begin(got, X)                       # `got` is the array cov_predict returned: no upload
+    step, _, _ = R.update_step(st, y_im, flow, y_m)
+    Hz, HTH, _ = R.measure(st, y_im, flow, y_m)
+    A = np.linalg.inv(ref) + HTH
+    assert np.linalg.norm(step - np.linalg.solve(A, Hz)) <= 1e-8 * np.linalg.norm(step)
+    R.update_begin(got.copy(), X)
+    R.update_step(st, y_im, flow, y_m)
+    Wp = R.update_cov(0)
+    nxt = R.cov_predict(Wp, dm.bars, blocks, 0.05, 0.05, 0.1)      # Wp is still on the device
+    ref2 = Fm @ Wp @ Fm.T + Weps
+    assert np.linalg.norm(nxt - ref2) <= 1e-12 * np.linalg.norm(ref2)
