@@ -46,6 +46,17 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, doub
     const int r = k + blockIdx.x;
     const int d0 = k * DNB;
     const int nd = min(DNB, n - d0);              // the last diagonal block may be short: pad with identity
+    // this workgroup's rows of the panel (8 threads per row, 4 entries each): requested now, needed
+    // only after the diagonal block has been factored
+    const int r0 = r * DNB;
+    const int nr = min(DNB, nrows - r0);
+    const int row = t / 8, part = t % 8;
+    double x[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int c = 8 * q + part;
+        x[q] = (r != k && row < nr && c < nd) ? A[(size_t)(r0 + row) * n + d0 + c] : 0.0;
+    }
     for (int e = t; e < DNB * DNB; e += 256) {
         int i = e / DNB, j = e % DNB;
         W[i][j] = (i < nd && j < nd && j <= i) ? A[(size_t)(d0 + i) * n + d0 + j] : (i == j ? 1.0 : 0.0);
@@ -54,6 +65,8 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, doub
     __syncthreads();
     // Right-looking elimination with ONE barrier per column: the rank-1 update uses the unscaled
     // column and 1/w_jj, so it does not wait for the scaled column, which goes to a separate array.
+    // (A single-wave, barrier-free variant of this loop was measured slower: the rank-1 update is
+    // LDS-throughput bound and wants all four waves.)
     const int ti = t / DNB, tc = t % DNB;         // 8 x 32 thread grid over (row, column)
     for (int j = 0; j < DNB; j++) {
         const double wjj = W[j][j];
@@ -79,15 +92,6 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, doub
     // rows of the panel: 8 threads per row, thread `part` keeps the entries x[c], c = part mod 8, in
     // four registers; each of the 32 substitution steps is a 4-term partial dot product per thread,
     // a butterfly sum over the 8 threads and one multiply
-    const int r0 = r * DNB;
-    const int nr = min(DNB, nrows - r0);
-    const int row = t / 8, part = t % 8;
-    double x[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int c = 8 * q + part;
-        x[q] = (row < nr && c < nd) ? A[(size_t)(r0 + row) * n + d0 + c] : 0.0;
-    }
 #pragma unroll
     for (int j = 0; j < DNB; j++) {
         double partial = 0.0;
