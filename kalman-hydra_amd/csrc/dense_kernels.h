@@ -69,16 +69,26 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, doub
     // LDS-throughput bound and wants all four waves.)
     const int ti = t / DNB, tc = t % DNB;         // 8 x 32 thread grid over (row, column)
     for (int j = 0; j < DNB; j++) {
+        // every LDS read of the step is issued up front (the stores below may alias them as far as
+        // the compiler knows, which would otherwise serialise the four updates of a thread)
         const double wjj = W[j][j];
+        const double wtj = W[tc][j];
+        double wa[4], wb[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            wa[q] = W[ti + 8 * q][j];
+            wb[q] = W[ti + 8 * q][tc];
+        }
         const double rd = d_rcp(wjj);
         if (tc > j) {
-            const double wcj = W[tc][j] * rd;
-            for (int i = ti; i < DNB; i += 256 / DNB)
-                if (i >= tc) W[i][tc] = W[i][tc] - W[i][j] * wcj;
+            const double wcj = wtj * rd;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (ti + 8 * q >= tc) W[ti + 8 * q][tc] = wb[q] - wa[q] * wcj;
         }
         if (t < DNB && t >= j) {
             const double rs = d_rsqrt(wjj);
-            D[t][j] = (t == j) ? wjj * rs : W[t][j] * rs;
+            D[t][j] = (t == j) ? wjj * rs : wtj * rs;     // for t < 32: tc == t, so wtj = W[t][j]
             if (t == j) rD[j] = rs;
         }
         __syncthreads();
@@ -89,23 +99,28 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, doub
         for (int e = t; e < DNB * DNB; e += 256) Ld[(size_t)k * DNB * DNB + e] = D[e / DNB][e % DNB];
         return;
     }
-    // rows of the panel: 8 threads per row, thread `part` keeps the entries x[c], c = part mod 8, in
-    // four registers; each of the 32 substitution steps is a 4-term partial dot product per thread,
-    // a butterfly sum over the 8 threads and one multiply
+    // Rows of the panel: 8 threads per row (consecutive lanes of one wave), thread `part` owns the
+    // entries x[8 q + part].  The 32 columns are done in four groups of 8: for a group, every thread
+    // first subtracts the contribution of the finished columns to ITS entry (a private dot product
+    // over values parked in LDS, no reduction), then the 8x8 triangle of the group is solved with
+    // one 8-lane shuffle per column.
+    __shared__ double Xs[DNB][DNB + 1];
 #pragma unroll
-    for (int j = 0; j < DNB; j++) {
-        double partial = 0.0;
+    for (int q = 0; q < 4; q++) {
+        const int j = 8 * q + part;
+        double sacc = x[q];
+        for (int c = 0; c < 8 * q; c++) sacc = sacc - Xs[row][c] * D[j][c];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int c = 8 * q + part;
-            if (c < j) partial = partial + x[q] * D[j][c];
+        for (int jj = 0; jj < 8; jj++) {
+            const int jc = 8 * q + jj;                        // column being finished
+            const double xj = __shfl(sacc * rD[jc], jj, 8);   // from its owner, already scaled
+            if (part == jj) sacc = xj;
+            else if (part > jj) sacc = sacc - xj * D[j][jc];
         }
-        partial += __shfl_xor(partial, 4, 8);
-        partial += __shfl_xor(partial, 2, 8);
-        partial += __shfl_xor(partial, 1, 8);
-        const double own = __shfl(x[j / 8], j % 8, 8);      // x[j] before the step, from its owner
-        const double xj = (own - partial) * rD[j];
-        if (part == j % 8) x[j / 8] = xj;
+        x[q] = sacc;
+        Xs[row][j] = sacc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                      // the 8 lanes of a row are in one wave
     }
     if (row < nr) {
 #pragma unroll
