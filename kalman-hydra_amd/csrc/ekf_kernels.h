@@ -22,7 +22,22 @@ struct TriSetup {              // one triangle in one configuration
     float inv;                 // 1 / (2 area)
     int i0, i1, i2;            // vertex ids after orientation normalisation
     int cmin, cmax, rmin, rmax;  // pixel bounding box (inclusive), empty if cmin > cmax
+    // attributes of the three vertices in that order: texture coordinates (pixels of the initial
+    // frame) and the two velocity render attributes vx, -vy.  Kept here so that a covered pixel
+    // needs no dependent global loads besides its texel.
+    float ux[3], uy[3], ax[3], ay[3];
 };
+
+__device__ __forceinline__ void d_tri_attr(TriSetup &s, const float *__restrict__ uv, const double *__restrict__ X, int N)
+{
+    const int id[3] = {s.i0, s.i1, s.i2};
+    for (int k = 0; k < 3; k++) {
+        s.ux[k] = uv[2 * id[k]];
+        s.uy[k] = uv[2 * id[k] + 1];
+        s.ax[k] = (float)X[2 * N + 2 * id[k]];
+        s.ay[k] = (float)(-X[2 * N + 2 * id[k] + 1]);
+    }
+}
 
 __device__ __forceinline__ long long d_snap(double x) { return (long long)rint(x * (double)EKF_SUB); }
 
@@ -90,11 +105,11 @@ __device__ __forceinline__ float d_lerp(float a0, float a1, float a2, float l1, 
     return (a0 + l1 * (a1 - a0)) + l2 * (a2 - a0);
 }
 
-__device__ __forceinline__ int d_texel(const uint8_t *__restrict__ tex, const float *__restrict__ uv,
-                                       const TriSetup &s, float l1, float l2, int W, int H)
+__device__ __forceinline__ int d_texel(const uint8_t *__restrict__ tex, const TriSetup &s, float l1, float l2, int W,
+                                       int H)
 {
-    float tx = d_lerp(uv[2 * s.i0], uv[2 * s.i1], uv[2 * s.i2], l1, l2);
-    float ty = d_lerp(uv[2 * s.i0 + 1], uv[2 * s.i1 + 1], uv[2 * s.i2 + 1], l1, l2);
+    float tx = d_lerp(s.ux[0], s.ux[1], s.ux[2], l1, l2);
+    float ty = d_lerp(s.uy[0], s.uy[1], s.uy[2], l1, l2);
     int cx = (int)floorf(tx), cy = (int)floorf(ty);
     cx = cx < 0 ? 0 : (cx > W - 1 ? W - 1 : cx);
     cy = cy < 0 ? 0 : (cy > H - 1 ? H - 1 : cy);
@@ -124,6 +139,7 @@ __global__ void k_setup_all(Mesh m, const double *__restrict__ X, TriSetup *__re
     TriSetup s;
     d_tri_setup(s, v0, v1, v2, d_snap(X[2 * v0]), d_snap(X[2 * v0 + 1]), d_snap(X[2 * v1]), d_snap(X[2 * v1 + 1]),
                 d_snap(X[2 * v2]), d_snap(X[2 * v2 + 1]), m.W, m.H);
+    d_tri_attr(s, m.uv, X, m.N);
     out[t] = s;
 }
 
@@ -147,7 +163,6 @@ __global__ __launch_bounds__(EKF_TILE *EKF_TILE) void k_render(Mesh m, const dou
     __syncthreads();
     const int c = c0 + threadIdx.x, r = r0 + threadIdx.y;
     if (c >= m.W || r >= m.H) return;
-    const int N = m.N;
     int acc = 0, cnt = 0;
     float fx = 0.0f, fy = 0.0f;
     for (int wd = 0; wd < words; wd++) {
@@ -158,10 +173,9 @@ __global__ __launch_bounds__(EKF_TILE *EKF_TILE) void k_render(Mesh m, const dou
             const TriSetup &s = setup[wd * 32 + b];
             float l1, l2;
             if (!d_tri_eval(s, c, r, l1, l2)) continue;
-            acc += d_texel(m.tex, m.uv, s, l1, l2, m.W, m.H);
-            fx = fx + d_lerp((float)X[2 * N + 2 * s.i0], (float)X[2 * N + 2 * s.i1], (float)X[2 * N + 2 * s.i2], l1, l2);
-            fy = fy + d_lerp((float)(-X[2 * N + 2 * s.i0 + 1]), (float)(-X[2 * N + 2 * s.i1 + 1]),
-                             (float)(-X[2 * N + 2 * s.i2 + 1]), l1, l2);
+            acc += d_texel(m.tex, s, l1, l2, m.W, m.H);
+            fx = fx + d_lerp(s.ax[0], s.ax[1], s.ax[2], l1, l2);
+            fy = fy + d_lerp(s.ay[0], s.ay[1], s.ay[2], l1, l2);
             cnt++;
         }
     }
@@ -313,15 +327,13 @@ __device__ __forceinline__ StarVal d_star_eval(const TriSetup *__restrict__ cfg,
 {
     StarVal s = {0, 0, 0.0f, 0.0f};
     if (VEL) { vel.fxp = 0.0f; vel.fxm = 0.0f; vel.fyp = 0.0f; vel.fym = 0.0f; }
-    const int N = m.N;
     for (int k = 0; k < ns; k++) {
         float l1, l2;
         if (!d_tri_eval(cfg[k], c, r, l1, l2)) continue;
         const TriSetup &t = cfg[k];
-        s.acc += d_texel(m.tex, m.uv, t, l1, l2, m.W, m.H);
-        const float a0 = (float)X[2 * N + 2 * t.i0], a1 = (float)X[2 * N + 2 * t.i1], a2 = (float)X[2 * N + 2 * t.i2];
-        const float b0 = (float)(-X[2 * N + 2 * t.i0 + 1]), b1 = (float)(-X[2 * N + 2 * t.i1 + 1]),
-                    b2 = (float)(-X[2 * N + 2 * t.i2 + 1]);
+        s.acc += d_texel(m.tex, t, l1, l2, m.W, m.H);
+        const float a0 = t.ax[0], a1 = t.ax[1], a2 = t.ax[2];
+        const float b0 = t.ay[0], b1 = t.ay[1], b2 = t.ay[2];
         s.fx = s.fx + d_lerp(a0, a1, a2, l1, l2);
         s.fy = s.fy + d_lerp(b0, b1, b2, l1, l2);
         s.cnt++;
@@ -374,6 +386,7 @@ __device__ inline void d_star_setups(TriSetup *dst, int ns, const int *tris, con
             if (vs[q] == v) { px[q] += dx; py[q] += dy; }
         d_tri_setup(dst[k], v0, v1, v2, d_snap(px[0]), d_snap(py[0]), d_snap(px[1]), d_snap(py[1]), d_snap(px[2]),
                     d_snap(py[2]), m.W, m.H);
+        d_tri_attr(dst[k], m.uv, X, m.N);
     }
 }
 
