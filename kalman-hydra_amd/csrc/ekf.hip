@@ -38,6 +38,8 @@ struct hm_ctx {
     int upd_last, upd_prev;          // which d_Af holds the factor of the last / previous step (-1: none)
     bool w_post_dev;                 // d_H holds the covariance hm_update_cov returned last
     bool w_pred_dev;                 // d_Wtmp holds the covariance hm_cov_predict returned last
+    DPool pool;                      // parked difference images (see ekf_kernels.h)
+    int *d_area;
     int *d_sp_off, *d_sp_bar, *d_sp_other;
     double *d_sp_blk;
     size_t sp_cap;                   // capacity (springs) of the d_sp_* arrays
@@ -69,7 +71,9 @@ static int ctx_free(hm_ctx *h)
     void *ptrs[] = {h->d_tri, h->d_star_off, h->d_star_tri, h->d_edges, h->d_uv, h->d_tex, h->d_yim, h->d_ym, h->d_yfx,
                     h->d_yfy, h->d_yfxm, h->d_yfym, h->d_setup, h->d_X, h->d_out, h->d_partial, h->d_im8, h->d_m8,
                     h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_Ld[0], h->d_Ld[1], h->d_rhs, h->d_dx,
-                    h->d_Wtmp, h->d_X0, h->d_Xn, h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk};
+                    h->d_Wtmp, h->d_X0, h->d_Xn, h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk,
+                    h->pool.hdr, h->pool.off, h->pool.xim, h->pool.xm, h->pool.yim, h->pool.ym, h->pool.xfx, h->pool.xfy,
+                    h->pool.yfx, h->pool.yfy, h->pool.vxfx, h->pool.vyfy, h->pool.overflow, h->d_area};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     free_targets(h->ref);
@@ -131,6 +135,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->d_H = h->d_Hz = h->d_Hzc = h->d_invW0 = h->d_Af[0] = h->d_Af[1] = h->d_rhs = h->d_dx = h->d_Wtmp = nullptr;
     h->d_Ld[0] = h->d_Ld[1] = nullptr; h->d_X0 = h->d_Xn = nullptr;
     h->w_post_dev = h->w_pred_dev = false;
+    memset(&h->pool, 0, sizeof h->pool); h->d_area = nullptr;
     h->d_sp_off = h->d_sp_bar = h->d_sp_other = nullptr; h->d_sp_blk = nullptr; h->sp_cap = 0;
     h->upd_last = h->upd_prev = -1; h->upd_open = false;
     for (const auto &e : eset) { h->edges.push_back(e.first); h->edges.push_back(e.second); }
@@ -175,6 +180,20 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_rhs, n4 * 4 * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_dx, n4 * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_X0, n4 * sizeof(double));
+        // pool of parked difference images: the star regions overlap a few times; 16 frames' worth of
+        // pixels is far above what a triangulated object needs (hm_measure reports an overflow)
+        h->pool.cap = (long long)16 * W * H;
+        const size_t pc = (size_t)h->pool.cap;
+        if (e == hipSuccess) e = hipMalloc((void **)&h->pool.hdr, (size_t)4 * N * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->pool.off, (size_t)(N + 1) * sizeof(long long));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->pool.overflow, sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_area, (size_t)N * sizeof(int));
+        short **sp[] = {&h->pool.xim, &h->pool.xm, &h->pool.yim, &h->pool.ym};
+        for (short **q : sp)
+            if (e == hipSuccess) e = hipMalloc((void **)q, pc * sizeof(short));
+        float **fp[] = {&h->pool.xfx, &h->pool.xfy, &h->pool.yfx, &h->pool.yfy, &h->pool.vxfx, &h->pool.vyfy};
+        for (float **q : fp)
+            if (e == hipSuccess) e = hipMalloc((void **)q, pc * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Xn, n4 * sizeof(double));
         if (e != hipSuccess) {
             hm_set_error("hm_ctx_create: device allocation failed: %s", hipGetErrorString(e));
@@ -397,8 +416,11 @@ static int measure_on_device(hm_ctx *h, const double *X, double deltaX, int mask
     a.X = h->d_X;
     a.delta = deltaX;
     a.out = h->d_out;
-    hipLaunchKernelGGL(k_measure<true>, dim3(h->N, MEAS_VSPLIT), dim3(MEAS_NT), 0, h->stream, a);
-    if (h->E > 0) hipLaunchKernelGGL(k_measure<false>, dim3(h->E), dim3(MEAS_NT), 0, h->stream, a);
+    a.pool = h->pool;
+    hipLaunchKernelGGL(k_star_regions, dim3(h->N), dim3(64), 0, h->stream, a, h->d_area);
+    hipLaunchKernelGGL(k_region_offsets, dim3(1), dim3(1), 0, h->stream, h->d_area, h->N, h->pool);
+    hipLaunchKernelGGL(k_measure_vertex, dim3(h->N, MEAS_VSPLIT), dim3(MEAS_NT), 0, h->stream, a);
+    if (h->E > 0) hipLaunchKernelGGL(k_measure_edge, dim3(h->E), dim3(MEAS_NT), 0, h->stream, a);
     const size_t n4 = (size_t)4 * h->N;
     h->w_post_dev = false;                       // d_H is about to be overwritten
     HM_HIP(hipMemsetAsync(h->d_H, 0, n4 * n4 * sizeof(double), h->stream));
@@ -421,7 +443,10 @@ extern "C" int hm_measure(hm_ctx_t h, const double *X, double deltaX, int masked
     HM_HIP(hipMemcpyAsync(Hz, h->d_Hz, n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (Hzc) HM_HIP(hipMemcpyAsync(Hzc, h->d_Hzc, n4 * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HM_HIP(hipMemcpyAsync(HTH, h->d_H, n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    int ovf = 0;
+    HM_HIP(hipMemcpyAsync(&ovf, h->pool.overflow, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HM_HIP(hipStreamSynchronize(h->stream));
+    if (ovf) { hm_set_error("hm_measure: the star regions do not fit the difference-image pool"); return HM_ERR_STATE; }
     return HM_OK;
 }
 
@@ -527,6 +552,8 @@ extern "C" int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int ma
     HM_HIP(hipGetLastError());
     HM_HIP(hipMemcpyAsync(step, rhs_row, (size_t)n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (Hzc) HM_HIP(hipMemcpyAsync(Hzc, h->d_Hzc, (size_t)n4 * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    int ovf = 0;
+    HM_HIP(hipMemcpyAsync(&ovf, h->pool.overflow, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (err) {
         // Renderer.error of the new iterate X0 + step, without another host round trip
         hipLaunchKernelGGL(k_vec_axpy, dim3(hm_cdiv(n4, 256)), dim3(256), 0, h->stream, h->d_X0, rhs_row, 1.0, h->d_Xn, n4);
@@ -539,6 +566,7 @@ extern "C" int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int ma
     } else {
         HM_HIP(hipStreamSynchronize(h->stream));
     }
+    if (ovf) { hm_set_error("hm_update_step: the star regions do not fit the difference-image pool"); return HM_ERR_STATE; }
     h->upd_prev = h->upd_last;
     h->upd_last = slot;
     return HM_OK;

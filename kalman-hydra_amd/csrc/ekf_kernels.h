@@ -348,6 +348,9 @@ __device__ __forceinline__ StarVal d_star_eval(const TriSetup *__restrict__ cfg,
     return s;
 }
 
+// numerator of a difference that is a multiple of 1/255 (image and mask channels)
+__device__ __forceinline__ int d_i255(double x) { return (int)rint(x * 255.0); }
+
 // Difference images D = render(perturbed) - render(ref) at one pixel, for the four channels,
 // given the reference accumulators of the pixel, the star's contribution to them (sref) and the
 // star's contribution in the perturbed configuration (sp).
@@ -390,6 +393,19 @@ __device__ inline void d_star_setups(TriSetup *dst, int ns, const int *tris, con
     }
 }
 
+// Difference images of the forward position perturbations, kept for the edge jobs.  For every
+// vertex v its star region (bounding box over all configurations) is a slab of the pool starting at
+// pixel offset off[v]; per pixel: D_{v,x} and D_{v,y} in the four channels (image and mask as 16-bit
+// integers in 1/255 units, flow as f32) and the flow channel of the two velocity perturbations.
+struct DPool {
+    int *hdr;                 // N x 4: c0, r0, rw, rh of the region
+    long long *off;           // N + 1 pixel offsets (exclusive prefix sum of the areas)
+    short *xim, *xm, *yim, *ym;
+    float *xfx, *xfy, *yfx, *yfy, *vxfx, *vyfy;
+    long long cap;            // pixels in the pool
+    int *overflow;            // set to 1 if the regions do not fit
+};
+
 struct MeasureArgs {
     Mesh m;
     StarTopo topo;
@@ -397,18 +413,14 @@ struct MeasureArgs {
     Obs obs;
     const double *X;
     double delta;
-    double *out;              // njobs * MEAS_OUT doubles
+    double *out;              // njobs * MEAS_VSPLIT * MEAS_OUT doubles
+    DPool pool;
 };
 
 #define MEAS_NT 256
 #define MEAS_OUT 40
 #define MEAS_VSPLIT 3          // workgroups per vertex job (their partial sums are added in order)
-// vertex job output layout (doubles):
-//   [0..15]  jz(+d) per (component x,y,vx,vy) x (channel im,fx,fy,m)        (sums, not yet / eps)
-//   [16..31] jz(-d) likewise
-//   [32..35] self block, image channel: (x,x) (x,y) (y,y) and unused
-//   ... see ekf.hip for the exact unpacking
-// To keep the register budget the kernel accumulates exactly the non-zero terms:
+// vertex job output layout (doubles): only the non-zero terms are accumulated
 enum {
     // jz sums: plus then minus; x and y have 4 channels, vx only fx, vy only fy
     A_XP = 0, A_YP = 4, A_VXP = 8, A_VYP = 9, A_XM = 10, A_YM = 14, A_VXM = 18, A_VYM = 19,
@@ -427,148 +439,172 @@ enum {
     B_NV = 26
 };
 
-// VERTEX selects the job kind at compile time: two kernels, each with only its own accumulators live
-// (38 / 26 doubles), so that more workgroups fit a CU.
-template <bool VERTEX>
-__global__ __launch_bounds__(MEAS_NT) void k_measure(MeasureArgs a)
+#define MEAS_NCFG 5            // reference, +x, -x, +y, -y of the vertex
+
+__device__ inline void d_vertex_cfgs(TriSetup (*cfg)[EKF_MAX_STAR], int nsv, const int *trv, const Mesh &m,
+                                     const double *X, int v, double d, int nthreads)
 {
-    __shared__ TriSetup s_cfg[6][EKF_MAX_STAR];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = nthreads >> 6;
+    const double dxs[MEAS_NCFG] = {0, d, -d, 0, 0}, dys[MEAS_NCFG] = {0, 0, 0, d, -d};
+    for (int c = wv; c < MEAS_NCFG; c += nw) d_star_setups(cfg[c], nsv, trv, m, X, v, dxs[c], dys[c], lane, 64);
+}
+
+// ---- pass 0: star regions and their places in the pool -------------------------------------------------
+__global__ __launch_bounds__(64) void k_star_regions(MeasureArgs a, int *__restrict__ area)
+{
+    __shared__ TriSetup s_cfg[MEAS_NCFG][EKF_MAX_STAR];
+    const Mesh &m = a.m;
+    const int v = blockIdx.x;
+    const int nsv = a.topo.star_off[v + 1] - a.topo.star_off[v];
+    d_vertex_cfgs(s_cfg, nsv, a.topo.star_tri + a.topo.star_off[v], m, a.X, v, a.delta, 64);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    int c0 = m.W, c1 = -1, r0 = m.H, r1 = -1;
+    for (int cfg = 0; cfg < MEAS_NCFG; cfg++)
+        for (int k = 0; k < nsv; k++) {
+            const TriSetup &s = s_cfg[cfg][k];
+            if (s.cmin > s.cmax) continue;
+            c0 = min(c0, s.cmin); c1 = max(c1, s.cmax); r0 = min(r0, s.rmin); r1 = max(r1, s.rmax);
+        }
+    const int rw = max(0, c1 - c0 + 1), rh = max(0, r1 - r0 + 1);
+    a.pool.hdr[4 * v] = c0; a.pool.hdr[4 * v + 1] = r0; a.pool.hdr[4 * v + 2] = rw; a.pool.hdr[4 * v + 3] = rh;
+    area[v] = rw * rh;
+}
+
+__global__ void k_region_offsets(const int *__restrict__ area, int N, DPool pool)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    long long o = 0;
+    for (int v = 0; v < N; v++) { pool.off[v] = o; o += area[v]; }
+    pool.off[N] = o;
+    *pool.overflow = o > pool.cap ? 1 : 0;
+}
+
+// ---- pass 1: vertex jobs ----------------------------------------------------------------------------------
+// One launch = every jz evaluation of KFState.update and the diagonal blocks of HTH.  MEAS_VSPLIT
+// workgroups per vertex; a perturbation of vertex v changes the render only inside the triangles
+// around v (its star), so every sum runs over the bounding box of that star; the perturbed renders
+// are never materialised.  The forward difference images are parked in the pool for pass 2.
+__global__ __launch_bounds__(MEAS_NT) void k_measure_vertex(MeasureArgs a)
+{
+    __shared__ TriSetup s_cfg[MEAS_NCFG][EKF_MAX_STAR];
     __shared__ double s_red[(MEAS_NT / 64) * MEAS_OUT];
     const Mesh &m = a.m;
-    const int N = m.N, W = m.W, H = m.H;
-    const int job = VERTEX ? blockIdx.x : N + blockIdx.x;
+    const int N = m.N, W = m.W;
+    const int v = blockIdx.x, job = v;
     const double *X = a.X;
     const double d = a.delta;
-    constexpr bool isv = VERTEX;
-    const int v = isv ? job : a.topo.edges[2 * (job - N)];
-    const int w = isv ? -1 : a.topo.edges[2 * (job - N) + 1];
     const int nsv = a.topo.star_off[v + 1] - a.topo.star_off[v];
-    const int *trv = a.topo.star_tri + a.topo.star_off[v];
-    int nsw = 0;
-    const int *trw = nullptr;
-    if (!isv) {
-        nsw = a.topo.star_off[w + 1] - a.topo.star_off[w];
-        trw = a.topo.star_tri + a.topo.star_off[w];
-    }
-    // configurations: vertex job: ref, +x, -x, +y, -y of v.   edge job: ref v, +x v, +y v, ref w, +x w, +y w
-    {
-        const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        if (isv) {
-            const double dxs[5] = {0, d, -d, 0, 0}, dys[5] = {0, 0, 0, d, -d};
-            for (int cfg = wv; cfg < 5; cfg += MEAS_NT / 64)
-                d_star_setups(s_cfg[cfg], nsv, trv, m, X, v, dxs[cfg], dys[cfg], lane, 64);
-        } else {
-            const double dxs[3] = {0, d, 0}, dys[3] = {0, 0, d};
-            for (int cfg = wv; cfg < 6; cfg += MEAS_NT / 64) {
-                if (cfg < 3) d_star_setups(s_cfg[cfg], nsv, trv, m, X, v, dxs[cfg], dys[cfg], lane, 64);
-                else d_star_setups(s_cfg[cfg], nsw, trw, m, X, w, dxs[cfg - 3], dys[cfg - 3], lane, 64);
-            }
-        }
-    }
+    d_vertex_cfgs(s_cfg, nsv, a.topo.star_tri + a.topo.star_off[v], m, X, v, d, MEAS_NT);
     __syncthreads();
-    // region: vertex job -- bounding boxes of the star of v in all its configurations; edge job --
-    // only the triangles that contain BOTH v and w (a product of two difference images vanishes
-    // wherever one of the stars does not reach), again in all configurations of either vertex
-    int c0 = W, c1 = -1, r0 = H, r1 = -1;
-    {
-        const int ncfg = isv ? 5 : 6;
-        for (int cfg = 0; cfg < ncfg; cfg++) {
-            const int ns = (isv || cfg < 3) ? nsv : nsw;
-            const int other = isv ? -1 : (cfg < 3 ? w : v);
-            for (int k = 0; k < ns; k++) {
-                const TriSetup &s = s_cfg[cfg][k];
-                if (s.cmin > s.cmax) continue;
-                if (!isv && s.i0 != other && s.i1 != other && s.i2 != other) continue;
-                c0 = min(c0, s.cmin); c1 = max(c1, s.cmax); r0 = min(r0, s.rmin); r1 = max(r1, s.rmax);
-            }
-        }
-    }
-    constexpr int NACC = VERTEX ? (int)A_NV : (int)B_NV;
-    double acc[NACC];
+    const int c0 = a.pool.hdr[4 * v], r0 = a.pool.hdr[4 * v + 1], rw = a.pool.hdr[4 * v + 2], rh = a.pool.hdr[4 * v + 3];
+    const long long base = a.pool.off[v];
+    const bool park = *a.pool.overflow == 0;
+    double acc[A_NV];
 #pragma unroll
-    for (int k = 0; k < NACC; k++) acc[k] = 0.0;
-
-    const int rw = c1 - c0 + 1, rh = r1 - r0 + 1;
-    const int npx = (rw > 0 && rh > 0) ? rw * rh : 0;
-    // a vertex job is shared by MEAS_VSPLIT workgroups (blockIdx.y), pixels dealt round-robin in chunks of 256
-    const int nsplit = VERTEX ? MEAS_VSPLIT : 1;
-    for (int i = threadIdx.x + MEAS_NT * blockIdx.y; i < npx; i += MEAS_NT * nsplit) {
+    for (int k = 0; k < A_NV; k++) acc[k] = 0.0;
+    const int npx = rw * rh;
+    for (int i = threadIdx.x + MEAS_NT * blockIdx.y; i < npx; i += MEAS_NT * MEAS_VSPLIT) {
         const int r = r0 + i / rw, c = c0 + i % rw;
         const int p = r * W + c;
         const int racc = a.ref.acc[p], rcnt = a.ref.cnt[p];
         const float rfx = a.ref.fx[p], rfy = a.ref.fy[p];
-        if (isv) {
-            StarVel vel, none;
-            const StarVal sref = d_star_eval<true>(s_cfg[0], nsv, c, r, m, X, v, (float)(X[2 * N + 2 * v] + d),
-                                                   (float)(X[2 * N + 2 * v] - d), (float)(-(X[2 * N + 2 * v + 1] + d)),
-                                                   (float)(-(X[2 * N + 2 * v + 1] - d)), vel);
-            const StarVal sxp = d_star_eval<false>(s_cfg[1], nsv, c, r, m, X, v, 0, 0, 0, 0, none);
-            const StarVal sxm = d_star_eval<false>(s_cfg[2], nsv, c, r, m, X, v, 0, 0, 0, 0, none);
-            const StarVal syp = d_star_eval<false>(s_cfg[3], nsv, c, r, m, X, v, 0, 0, 0, 0, none);
-            const StarVal sym = d_star_eval<false>(s_cfg[4], nsv, c, r, m, X, v, 0, 0, 0, 0, none);
-            if (sref.cnt + sxp.cnt + sxm.cnt + syp.cnt + sym.cnt == 0) continue;
-            // velocity perturbations keep the geometry: same coverage and texels as the reference
-            const StarVal svxp = {sref.acc, sref.cnt, vel.fxp, sref.fy}, svxm = {sref.acc, sref.cnt, vel.fxm, sref.fy};
-            const StarVal svyp = {sref.acc, sref.cnt, sref.fx, vel.fyp}, svym = {sref.acc, sref.cnt, sref.fx, vel.fym};
-            const Diff dxp = d_diff(racc, rcnt, rfx, rfy, sref, sxp), dxm = d_diff(racc, rcnt, rfx, rfy, sref, sxm);
-            const Diff dyp = d_diff(racc, rcnt, rfx, rfy, sref, syp), dym = d_diff(racc, rcnt, rfx, rfy, sref, sym);
-            const Diff dvxp = d_diff(racc, rcnt, rfx, rfy, sref, svxp), dvxm = d_diff(racc, rcnt, rfx, rfy, sref, svxm);
-            const Diff dvyp = d_diff(racc, rcnt, rfx, rfy, sref, svyp), dvym = d_diff(racc, rcnt, rfx, rfy, sref, svym);
-            // residuals (cuda.py:943-950)
-            const int rim = racc > 255 ? 255 : racc, rm = rcnt > 0 ? 255 : 0;
-            const double z = ((double)a.obs.yim[p] - (double)rim) / 255.0;
-            const double zm = (255.0 * (double)a.obs.ym[p] - (double)rm) / 255.0;
-            const double zfx = (double)(a.obs.yfx[p] - rfx), zfy = (double)(a.obs.yfy[p] + rfy);
-            acc[A_XP + 0] += dxp.im * z; acc[A_XP + 1] += (double)dxp.fx * zfx; acc[A_XP + 2] += (double)dxp.fy * zfy; acc[A_XP + 3] += dxp.m * zm;
-            acc[A_YP + 0] += dyp.im * z; acc[A_YP + 1] += (double)dyp.fx * zfx; acc[A_YP + 2] += (double)dyp.fy * zfy; acc[A_YP + 3] += dyp.m * zm;
-            acc[A_XM + 0] += dxm.im * z; acc[A_XM + 1] += (double)dxm.fx * zfx; acc[A_XM + 2] += (double)dxm.fy * zfy; acc[A_XM + 3] += dxm.m * zm;
-            acc[A_YM + 0] += dym.im * z; acc[A_YM + 1] += (double)dym.fx * zfx; acc[A_YM + 2] += (double)dym.fy * zfy; acc[A_YM + 3] += dym.m * zm;
-            acc[A_VXP] += (double)dvxp.fx * zfx; acc[A_VXM] += (double)dvxm.fx * zfx;
-            acc[A_VYP] += (double)dvyp.fy * zfy; acc[A_VYM] += (double)dvym.fy * zfy;
-            // HTH diagonal block (forward differences, cuda.py:993-996)
-            acc[A_XX + 0] += dxp.im * dxp.im; acc[A_XX + 1] += (double)dxp.fx * (double)dxp.fx;
-            acc[A_XX + 2] += (double)dxp.fy * (double)dxp.fy; acc[A_XX + 3] += dxp.m * dxp.m;
-            acc[A_XY + 0] += dxp.im * dyp.im; acc[A_XY + 1] += (double)dxp.fx * (double)dyp.fx;
-            acc[A_XY + 2] += (double)dxp.fy * (double)dyp.fy; acc[A_XY + 3] += dxp.m * dyp.m;
-            acc[A_YY + 0] += dyp.im * dyp.im; acc[A_YY + 1] += (double)dyp.fx * (double)dyp.fx;
-            acc[A_YY + 2] += (double)dyp.fy * (double)dyp.fy; acc[A_YY + 3] += dyp.m * dyp.m;
-            acc[A_XVX] += (double)dxp.fx * (double)dvxp.fx; acc[A_YVX] += (double)dyp.fx * (double)dvxp.fx;
-            acc[A_XVY] += (double)dxp.fy * (double)dvyp.fy; acc[A_YVY] += (double)dyp.fy * (double)dvyp.fy;
-            acc[A_VXVX] += (double)dvxp.fx * (double)dvxp.fx; acc[A_VYVY] += (double)dvyp.fy * (double)dvyp.fy;
-        } else {
-            StarVel velv, velw, none;
-            const StarVal vref = d_star_eval<true>(s_cfg[0], nsv, c, r, m, X, v, (float)(X[2 * N + 2 * v] + d), 0.0f,
-                                                   (float)(-(X[2 * N + 2 * v + 1] + d)), 0.0f, velv);
-            const StarVal vxp = d_star_eval<false>(s_cfg[1], nsv, c, r, m, X, v, 0, 0, 0, 0, none);
-            const StarVal vyp = d_star_eval<false>(s_cfg[2], nsv, c, r, m, X, v, 0, 0, 0, 0, none);
-            if (vref.cnt + vxp.cnt + vyp.cnt == 0) continue;
-            const StarVal wref = d_star_eval<true>(s_cfg[3], nsw, c, r, m, X, w, (float)(X[2 * N + 2 * w] + d), 0.0f,
-                                                   (float)(-(X[2 * N + 2 * w + 1] + d)), 0.0f, velw);
-            const StarVal wxp = d_star_eval<false>(s_cfg[4], nsw, c, r, m, X, w, 0, 0, 0, 0, none);
-            const StarVal wyp = d_star_eval<false>(s_cfg[5], nsw, c, r, m, X, w, 0, 0, 0, 0, none);
-            if (wref.cnt + wxp.cnt + wyp.cnt == 0) continue;
-            const StarVal vvx = {vref.acc, vref.cnt, velv.fxp, vref.fy}, vvy = {vref.acc, vref.cnt, vref.fx, velv.fyp};
-            const StarVal wvx = {wref.acc, wref.cnt, velw.fxp, wref.fy}, wvy = {wref.acc, wref.cnt, wref.fx, velw.fyp};
-            const Diff ax = d_diff(racc, rcnt, rfx, rfy, vref, vxp), ay = d_diff(racc, rcnt, rfx, rfy, vref, vyp);
-            const Diff avx = d_diff(racc, rcnt, rfx, rfy, vref, vvx), avy = d_diff(racc, rcnt, rfx, rfy, vref, vvy);
-            const Diff bx = d_diff(racc, rcnt, rfx, rfy, wref, wxp), by = d_diff(racc, rcnt, rfx, rfy, wref, wyp);
-            const Diff bvx = d_diff(racc, rcnt, rfx, rfy, wref, wvx), bvy = d_diff(racc, rcnt, rfx, rfy, wref, wvy);
-#define CH4(base, P, Q)                                                                           \
-    acc[base + 0] += P.im * Q.im; acc[base + 1] += (double)P.fx * (double)Q.fx;                   \
-    acc[base + 2] += (double)P.fy * (double)Q.fy; acc[base + 3] += P.m * Q.m;
-            CH4(B_XX, ax, bx) CH4(B_XY, ax, by) CH4(B_YX, ay, bx) CH4(B_YY, ay, by)
-#undef CH4
-            acc[B_XVX] += (double)ax.fx * (double)bvx.fx; acc[B_YVX] += (double)ay.fx * (double)bvx.fx;
-            acc[B_VXX] += (double)avx.fx * (double)bx.fx; acc[B_VXY] += (double)avx.fx * (double)by.fx;
-            acc[B_VXVX] += (double)avx.fx * (double)bvx.fx;
-            acc[B_XVY] += (double)ax.fy * (double)bvy.fy; acc[B_YVY] += (double)ay.fy * (double)bvy.fy;
-            acc[B_VYX] += (double)avy.fy * (double)bx.fy; acc[B_VYY] += (double)avy.fy * (double)by.fy;
-            acc[B_VYVY] += (double)avy.fy * (double)bvy.fy;
+        const long long pp = base + i;
+        StarVel vel, none;
+        const StarVal sref = d_star_eval<true>(s_cfg[0], nsv, c, r, m, X, v, (float)(X[2 * N + 2 * v] + d),
+                                               (float)(X[2 * N + 2 * v] - d), (float)(-(X[2 * N + 2 * v + 1] + d)),
+                                               (float)(-(X[2 * N + 2 * v + 1] - d)), vel);
+        const StarVal sxp = d_star_eval<false>(s_cfg[1], nsv, c, r, m, X, v, 0, 0, 0, 0, none);
+        const StarVal sxm = d_star_eval<false>(s_cfg[2], nsv, c, r, m, X, v, 0, 0, 0, 0, none);
+        const StarVal syp = d_star_eval<false>(s_cfg[3], nsv, c, r, m, X, v, 0, 0, 0, 0, none);
+        const StarVal sym = d_star_eval<false>(s_cfg[4], nsv, c, r, m, X, v, 0, 0, 0, 0, none);
+        if (sref.cnt + sxp.cnt + sxm.cnt + syp.cnt + sym.cnt == 0) {
+            if (park) {
+                a.pool.xim[pp] = 0; a.pool.xm[pp] = 0; a.pool.yim[pp] = 0; a.pool.ym[pp] = 0;
+                a.pool.xfx[pp] = 0.0f; a.pool.xfy[pp] = 0.0f; a.pool.yfx[pp] = 0.0f; a.pool.yfy[pp] = 0.0f;
+                a.pool.vxfx[pp] = 0.0f; a.pool.vyfy[pp] = 0.0f;
+            }
+            continue;
+        }
+        // velocity perturbations keep the geometry: same coverage and texels as the reference
+        const StarVal svxp = {sref.acc, sref.cnt, vel.fxp, sref.fy}, svxm = {sref.acc, sref.cnt, vel.fxm, sref.fy};
+        const StarVal svyp = {sref.acc, sref.cnt, sref.fx, vel.fyp}, svym = {sref.acc, sref.cnt, sref.fx, vel.fym};
+        const Diff dxp = d_diff(racc, rcnt, rfx, rfy, sref, sxp), dxm = d_diff(racc, rcnt, rfx, rfy, sref, sxm);
+        const Diff dyp = d_diff(racc, rcnt, rfx, rfy, sref, syp), dym = d_diff(racc, rcnt, rfx, rfy, sref, sym);
+        const Diff dvxp = d_diff(racc, rcnt, rfx, rfy, sref, svxp), dvxm = d_diff(racc, rcnt, rfx, rfy, sref, svxm);
+        const Diff dvyp = d_diff(racc, rcnt, rfx, rfy, sref, svyp), dvym = d_diff(racc, rcnt, rfx, rfy, sref, svym);
+        // residuals (cuda.py:943-950)
+        const int rim = racc > 255 ? 255 : racc, rm = rcnt > 0 ? 255 : 0;
+        const double z = ((double)a.obs.yim[p] - (double)rim) / 255.0;
+        const double zm = (255.0 * (double)a.obs.ym[p] - (double)rm) / 255.0;
+        const double zfx = (double)(a.obs.yfx[p] - rfx), zfy = (double)(a.obs.yfy[p] + rfy);
+        acc[A_XP + 0] += dxp.im * z; acc[A_XP + 1] += (double)dxp.fx * zfx; acc[A_XP + 2] += (double)dxp.fy * zfy; acc[A_XP + 3] += dxp.m * zm;
+        acc[A_YP + 0] += dyp.im * z; acc[A_YP + 1] += (double)dyp.fx * zfx; acc[A_YP + 2] += (double)dyp.fy * zfy; acc[A_YP + 3] += dyp.m * zm;
+        acc[A_XM + 0] += dxm.im * z; acc[A_XM + 1] += (double)dxm.fx * zfx; acc[A_XM + 2] += (double)dxm.fy * zfy; acc[A_XM + 3] += dxm.m * zm;
+        acc[A_YM + 0] += dym.im * z; acc[A_YM + 1] += (double)dym.fx * zfx; acc[A_YM + 2] += (double)dym.fy * zfy; acc[A_YM + 3] += dym.m * zm;
+        acc[A_VXP] += (double)dvxp.fx * zfx; acc[A_VXM] += (double)dvxm.fx * zfx;
+        acc[A_VYP] += (double)dvyp.fy * zfy; acc[A_VYM] += (double)dvym.fy * zfy;
+        // HTH diagonal block (forward differences, cuda.py:993-996)
+        acc[A_XX + 0] += dxp.im * dxp.im; acc[A_XX + 1] += (double)dxp.fx * (double)dxp.fx;
+        acc[A_XX + 2] += (double)dxp.fy * (double)dxp.fy; acc[A_XX + 3] += dxp.m * dxp.m;
+        acc[A_XY + 0] += dxp.im * dyp.im; acc[A_XY + 1] += (double)dxp.fx * (double)dyp.fx;
+        acc[A_XY + 2] += (double)dxp.fy * (double)dyp.fy; acc[A_XY + 3] += dxp.m * dyp.m;
+        acc[A_YY + 0] += dyp.im * dyp.im; acc[A_YY + 1] += (double)dyp.fx * (double)dyp.fx;
+        acc[A_YY + 2] += (double)dyp.fy * (double)dyp.fy; acc[A_YY + 3] += dyp.m * dyp.m;
+        acc[A_XVX] += (double)dxp.fx * (double)dvxp.fx; acc[A_YVX] += (double)dyp.fx * (double)dvxp.fx;
+        acc[A_XVY] += (double)dxp.fy * (double)dvyp.fy; acc[A_YVY] += (double)dyp.fy * (double)dvyp.fy;
+        acc[A_VXVX] += (double)dvxp.fx * (double)dvxp.fx; acc[A_VYVY] += (double)dvyp.fy * (double)dvyp.fy;
+        if (park) {
+            a.pool.xim[pp] = (short)d_i255(dxp.im); a.pool.xm[pp] = (short)d_i255(dxp.m);
+            a.pool.yim[pp] = (short)d_i255(dyp.im); a.pool.ym[pp] = (short)d_i255(dyp.m);
+            a.pool.xfx[pp] = dxp.fx; a.pool.xfy[pp] = dxp.fy; a.pool.yfx[pp] = dyp.fx; a.pool.yfy[pp] = dyp.fy;
+            a.pool.vxfx[pp] = dvxp.fx; a.pool.vyfy[pp] = dvyp.fy;
         }
     }
-    d_block_reduce<NACC, MEAS_NT>(acc, s_red, a.out + ((size_t)job * MEAS_VSPLIT + blockIdx.y) * MEAS_OUT);
+    d_block_reduce<A_NV, MEAS_NT>(acc, s_red, a.out + ((size_t)job * MEAS_VSPLIT + blockIdx.y) * MEAS_OUT);
 }
 
+// ---- pass 2: edge jobs ----------------------------------------------------------------------------------------
+// HTH[(v,.),(w,.)] for adjacent vertices: sums of products of the parked difference images over the
+// intersection of the two star regions (outside its own star a difference image is zero).
+__global__ __launch_bounds__(MEAS_NT) void k_measure_edge(MeasureArgs a)
+{
+    __shared__ double s_red[(MEAS_NT / 64) * MEAS_OUT];
+    const int N = a.m.N;
+    const int e = blockIdx.x;
+    const int v = a.topo.edges[2 * e], w = a.topo.edges[2 * e + 1];
+    const int *hv = a.pool.hdr + 4 * v, *hw = a.pool.hdr + 4 * w;
+    const int c0 = max(hv[0], hw[0]), r0 = max(hv[1], hw[1]);
+    const int c1 = min(hv[0] + hv[2], hw[0] + hw[2]) - 1, r1 = min(hv[1] + hv[3], hw[1] + hw[3]) - 1;
+    const int rw = c1 - c0 + 1, rh = r1 - r0 + 1;
+    const int npx = (rw > 0 && rh > 0) ? rw * rh : 0;
+    const long long bv = a.pool.off[v], bw = a.pool.off[w];
+    double acc[B_NV];
+#pragma unroll
+    for (int k = 0; k < B_NV; k++) acc[k] = 0.0;
+    const DPool &P = a.pool;
+    for (int i = threadIdx.x; i < npx; i += MEAS_NT) {
+        const int r = r0 + i / rw, c = c0 + i % rw;
+        const long long pv = bv + (long long)(r - hv[1]) * hv[2] + (c - hv[0]);
+        const long long pw = bw + (long long)(r - hw[1]) * hw[2] + (c - hw[0]);
+        const double axim = (double)P.xim[pv] / 255.0, axm = (double)P.xm[pv] / 255.0;
+        const double ayim = (double)P.yim[pv] / 255.0, aym = (double)P.ym[pv] / 255.0;
+        const double bxim = (double)P.xim[pw] / 255.0, bxm = (double)P.xm[pw] / 255.0;
+        const double byim = (double)P.yim[pw] / 255.0, bym = (double)P.ym[pw] / 255.0;
+        const double axfx = P.xfx[pv], axfy = P.xfy[pv], ayfx = P.yfx[pv], ayfy = P.yfy[pv];
+        const double bxfx = P.xfx[pw], bxfy = P.xfy[pw], byfx = P.yfx[pw], byfy = P.yfy[pw];
+        const double avx = P.vxfx[pv], avy = P.vyfy[pv], bvx = P.vxfx[pw], bvy = P.vyfy[pw];
+        acc[B_XX + 0] += axim * bxim; acc[B_XX + 1] += axfx * bxfx; acc[B_XX + 2] += axfy * bxfy; acc[B_XX + 3] += axm * bxm;
+        acc[B_XY + 0] += axim * byim; acc[B_XY + 1] += axfx * byfx; acc[B_XY + 2] += axfy * byfy; acc[B_XY + 3] += axm * bym;
+        acc[B_YX + 0] += ayim * bxim; acc[B_YX + 1] += ayfx * bxfx; acc[B_YX + 2] += ayfy * bxfy; acc[B_YX + 3] += aym * bxm;
+        acc[B_YY + 0] += ayim * byim; acc[B_YY + 1] += ayfx * byfx; acc[B_YY + 2] += ayfy * byfy; acc[B_YY + 3] += aym * bym;
+        acc[B_XVX] += axfx * bvx; acc[B_YVX] += ayfx * bvx; acc[B_VXX] += avx * bxfx; acc[B_VXY] += avx * byfx;
+        acc[B_VXVX] += avx * bvx;
+        acc[B_XVY] += axfy * bvy; acc[B_YVY] += ayfy * bvy; acc[B_VYX] += avy * bxfy; acc[B_VYY] += avy * byfy;
+        acc[B_VYVY] += avy * bvy;
+    }
+    d_block_reduce<B_NV, MEAS_NT>(acc, s_red, a.out + ((size_t)(N + e) * MEAS_VSPLIT) * MEAS_OUT);
+}
 
 // ---- job sums -> Hz, Hz components, dense HTH (device twin of the unpacking in KFState.update) -------
 // One thread per job; every entry of H is written by exactly one job (vertex jobs own the diagonal
