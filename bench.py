@@ -87,7 +87,7 @@ def cpu_baseline(n, video, masks, dm, iters_per_frame, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--h0", type=float, default=0.047, help="mesh edge length as a fraction of the frame size")

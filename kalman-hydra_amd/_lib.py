@@ -73,6 +73,29 @@ SIGNATURES = {
 _lib = None
 
 
+def _one_hip_runtime():
+    """Keep ONE HIP runtime in the process.  PyTorch wheels carry their own libamdhip64; if
+    libhydra_mi.so pulled in the system copy first and torch were imported afterwards, torch would
+    find the runtime already initialised by a different build and report "No HIP GPUs are available".
+    So when torch is installed its copy is loaded (globally) before ours, whatever the import order;
+    HYDRA_MI_HIP_RUNTIME=<path> overrides, HYDRA_MI_HIP_RUNTIME=system skips this."""
+    choice = os.environ.get("HYDRA_MI_HIP_RUNTIME", "")
+    if choice == "system":
+        return
+    path = choice
+    if not path:
+        import importlib.util
+        import sys
+        if "torch" in sys.modules:
+            return                         # already in the process
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+
+
 def lib():
     """The loaded library; raises if it was never built (no fallback path exists)."""
     global _lib
@@ -81,6 +104,7 @@ def lib():
             raise RuntimeError(
                 "%s is missing: the HIP extension has not been built "
                 "(run `python __graft_entry__.py build`); there is no CPU fallback" % SO_PATH)
+        _one_hip_runtime()
         L = ctypes.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name, None)

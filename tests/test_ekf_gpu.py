@@ -308,3 +308,41 @@ def test_device_covariance_prediction(hm):
     nxt = R.cov_predict(Wp, dm.bars, blocks, 0.05, 0.05, 0.1)      # Wp is still on the device
     ref2 = Fm @ Wp @ Fm.T + Weps
     assert np.linalg.norm(nxt - ref2) <= 1e-12 * np.linalg.norm(ref2)
+
+
+def test_dense_update_is_deterministic_under_contention(hm):
+    """The update kernels exchange data between workgroups only across launches; their result must
+    not depend on when workgroups start.  Run the same step on a quiet GPU and while a flow batch
+    keeps every CU busy on another stream: bit-identical (this catches in-place races such as a
+    panel workgroup overwriting a block its neighbours still have to read)."""
+    torch = pytest.importorskip("torch")
+    from hydra_mi import brox, synth
+    n = 160
+    dm, N, tex, R, meas = _setup(hm, n, 8.0, seed=8)
+    rng = np.random.default_rng(31)
+    X = _state(dm, rng, pos_sigma=0.5)
+    y_im, flow, y_m = _observation(dm, meas, rng, n)
+    n4 = 4 * N
+    M = rng.normal(size=(n4, n4))
+    W = np.eye(n4) * 0.5 + 0.05 * (M @ M.T) / n4
+    st = _Flow()
+    st.X = X.reshape(-1, 1)
+    R.update_begin(W, X)
+    quiet, _, e_quiet = R.update_step(st, y_im, flow, y_m)
+    cov_quiet = R.update_cov(0)
+    m = 512
+    f0, f1, _, _ = synth.warp_pair(m, "warp", 0)
+    B = 6
+    F0 = torch.from_numpy(np.stack([f0] * B)).cuda()
+    F1 = torch.from_numpy(np.stack([f1] * B)).cuda()
+    U = torch.empty((B, m, m), dtype=torch.float32, device="cuda")
+    V = torch.empty_like(U)
+    torch.cuda.synchronize()
+    bf = brox.BroxOpticalFlow(m, m, max_batch=B)
+    for trial in range(3):
+        bf.calc_dev(B, F0.data_ptr(), F1.data_ptr(), U.data_ptr(), V.data_ptr())      # asynchronous
+        R.update_begin(W, X)
+        busy, _, e_busy = R.update_step(st, y_im, flow, y_m)
+        cov_busy = R.update_cov(0)
+        bf.sync()
+        assert np.array_equal(busy, quiet) and e_busy == e_quiet and np.array_equal(cov_busy, cov_quiet), trial
