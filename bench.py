@@ -84,6 +84,68 @@ def cpu_baseline(n, video, masks, dm, iters_per_frame, budget_s=25.0):
                       % (threads, t_brox, n_jz, n_j, 8 * N, int(nzj), iters_per_frame)}
 
 
+def flowbatch(args, rank, world, dev, coll_dev):
+    """BASELINE config 5: `pairs-per-gpu` independent 1024^2 pairs per rank (seeds differ per pair),
+    one step = the flow of all of them in launch series of --flow-batch pairs; no communication while
+    computing, one gather of all flow planes to rank 0 at the end of the timed region."""
+    import torch
+    import torch.distributed as dist
+    from hydra_mi import brox, synth, batch
+    n, P, B = args.size, args.pairs_per_gpu, max(1, args.flow_batch)
+    mine = batch.shard(P * world, rank, world)
+    base = [synth.warp_pair(n, "translate_leftup_stretch", seed)[:2] for seed in range(4)]   # 4 distinct pairs, cycled
+    F0 = torch.from_numpy(np.stack([base[i % 4][0] for i in mine])).cuda()
+    F1 = torch.from_numpy(np.stack([base[i % 4][1] for i in mine])).cuda()
+    U = torch.empty((P, n, n), dtype=torch.float32, device="cuda")
+    V = torch.empty_like(U)
+    torch.cuda.synchronize()
+    bf = brox.BroxOpticalFlow(n, n, max_batch=B, device=dev)
+    bf.tune("sor_threads", 512)
+
+    def step():
+        for s in range(0, P, B):
+            nb = min(B, P - s)
+            bf.calc_dev(nb, F0[s].data_ptr(), F1[s].data_ptr(), U[s].data_ptr(), V[s].data_ptr())
+        bf.sync()
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        if k == args.steps - 1:
+            bf.profile(True)
+        step()
+    sor_ms, sor_launches, sor_pxit = bf.profile_read()
+    if world > 1:
+        flows = torch.stack((U, V)).to(coll_dev)
+        parts = [torch.empty_like(flows) for _ in range(world)] if rank == 0 else None
+        dist.gather(flows, parts, dst=0)
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        achieved = SOR_BYTES_PER_PIXEL_ITERATION * sor_pxit / (sor_ms * 1e-3) / 1e9 if sor_ms > 0 else 0.0
+        print(json.dumps({
+            "metric": "frame pairs/sec (Brox flow) at %d^2" % n, "value": world * P * args.steps / elapsed,
+            "unit": "pairs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%d independent %dx%d frame pairs per GPU, Brox defaults, flows gathered to rank 0"
+                                   % (P, n, n), "flow_batch": B, "parallelism": "pairs x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_sor", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic() if (n == 1024 and B == 8) else None,
+                         "launches": sor_launches, "profiled": "last step of the timed region"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +155,10 @@ def main():
     ap.add_argument("--h0", type=float, default=0.047, help="mesh edge length as a fraction of the frame size")
     ap.add_argument("--flow-batch", type=int, default=8, help="consecutive frame pairs per Brox launch series")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="video", choices=["video", "flowbatch"],
+                    help="video = the headline metric (flow + EKF per frame); flowbatch = BASELINE config 5: "
+                         "independent frame pairs sharded over the GPUs, one gather of the flows at the end")
+    ap.add_argument("--pairs-per-gpu", type=int, default=32)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real run); gloo only to rehearse several ranks on one GPU")
     args = ap.parse_args()
@@ -125,6 +191,8 @@ def main():
 
     n = args.size
     K, Wm = args.steps, args.warmup
+    if args.workload == "flowbatch":
+        return flowbatch(args, rank, world, dev, coll_dev)
     frames = K + Wm + 1
     video, masks, centre, radius = make_video(n, frames, seed=rank)
     dm = mesh.disk_mesh(centre[0], centre[1], radius - 1.0, args.h0 * n)
