@@ -71,7 +71,7 @@ int hm_brox_levels(hm_brox_t h, int *widths, int *heights, int cap);
 int hm_brox_set_omega(hm_brox_t h, float omega);
 /* launch tuning, never changes results: "sor_fuse" = red-black iterations fused
  * per SOR launch (0 = choose per level, else a divisor of solver_iterations),
- * "sor_threads" = 256 or 512 threads per SOR workgroup */
+ * "sor_threads" = 256, 512 or 1024 threads per SOR workgroup */
 int hm_brox_tune(hm_brox_t h, const char *key, int value);
 
 /* HIP-event timing of the SOR launches of subsequent calc calls.
@@ -92,7 +92,7 @@ int hm_op_warp(const float *const in[11], int w, int h, float *const out[8]);
 int hm_op_prepare(const float *const in[12], int w, int h, float alpha, float gamma,
                   float *const out[7]);
 /* du,dv updated in place; coef = nu,nv,a12,idu,idv,sx,sy; fuse = sor_fuse (+100 selects
- * 512-thread workgroups) */
+ * 512-thread, +200 1024-thread workgroups) */
 int hm_op_sor(float *du, float *dv, const float *const coef[7], int w, int h,
               int iterations, int fuse, float omega);
 

@@ -121,7 +121,9 @@ static void sor_launch(const SorPlan &p, SorArgs a, int n, hipStream_t s)
     a.step_x = p.step_x; a.step_y = p.step_y;
     a.halo_x = p.halo_x; a.halo_y = p.halo_y;
     dim3 grid(p.tiles_x * p.tiles_y, 1, n);
-    if (p.threads == 512)
+    if (p.threads == 1024)
+        hipLaunchKernelGGL((k_sor<SOR_TW, SOR_TH, 1024>), grid, dim3(1024), 0, s, a, p.K);
+    else if (p.threads == 512)
         hipLaunchKernelGGL((k_sor<SOR_TW, SOR_TH, 512>), grid, dim3(512), 0, s, a, p.K);
     else
         hipLaunchKernelGGL((k_sor<SOR_TW, SOR_TH, 256>), grid, dim3(256), 0, s, a, p.K);
@@ -259,7 +261,7 @@ extern "C" int hm_brox_tune(hm_brox_t h, const char *key, int value)
                "hm_brox_tune: sor_fuse=%d must be 0 or a divisor of solver_iterations (%d) not above 7", value, h->solver);
         h->fuse = value;
     } else if (!strcmp(key, "sor_threads")) {
-        HM_ARG(value == 256 || value == 512, "hm_brox_tune: sor_threads must be 256 or 512");
+        HM_ARG(value == 256 || value == 512 || value == 1024, "hm_brox_tune: sor_threads must be 256, 512 or 1024");
         h->sor_threads = value;
     } else {
         hm_set_error("hm_brox_tune: unknown key '%s'", key);
@@ -568,7 +570,7 @@ extern "C" int hm_op_sor(float *du, float *dv, const float *const coef[7], int w
     for (int i = 0; i < 7; i++) { c[i] = sc.up(g, coef[i]); OP_CHECK(c[i]); }
     float *b[4] = {sc.up(g, du), sc.up(g, dv), sc.plane(g), sc.plane(g)};
     OP_CHECK(b[0] && b[1] && b[2] && b[3]);
-    SorPlan plan = sor_plan(g, iterations, fuse % 100, fuse >= 100 ? 512 : 256);
+    SorPlan plan = sor_plan(g, iterations, fuse % 100, fuse >= 200 ? 1024 : (fuse >= 100 ? 512 : 256));
     int cur = 0;
     for (int done = 0; done < iterations; done += plan.K) {
         SorArgs a;

@@ -272,7 +272,7 @@ __global__ void k_add(float *__restrict__ u, float *__restrict__ v, const float 
 //
 //  * the seven coefficient fields of a thread's pixels live in registers for all K
 //    iterations (loaded once, coalesced float2 per pixel pair);
-//  * du / dv live in LDS in a checkerboard-compressed layout -- in each row the
+//  * du / dv live in LDS (interleaved as float2) in a checkerboard-compressed layout -- in each row the
 //    pixels of colour 0 come first, then colour 1 -- so every access of a
 //    half-sweep (own pixel and its four neighbours, which all have the other
 //    colour) is unit-stride across lanes: no bank conflicts, all lanes active;
@@ -296,8 +296,7 @@ __global__ __launch_bounds__(NT) void k_sor(SorArgs a, int K)
     constexpr int NG = NT / HALF;            // lane groups, each owns whole rows
     constexpr int RPT = TH / NG;             // rows per thread
     static_assert(TH % NG == 0 && RPT % 2 == 0, "rows per thread must be even");
-    __shared__ float s_du[TH * TW];
-    __shared__ float s_dv[TH * TW];
+    __shared__ float2 s_uv[TH * TW];          // (du, dv) of a pixel side by side: one 8-byte LDS access each
 
     // XCD-aware tile order: consecutive workgroup ids land on different XCDs, so
     // give each XCD a contiguous run of tiles (neighbouring tiles share halo lines
@@ -361,10 +360,8 @@ __global__ __launch_bounds__(NT) void k_sor(SorArgs a, int K)
         sr[j][1] = ok1 ? f_sx.y : 0.0f; sb[j][1] = ok1 ? f_sy.y : 0.0f;
         // checkerboard-compressed LDS row: colour of the even pixel is (r & 1) == (j & 1)
         const int c0 = j & 1;
-        s_du[r * TW + c0 * HALF + i] = f_du.x;
-        s_dv[r * TW + c0 * HALF + i] = f_dv.x;
-        s_du[r * TW + (1 - c0) * HALF + i] = ok1 ? f_du.y : 0.0f;
-        s_dv[r * TW + (1 - c0) * HALF + i] = ok1 ? f_dv.y : 0.0f;
+        s_uv[r * TW + c0 * HALF + i] = make_float2(f_du.x, f_dv.x);
+        s_uv[r * TW + (1 - c0) * HALF + i] = ok1 ? make_float2(f_du.y, f_dv.y) : make_float2(0.0f, 0.0f);
     }
     __syncthreads();
 
@@ -384,11 +381,12 @@ __global__ __launch_bounds__(NT) void k_sor(SorArgs a, int K)
                 il = il < 0 ? 0 : il;
                 ir = ir > HALF - 1 ? HALF - 1 : ir;
                 const int ru = r > 0 ? r - 1 : 0, rd = r < TH - 1 ? r + 1 : TH - 1;
-                const float cu = s_du[r * TW + c * HALF + i], cv = s_dv[r * TW + c * HALF + i];
-                float ul = s_du[r * TW + oc + il], ur = s_du[r * TW + oc + ir];
-                float ut = s_du[ru * TW + oc + i], ub = s_du[rd * TW + oc + i];
-                float vl = s_dv[r * TW + oc + il], vr = s_dv[r * TW + oc + ir];
-                float vt = s_dv[ru * TW + oc + i], vb = s_dv[rd * TW + oc + i];
+                const float2 pc = s_uv[r * TW + c * HALF + i];
+                const float2 pl = s_uv[r * TW + oc + il], pr = s_uv[r * TW + oc + ir];
+                const float2 pt = s_uv[ru * TW + oc + i], pb = s_uv[rd * TW + oc + i];
+                const float cu = pc.x, cv = pc.y;
+                float ul = pl.x, ur = pr.x, ut = pt.x, ub = pb.x;
+                float vl = pl.y, vr = pr.y, vt = pt.y, vb = pb.y;
                 // at the image border the oracle pairs the (zero) weight with the pixel itself
                 if (gx <= 0) { ul = cu; vl = cv; }
                 if (gx >= w - 1) { ur = cu; vr = cv; }
@@ -400,8 +398,7 @@ __global__ __launch_bounds__(NT) void k_sor(SorArgs a, int K)
                 const float sv = ((wl * vl + sr[j][q] * vr) + wt * vt) + sb[j][q] * vb;
                 const float dun = om1 * cu + om * (((nu[j][q] - a12[j][q] * cv) + su) * idu[j][q]);
                 const float dvn = om1 * cv + om * (((nv[j][q] - a12[j][q] * dun) + sv) * idv[j][q]);
-                s_du[r * TW + c * HALF + i] = dun;
-                s_dv[r * TW + c * HALF + i] = dvn;
+                s_uv[r * TW + c * HALF + i] = make_float2(dun, dvn);
             }
             __syncthreads();
         }
@@ -416,8 +413,8 @@ __global__ __launch_bounds__(NT) void k_sor(SorArgs a, int K)
         if (!colin || r < a.halo_y || r >= a.halo_y + a.step_y || gy >= h || gxa >= w) continue;
         const size_t p = off + (size_t)gy * pitch + gxa;
         const int c0 = j & 1;
-        const float u0 = s_du[r * TW + c0 * HALF + i], u1 = s_du[r * TW + (1 - c0) * HALF + i];
-        const float v0 = s_dv[r * TW + c0 * HALF + i], v1 = s_dv[r * TW + (1 - c0) * HALF + i];
+        const float2 q0 = s_uv[r * TW + c0 * HALF + i], q1 = s_uv[r * TW + (1 - c0) * HALF + i];
+        const float u0 = q0.x, u1 = q1.x, v0 = q0.y, v1 = q1.y;
         if (gxa + 1 < w) {
             *(float2 *)(a.du_out + p) = make_float2(u0, u1);
             *(float2 *)(a.dv_out + p) = make_float2(v0, v1);

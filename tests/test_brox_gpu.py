@@ -70,7 +70,7 @@ def test_warp_prepare(hm, oracle_brox, w, h):
 
 
 @pytest.mark.parametrize("w,h", SIZES + [(300, 300)])
-@pytest.mark.parametrize("fuse", [0, 1, 2, 5, 105])
+@pytest.mark.parametrize("fuse", [0, 1, 2, 5, 105, 205])
 def test_sor(hm, oracle_brox, w, h, fuse):
     from hydra_mi import brox
     f = _level_fields(oracle_brox, w, h, 30)
@@ -132,7 +132,7 @@ def test_calc_batch_and_tuning_do_not_change_results(hm, oracle_brox):
     for i in range(3):
         ru, rv = oracle_brox.calc(F0[i], F1[i])
         assert np.array_equal(U[i], ru) and np.array_equal(V[i], rv)
-    for key, val in [("sor_fuse", 1), ("sor_fuse", 2), ("sor_threads", 512), ("sor_fuse", 0)]:
+    for key, val in [("sor_fuse", 1), ("sor_fuse", 2), ("sor_threads", 512), ("sor_fuse", 0), ("sor_threads", 1024)]:
         bf.tune(key, val)
         U2, V2 = bf.calc_batch(F0, F1)
         assert np.array_equal(U, U2) and np.array_equal(V, V2), (key, val)

@@ -35,9 +35,8 @@ def run(n, batch, reps, tunes):
                               sor_GBps_alg=52.0 * pxit / (ms * 1e-3) / 1e9 if ms else None)), flush=True)
 
 if __name__ == "__main__":
-    tunes = [dict(sor_fuse=0, sor_threads=256), dict(sor_fuse=0, sor_threads=512),
-             dict(sor_fuse=1, sor_threads=256), dict(sor_fuse=1, sor_threads=512),
-             dict(sor_fuse=2, sor_threads=256), dict(sor_fuse=2, sor_threads=512)]
-    run(512, 1, 5, tunes)
+    tunes = [dict(sor_fuse=0, sor_threads=256), dict(sor_fuse=0, sor_threads=512), dict(sor_fuse=0, sor_threads=1024),
+             dict(sor_fuse=2, sor_threads=512), dict(sor_fuse=2, sor_threads=1024)]
+    run(512, 1, 5, tunes[:3])
     run(1024, 1, 5, tunes)
-    run(1024, 8, 3, tunes[:2])
+    run(1024, 8, 3, tunes)
