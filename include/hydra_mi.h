@@ -29,6 +29,7 @@ extern "C" {
 #define HM_ERR_ARG (-1)     /* bad argument (reference: Python exception / assert) */
 #define HM_ERR_HIP (-2)     /* HIP runtime failure, including "no GPU" */
 #define HM_ERR_STATE (-3)   /* call sequence error, e.g. jz before initjacobian (cuda_multi.py:611) */
+#define HM_ERR_NUMERIC (-4) /* the update system is not positive definite (non-finite input) */
 
 const char *hm_last_error(void);
 const char *hm_version(void);
@@ -71,7 +72,8 @@ int hm_brox_levels(hm_brox_t h, int *widths, int *heights, int cap);
 int hm_brox_set_omega(hm_brox_t h, float omega);
 /* launch tuning, never changes results: "sor_fuse" = red-black iterations fused
  * per SOR launch (0 = choose per level, else a divisor of solver_iterations),
- * "sor_threads" = 256, 512 or 1024 threads per SOR workgroup */
+ * "sor_threads" = 256, 512 or 1024 threads per SOR workgroup, "graph" = 1/0 replay the launch
+ * series of a calc call as a captured hipGraph (default 1) or launch kernel by kernel */
 int hm_brox_tune(hm_brox_t h, const char *key, int value);
 
 /* HIP-event timing of the SOR launches of subsequent calc calls.
@@ -163,13 +165,31 @@ int hm_measure(hm_ctx_t h, const double *X, double deltaX, int masked,
  *           multiplies); the new iterate is X0 + step.  Hzc (4N x 4, may be NULL) as hm_measure;
  *           err (may be NULL) receives hm_error of the new iterate X0 + step (kalman.py:813);
  *   cov   : (inv(W) + HTH)^-1 of the last step (which = 0) or of the one before (which = 1,
- *           what the reference keeps as W_old for its mesh-inversion rollback, kalman.py:806-811).
+ *           what the reference keeps as W_old for its mesh-inversion rollback, kalman.py:806-811);
+ *           which = -1: the prior itself (no iterate was accepted).
  * A non-positive-definite system shows up as NaNs in `step`. */
-int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *X0);   /* W_prior NULL: the result of
-                                                                              hm_cov_predict, still on the device */
+int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *X0);   /* W_prior NULL: the covariance
+                                                                              resident on the device */
 int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int masked, double *step, double *Hzc,
                    double err[4]);
-int hm_update_cov(hm_ctx_t h, int which, double *W_out);
+int hm_update_cov(hm_ctx_t h, int which, double *W_out);                     /* W_out NULL: stays on the device */
+/* The whole of IteratedKalmanFilter.update (kalman.py:774-831) in one call: begin, up to max_iter
+ * steps with the reference's acceptance logic between them, cov of the state that is kept.
+ *   X       in: the predicted state (prior mean); out: the state kept;
+ *   info    iterations run, iterations accepted, reverted (a triangle flipped, :806-811), converged
+ *           (|e_new - e_old| / e_new < reltol, :817-819);
+ *   errs    max_iter x 4 (may be NULL): hm_error of every new iterate;
+ *   Hzc     4N x 4 (may be NULL) of the last measurement; gains 3 x 4N (may be NULL): W Hzc[:,0],
+ *           W (Hzc[:,1] + Hzc[:,2]), W Hzc[:,3] with the covariance kept (:828-830);
+ *   W_out   4N x 4N, or NULL to leave the covariance on the device (hm_cov_fetch / hm_cov_predict).
+ * Between iterations the state stays on the device and the render that gave an iterate's error is
+ * the reference render of the next measurement; the numbers are those of the step-by-step calls.
+ * HM_ERR_NUMERIC: the system inv(W) + HTH was not positive definite. */
+int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, double deltaX, int masked, int max_iter,
+                  double reltol, int info[4], double *errs, double *Hzc, double *gains, double *W_out);
+/* the covariance resident on the device (result of the last hm_cov_predict, hm_update_cov or
+ * hm_update_run) copied to W_out (4N x 4N) */
+int hm_cov_fetch(hm_ctx_t h, double *W_out);
 /* IteratedMSKalmanFilter._newton (kalman.py:923-960): the mass-spring state prediction, ceil(1/dt)
  * implicit-Euler sub-steps each solved by Newton's method.  Host code, no GPU involved.
  * bars: I*2 vertex ids (distmesh.bars), l0: rest lengths; X: 4N doubles, advanced in place. */
@@ -178,8 +198,8 @@ int hm_ms_newton(int n_vertices, int n_bars, const int32_t *bars, const double *
 /* Covariance prediction W' = F W F^T + Weps (kalman.py:717 and :863) on the device, with
  * F = [[I, a I], [s dfdy, I]], dfdy given as one symmetric 2x2 block (Bxx, Bxy, Byy) per spring
  * (kalman.py:865-902; n_bars = 0: the constant-velocity model), Weps = eps_F [[I/4, I/2], [I/2, I]]
- * (:182).  W_in NULL: propagate the covariance hm_update_cov returned last (still on the device).
- * The result is copied to W_out and kept on the device for hm_update_begin(h, NULL, X0). */
+ * (:182).  W_in NULL: propagate the covariance resident on the device.  The result is copied to
+ * W_out (NULL: not copied) and kept on the device for hm_update_begin / hm_update_run(h, NULL, ...). */
 int hm_cov_predict(hm_ctx_t h, const double *W_in, int n_bars, const int32_t *bars, const double *blocks,
                    double a, double s, double eps_F, double *W_out);
 int hm_ctx_sync(hm_ctx_t h);

@@ -62,6 +62,9 @@ SIGNATURES = {
     "hm_update_begin": (ctypes.c_int, [c_vp, c_vp, c_vp]),
     "hm_update_step": (ctypes.c_int, [c_vp, c_vp, ctypes.c_double, ctypes.c_int, c_vp, c_vp, c_f64p]),
     "hm_update_cov": (ctypes.c_int, [c_vp, ctypes.c_int, c_vp]),
+    "hm_update_run": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                     ctypes.POINTER(ctypes.c_int), c_vp, c_vp, c_vp, c_vp]),
+    "hm_cov_fetch": (ctypes.c_int, [c_vp, c_vp]),
     "hm_cov_predict": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_vp, c_vp, ctypes.c_double, ctypes.c_double,
                                       ctypes.c_double, c_vp]),
     "hm_ms_newton": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp, c_vp, ctypes.c_double, ctypes.c_double,
@@ -120,6 +123,9 @@ def missing_symbols():
     """Declared in include/hydra_mi.h but absent from the built library (must be empty)."""
     L = lib()
     return [name for name in SIGNATURES if getattr(L, name, None) is None]
+
+
+HM_ERR_NUMERIC = -4
 
 
 def check(rc, what=""):

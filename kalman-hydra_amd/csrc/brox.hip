@@ -147,6 +147,10 @@ struct hm_brox {
     float *u, *v, *u2, *v2, *du[2], *dv[2];
     uint8_t *d_f0, *d_f1;        // staging of host frames
     float *d_ox, *d_oy;          // staging of the host-bound result (tight W*H per pair)
+    // one captured launch series (hipGraph) per batch size; replaying it costs the host a few tens of
+    // microseconds instead of ~1100 kernel launches.  Dropped when a tuning knob changes.
+    std::vector<hipGraphExec_t> graphs;   // index n-1
+    bool use_graph;
     // profiling
     bool prof;
     std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -161,6 +165,8 @@ static int brox_free(hm_brox *h)
     if (!h) return HM_OK;
     hipSetDevice(h->device);
     for (hipEvent_t e : h->ev) hipEventDestroy(e);
+    for (hipGraphExec_t g : h->graphs)
+        if (g) hipGraphExecDestroy(g);
     if (h->arena) hipFree(h->arena);
     if (h->d_f0) hipFree(h->d_f0);
     if (h->d_f1) hipFree(h->d_f1);
@@ -188,6 +194,8 @@ extern "C" int hm_brox_create(int device, int W, int H, int max_batch, float alp
     h->inner = inner; h->outer = outer; h->solver = solver; h->fuse = 0; h->sor_threads = 256;
     h->arena = nullptr; h->d_f0 = h->d_f1 = nullptr; h->d_ox = h->d_oy = nullptr; h->stream = nullptr;
     h->prof = false; h->ev_used = 0; h->prof_ms = 0; h->prof_pxit = 0; h->prof_launches = 0;
+    h->graphs.assign(max_batch, nullptr);
+    h->use_graph = true;
     make_levels(W, H, scale, outer, h->geo);
     h->taps = make_taps(scale);
 
@@ -245,11 +253,21 @@ extern "C" int hm_brox_levels(hm_brox_t h, int *ws, int *hs, int cap)
     return n;
 }
 
+// captured launch series bake kernel arguments and the launch plan in: drop them when either changes
+static void drop_graphs(hm_brox *h)
+{
+    for (hipGraphExec_t &g : h->graphs) {
+        if (g) (void)hipGraphExecDestroy(g);
+        g = nullptr;
+    }
+}
+
 extern "C" int hm_brox_set_omega(hm_brox_t h, float omega)
 {
     HM_ARG(h != nullptr, "hm_brox_set_omega: NULL handle");
     HM_ARG(omega > 0.0f && omega < 2.0f, "hm_brox_set_omega: omega must be in (0,2), got %g", omega);
     h->omega = omega;
+    drop_graphs(h);
     return HM_OK;
 }
 
@@ -263,10 +281,14 @@ extern "C" int hm_brox_tune(hm_brox_t h, const char *key, int value)
     } else if (!strcmp(key, "sor_threads")) {
         HM_ARG(value == 256 || value == 512 || value == 1024, "hm_brox_tune: sor_threads must be 256, 512 or 1024");
         h->sor_threads = value;
+    } else if (!strcmp(key, "graph")) {
+        HM_ARG(value == 0 || value == 1, "hm_brox_tune: graph must be 0 or 1");
+        h->use_graph = value != 0;
     } else {
         hm_set_error("hm_brox_tune: unknown key '%s'", key);
         return HM_ERR_ARG;
     }
+    drop_graphs(h);
     return HM_OK;
 }
 
@@ -418,7 +440,34 @@ extern "C" int hm_brox_calc_dev(hm_brox_t h, int n, const uint8_t *d_f0, const u
     HM_ARG(n >= 1 && n <= h->B, "hm_brox_calc_dev: n=%d outside 1..max_batch=%d", n, h->B);
     HM_ARG(d_f0 && d_f1 && d_ox && d_oy, "hm_brox_calc_dev: NULL pointer");
     HM_HIP(hipSetDevice(h->device));
-    return brox_run(h, n, d_f0, d_f1, d_ox, d_oy);
+    if (h->prof || !h->use_graph)                  // per-launch events need real launches
+        return brox_run(h, n, d_f0, d_f1, d_ox, d_oy);
+    // The captured series works on the handle's own staging buffers (graph nodes hold fixed
+    // addresses); the caller's frames and flow planes are copied in and out around it.
+    const size_t px = (size_t)h->W * h->H * n;
+    const bool in_place = d_f0 == h->d_f0 && d_f1 == h->d_f1 && d_ox == h->d_ox && d_oy == h->d_oy;
+    if (!in_place) {
+        HM_HIP(hipMemcpyAsync(h->d_f0, d_f0, px, hipMemcpyDeviceToDevice, h->stream));
+        HM_HIP(hipMemcpyAsync(h->d_f1, d_f1, px, hipMemcpyDeviceToDevice, h->stream));
+    }
+    hipGraphExec_t &exec = h->graphs[n - 1];
+    if (!exec) {
+        hipGraph_t graph = nullptr;
+        HM_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        int rc = brox_run(h, n, h->d_f0, h->d_f1, h->d_ox, h->d_oy);
+        hipError_t e = hipStreamEndCapture(h->stream, &graph);
+        if (rc != HM_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess) { hm_set_error("hm_brox_calc_dev: stream capture failed: %s", hipGetErrorString(e)); return HM_ERR_HIP; }
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { exec = nullptr; hm_set_error("hm_brox_calc_dev: hipGraphInstantiate failed: %s", hipGetErrorString(e)); return HM_ERR_HIP; }
+    }
+    HM_HIP(hipGraphLaunch(exec, h->stream));
+    if (!in_place) {
+        HM_HIP(hipMemcpyAsync(d_ox, h->d_ox, px * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        HM_HIP(hipMemcpyAsync(d_oy, h->d_oy, px * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    }
+    return HM_OK;
 }
 
 extern "C" int hm_brox_calc_batch(hm_brox_t h, int n, const uint8_t *f0, const uint8_t *f1, float *ox, float *oy)

@@ -369,6 +369,56 @@ __global__ __launch_bounds__(256) void k_rhs(const double *__restrict__ M, const
 }
 
 
+// ---- end of one iteration of hm_update_run ---------------------------------------------------------------
+// res (host-visible) = [step (n) | the four error sums, partials added in index order | overflow flag]
+__global__ void k_iter_result(const double *__restrict__ step, int n, const double *__restrict__ partial, int nblocks,
+                              const int *__restrict__ overflow, double *__restrict__ res)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        res[i] = step[i];
+    } else if (i < n + 4) {
+        const int k = i - n;
+        double s = 0.0;
+        for (int b = 0; b < nblocks; b++) s += partial[(size_t)4 * b + k];
+        res[i] = s;
+    } else if (i == n + 4) {
+        res[i] = (double)*overflow;
+    }
+}
+
+// gains of the three measurement channels (kalman.py:828-830): out[0] = W c0, out[1] = W (c1 + c2),
+// out[2] = W c3 for the columns c* of Hzc (n x 4); one workgroup per row, fixed-order reduction
+__global__ __launch_bounds__(256) void k_gains(const double *__restrict__ W, const double *__restrict__ Hzc, int n,
+                                               double *__restrict__ out)
+{
+    __shared__ double sm[3][4];
+    const int row = blockIdx.x;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        const double w = W[(size_t)row * n + j];
+        const double *c = Hzc + (size_t)4 * j;
+        a0 += w * c[0];
+        a1 += w * (c[1] + c[2]);
+        a2 += w * c[3];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        a0 += __shfl_down(a0, o, 64);
+        a1 += __shfl_down(a1, o, 64);
+        a2 += __shfl_down(a2, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sm[0][threadIdx.x >> 6] = a0;
+        sm[1][threadIdx.x >> 6] = a1;
+        sm[2][threadIdx.x >> 6] = a2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const double *q = sm[threadIdx.x];
+        out[(size_t)threadIdx.x * n + row] = ((q[0] + q[1]) + q[2]) + q[3];
+    }
+}
+
 // ---- covariance prediction W' = F W F^T + Weps on the device -------------------------------------------
 // F = [[I, a I], [A, I]] with A = s * dfdy, dfdy assembled from one symmetric 2x2 block per spring
 // (see predict.cpp): (dfdy M)[rows of vertex v] = - sum over springs (v,u) of B (M[rows v] - M[rows u]).

@@ -5,6 +5,7 @@
 #include "ekf_kernels.h"
 #include "dense_kernels.h"
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <set>
 #include <utility>
@@ -33,18 +34,24 @@ struct hm_ctx {
     uint8_t *d_im8, *d_m8;
     std::vector<double> X0;          // state of the reference render
     // dense update on the device (n4 = 4N)
-    double *d_H, *d_Hz, *d_Hzc, *d_invW0, *d_Af[2], *d_Ld[2], *d_rhs, *d_dx, *d_Wtmp, *d_X0, *d_Xn;
+    double *d_H, *d_Hz, *d_Hzc, *d_invW0, *d_Af[2], *d_Ld[2], *d_dx, *d_Wtmp, *d_X0, *d_Xn, *d_Wprior, *d_gain;
     std::vector<double> upd_X0;      // prior mean given to hm_update_begin
     int upd_last, upd_prev;          // which d_Af holds the factor of the last / previous step (-1: none)
-    bool w_post_dev;                 // d_H holds the covariance hm_update_cov returned last
-    bool w_pred_dev;                 // d_Wtmp holds the covariance hm_cov_predict returned last
+    double *d_Wres;                  // the covariance resident on the device (the result of the last
+                                     // hm_cov_predict / hm_update_cov / hm_update_run): d_Wtmp, d_H or
+                                     // d_Wprior, or NULL when that buffer has been reused since
+    double *pin;                     // host-visible (pinned, device-mapped) result block of hm_update_run
+    size_t pin_n;
+    std::vector<int> sp_h_off, sp_h_bar, sp_h_other;   // host staging of the spring topology
+    std::vector<double> sp_h_blk;
+    std::vector<int> tri;            // host copy of the triangles (orientation test of hm_update_run)
     DPool pool;                      // parked difference images (see ekf_kernels.h)
     int *d_area;
     int *d_sp_off, *d_sp_bar, *d_sp_other;
     double *d_sp_blk;
     size_t sp_cap;                   // capacity (springs) of the d_sp_* arrays
     bool upd_open;
-    std::vector<double> h_out, h_partial;
+    std::vector<double> h_partial;
     int red_blocks;
 };
 
@@ -70,7 +77,7 @@ static int ctx_free(hm_ctx *h)
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_tri, h->d_star_off, h->d_star_tri, h->d_edges, h->d_uv, h->d_tex, h->d_yim, h->d_ym, h->d_yfx,
                     h->d_yfy, h->d_yfxm, h->d_yfym, h->d_setup, h->d_X, h->d_out, h->d_partial, h->d_im8, h->d_m8,
-                    h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_Ld[0], h->d_Ld[1], h->d_rhs, h->d_dx,
+                    h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_Ld[0], h->d_Ld[1], h->d_Wprior, h->d_gain, h->d_dx,
                     h->d_Wtmp, h->d_X0, h->d_Xn, h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk,
                     h->pool.hdr, h->pool.off, h->pool.xim, h->pool.xm, h->pool.yim, h->pool.ym, h->pool.xfx, h->pool.xfy,
                     h->pool.yfx, h->pool.yfy, h->pool.vxfx, h->pool.vyfy, h->pool.overflow, h->d_area};
@@ -79,6 +86,7 @@ static int ctx_free(hm_ctx *h)
     free_targets(h->ref);
     free_targets(h->P);
     free_targets(h->Q);
+    if (h->pin) (void)hipHostFree(h->pin);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return HM_OK;
@@ -132,9 +140,10 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->d_yim = h->d_ym = nullptr; h->d_yfx = h->d_yfy = h->d_yfxm = h->d_yfym = nullptr;
     h->ref = Targets{nullptr, nullptr, nullptr, nullptr}; h->P = h->ref; h->Q = h->ref;
     h->d_setup = nullptr; h->d_X = h->d_out = h->d_partial = nullptr; h->d_im8 = h->d_m8 = nullptr;
-    h->d_H = h->d_Hz = h->d_Hzc = h->d_invW0 = h->d_Af[0] = h->d_Af[1] = h->d_rhs = h->d_dx = h->d_Wtmp = nullptr;
+    h->d_H = h->d_Hz = h->d_Hzc = h->d_invW0 = h->d_Af[0] = h->d_Af[1] = h->d_dx = h->d_Wtmp = nullptr;
+    h->d_Wprior = h->d_gain = nullptr; h->d_Wres = nullptr; h->pin = nullptr; h->pin_n = 0;
+    h->tri.assign(tri, tri + (size_t)3 * T);
     h->d_Ld[0] = h->d_Ld[1] = nullptr; h->d_X0 = h->d_Xn = nullptr;
-    h->w_post_dev = h->w_pred_dev = false;
     memset(&h->pool, 0, sizeof h->pool); h->d_area = nullptr;
     h->d_sp_off = h->d_sp_bar = h->d_sp_other = nullptr; h->d_sp_blk = nullptr; h->sp_cap = 0;
     h->upd_last = h->upd_prev = -1; h->upd_open = false;
@@ -177,7 +186,11 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Wtmp, nn);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Hz, n4 * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Hzc, n4 * 4 * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_rhs, n4 * 4 * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Wprior, nn);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_gain, n4 * 3 * sizeof(double));
+        // [step (n4) | four error sums | overflow flag] per iteration, then Hzc (n4 x 4) and the gains (3 x n4)
+        h->pin_n = n4 + 8 + n4 * 4 + n4 * 3;
+        if (e == hipSuccess) e = hipHostMalloc((void **)&h->pin, h->pin_n * sizeof(double), hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_dx, n4 * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_X0, n4 * sizeof(double));
         // pool of parked difference images: the star regions overlap a few times; 16 frames' worth of
@@ -207,7 +220,6 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         ctx_free(h);
         return rc;
     }
-    h->h_out.resize((size_t)h->njobs * MEAS_OUT);
     h->h_partial.resize((size_t)h->red_blocks * 4);
     *out = h;
     return HM_OK;
@@ -402,18 +414,19 @@ extern "C" int hm_error(hm_ctx_t h, const double *X, int masked, double err[4], 
 }
 
 // render X as the reference, run the fused perturb-and-reduce kernel, unpack into d_H / d_Hz / d_Hzc
-static int measure_on_device(hm_ctx *h, const double *X, double deltaX, int masked)
+// the measurement at the device-resident state dX, whose render is (ref_ready) or is to be put in h->ref
+static int measure_dev(hm_ctx *h, const double *dX, bool ref_ready, double deltaX, int masked)
 {
-    int rc = render_into(h, X, h->ref);
-    if (rc) return rc;
-    h->X0.assign(X, X + 4 * h->N);
-    h->have_ref = true;
+    if (!ref_ready) {
+        int rc = render_dev(h, dX, h->ref);
+        if (rc) return rc;
+    }
     MeasureArgs a;
     a.m = Mesh{h->W, h->H, h->N, h->T, h->d_tri, h->d_uv, h->d_tex};
     a.topo = StarTopo{h->d_star_off, h->d_star_tri, h->d_edges, h->E};
     a.ref = h->ref;
     a.obs = obs_of(h, masked);
-    a.X = h->d_X;
+    a.X = dX;
     a.delta = deltaX;
     a.out = h->d_out;
     a.pool = h->pool;
@@ -422,12 +435,20 @@ static int measure_on_device(hm_ctx *h, const double *X, double deltaX, int mask
     hipLaunchKernelGGL(k_measure_vertex, dim3(h->N, MEAS_VSPLIT), dim3(MEAS_NT), 0, h->stream, a);
     if (h->E > 0) hipLaunchKernelGGL(k_measure_edge, dim3(h->E), dim3(MEAS_NT), 0, h->stream, a);
     const size_t n4 = (size_t)4 * h->N;
-    h->w_post_dev = false;                       // d_H is about to be overwritten
+    if (h->d_Wres == h->d_H) h->d_Wres = nullptr;    // d_H is about to be overwritten
     HM_HIP(hipMemsetAsync(h->d_H, 0, n4 * n4 * sizeof(double), h->stream));
     ScatterArgs s = {h->d_out, h->d_edges, h->N, h->E, h->eps_Z, h->eps_J, h->eps_M, deltaX, h->d_H, h->d_Hz, h->d_Hzc};
     hipLaunchKernelGGL(k_hth_scatter, dim3(hm_cdiv(h->njobs, 64)), dim3(64), 0, h->stream, s);
     HM_HIP(hipGetLastError());
     return HM_OK;
+}
+
+static int measure_on_device(hm_ctx *h, const double *X, double deltaX, int masked)
+{
+    HM_HIP(hipMemcpyAsync(h->d_X, X, (size_t)4 * h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    h->X0.assign(X, X + 4 * h->N);
+    h->have_ref = true;
+    return measure_dev(h, h->d_X, false, deltaX, masked);
 }
 
 extern "C" int hm_measure(hm_ctx_t h, const double *X, double deltaX, int masked, double *Hz, double *Hzc, double *HTH)
@@ -487,10 +508,30 @@ static void chol_backsolve_row(hm_ctx *h, double *A, const double *Ld, int n)
                        h->stream, A, Ld, n, row, (size_t)1, (size_t)n, 1);
 }
 
+// one iteration's worth of launches of the update: system assembly, factorisation, solve.
+// d_X holds the iterate the measurement was taken at; the step ends up in the right-hand-side row.
+static double *solve_step(hm_ctx *h, int slot)
+{
+    const int n4 = 4 * h->N;
+    hipLaunchKernelGGL(k_vec_axpy, dim3(hm_cdiv(n4, 256)), dim3(256), 0, h->stream, h->d_X0, h->d_X, -1.0, h->d_dx, n4);
+    double *A = h->d_Af[slot];
+    const size_t nn = (size_t)n4 * n4;
+    hipLaunchKernelGGL(k_add_mat, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, h->d_invW0, h->d_H, A, nn);
+    // right-hand side Hz - H (X0 - X) as the first row of the block below the matrix; the rows in
+    // between and the rest of that block stay zero
+    const size_t pad_n = (size_t)aug_rows(n4) * n4 - nn;
+    (void)hipMemsetAsync(A + nn, 0, pad_n * sizeof(double), h->stream);
+    double *rhs_row = A + (size_t)hm_cdiv(n4, DNB) * DNB * n4;
+    hipLaunchKernelGGL(k_rhs, dim3(n4), dim3(256), 0, h->stream, h->d_H, h->d_dx, h->d_Hz, rhs_row, n4);
+    chol_factor(h, A, h->d_Ld[slot], n4, true);
+    chol_backsolve_row(h, A, h->d_Ld[slot], n4);
+    return rhs_row;
+}
+
 extern "C" int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *X0)
 {
     HM_ARG(h && X0, "hm_update_begin: NULL argument");
-    if (!W_prior && !h->w_pred_dev) {
+    if (!W_prior && !h->d_Wres) {
         hm_set_error("hm_update_begin: no prior given and none resident on the device");
         return HM_ERR_STATE;
     }
@@ -509,11 +550,14 @@ extern "C" int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *
     }
     HM_ARG((size_t)n4 * (INV_CH + 1) * sizeof(double) <= inv_lds_cap, "hm_update_begin: state dimension %d too large for "
            "the on-device inverse (limit %d)", n4, (int)(inv_lds_cap / ((INV_CH + 1) * sizeof(double))));
+    // the prior stays in d_Wprior: it is the covariance to keep when no iterate is accepted
+    const size_t nnb = (size_t)n4 * n4 * sizeof(double);
     if (W_prior)
-        HM_HIP(hipMemcpyAsync(h->d_Af[0], W_prior, (size_t)n4 * n4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    else        // the covariance hm_cov_predict left on the device
-        HM_HIP(hipMemcpyAsync(h->d_Af[0], h->d_Wtmp, (size_t)n4 * n4 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    h->w_pred_dev = false;                       // d_Wtmp is scratch from here on
+        HM_HIP(hipMemcpyAsync(h->d_Wprior, W_prior, nnb, hipMemcpyHostToDevice, h->stream));
+    else if (h->d_Wres != h->d_Wprior)
+        HM_HIP(hipMemcpyAsync(h->d_Wprior, h->d_Wres, nnb, hipMemcpyDeviceToDevice, h->stream));
+    HM_HIP(hipMemcpyAsync(h->d_Af[0], h->d_Wprior, nnb, hipMemcpyDeviceToDevice, h->stream));
+    h->d_Wres = h->d_Wprior;                     // d_Wtmp is scratch from here on
     chol_factor(h, h->d_Af[0], h->d_Ld[0], n4, false);
     chol_inverse(h, h->d_Af[0], h->d_Ld[0], n4, h->d_Wtmp, h->d_invW0);
     HM_HIP(hipGetLastError());
@@ -536,19 +580,8 @@ extern "C" int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int ma
     const int n4 = 4 * h->N;
     int rc = measure_on_device(h, X, deltaX, masked);          // leaves X in d_X
     if (rc) return rc;
-    hipLaunchKernelGGL(k_vec_axpy, dim3(hm_cdiv(n4, 256)), dim3(256), 0, h->stream, h->d_X0, h->d_X, -1.0, h->d_dx, n4);
     const int slot = h->upd_last == 0 ? 1 : 0;
-    double *A = h->d_Af[slot];
-    const size_t nn = (size_t)n4 * n4;
-    hipLaunchKernelGGL(k_add_mat, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, h->d_invW0, h->d_H, A, nn);
-    // right-hand side Hz - H (X0 - X) as the first row of the block below the matrix; the rows in
-    // between and the rest of that block stay zero
-    const size_t pad_n = (size_t)aug_rows(n4) * n4 - nn;
-    HM_HIP(hipMemsetAsync(A + nn, 0, pad_n * sizeof(double), h->stream));
-    double *rhs_row = A + (size_t)hm_cdiv(n4, DNB) * DNB * n4;
-    hipLaunchKernelGGL(k_rhs, dim3(n4), dim3(256), 0, h->stream, h->d_H, h->d_dx, h->d_Hz, rhs_row, n4);
-    chol_factor(h, A, h->d_Ld[slot], n4, true);
-    chol_backsolve_row(h, A, h->d_Ld[slot], n4);
+    double *rhs_row = solve_step(h, slot);
     HM_HIP(hipGetLastError());
     HM_HIP(hipMemcpyAsync(step, rhs_row, (size_t)n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (Hzc) HM_HIP(hipMemcpyAsync(Hzc, h->d_Hzc, (size_t)n4 * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -574,19 +607,144 @@ extern "C" int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int ma
 
 extern "C" int hm_update_cov(hm_ctx_t h, int which, double *W_out)
 {
-    HM_ARG(h && W_out, "hm_update_cov: NULL argument");
-    HM_ARG(which == 0 || which == 1, "hm_update_cov: which must be 0 (last step) or 1 (the step before)");
+    HM_ARG(h != nullptr, "hm_update_cov: NULL handle");
+    HM_ARG(which >= -1 && which <= 1, "hm_update_cov: which must be 0 (last step), 1 (the step before) or -1 (the prior)");
     if (!h->upd_open) { hm_set_error("hm_update_cov: hm_update_begin has not been called"); return HM_ERR_STATE; }
-    const int slot = which == 0 ? h->upd_last : h->upd_prev;
-    if (slot < 0) { hm_set_error("hm_update_cov: no such step"); return HM_ERR_STATE; }
     HM_HIP(hipSetDevice(h->device));
     const int n4 = 4 * h->N;
-    chol_inverse(h, h->d_Af[slot], h->d_Ld[slot], n4, h->d_Wtmp, h->d_H);      // d_H is free between steps
-    HM_HIP(hipGetLastError());
-    HM_HIP(hipMemcpyAsync(W_out, h->d_H, (size_t)n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (which < 0) {
+        h->d_Wres = h->d_Wprior;
+    } else {
+        const int slot = which == 0 ? h->upd_last : h->upd_prev;
+        if (slot < 0) { hm_set_error("hm_update_cov: no such step"); return HM_ERR_STATE; }
+        chol_inverse(h, h->d_Af[slot], h->d_Ld[slot], n4, h->d_Wtmp, h->d_H);      // d_H is free between steps
+        HM_HIP(hipGetLastError());
+        h->d_Wres = h->d_H;
+    }
+    if (W_out) {
+        HM_HIP(hipMemcpyAsync(W_out, h->d_Wres, (size_t)n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HM_HIP(hipStreamSynchronize(h->stream));
+    }
+    return HM_OK;
+}
+
+// The covariance resident on the device (the result of the last hm_cov_predict, hm_update_cov or
+// hm_update_run) copied to the host.
+extern "C" int hm_cov_fetch(hm_ctx_t h, double *W_out)
+{
+    HM_ARG(h && W_out, "hm_cov_fetch: NULL argument");
+    if (!h->d_Wres) { hm_set_error("hm_cov_fetch: no covariance resident on the device"); return HM_ERR_STATE; }
+    HM_HIP(hipSetDevice(h->device));
+    const size_t n4 = (size_t)4 * h->N;
+    HM_HIP(hipMemcpyAsync(W_out, h->d_Wres, n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HM_HIP(hipStreamSynchronize(h->stream));
-    h->w_post_dev = true;
-    h->w_pred_dev = false;
+    return HM_OK;
+}
+
+// IteratedKalmanFilter.update (kalman.py:774-831) in one call: hm_update_begin, up to max_iter
+// hm_update_step's with the reference's acceptance logic between them, hm_update_cov of the state
+// that is kept.  Per iteration the host sees one small result block (step, the four error sums)
+// that the last kernel writes into pinned memory; the iterate itself never leaves the device, and
+// the render that gave an iterate's error is the reference render of the next measurement.
+extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, double deltaX, int masked, int max_iter,
+                             double reltol, int info[4], double *errs, double *Hzc, double *gains, double *W_out)
+{
+    HM_ARG(h && X && info, "hm_update_run: NULL argument");
+    HM_ARG(deltaX > 0 && max_iter >= 0, "hm_update_run: deltaX must be positive, max_iter >= 0");
+    NEED_TEX(h, "hm_update_run");
+    NEED_OBS(h, "hm_update_run");
+    int rc = hm_update_begin(h, W_prior, X);
+    if (rc) return rc;
+    const int N = h->N, n4 = 4 * N;
+    std::vector<double> X0(X, X + n4), Xcur(X0), Xold(X0);
+    HM_HIP(hipMemcpyAsync(h->d_X, h->d_X0, (size_t)n4 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    double *res = h->pin, *pin_hzc = h->pin + n4 + 8, *pin_gain = pin_hzc + (size_t)n4 * 4;
+    int niter = 0, accepted = 0;
+    bool reverted = false, conv = false, ref_ready = false;
+    double eold = 0.0;
+    for (int it = 0; it < max_iter; it++) {
+        rc = measure_dev(h, h->d_X, ref_ready, deltaX, masked);
+        if (rc) return rc;
+        h->X0 = Xcur;                              // the state of the reference render (hm_jz / hm_j)
+        h->have_ref = true;
+        const int slot = h->upd_last == 0 ? 1 : 0;
+        double *rhs_row = solve_step(h, slot);
+        // the new iterate, its render and Renderer.error (kalman.py:813)
+        hipLaunchKernelGGL(k_vec_axpy, dim3(hm_cdiv(n4, 256)), dim3(256), 0, h->stream, h->d_X0, rhs_row, 1.0, h->d_Xn, n4);
+        rc = render_dev(h, h->d_Xn, h->P);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_error, dim3(h->red_blocks), dim3(RED_NT), 0, h->stream, h->P, obs_of(h, masked),
+                           h->W * h->H, h->d_partial);
+        hipLaunchKernelGGL(k_iter_result, dim3(hm_cdiv(n4 + 5, 256)), dim3(256), 0, h->stream, rhs_row, n4, h->d_partial,
+                           h->red_blocks, h->pool.overflow, res);
+        HM_HIP(hipGetLastError());
+        HM_HIP(hipStreamSynchronize(h->stream));
+        h->upd_prev = h->upd_last;
+        h->upd_last = slot;
+        niter++;
+        if (res[n4 + 4] != 0.0) {
+            hm_set_error("hm_update_run: the star regions do not fit the difference-image pool");
+            return HM_ERR_STATE;
+        }
+        bool finite = true;
+        for (int i = 0; i < n4; i++) finite = finite && std::isfinite(res[i]);
+        if (!finite) {
+            hm_set_error("hm_update_run: the update system inv(W) + HTH is not positive definite "
+                         "(non-finite state, covariance or observation?)");
+            return HM_ERR_NUMERIC;
+        }
+        for (int i = 0; i < n4; i++) Xcur[i] = X0[i] + res[i];
+        if (errs) for (int k = 0; k < 4; k++) errs[4 * it + k] = res[n4 + k];
+        // a triangle that flipped: back to the last good state (kalman.py:806-811)
+        bool flipped = false;
+        for (int t = 0; t < h->T && !flipped; t++) {
+            const int a = h->tri[3 * t], b = h->tri[3 * t + 1], c = h->tri[3 * t + 2];
+            const double ax = Xcur[2 * b] - Xcur[2 * a], ay = Xcur[2 * b + 1] - Xcur[2 * a + 1];
+            const double bx = Xcur[2 * c] - Xcur[2 * a], by = Xcur[2 * c + 1] - Xcur[2 * a + 1];
+            flipped = ax * by - ay * bx < 0.0;
+        }
+        if (flipped) {
+            Xcur = Xold;
+            reverted = true;
+            break;
+        }
+        // the error sums of the image and mask terms are whole numbers (the reference truncates
+        // them to int before combining, kalman.py:813-816)
+        const double e_im = std::trunc(res[n4]), e_m = std::trunc(res[n4 + 3]);
+        const double enew = std::sqrt(e_im * e_im + res[n4 + 1] * res[n4 + 1] + res[n4 + 2] * res[n4 + 2] + e_m * e_m);
+        accepted++;
+        if (std::fabs(enew - eold) / enew < reltol) { conv = true; break; }
+        eold = enew;
+        Xold = Xcur;
+        // the new iterate becomes the point of the next measurement; its render is already there
+        std::swap(h->ref, h->P);
+        std::swap(h->d_X, h->d_Xn);
+        ref_ready = true;
+        h->X0 = Xcur;
+    }
+    // covariance of the state that is kept (kalman.py:806-811, 826)
+    int which = -1;                                // -1: the prior
+    if (reverted) which = accepted == 0 ? -1 : 1;
+    else which = niter == 0 ? -1 : 0;
+    rc = hm_update_cov(h, which, nullptr);
+    if (rc) return rc;
+    if (niter > 0) {
+        hipLaunchKernelGGL(k_gains, dim3(n4), dim3(256), 0, h->stream, h->d_Wres, h->d_Hzc, n4, h->d_gain);
+        HM_HIP(hipMemcpyAsync(pin_hzc, h->d_Hzc, (size_t)n4 * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HM_HIP(hipMemcpyAsync(pin_gain, h->d_gain, (size_t)n4 * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    if (W_out) HM_HIP(hipMemcpyAsync(W_out, h->d_Wres, (size_t)n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HM_HIP(hipGetLastError());
+    HM_HIP(hipStreamSynchronize(h->stream));
+    if (niter > 0) {
+        if (Hzc) memcpy(Hzc, pin_hzc, (size_t)n4 * 4 * sizeof(double));
+        if (gains) memcpy(gains, pin_gain, (size_t)n4 * 3 * sizeof(double));
+    } else {
+        if (Hzc) memset(Hzc, 0, (size_t)n4 * 4 * sizeof(double));
+        if (gains) memset(gains, 0, (size_t)n4 * 3 * sizeof(double));
+    }
+    memcpy(X, Xcur.data(), (size_t)n4 * sizeof(double));
+    info[0] = niter; info[1] = accepted; info[2] = reverted ? 1 : 0; info[3] = conv ? 1 : 0;
     return HM_OK;
 }
 
@@ -600,15 +758,17 @@ extern "C" int hm_update_cov(hm_ctx_t h, int which, double *W_out)
 extern "C" int hm_cov_predict(hm_ctx_t h, const double *W_in, int n_bars, const int32_t *bars, const double *blocks,
                               double a, double s, double eps_F, double *W_out)
 {
-    HM_ARG(h && W_out && n_bars >= 0 && (n_bars == 0 || (bars && blocks)), "hm_cov_predict: bad argument");
-    if (!W_in && !h->w_post_dev) {
+    HM_ARG(h && n_bars >= 0 && (n_bars == 0 || (bars && blocks)), "hm_cov_predict: bad argument");
+    if (!W_in && !h->d_Wres) {
         hm_set_error("hm_cov_predict: no covariance given and none resident on the device");
         return HM_ERR_STATE;
     }
     HM_HIP(hipSetDevice(h->device));
     const int N = h->N, n4 = 4 * N;
     const size_t nn = (size_t)n4 * n4 * sizeof(double);
-    std::vector<int> off(N + 1, 0), bar, other;
+    std::vector<int> &off = h->sp_h_off, &bar = h->sp_h_bar, &other = h->sp_h_other;   // live until the copies ran
+    HM_HIP(hipStreamSynchronize(h->stream));      // ... of the previous call
+    off.assign(N + 1, 0);
     for (int i = 0; i < n_bars; i++) {
         HM_ARG(bars[2 * i] >= 0 && bars[2 * i] < N && bars[2 * i + 1] >= 0 && bars[2 * i + 1] < N,
                "hm_cov_predict: spring %d refers to a vertex outside 0..%d", i, N - 1);
@@ -640,18 +800,25 @@ extern "C" int hm_cov_predict(hm_ctx_t h, const double *W_in, int n_bars, const 
     if (n_bars > 0) {
         HM_HIP(hipMemcpyAsync(h->d_sp_bar, bar.data(), bar.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
         HM_HIP(hipMemcpyAsync(h->d_sp_other, other.data(), other.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-        HM_HIP(hipMemcpyAsync(h->d_sp_blk, blocks, 3 * (size_t)n_bars * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        h->sp_h_blk.assign(blocks, blocks + 3 * (size_t)n_bars);
+        HM_HIP(hipMemcpyAsync(h->d_sp_blk, h->sp_h_blk.data(), 3 * (size_t)n_bars * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
-    if (W_in) HM_HIP(hipMemcpyAsync(h->d_H, W_in, nn, hipMemcpyHostToDevice, h->stream));
+    const double *src = h->d_Wres;
+    if (W_in) {
+        HM_HIP(hipMemcpyAsync(h->d_H, W_in, nn, hipMemcpyHostToDevice, h->stream));
+        src = h->d_H;
+    } else if (src == h->d_Wtmp) {               // the output buffer: move the input out of the way
+        HM_HIP(hipMemcpyAsync(h->d_H, h->d_Wtmp, nn, hipMemcpyDeviceToDevice, h->stream));
+        src = h->d_H;
+    }
     SpringTopo tp = {h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk};
     double *P = h->d_Af[1];                      // scratch: no factor is live between two updates
-    hipLaunchKernelGGL(k_fw_rows, dim3(hm_cdiv(n4, 256), N), dim3(256), 0, h->stream, h->d_H, P, N, tp, a, s);
+    hipLaunchKernelGGL(k_fw_rows, dim3(hm_cdiv(n4, 256), N), dim3(256), 0, h->stream, src, P, N, tp, a, s);
     hipLaunchKernelGGL(k_pft_cols, dim3(hm_cdiv(n4, 256), N), dim3(256), 0, h->stream, P, h->d_Wtmp, N, tp, a, s, eps_F);
     HM_HIP(hipGetLastError());
-    HM_HIP(hipMemcpyAsync(W_out, h->d_Wtmp, nn, hipMemcpyDeviceToHost, h->stream));
-    HM_HIP(hipStreamSynchronize(h->stream));      // off / bar / other are locals
-    h->w_post_dev = false;
-    h->w_pred_dev = true;
+    if (W_out) HM_HIP(hipMemcpyAsync(W_out, h->d_Wtmp, nn, hipMemcpyDeviceToHost, h->stream));
+    if (W_out) HM_HIP(hipStreamSynchronize(h->stream));
+    h->d_Wres = h->d_Wtmp;
     h->upd_open = false;                          // the factors of the last update are gone (d_Af[1] was scratch)
     return HM_OK;
 }

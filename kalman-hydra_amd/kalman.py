@@ -32,7 +32,7 @@ import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
 from . import _lib
-from .renderer import Renderer, MaskedFlow, DeviceObservation
+from .renderer import DeviceCovariance, Renderer, MaskedFlow, DeviceObservation
 
 
 class Statistics:
@@ -274,6 +274,18 @@ class KFState:
         d = self.Ks.T.dot(self.vertices().reshape(-1, 1)).reshape(-1, 2)
         return np.sqrt((d * d).sum(axis=1)).reshape(-1, 1)
 
+    # The covariance may live on the device between the calls of a filter step (renderer.DeviceCovariance);
+    # reading state.W brings it to the host once, assigning replaces it.
+    @property
+    def W(self):
+        if isinstance(self._W, DeviceCovariance):
+            self._W = self._W.fetch()
+        return self._W
+
+    @W.setter
+    def W(self, value):
+        self._W = value
+
     def update_orientation(self):
         ver = self.vertices()
         a = ver[self.tri[:, 1]] - ver[self.tri[:, 0]]
@@ -411,7 +423,7 @@ class KalmanFilter:
         st.X = st.F.dot(st.X)
         self.pred_x = st.X.copy()
         if hasattr(st.renderer, "cov_predict"):
-            st.W = st.renderer.cov_predict(st.W, None, None, 1.0, 0.0, st.eps_F)
+            st.W = st.renderer.cov_predict(st._W, None, None, 1.0, 0.0, st.eps_F, fetch=False)
         else:
             st.W = st.F.dot(st.W.dot(st.F.T)) + st.Weps
         stats.statepredtime[0] += time.time() - t0
@@ -476,6 +488,29 @@ class IteratedKalmanFilter(KalmanFilter):
                               eps_J=eps_J, eps_M=eps_M, **kw)
         self.nI = nI
         self.reltol = 1e-4
+        self.fused_update = True         # hm_update_run; False: the same loop in Python over hm_update_step
+
+    def _update_fused(self, y_im, y_flow, y_m):
+        """The whole loop below in one native call (hm_update_run): same numbers, the iterate and
+        the covariance stay on the device."""
+        st = self.state
+        t0 = time.time()
+        X, info, errs, Hzc, gains, W = st.renderer.update_run(st._W, st.X, y_im, y_flow, y_m, self.nI, self.reltol)
+        stats.stateupdatetc[0] += time.time() - t0
+        stats.stateupdatetc[1] += info["niter"]
+        for i, e in enumerate(errs):
+            self._say("   IEKF K = %d" % i)
+            if info["reverted"] and i == len(errs) - 1:
+                self._say("** Mesh inconsistent ** Reverting to last good state and continuing")
+            else:
+                self._say("-- e_im: %d, e_fx: %d, e_fy: %d, e_m: %d" % tuple(e))
+        st.X = X
+        st.W = W
+        st.update_orientation()
+        self.niter = info["niter"]
+        stats.niter += self.niter
+        self.reverted, self.converged = info["reverted"], info["converged"]
+        self.tv, self.fv, self.mv = gains[0], gains[1], gains[2]
 
     def update(self, y_im, y_flow, y_m):
         """Iterated EKF in information form (:774-831).
@@ -487,14 +522,17 @@ class IteratedKalmanFilter(KalmanFilter):
         factorisations run on the device (hm_update_begin / _step / _cov) and only the 4N-vector
         of the step crosses PCIe per iteration."""
         st = self.state
+        if self.fused_update and hasattr(st.renderer, "update_run"):
+            return self._update_fused(y_im, y_flow, y_m)
         on_device = hasattr(st.renderer, "update_step")
         X = st.X
         X_orig, X_old = X.copy(), X.copy()
-        W_old = st.W
+        W_old = st._W
         if on_device:
-            st.renderer.update_begin(st.W, X_orig)
+            st.renderer.update_begin(W_old, X_orig)
         else:
-            invW_orig = _spd_inverse(st.W)
+            W_old = st.W
+            invW_orig = _spd_inverse(W_old)
         A = A_old = None                 # host path: information matrices of X and X_old (None = the prior)
         accepted = 0                     # iterations whose state was kept
         eold = 0.0
@@ -546,9 +584,9 @@ class IteratedKalmanFilter(KalmanFilter):
         stats.niter += self.niter
         if on_device:
             if reverted:
-                st.W = W_old if accepted == 0 else st.renderer.update_cov(1)
+                st.W = st.renderer.update_cov(-1 if accepted == 0 else 1, fetch=False)
             else:
-                st.W = W_old if self.niter == 0 else st.renderer.update_cov(0)
+                st.W = st.renderer.update_cov(-1 if self.niter == 0 else 0, fetch=False)
         else:
             st.W = W_old if A is None else _spd_inverse(A)
         self.reverted = reverted
@@ -642,7 +680,8 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
         if hasattr(st.renderer, "cov_predict"):
             blocks = self._spring_blocks()
             self._newton()
-            st.W = st.renderer.cov_predict(st.W, self._bars, blocks, self.deltat, self.deltat / self.M, st.eps_F)
+            st.W = st.renderer.cov_predict(st._W, self._bars, blocks, self.deltat, self.deltat / self.M, st.eps_F,
+                                           fetch=False)
         else:
             A = self._jacobian() * (self.deltat / self.M)
             self._newton()

@@ -56,7 +56,7 @@ class Renderer:
         self.vertices = np.array(distmesh.p, np.float64)
         self.velocities = np.array(vel, np.float64).reshape(self.vertices.shape)
         self._obs = None
-        self._w_post = self._w_pred = None      # covariance arrays whose values are still on the device
+        self._cov_serial = 0                    # names the covariance resident on the device (DeviceCovariance)
         self.current_frame = tex
         self.current_flowx, self.current_flowy = flow[:, :, 0], flow[:, :, 1]
 
@@ -188,34 +188,69 @@ class Renderer:
         HTH = np.empty((n4, n4))
         _lib.check(_lib.lib().hm_measure(self._h, _lib.ptr(self._X(state)), float(deltaX), masked, _lib.ptr(Hz),
                                          _lib.ptr(Hzc), _lib.ptr(HTH)), "hm_measure")
-        self._w_post = None
+        self._cov_serial += 1                   # the resident covariance may have shared that buffer
         return Hz.reshape(-1, 1), HTH, Hzc
 
     # -- the dense update on the device (information form) --------------------------------------
-    def cov_predict(self, W, bars, blocks, a, s, eps_F):
-        """hm_cov_predict: F W F^T + Weps on the device.  If W is the very array update_cov returned
-        last, the copy still on the device is used instead of uploading it again."""
+    def _cov_arg(self, W, who):
+        """NULL for the covariance resident on the device, else a contiguous host array."""
+        if isinstance(W, DeviceCovariance):
+            if not W.valid(self):
+                raise RuntimeError("%s: this DeviceCovariance is no longer resident on the device" % who)
+            return None
+        return np.ascontiguousarray(W, np.float64)
+
+    def _cov_result(self, fetch):
+        self._cov_serial += 1
+        tok = DeviceCovariance(self, self._cov_serial)
+        return tok.fetch() if fetch else tok
+
+    def cov_fetch(self):
         n4 = 4 * self.n
-        out = np.empty((n4, n4))
-        on_dev = W is self._w_post
-        Win = None if on_dev else np.ascontiguousarray(W, np.float64)
+        W = np.empty((n4, n4))
+        _lib.check(_lib.lib().hm_cov_fetch(self._h, _lib.ptr(W)), "hm_cov_fetch")
+        return W
+
+    def cov_predict(self, W, bars, blocks, a, s, eps_F, fetch=True):
+        """hm_cov_predict: F W F^T + Weps on the device.  W is a host array or the DeviceCovariance
+        the last update left on the device; fetch=False returns a DeviceCovariance instead of
+        copying 4N x 4N doubles back."""
+        Win = self._cov_arg(W, "cov_predict")
         nb = 0 if bars is None else int(len(bars))
         b = None if nb == 0 else np.ascontiguousarray(bars, np.int32)
         blk = None if nb == 0 else np.ascontiguousarray(blocks, np.float64)
         _lib.check(_lib.lib().hm_cov_predict(self._h, _lib.ptr(Win), nb, _lib.ptr(b), _lib.ptr(blk), float(a), float(s),
-                                             float(eps_F), _lib.ptr(out)), "hm_cov_predict")
-        self._w_post = None
-        self._w_pred = out
-        return out
+                                             float(eps_F), None), "hm_cov_predict")
+        return self._cov_result(fetch)
 
     def update_begin(self, W_prior, X0):
         """Factor the prior covariance on the device and keep inv(W), X0 there (hm_update_begin).
-        The array cov_predict returned last is already on the device and is not uploaded again."""
-        on_dev = W_prior is self._w_pred
-        W = None if on_dev else np.ascontiguousarray(W_prior, np.float64)
+        A DeviceCovariance is used where it is."""
+        W = self._cov_arg(W_prior, "update_begin")
         x0 = np.ascontiguousarray(np.asarray(X0, np.float64).reshape(-1))
         _lib.check(_lib.lib().hm_update_begin(self._h, _lib.ptr(W), _lib.ptr(x0)), "hm_update_begin")
-        self._w_pred = None
+        if W is not None:
+            self._cov_serial += 1
+
+    def update_run(self, W_prior, X0, y_im, y_flow, y_m, max_iter, reltol, deltaX=2.0, fetch=False):
+        """hm_update_run: the whole iterated update (kalman.py:774-831) ->
+        (X kept [4N,1], info dict, errs [niter,4], Hz_components [4N,4], gains [3,4N], covariance)."""
+        masked = self._masked_flag(y_im, y_flow, y_m)
+        W = self._cov_arg(W_prior, "update_run")
+        n4 = 4 * self.n
+        X = np.ascontiguousarray(np.asarray(X0, np.float64).reshape(-1)).copy()
+        info = (ctypes.c_int * 4)()
+        errs = np.zeros((max(int(max_iter), 1), 4))
+        Hzc = np.empty((n4, 4))
+        gains = np.empty((3, n4))
+        rc = _lib.lib().hm_update_run(self._h, _lib.ptr(W), _lib.ptr(X), float(deltaX), masked, int(max_iter),
+                                      float(reltol), info, _lib.ptr(errs), _lib.ptr(Hzc), _lib.ptr(gains), None)
+        self._cov_serial += 1
+        if rc == _lib.HM_ERR_NUMERIC:
+            raise FloatingPointError(_lib.lib().hm_last_error().decode())
+        _lib.check(rc, "hm_update_run")
+        out = dict(niter=info[0], accepted=info[1], reverted=bool(info[2]), converged=bool(info[3]))
+        return X.reshape(-1, 1), out, errs[:info[0]], Hzc, gains, self._cov_result(fetch)
 
     def update_step(self, state, y_im, y_flow, y_m, deltaX=2.0, want_error=True):
         """hm_update_step: measurement at state.X, the solve and (want_error) Renderer.error of the new
@@ -228,15 +263,14 @@ class Renderer:
         _lib.check(_lib.lib().hm_update_step(self._h, _lib.ptr(self._X(state)), float(deltaX), masked,
                                              _lib.ptr(step), _lib.ptr(Hzc), err if want_error else None),
                    "hm_update_step")
+        self._cov_serial += 1                   # the measurement reuses the buffer of update_cov's result
         e = (int(err[0]), err[1], err[2], int(err[3])) if want_error else None
         return step.reshape(-1, 1), Hzc, e
 
-    def update_cov(self, which=0):
-        n4 = 4 * self.n
-        W = np.empty((n4, n4))
-        _lib.check(_lib.lib().hm_update_cov(self._h, int(which), _lib.ptr(W)), "hm_update_cov")
-        self._w_post = W
-        return W
+    def update_cov(self, which=0, fetch=True):
+        """hm_update_cov: covariance of the last step (0), of the one before (1) or the prior (-1)."""
+        _lib.check(_lib.lib().hm_update_cov(self._h, int(which), None), "hm_update_cov")
+        return self._cov_result(fetch)
 
     def error(self, state, y_im, y_flow, y_m, want_flow=True):
         """reference renderer.py:485-501 -> (e_im, e_fx, e_fy, e_m, fx, fy).
@@ -254,6 +288,24 @@ class Renderer:
         if want_flow:      # the reference returns read_pixels arrays of shape (ny, nx, 1)
             fx, fy = fx[:, :, None], fy[:, :, None]
         return int(err[0]), err[1], err[2], int(err[3]), fx, fy
+
+
+class DeviceCovariance:
+    """A 4N x 4N covariance that lives on the device: what the last cov_predict / update_cov /
+    update_run of one Renderer left there.  fetch() copies it to the host; it stops being valid
+    when that renderer produces the next one."""
+
+    def __init__(self, renderer, serial):
+        self._renderer, self._serial = renderer, serial
+
+    def valid(self, renderer=None):
+        r = self._renderer
+        return (renderer is None or renderer is r) and r._cov_serial == self._serial
+
+    def fetch(self):
+        if not self.valid():
+            raise RuntimeError("this DeviceCovariance is no longer resident on the device")
+        return self._renderer.cov_fetch()
 
 
 class DeviceObservation:

@@ -132,7 +132,8 @@ def test_calc_batch_and_tuning_do_not_change_results(hm, oracle_brox):
     for i in range(3):
         ru, rv = oracle_brox.calc(F0[i], F1[i])
         assert np.array_equal(U[i], ru) and np.array_equal(V[i], rv)
-    for key, val in [("sor_fuse", 1), ("sor_fuse", 2), ("sor_threads", 512), ("sor_fuse", 0), ("sor_threads", 1024)]:
+    for key, val in [("sor_fuse", 1), ("sor_fuse", 2), ("sor_threads", 512), ("sor_fuse", 0), ("sor_threads", 1024), ("graph", 0),
+                     ("graph", 1)]:
         bf.tune(key, val)
         U2, V2 = bf.calc_batch(F0, F1)
         assert np.array_equal(U, U2) and np.array_equal(V, V2), (key, val)

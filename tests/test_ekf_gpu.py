@@ -267,7 +267,7 @@ def test_plain_kalman_filter_update_on_device(hm):
 
 def test_device_covariance_prediction(hm):
     """hm_cov_predict against the host formula F W F^T + Weps, for both dynamics, with the covariance
-    uploaded and with the copy that update_cov leaves on the device."""
+    uploaded and with the copy that the previous call left on the device (DeviceCovariance)."""
     from hydra_mi import kalman
     n = 64
     dm, N, tex, R, meas = _setup(hm, n, 9.0, seed=3)
@@ -297,17 +297,71 @@ def test_device_covariance_prediction(hm):
     y_im, flow, y_m = _observation(dm, meas, rng, n)
     st = _Flow()
     st.X = X.reshape(-1, 1)
-    R.update_begin(got, X)                       # `got` is the array cov_predict returned: no upload
+    tok = R.cov_predict(W, dm.bars, blocks, 0.05, 0.05, 0.1, fetch=False)
+    assert np.array_equal(tok.fetch(), got)
+    R.update_begin(tok, X)                       # the prior is used where it is: no upload
     step, _, _ = R.update_step(st, y_im, flow, y_m)
     Hz, HTH, _ = R.measure(st, y_im, flow, y_m)
     A = np.linalg.inv(ref) + HTH
     assert np.linalg.norm(step - np.linalg.solve(A, Hz)) <= 1e-8 * np.linalg.norm(step)
     R.update_begin(got.copy(), X)
     R.update_step(st, y_im, flow, y_m)
-    Wp = R.update_cov(0)
-    nxt = R.cov_predict(Wp, dm.bars, blocks, 0.05, 0.05, 0.1)      # Wp is still on the device
+    assert not tok.valid()                       # that covariance has been replaced on the device
+    with pytest.raises(RuntimeError):
+        tok.fetch()
+    Wtok = R.update_cov(0, fetch=False)
+    Wp = Wtok.fetch()
+    assert np.array_equal(R.update_cov(-1), got)                   # the prior is still there
+    Wtok = R.update_cov(0, fetch=False)
+    nxt = R.cov_predict(Wtok, dm.bars, blocks, 0.05, 0.05, 0.1)    # propagated where it is
     ref2 = Fm @ Wp @ Fm.T + Weps
     assert np.linalg.norm(nxt - ref2) <= 1e-12 * np.linalg.norm(ref2)
+
+
+@pytest.mark.parametrize("stress", [False, True])
+def test_fused_update_equals_stepwise_loop(hm, stress):
+    """hm_update_run (the whole iterated update in one call) against the same loop written in
+    Python over hm_update_begin / _step / _cov: same iterations, acceptance decisions, state and
+    covariance, bit for bit.  stress: a vague prior and a fast flow, so that large steps (and,
+    if they occur, mesh inversions and the rollback) are covered too."""
+    from hydra_mi import mesh, synth, kalman
+    n = 128
+    video, flow = synth.test_data(n, n)
+    if stress:
+        flow = flow * 2.0
+    kfs = []
+    for fused in (True, False):
+        dm = mesh.mask_mesh(video[:, :, 0] > 0, 12.0)
+        kf = kalman.IteratedMSKalmanFilter(dm, video[:, :, 0], flow[:, :, :, 0], True)
+        kf.fused_update = fused
+        if stress:
+            kf.state.W = kf.state.W * 400.0
+        kfs.append(kf)
+    for k in range(4):
+        frame = video[:, :, k]
+        mask = (frame > 0).astype(np.uint8)
+        out = [kf.compute(frame, flow[:, :, :, k], mask) for kf in kfs]
+        a, b = kfs
+        assert (a.niter, a.reverted, a.converged) == (b.niter, b.reverted, b.converged), k
+        assert np.array_equal(a.state.X, b.state.X), k
+        assert out[0][:4] == out[1][:4], k
+        Wa, Wb = a.state.W, b.state.W
+        assert np.array_equal(Wa, Wb), k
+        assert np.allclose(a.tv, b.tv, rtol=1e-9, atol=1e-12) and np.allclose(a.fv, b.fv, rtol=1e-9, atol=1e-12)
+        assert np.allclose(a.mv, b.mv, rtol=1e-9, atol=1e-12)
+
+
+def test_update_run_without_iterations_keeps_the_prior(hm):
+    dm, N, tex, R, meas = _setup(hm, 64, 9.0, seed=5)
+    rng = np.random.default_rng(2)
+    X = _state(dm, rng, pos_sigma=0.3)
+    y_im, flow, y_m = _observation(dm, meas, rng, 64)
+    n4 = 4 * N
+    W = np.eye(n4) * 0.7
+    R.update_frame(y_im, flow, y_m)
+    Xk, info, errs, Hzc, gains, tok = R.update_run(W, X, y_im, flow, y_m, 0, 1e-4)
+    assert info == dict(niter=0, accepted=0, reverted=False, converged=False) and errs.shape == (0, 4)
+    assert np.array_equal(Xk.reshape(-1), X) and np.array_equal(tok.fetch(), W)
 
 
 def test_dense_update_is_deterministic_under_contention(hm):
