@@ -160,6 +160,211 @@ __global__ __launch_bounds__(256) void k_chol_update(double *__restrict__ A, int
     }
 }
 
+// ---- potrf, one launch per block column -----------------------------------------------------------
+// The factorisation reads a working copy A and writes the factor to a separate array L (same
+// shape; blocks below the block diagonal) and the factored diagonal blocks to Ld.  Launch k
+// (k_chol_step) does everything that involves block column k and has no later dependency:
+//   workgroup (r, c), r >= c > k:  X_r = A_rk L_kk^-T and X_c = A_ck L_kk^-T (each workgroup solves
+//       the two small triangular systems it needs itself, from the raw panel in A and the factored
+//       diagonal block Ld[k] of the previous launch), then A_rc -= X_r X_c^T;
+//   workgroups of block column c = k+1 also store X_r as L_rk;
+//   workgroup (k+1, k+1) goes on to factor its updated block into Ld[k+1] -- the only part that
+//       is sequential across launches.
+// Nothing is written that another workgroup of the same launch reads (the panel stays raw in A),
+// so the result does not depend on workgroup scheduling.  Launches: nb instead of 2 nb.
+__device__ __forceinline__ double d_readlane(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Cholesky of the 32x32 block whose lower triangle is in W (LDS, identity padded); the factor goes to
+// D (upper triangle zero), the reciprocals of its diagonal to rD.  Two-level: the columns are taken
+// four at a time; wave 0 factors a 32x4 strip in registers (row i in lane i, pivots and multipliers
+// passed by v_readlane: no LDS, no barrier on the column-to-column chain), then all four waves
+// apply the rank-4 update to the columns to the right.  16 barriers instead of 32.
+__device__ __forceinline__ void chol_block_factor(double (*W)[DNB + 1], double (*D)[DNB + 1], double *rD,
+                                                  double (*LS)[5], int t)
+{
+    const int ti = t / DNB, tc = t % DNB;
+#pragma unroll
+    for (int g = 0; g < DNB / 4; g++) {
+        const int j0 = 4 * g;
+        if (t < 64) {
+            const int i = t & (DNB - 1);          // lanes 32..63 mirror 0..31 and do not store
+            double w[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) w[jj] = W[i][j0 + jj];
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const double piv = d_readlane(w[jj], j0 + jj);
+                const double rs = d_rsqrt(piv);
+                const double l = w[jj] * rs;       // lane j0+jj: piv / sqrt(piv) = sqrt(piv)
+                if (t == j0 + jj) rD[j0 + jj] = rs;
+#pragma unroll
+                for (int j2 = jj + 1; j2 < 4; j2++) w[j2] = w[j2] - l * d_readlane(l, j0 + j2);
+                w[jj] = l;
+            }
+            if (t < DNB) {
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    const double v = i >= j0 + jj ? w[jj] : 0.0;
+                    D[i][j0 + jj] = v;
+                    LS[i][jj] = v;
+                }
+            }
+        }
+        if (g == DNB / 4 - 1) break;
+        __syncthreads();
+        if (tc >= j0 + 4) {
+            const double c0 = LS[tc][0], c1 = LS[tc][1], c2 = LS[tc][2], c3 = LS[tc][3];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = ti + 8 * q;
+                if (i >= tc) {
+                    double v = W[i][tc];
+                    v = v - LS[i][0] * c0;
+                    v = v - LS[i][1] * c1;
+                    v = v - LS[i][2] * c2;
+                    v = v - LS[i][3] * c3;
+                    W[i][tc] = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// the first diagonal block: A_00 -> Ld[0]
+__global__ __launch_bounds__(256) void k_chol_first(const double *__restrict__ A, double *__restrict__ Ld, int n)
+{
+    __shared__ double W[DNB][DNB + 1];
+    __shared__ double D[DNB][DNB + 1];
+    __shared__ double rD[DNB];
+    __shared__ double LS[DNB][5];
+    const int t = threadIdx.x;
+    const int nd = min(DNB, n);
+    for (int e = t; e < DNB * DNB; e += 256) {
+        const int i = e / DNB, j = e % DNB;
+        W[i][j] = (i < nd && j <= i) ? A[(size_t)i * n + j] : (i == j ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    chol_block_factor(W, D, rD, LS, t);
+    __syncthreads();
+    for (int e = t; e < DNB * DNB; e += 256) Ld[e] = D[e / DNB][e % DNB];
+}
+
+__global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, double *__restrict__ L, double *__restrict__ Ld,
+                                                   int n, int nrows, int nb, int k)
+{
+    const int r = k + 1 + blockIdx.y;
+    const int c = k + 1 + blockIdx.x;             // c >= nb: no block to update, the panel row only
+    const bool panel_only = c >= nb;
+    if (!panel_only && c > r) return;
+    __shared__ double D[DNB][DNB + 1];            // L_kk, later the factor of block k+1
+    __shared__ double rD[DNB];
+    __shared__ double Xr[DNB][DNB + 1];
+    __shared__ double Xc[DNB][DNB + 1];
+    __shared__ double LS[DNB][5];
+    const int t = threadIdx.x;
+    const int d0 = k * DNB;
+    const int nd = min(DNB, n - d0);
+    const int r0 = r * DNB, c0 = c * DNB;
+    const int nr = min(DNB, nrows - r0);
+    const int nc = panel_only ? 0 : min(DNB, n - c0);
+    const bool two = !panel_only && c != r;       // a second panel row to solve
+    // panel rows: 8 threads per row, thread `part` owns the entries 8 q + part
+    const int row = t / 8, part = t % 8;
+    double x[2][4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int cc = 8 * q + part;
+        x[0][q] = (row < nr && cc < nd) ? A[(size_t)(r0 + row) * n + d0 + cc] : 0.0;
+        x[1][q] = (two && row < nc && cc < nd) ? A[(size_t)(c0 + row) * n + d0 + cc] : 0.0;
+    }
+    // the block the product will be subtracted from: requested now, needed after the solves
+    const int tj = t % DNB, ti = t / DNB;
+    double a[4];
+    if (!panel_only) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = ti + 8 * q;
+            a[q] = (i < nr && tj < nc) ? A[(size_t)(r0 + i) * n + c0 + tj] : 0.0;
+        }
+    }
+    for (int e = t; e < DNB * DNB; e += 256) {
+        const int i = e / DNB, j = e % DNB;
+        const double v = Ld[(size_t)k * DNB * DNB + e];
+        D[i][j] = v;
+        if (i == j) rD[i] = d_rcp(v);
+    }
+    __syncthreads();
+    // X L_kk^T = A_.k for the two rows at once (independent chains): the 32 columns in four groups
+    // of 8 -- a private dot product over the finished columns, then the 8x8 triangle of the group
+    // with one 8-lane shuffle per column
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int j = 8 * q + part;
+        double s0 = x[0][q], s1 = x[1][q];
+        for (int cc = 0; cc < 8 * q; cc++) {
+            const double d = D[j][cc];
+            s0 = s0 - Xr[row][cc] * d;
+            s1 = s1 - Xc[row][cc] * d;
+        }
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) {
+            const int jc = 8 * q + jj;
+            const double y0 = __shfl(s0 * rD[jc], jj, 8);
+            const double y1 = __shfl(s1 * rD[jc], jj, 8);
+            if (part == jj) { s0 = y0; s1 = y1; }
+            else if (part > jj) { const double d = D[j][jc]; s0 = s0 - y0 * d; s1 = s1 - y1 * d; }
+        }
+        x[0][q] = s0;
+        Xr[row][j] = s0;
+        Xc[row][j] = two ? s1 : s0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();          // the 8 lanes of a row are in one wave
+    }
+    if (blockIdx.x == 0 && row < nr) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int cc = 8 * q + part;
+            if (cc < nd) L[(size_t)(r0 + row) * n + d0 + cc] = x[0][q];
+        }
+    }
+    if (panel_only) return;
+    __syncthreads();
+    // A_rc -= X_r X_c^T: thread (ti, tj) owns rows ti + 8 q of column tj
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 8
+    for (int qq = 0; qq < DNB; qq++) {
+        const double cv = Xc[tj][qq];
+#pragma unroll
+        for (int q = 0; q < 4; q++) s[q] = s[q] + Xr[ti + 8 * q][qq] * cv;
+    }
+    const bool diag = r == k + 1 && c == k + 1;
+    if (!diag) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = ti + 8 * q;
+            if (i < nr && tj < nc) A[(size_t)(r0 + i) * n + c0 + tj] = a[q] - s[q];
+        }
+        return;
+    }
+    // the next diagonal block: finish its update and factor it now
+    __syncthreads();                              // everyone is done reading Xr as the panel
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int i = ti + 8 * q;
+        Xr[i][tj] = (i < nc && tj <= i) ? a[q] - s[q] : (i == tj ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    chol_block_factor(Xr, D, rD, LS, t);
+    __syncthreads();
+    for (int e = t; e < DNB * DNB; e += 256) Ld[(size_t)(k + 1) * DNB * DNB + e] = D[e / DNB][e % DNB];
+}
+
 // ---- triangular solves with the factor, a slab of CH right-hand sides per workgroup --------------
 // Element (i, c) of the right-hand side / solution lives at B[i * sbi + c * sbc].
 //   FWD: L Y = B,   BWD: L^T X = Y   (both: the full solve of L L^T X = B)

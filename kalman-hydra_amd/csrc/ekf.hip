@@ -34,7 +34,7 @@ struct hm_ctx {
     uint8_t *d_im8, *d_m8;
     std::vector<double> X0;          // state of the reference render
     // dense update on the device (n4 = 4N)
-    double *d_H, *d_Hz, *d_Hzc, *d_invW0, *d_Af[2], *d_Ld[2], *d_dx, *d_Wtmp, *d_X0, *d_Xn, *d_Wprior, *d_gain;
+    double *d_H, *d_Hz, *d_Hzc, *d_invW0, *d_Af[2], *d_Ld[2], *d_dx, *d_Wtmp, *d_X0, *d_Xn, *d_Wprior, *d_gain, *d_Awork;
     std::vector<double> upd_X0;      // prior mean given to hm_update_begin
     int upd_last, upd_prev;          // which d_Af holds the factor of the last / previous step (-1: none)
     double *d_Wres;                  // the covariance resident on the device (the result of the last
@@ -77,7 +77,7 @@ static int ctx_free(hm_ctx *h)
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_tri, h->d_star_off, h->d_star_tri, h->d_edges, h->d_uv, h->d_tex, h->d_yim, h->d_ym, h->d_yfx,
                     h->d_yfy, h->d_yfxm, h->d_yfym, h->d_setup, h->d_X, h->d_out, h->d_partial, h->d_im8, h->d_m8,
-                    h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_Ld[0], h->d_Ld[1], h->d_Wprior, h->d_gain, h->d_dx,
+                    h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_Ld[0], h->d_Ld[1], h->d_Wprior, h->d_gain, h->d_Awork, h->d_dx,
                     h->d_Wtmp, h->d_X0, h->d_Xn, h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk,
                     h->pool.hdr, h->pool.off, h->pool.xim, h->pool.xm, h->pool.yim, h->pool.ym, h->pool.xfx, h->pool.xfy,
                     h->pool.yfx, h->pool.yfy, h->pool.vxfx, h->pool.vyfy, h->pool.overflow, h->d_area};
@@ -141,7 +141,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->ref = Targets{nullptr, nullptr, nullptr, nullptr}; h->P = h->ref; h->Q = h->ref;
     h->d_setup = nullptr; h->d_X = h->d_out = h->d_partial = nullptr; h->d_im8 = h->d_m8 = nullptr;
     h->d_H = h->d_Hz = h->d_Hzc = h->d_invW0 = h->d_Af[0] = h->d_Af[1] = h->d_dx = h->d_Wtmp = nullptr;
-    h->d_Wprior = h->d_gain = nullptr; h->d_Wres = nullptr; h->pin = nullptr; h->pin_n = 0;
+    h->d_Wprior = h->d_gain = h->d_Awork = nullptr; h->d_Wres = nullptr; h->pin = nullptr; h->pin_n = 0;
     h->tri.assign(tri, tri + (size_t)3 * T);
     h->d_Ld[0] = h->d_Ld[1] = nullptr; h->d_X0 = h->d_Xn = nullptr;
     memset(&h->pool, 0, sizeof h->pool); h->d_area = nullptr;
@@ -180,6 +180,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         const size_t nn_aug = (size_t)(hm_cdiv((int)n4, DNB) * DNB + DNB) * n4 * sizeof(double);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Af[0], nn_aug);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Af[1], nn_aug);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Awork, nn_aug);
         const size_t ld_bytes = (size_t)hm_cdiv((int)n4, DNB) * DNB * DNB * sizeof(double);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Ld[0], ld_bytes);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Ld[1], ld_bytes);
@@ -476,16 +477,17 @@ extern "C" int hm_measure(hm_ctx_t h, const double *X, double deltaX, int masked
 // 32-row block whose first row carries the right-hand side (see dense_kernels.h).
 static int aug_rows(int n) { return hm_cdiv(n, DNB) * DNB + DNB; }
 
-// Cholesky of the n x n matrix in A; with_rhs: the right-hand-side rows go through the elimination too
-static void chol_factor(hm_ctx *h, double *A, double *Ld, int n, bool with_rhs)
+// Cholesky of the n x n matrix in the working copy A (destroyed) into L / Ld; with_rhs: the
+// right-hand-side rows below the matrix go through the elimination too (dense_kernels.h)
+static void chol_factor(hm_ctx *h, double *A, double *L, double *Ld, int n, bool with_rhs)
 {
     const int nb = hm_cdiv(n, DNB);
     const int nrows = with_rhs ? aug_rows(n) : n;
     const int nbr = hm_cdiv(nrows, DNB);
+    hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, h->stream, A, Ld, n);
     for (int k = 0; k < nb; k++) {
-        hipLaunchKernelGGL(k_chol_panel, dim3(nbr - k), dim3(256), 0, h->stream, A, Ld, n, nrows, k);
-        const int mc = nb - k - 1, mr = nbr - k - 1;
-        if (mr > 0 && mc > 0) hipLaunchKernelGGL(k_chol_update, dim3(mc, mr), dim3(256), 0, h->stream, A, n, nrows, k);
+        const int mr = nbr - k - 1, mc = std::max(nb - k - 1, 1);
+        if (mr > 0) hipLaunchKernelGGL(k_chol_step, dim3(mc, mr), dim3(256), 0, h->stream, A, L, Ld, n, nrows, nb, k);
     }
 }
 
@@ -514,7 +516,7 @@ static double *solve_step(hm_ctx *h, int slot)
 {
     const int n4 = 4 * h->N;
     hipLaunchKernelGGL(k_vec_axpy, dim3(hm_cdiv(n4, 256)), dim3(256), 0, h->stream, h->d_X0, h->d_X, -1.0, h->d_dx, n4);
-    double *A = h->d_Af[slot];
+    double *A = h->d_Awork;
     const size_t nn = (size_t)n4 * n4;
     hipLaunchKernelGGL(k_add_mat, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, h->d_invW0, h->d_H, A, nn);
     // right-hand side Hz - H (X0 - X) as the first row of the block below the matrix; the rows in
@@ -523,9 +525,9 @@ static double *solve_step(hm_ctx *h, int slot)
     (void)hipMemsetAsync(A + nn, 0, pad_n * sizeof(double), h->stream);
     double *rhs_row = A + (size_t)hm_cdiv(n4, DNB) * DNB * n4;
     hipLaunchKernelGGL(k_rhs, dim3(n4), dim3(256), 0, h->stream, h->d_H, h->d_dx, h->d_Hz, rhs_row, n4);
-    chol_factor(h, A, h->d_Ld[slot], n4, true);
-    chol_backsolve_row(h, A, h->d_Ld[slot], n4);
-    return rhs_row;
+    chol_factor(h, A, h->d_Af[slot], h->d_Ld[slot], n4, true);
+    chol_backsolve_row(h, h->d_Af[slot], h->d_Ld[slot], n4);
+    return h->d_Af[slot] + (rhs_row - A);
 }
 
 extern "C" int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *X0)
@@ -556,9 +558,9 @@ extern "C" int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *
         HM_HIP(hipMemcpyAsync(h->d_Wprior, W_prior, nnb, hipMemcpyHostToDevice, h->stream));
     else if (h->d_Wres != h->d_Wprior)
         HM_HIP(hipMemcpyAsync(h->d_Wprior, h->d_Wres, nnb, hipMemcpyDeviceToDevice, h->stream));
-    HM_HIP(hipMemcpyAsync(h->d_Af[0], h->d_Wprior, nnb, hipMemcpyDeviceToDevice, h->stream));
+    HM_HIP(hipMemcpyAsync(h->d_Awork, h->d_Wprior, nnb, hipMemcpyDeviceToDevice, h->stream));
     h->d_Wres = h->d_Wprior;                     // d_Wtmp is scratch from here on
-    chol_factor(h, h->d_Af[0], h->d_Ld[0], n4, false);
+    chol_factor(h, h->d_Awork, h->d_Af[0], h->d_Ld[0], n4, false);
     chol_inverse(h, h->d_Af[0], h->d_Ld[0], n4, h->d_Wtmp, h->d_invW0);
     HM_HIP(hipGetLastError());
     h->upd_X0.assign(X0, X0 + n4);
@@ -812,13 +814,12 @@ extern "C" int hm_cov_predict(hm_ctx_t h, const double *W_in, int n_bars, const 
         src = h->d_H;
     }
     SpringTopo tp = {h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk};
-    double *P = h->d_Af[1];                      // scratch: no factor is live between two updates
+    double *P = h->d_Awork;                      // scratch
     hipLaunchKernelGGL(k_fw_rows, dim3(hm_cdiv(n4, 256), N), dim3(256), 0, h->stream, src, P, N, tp, a, s);
     hipLaunchKernelGGL(k_pft_cols, dim3(hm_cdiv(n4, 256), N), dim3(256), 0, h->stream, P, h->d_Wtmp, N, tp, a, s, eps_F);
     HM_HIP(hipGetLastError());
     if (W_out) HM_HIP(hipMemcpyAsync(W_out, h->d_Wtmp, nn, hipMemcpyDeviceToHost, h->stream));
     if (W_out) HM_HIP(hipStreamSynchronize(h->stream));
     h->d_Wres = h->d_Wtmp;
-    h->upd_open = false;                          // the factors of the last update are gone (d_Af[1] was scratch)
     return HM_OK;
 }
