@@ -575,20 +575,22 @@ __global__ __launch_bounds__(256) void k_rhs(const double *__restrict__ M, const
 
 
 // ---- end of one iteration of hm_update_run ---------------------------------------------------------------
-// res (host-visible) = [step (n) | the four error sums, partials added in index order | overflow flag]
-__global__ void k_iter_result(const double *__restrict__ step, int n, const double *__restrict__ partial, int nblocks,
-                              const int *__restrict__ overflow, double *__restrict__ res)
+// res (host-visible) = [step (n) | the four error sums, partials added in index order | overflow flag].
+// One workgroup; the partials are staged in LDS so that the in-order sums do not wait on memory.
+__global__ __launch_bounds__(256) void k_iter_result(const double *__restrict__ step, int n, const double *__restrict__ partial,
+                                                     int nblocks, const int *__restrict__ overflow, double *__restrict__ res)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        res[i] = step[i];
-    } else if (i < n + 4) {
-        const int k = i - n;
+    extern __shared__ double sp[];                // 4 * nblocks
+    const int t = threadIdx.x;
+    for (int i = t; i < 4 * nblocks; i += 256) sp[i] = partial[i];
+    for (int i = t; i < n; i += 256) res[i] = step[i];
+    __syncthreads();
+    if (t < 4) {
         double s = 0.0;
-        for (int b = 0; b < nblocks; b++) s += partial[(size_t)4 * b + k];
-        res[i] = s;
-    } else if (i == n + 4) {
-        res[i] = (double)*overflow;
+        for (int b = 0; b < nblocks; b++) s += sp[4 * b + t];
+        res[n + t] = s;
+    } else if (t == 4) {
+        res[n + 4] = (double)*overflow;
     }
 }
 

@@ -53,6 +53,7 @@ struct hm_ctx {
     bool upd_open;
     std::vector<double> h_partial;
     int red_blocks;
+    int vsplit;                      // workgroups per vertex job of the measurement (hm_ctx_tune)
 };
 
 static int alloc_targets(Targets &t, size_t n)
@@ -151,6 +152,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->E = (int)eset.size();
     h->njobs = N + h->E;
     h->red_blocks = 512;
+    h->vsplit = 3;
     const size_t n = (size_t)W * H;
     int rc = HM_OK;
     auto step = [&](int r) { if (rc == HM_OK) rc = r; };
@@ -170,7 +172,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_yfym, n * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_setup, (size_t)T * sizeof(TriSetup));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_X, (size_t)4 * N * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_out, (size_t)h->njobs * MEAS_VSPLIT * MEAS_OUT * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_out, (size_t)h->njobs * MEAS_VSPLIT_MAX * MEAS_OUT * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_partial, (size_t)h->red_blocks * 4 * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_im8, n);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_m8, n);
@@ -227,6 +229,19 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
 }
 
 extern "C" int hm_ctx_destroy(hm_ctx_t h) { return ctx_free(h); }
+
+extern "C" int hm_ctx_tune(hm_ctx_t h, const char *key, int value)
+{
+    HM_ARG(h != nullptr && key != nullptr, "hm_ctx_tune: NULL argument");
+    if (!strcmp(key, "measure_split")) {
+        HM_ARG(value >= 1 && value <= MEAS_VSPLIT_MAX, "hm_ctx_tune: measure_split must be in 1..%d", MEAS_VSPLIT_MAX);
+        h->vsplit = value;
+    } else {
+        hm_set_error("hm_ctx_tune: unknown key '%s'", key);
+        return HM_ERR_ARG;
+    }
+    return HM_OK;
+}
 extern "C" void *hm_ctx_stream(hm_ctx_t h) { return h ? (void *)h->stream : nullptr; }
 extern "C" int hm_ctx_sync(hm_ctx_t h)
 {
@@ -431,14 +446,15 @@ static int measure_dev(hm_ctx *h, const double *dX, bool ref_ready, double delta
     a.delta = deltaX;
     a.out = h->d_out;
     a.pool = h->pool;
+    a.vsplit = h->vsplit;
     hipLaunchKernelGGL(k_star_regions, dim3(h->N), dim3(64), 0, h->stream, a, h->d_area);
     hipLaunchKernelGGL(k_region_offsets, dim3(1), dim3(1), 0, h->stream, h->d_area, h->N, h->pool);
-    hipLaunchKernelGGL(k_measure_vertex, dim3(h->N, MEAS_VSPLIT), dim3(MEAS_NT), 0, h->stream, a);
+    hipLaunchKernelGGL(k_measure_vertex, dim3(h->N, h->vsplit), dim3(MEAS_NT), 0, h->stream, a);
     if (h->E > 0) hipLaunchKernelGGL(k_measure_edge, dim3(h->E), dim3(MEAS_NT), 0, h->stream, a);
     const size_t n4 = (size_t)4 * h->N;
     if (h->d_Wres == h->d_H) h->d_Wres = nullptr;    // d_H is about to be overwritten
     HM_HIP(hipMemsetAsync(h->d_H, 0, n4 * n4 * sizeof(double), h->stream));
-    ScatterArgs s = {h->d_out, h->d_edges, h->N, h->E, h->eps_Z, h->eps_J, h->eps_M, deltaX, h->d_H, h->d_Hz, h->d_Hzc};
+    ScatterArgs s = {h->d_out, h->d_edges, h->N, h->E, h->vsplit, h->eps_Z, h->eps_J, h->eps_M, deltaX, h->d_H, h->d_Hz, h->d_Hzc};
     hipLaunchKernelGGL(k_hth_scatter, dim3(hm_cdiv(h->njobs, 64)), dim3(64), 0, h->stream, s);
     HM_HIP(hipGetLastError());
     return HM_OK;
@@ -677,7 +693,7 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
         if (rc) return rc;
         hipLaunchKernelGGL(k_error, dim3(h->red_blocks), dim3(RED_NT), 0, h->stream, h->P, obs_of(h, masked),
                            h->W * h->H, h->d_partial);
-        hipLaunchKernelGGL(k_iter_result, dim3(hm_cdiv(n4 + 5, 256)), dim3(256), 0, h->stream, rhs_row, n4, h->d_partial,
+        hipLaunchKernelGGL(k_iter_result, dim3(1), dim3(256), (size_t)h->red_blocks * 4 * sizeof(double), h->stream, rhs_row, n4, h->d_partial,
                            h->red_blocks, h->pool.overflow, res);
         HM_HIP(hipGetLastError());
         HM_HIP(hipStreamSynchronize(h->stream));

@@ -16,8 +16,14 @@
 #define EKF_MAX_TRI 4096
 
 struct TriSetup {              // one triangle in one configuration
-    int a256[3], b256[3];      // edge function E_k = a256*c + b256*r + c0 at pixel (col c, row r)
-    long long c0[3];
+    // edge function E_k = ea*c + eb*r + ec at pixel (col c, row r).  Whole numbers kept as doubles:
+    // for coordinates within +-2^24 px every product and sum stays below 2^53, so binary64 evaluates
+    // them exactly -- the same values as 64-bit integers at the cost of two full-rate v_fma_f64
+    // (64-bit integer multiplies are built from quarter-rate 32-bit ones on gfx950).
+    double ea[3], eb[3], ec[3];
+    // ec + (1 if a zero edge value counts as inside, the top-left rule): E is a whole number, so
+    // "E > 0 or (E == 0 and top-left)" is the single comparison ea*c + eb*r + ecb > 0
+    double ecb[3];
     int tl[3];                 // 1 if a zero edge value counts as inside (top-left edge)
     float inv;                 // 1 / (2 area)
     int i0, i1, i2;            // vertex ids after orientation normalisation
@@ -45,11 +51,14 @@ __device__ __forceinline__ long long d_snap(double x) { return (long long)rint(x
 __device__ inline void d_tri_setup(TriSetup &s, int v0, int v1, int v2, long long x0, long long y0,
                                    long long x1, long long y1, long long x2, long long y2, int W, int H)
 {
-    long long area = (x1 - x0) * (y2 - y0) - (y1 - y0) * (x2 - x0);
     s.cmin = 1; s.cmax = 0; s.rmin = 1; s.rmax = 0;
+    const long long lim = (long long)1 << 32;     // 2^24 px in 1/256 px units: the exact range of the edge functions
+    const bool sane = x0 > -lim && x0 < lim && y0 > -lim && y0 < lim && x1 > -lim && x1 < lim && y1 > -lim && y1 < lim &&
+                      x2 > -lim && x2 < lim && y2 > -lim && y2 < lim;
+    long long area = sane ? (x1 - x0) * (y2 - y0) - (y1 - y0) * (x2 - x0) : 0;
     s.i0 = v0; s.i1 = v1; s.i2 = v2;
     s.inv = 0.0f;
-    for (int k = 0; k < 3; k++) { s.a256[k] = 0; s.b256[k] = 0; s.c0[k] = -1; s.tl[k] = 0; }
+    for (int k = 0; k < 3; k++) { s.ea[k] = 0.0; s.eb[k] = 0.0; s.ec[k] = -1.0; s.ecb[k] = -1.0; s.tl[k] = 0; }
     if (area == 0) return;
     if (area < 0) {
         long long t;
@@ -65,10 +74,11 @@ __device__ inline void d_tri_setup(TriSetup &s, int v0, int v1, int v2, long lon
     const long long oy[3] = {y1, y2, y0};
     for (int k = 0; k < 3; k++) {
         // E(px,py) = ex*(py-oy) - ey*(px-ox), px = 256 c + 128, py = 256 r + 128
-        s.a256[k] = (int)(-ey[k] * EKF_SUB);
-        s.b256[k] = (int)(ex[k] * EKF_SUB);
-        s.c0[k] = ex[k] * (128 - oy[k]) - ey[k] * (128 - ox[k]);
+        s.ea[k] = (double)(-ey[k] * EKF_SUB);
+        s.eb[k] = (double)(ex[k] * EKF_SUB);
+        s.ec[k] = (double)(ex[k] * (128 - oy[k]) - ey[k] * (128 - ox[k]));
         s.tl[k] = (ey[k] > 0) || (ey[k] == 0 && ex[k] < 0);
+        s.ecb[k] = s.ec[k] + (double)s.tl[k];
     }
     s.inv = 1.0f / (float)area;
     long long xmin = x0 < x1 ? (x0 < x2 ? x0 : x2) : (x1 < x2 ? x1 : x2);
@@ -85,13 +95,29 @@ __device__ inline void d_tri_setup(TriSetup &s, int v0, int v1, int v2, long lon
     s.cmin = (int)cl; s.cmax = (int)ch; s.rmin = (int)rl; s.rmax = (int)rh;
 }
 
+// coverage of the pixel centre (dc, dr) without the bounding-box shortcut and without branches (for
+// pixels inside the frame the three edge tests imply the box); barycentrics separately
+__device__ __forceinline__ bool d_tri_cover(const TriSetup &s, double dc, double dr)
+{
+    const double e0 = fma(s.ea[0], dc, fma(s.eb[0], dr, s.ecb[0]));
+    const double e1 = fma(s.ea[1], dc, fma(s.eb[1], dr, s.ecb[1]));
+    const double e2 = fma(s.ea[2], dc, fma(s.eb[2], dr, s.ecb[2]));
+    return (e0 > 0.0) & (e1 > 0.0) & (e2 > 0.0);
+}
+__device__ __forceinline__ void d_tri_bary(const TriSetup &s, double dc, double dr, float &l1, float &l2)
+{
+    l1 = (float)fma(s.ea[1], dc, fma(s.eb[1], dr, s.ec[1])) * s.inv;
+    l2 = (float)fma(s.ea[2], dc, fma(s.eb[2], dr, s.ec[2])) * s.inv;
+}
+
 // coverage + barycentrics of pixel (c, r)
 __device__ __forceinline__ bool d_tri_eval(const TriSetup &s, int c, int r, float &l1, float &l2)
 {
     if (c < s.cmin || c > s.cmax || r < s.rmin || r > s.rmax) return false;
-    long long e0 = (long long)s.a256[0] * c + (long long)s.b256[0] * r + s.c0[0];
-    long long e1 = (long long)s.a256[1] * c + (long long)s.b256[1] * r + s.c0[1];
-    long long e2 = (long long)s.a256[2] * c + (long long)s.b256[2] * r + s.c0[2];
+    const double dc = (double)c, dr = (double)r;
+    const double e0 = fma(s.ea[0], dc, fma(s.eb[0], dr, s.ec[0]));      // exact: see TriSetup
+    const double e1 = fma(s.ea[1], dc, fma(s.eb[1], dr, s.ec[1]));
+    const double e2 = fma(s.ea[2], dc, fma(s.eb[2], dr, s.ec[2]));
     bool in = (e0 > 0 || (e0 == 0 && s.tl[0])) && (e1 > 0 || (e1 == 0 && s.tl[1])) &&
               (e2 > 0 || (e2 == 0 && s.tl[2]));
     if (!in) return false;
@@ -105,15 +131,20 @@ __device__ __forceinline__ float d_lerp(float a0, float a1, float a2, float l1, 
     return (a0 + l1 * (a1 - a0)) + l2 * (a2 - a0);
 }
 
-__device__ __forceinline__ int d_texel(const uint8_t *__restrict__ tex, const TriSetup &s, float l1, float l2, int W,
-                                       int H)
+// offset of the nearest texel in the initial frame
+__device__ __forceinline__ int d_texel_at(const TriSetup &s, float l1, float l2, int W, int H)
 {
     float tx = d_lerp(s.ux[0], s.ux[1], s.ux[2], l1, l2);
     float ty = d_lerp(s.uy[0], s.uy[1], s.uy[2], l1, l2);
     int cx = (int)floorf(tx), cy = (int)floorf(ty);
     cx = cx < 0 ? 0 : (cx > W - 1 ? W - 1 : cx);
     cy = cy < 0 ? 0 : (cy > H - 1 ? H - 1 : cy);
-    return tex[cy * W + cx];
+    return cy * W + cx;
+}
+__device__ __forceinline__ int d_texel(const uint8_t *__restrict__ tex, const TriSetup &s, float l1, float l2, int W,
+                                       int H)
+{
+    return tex[d_texel_at(s, l1, l2, W, H)];
 }
 
 struct Mesh {
@@ -311,6 +342,18 @@ struct StarVal {
     int acc, cnt;
     float fx, fy;
 };
+// The texels of the first two covering triangles are not fetched inside the loop over the star but
+// handed back as offsets (-1: none): the caller fetches the texels of all its configurations in one
+// go, so that their memory latencies overlap instead of adding up (a wave would otherwise wait for
+// every texel where it is found; with ~155 VGPRs there are not enough waves to hide that).
+struct StarTex {
+    int t0, t1;
+};
+__device__ __forceinline__ int d_star_texels(const uint8_t *__restrict__ tex, const StarTex &q)
+{
+    const int a = tex[q.t0 < 0 ? 0 : q.t0], b = tex[q.t1 < 0 ? 0 : q.t1];
+    return (q.t0 < 0 ? 0 : a) + (q.t1 < 0 ? 0 : b);
+}
 
 // In the reference configuration the four velocity perturbations of v (vx +- d, vy +- d) leave the
 // geometry alone: the same covering triangles, the same barycentrics, only the attribute of v differs.
@@ -320,18 +363,25 @@ struct StarVel {
     float fxp, fxm, fyp, fym;
 };
 
+// The star's setups are padded to an even count with an empty one (d_star_setups); two triangles are
+// tested per round, branch-free, so that the LDS reads of both are in flight together -- the walk
+// over the star is a chain of LDS latencies otherwise.
 template <bool VEL>
 __device__ __forceinline__ StarVal d_star_eval(const TriSetup *__restrict__ cfg, int ns, int c, int r, const Mesh &m,
-                                               const double *__restrict__ X, int v, float vxp, float vxm, float nvyp,
-                                               float nvym, StarVel &vel)
+                                               int v, float vxp, float vxm, float nvyp, float nvym, StarVel &vel,
+                                               StarTex &q)
 {
     StarVal s = {0, 0, 0.0f, 0.0f};
+    q.t0 = -1; q.t1 = -1;
     if (VEL) { vel.fxp = 0.0f; vel.fxm = 0.0f; vel.fyp = 0.0f; vel.fym = 0.0f; }
-    for (int k = 0; k < ns; k++) {
+    const double dc = (double)c, dr = (double)r;
+    auto add = [&](const TriSetup &t) {
         float l1, l2;
-        if (!d_tri_eval(cfg[k], c, r, l1, l2)) continue;
-        const TriSetup &t = cfg[k];
-        s.acc += d_texel(m.tex, t, l1, l2, m.W, m.H);
+        d_tri_bary(t, dc, dr, l1, l2);
+        const int at = d_texel_at(t, l1, l2, m.W, m.H);
+        if (s.cnt == 0) q.t0 = at;
+        else if (s.cnt == 1) q.t1 = at;
+        else s.acc += m.tex[at];                   // three triangles over one pixel: a folded mesh
         const float a0 = t.ax[0], a1 = t.ax[1], a2 = t.ax[2];
         const float b0 = t.ay[0], b1 = t.ay[1], b2 = t.ay[2];
         s.fx = s.fx + d_lerp(a0, a1, a2, l1, l2);
@@ -344,6 +394,11 @@ __device__ __forceinline__ StarVal d_star_eval(const TriSetup *__restrict__ cfg,
             vel.fyp = vel.fyp + d_lerp(v0 ? nvyp : b0, v1 ? nvyp : b1, v2 ? nvyp : b2, l1, l2);
             vel.fym = vel.fym + d_lerp(v0 ? nvym : b0, v1 ? nvym : b1, v2 ? nvym : b2, l1, l2);
         }
+    };
+    for (int k = 0; k < ns; k += 2) {
+        const bool in0 = d_tri_cover(cfg[k], dc, dr), in1 = d_tri_cover(cfg[k + 1], dc, dr);
+        if (in0) add(cfg[k]);
+        if (in1) add(cfg[k + 1]);
     }
     return s;
 }
@@ -359,7 +414,19 @@ struct Diff {
     float fx, fy;
 };
 
-__device__ __forceinline__ Diff d_diff(int racc, int rcnt, float rfx, float rfy, const StarVal &sref, const StarVal &sp)
+// k255[x] = (double)x / 255.0 for x in -255..255 (a table in LDS, filled with real divisions: the
+// image and mask differences are such quotients and a binary64 division costs ~35 instructions)
+__device__ __forceinline__ void d_fill_k255(double *tab, int nthreads)
+{
+    for (int i = threadIdx.x; i < 511; i += nthreads) tab[i] = (double)(i - 255) / 255.0;
+}
+__device__ __forceinline__ double d_q255(const double *k255, int x)
+{
+    return (x >= -255 && x <= 255) ? k255[x] : (double)x / 255.0;
+}
+
+__device__ __forceinline__ Diff d_diff(const double *k255, int racc, int rcnt, float rfx, float rfy, const StarVal &sref,
+                                       const StarVal &sp)
 {
     int rim = racc > 255 ? 255 : racc;
     int pacc = racc - sref.acc + sp.acc;
@@ -367,8 +434,8 @@ __device__ __forceinline__ Diff d_diff(int racc, int rcnt, float rfx, float rfy,
     int rm = rcnt > 0 ? 255 : 0;
     int pm = (rcnt - sref.cnt + sp.cnt) > 0 ? 255 : 0;
     Diff d;
-    d.im = (double)(pim - rim) / 255.0;
-    d.m = (double)(pm - rm) / 255.0;
+    d.im = k255[pim - rim];                        // both in 0..255
+    d.m = (double)((pm - rm) / 255);               // -1, 0 or 1: the quotient is exact
     float pfx = (rfx - sref.fx) + sp.fx;
     float pfy = (rfy - sref.fy) + sp.fy;
     d.fx = pfx - rfx;
@@ -390,6 +457,11 @@ __device__ inline void d_star_setups(TriSetup *dst, int ns, const int *tris, con
         d_tri_setup(dst[k], v0, v1, v2, d_snap(px[0]), d_snap(py[0]), d_snap(px[1]), d_snap(py[1]), d_snap(px[2]),
                     d_snap(py[2]), m.W, m.H);
         d_tri_attr(dst[k], m.uv, X, m.N);
+    }
+    if ((ns & 1) && lane == 0) {                   // pad to an even count with a triangle that covers nothing
+        TriSetup &e = dst[ns];
+        e.cmin = 1; e.cmax = 0; e.rmin = 1; e.rmax = 0;
+        for (int k = 0; k < 3; k++) { e.ea[k] = 0.0; e.eb[k] = 0.0; e.ec[k] = -1.0; e.ecb[k] = -1.0; e.tl[k] = 0; }
     }
 }
 
@@ -413,13 +485,14 @@ struct MeasureArgs {
     Obs obs;
     const double *X;
     double delta;
-    double *out;              // njobs * MEAS_VSPLIT * MEAS_OUT doubles
+    double *out;              // njobs * MEAS_VSPLIT_MAX * MEAS_OUT doubles
     DPool pool;
+    int vsplit;               // workgroups per vertex job (gridDim.y of k_measure_vertex)
 };
 
 #define MEAS_NT 256
 #define MEAS_OUT 40
-#define MEAS_VSPLIT 3          // workgroups per vertex job (their partial sums are added in order)
+#define MEAS_VSPLIT_MAX 16     // most workgroups per vertex job (their partial sums are added in order)
 // vertex job output layout (doubles): only the non-zero terms are accumulated
 enum {
     // jz sums: plus then minus; x and y have 4 channels, vx only fx, vy only fy
@@ -441,7 +514,7 @@ enum {
 
 #define MEAS_NCFG 5            // reference, +x, -x, +y, -y of the vertex
 
-__device__ inline void d_vertex_cfgs(TriSetup (*cfg)[EKF_MAX_STAR], int nsv, const int *trv, const Mesh &m,
+__device__ inline void d_vertex_cfgs(TriSetup (*cfg)[EKF_MAX_STAR + 1], int nsv, const int *trv, const Mesh &m,
                                      const double *X, int v, double d, int nthreads)
 {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = nthreads >> 6;
@@ -452,7 +525,7 @@ __device__ inline void d_vertex_cfgs(TriSetup (*cfg)[EKF_MAX_STAR], int nsv, con
 // ---- pass 0: star regions and their places in the pool -------------------------------------------------
 __global__ __launch_bounds__(64) void k_star_regions(MeasureArgs a, int *__restrict__ area)
 {
-    __shared__ TriSetup s_cfg[MEAS_NCFG][EKF_MAX_STAR];
+    __shared__ TriSetup s_cfg[MEAS_NCFG][EKF_MAX_STAR + 1];
     const Mesh &m = a.m;
     const int v = blockIdx.x;
     const int nsv = a.topo.star_off[v + 1] - a.topo.star_off[v];
@@ -481,14 +554,17 @@ __global__ void k_region_offsets(const int *__restrict__ area, int N, DPool pool
 }
 
 // ---- pass 1: vertex jobs ----------------------------------------------------------------------------------
-// One launch = every jz evaluation of KFState.update and the diagonal blocks of HTH.  MEAS_VSPLIT
+// One launch = every jz evaluation of KFState.update and the diagonal blocks of HTH.  gridDim.y
 // workgroups per vertex; a perturbation of vertex v changes the render only inside the triangles
 // around v (its star), so every sum runs over the bounding box of that star; the perturbed renders
 // are never materialised.  The forward difference images are parked in the pool for pass 2.
 __global__ __launch_bounds__(MEAS_NT) void k_measure_vertex(MeasureArgs a)
 {
-    __shared__ TriSetup s_cfg[MEAS_NCFG][EKF_MAX_STAR];
+    __shared__ TriSetup s_cfg[MEAS_NCFG][EKF_MAX_STAR + 1];
     __shared__ double s_red[(MEAS_NT / 64) * MEAS_OUT];
+    __shared__ double s_k255[511];
+    const double *k255 = s_k255 + 255;
+    d_fill_k255(s_k255, MEAS_NT);
     const Mesh &m = a.m;
     const int N = m.N, W = m.W;
     const int v = blockIdx.x, job = v;
@@ -503,21 +579,36 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure_vertex(MeasureArgs a)
     double acc[A_NV];
 #pragma unroll
     for (int k = 0; k < A_NV; k++) acc[k] = 0.0;
-    const int npx = rw * rh;
-    for (int i = threadIdx.x + MEAS_NT * blockIdx.y; i < npx; i += MEAS_NT * MEAS_VSPLIT) {
-        const int r = r0 + i / rw, c = c0 + i % rw;
+    // A wave works on 8x8 pixel tiles of the region (a compact tile meets one or two triangles of
+    // the star, a 64x1 strip three or four); the tiles are dealt to the waves of the vertex's
+    // workgroups round robin.
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lx = threadIdx.x & 7, ly = (threadIdx.x & 63) >> 3;
+    const int ntx = (rw + 7) >> 3, ntiles = ntx * ((rh + 7) >> 3);
+    const int nwaves = (MEAS_NT / 64) * gridDim.y;
+    for (int tile = blockIdx.y * (MEAS_NT / 64) + wave; tile < ntiles; tile += nwaves) {
+        const int tr0 = r0 + 8 * (tile / ntx), tc0 = c0 + 8 * (tile % ntx);
+        const int r = tr0 + ly, c = tc0 + lx;
+        if (r >= r0 + rh || c >= c0 + rw) continue;
+        const int i = (r - r0) * rw + (c - c0);
         const int p = r * W + c;
         const int racc = a.ref.acc[p], rcnt = a.ref.cnt[p];
         const float rfx = a.ref.fx[p], rfy = a.ref.fy[p];
         const long long pp = base + i;
         StarVel vel, none;
-        const StarVal sref = d_star_eval<true>(s_cfg[0], nsv, c, r, m, X, v, (float)(X[2 * N + 2 * v] + d),
-                                               (float)(X[2 * N + 2 * v] - d), (float)(-(X[2 * N + 2 * v + 1] + d)),
-                                               (float)(-(X[2 * N + 2 * v + 1] - d)), vel);
-        const StarVal sxp = d_star_eval<false>(s_cfg[1], nsv, c, r, m, X, v, 0, 0, 0, 0, none);
-        const StarVal sxm = d_star_eval<false>(s_cfg[2], nsv, c, r, m, X, v, 0, 0, 0, 0, none);
-        const StarVal syp = d_star_eval<false>(s_cfg[3], nsv, c, r, m, X, v, 0, 0, 0, 0, none);
-        const StarVal sym = d_star_eval<false>(s_cfg[4], nsv, c, r, m, X, v, 0, 0, 0, 0, none);
+        StarTex q0, q1, q2, q3, q4;
+        StarVal sref = d_star_eval<true>(s_cfg[0], nsv, c, r, m, v, (float)(X[2 * N + 2 * v] + d),
+                                         (float)(X[2 * N + 2 * v] - d), (float)(-(X[2 * N + 2 * v + 1] + d)),
+                                         (float)(-(X[2 * N + 2 * v + 1] - d)), vel, q0);
+        StarVal sxp = d_star_eval<false>(s_cfg[1], nsv, c, r, m, v, 0, 0, 0, 0, none, q1);
+        StarVal sxm = d_star_eval<false>(s_cfg[2], nsv, c, r, m, v, 0, 0, 0, 0, none, q2);
+        StarVal syp = d_star_eval<false>(s_cfg[3], nsv, c, r, m, v, 0, 0, 0, 0, none, q3);
+        StarVal sym = d_star_eval<false>(s_cfg[4], nsv, c, r, m, v, 0, 0, 0, 0, none, q4);
+        {   // all texels at once
+            const int e0 = d_star_texels(m.tex, q0), e1 = d_star_texels(m.tex, q1), e2 = d_star_texels(m.tex, q2);
+            const int e3 = d_star_texels(m.tex, q3), e4 = d_star_texels(m.tex, q4);
+            sref.acc += e0; sxp.acc += e1; sxm.acc += e2; syp.acc += e3; sym.acc += e4;
+        }
         if (sref.cnt + sxp.cnt + sxm.cnt + syp.cnt + sym.cnt == 0) {
             if (park) {
                 a.pool.xim[pp] = 0; a.pool.xm[pp] = 0; a.pool.yim[pp] = 0; a.pool.ym[pp] = 0;
@@ -529,14 +620,14 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure_vertex(MeasureArgs a)
         // velocity perturbations keep the geometry: same coverage and texels as the reference
         const StarVal svxp = {sref.acc, sref.cnt, vel.fxp, sref.fy}, svxm = {sref.acc, sref.cnt, vel.fxm, sref.fy};
         const StarVal svyp = {sref.acc, sref.cnt, sref.fx, vel.fyp}, svym = {sref.acc, sref.cnt, sref.fx, vel.fym};
-        const Diff dxp = d_diff(racc, rcnt, rfx, rfy, sref, sxp), dxm = d_diff(racc, rcnt, rfx, rfy, sref, sxm);
-        const Diff dyp = d_diff(racc, rcnt, rfx, rfy, sref, syp), dym = d_diff(racc, rcnt, rfx, rfy, sref, sym);
-        const Diff dvxp = d_diff(racc, rcnt, rfx, rfy, sref, svxp), dvxm = d_diff(racc, rcnt, rfx, rfy, sref, svxm);
-        const Diff dvyp = d_diff(racc, rcnt, rfx, rfy, sref, svyp), dvym = d_diff(racc, rcnt, rfx, rfy, sref, svym);
+        const Diff dxp = d_diff(k255, racc, rcnt, rfx, rfy, sref, sxp), dxm = d_diff(k255, racc, rcnt, rfx, rfy, sref, sxm);
+        const Diff dyp = d_diff(k255, racc, rcnt, rfx, rfy, sref, syp), dym = d_diff(k255, racc, rcnt, rfx, rfy, sref, sym);
+        const Diff dvxp = d_diff(k255, racc, rcnt, rfx, rfy, sref, svxp), dvxm = d_diff(k255, racc, rcnt, rfx, rfy, sref, svxm);
+        const Diff dvyp = d_diff(k255, racc, rcnt, rfx, rfy, sref, svyp), dvym = d_diff(k255, racc, rcnt, rfx, rfy, sref, svym);
         // residuals (cuda.py:943-950)
         const int rim = racc > 255 ? 255 : racc, rm = rcnt > 0 ? 255 : 0;
-        const double z = ((double)a.obs.yim[p] - (double)rim) / 255.0;
-        const double zm = (255.0 * (double)a.obs.ym[p] - (double)rm) / 255.0;
+        const double z = k255[(int)a.obs.yim[p] - rim];
+        const double zm = d_q255(k255, 255 * (int)a.obs.ym[p] - rm);
         const double zfx = (double)(a.obs.yfx[p] - rfx), zfy = (double)(a.obs.yfy[p] + rfy);
         acc[A_XP + 0] += dxp.im * z; acc[A_XP + 1] += (double)dxp.fx * zfx; acc[A_XP + 2] += (double)dxp.fy * zfy; acc[A_XP + 3] += dxp.m * zm;
         acc[A_YP + 0] += dyp.im * z; acc[A_YP + 1] += (double)dyp.fx * zfx; acc[A_YP + 2] += (double)dyp.fy * zfy; acc[A_YP + 3] += dyp.m * zm;
@@ -561,7 +652,7 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure_vertex(MeasureArgs a)
             a.pool.vxfx[pp] = dvxp.fx; a.pool.vyfy[pp] = dvyp.fy;
         }
     }
-    d_block_reduce<A_NV, MEAS_NT>(acc, s_red, a.out + ((size_t)job * MEAS_VSPLIT + blockIdx.y) * MEAS_OUT);
+    d_block_reduce<A_NV, MEAS_NT>(acc, s_red, a.out + ((size_t)job * MEAS_VSPLIT_MAX + blockIdx.y) * MEAS_OUT);
 }
 
 // ---- pass 2: edge jobs ----------------------------------------------------------------------------------------
@@ -570,6 +661,10 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure_vertex(MeasureArgs a)
 __global__ __launch_bounds__(MEAS_NT) void k_measure_edge(MeasureArgs a)
 {
     __shared__ double s_red[(MEAS_NT / 64) * MEAS_OUT];
+    __shared__ double s_k255[511];
+    const double *k255 = s_k255 + 255;
+    d_fill_k255(s_k255, MEAS_NT);
+    __syncthreads();
     const int N = a.m.N;
     const int e = blockIdx.x;
     const int v = a.topo.edges[2 * e], w = a.topo.edges[2 * e + 1];
@@ -587,10 +682,10 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure_edge(MeasureArgs a)
         const int r = r0 + i / rw, c = c0 + i % rw;
         const long long pv = bv + (long long)(r - hv[1]) * hv[2] + (c - hv[0]);
         const long long pw = bw + (long long)(r - hw[1]) * hw[2] + (c - hw[0]);
-        const double axim = (double)P.xim[pv] / 255.0, axm = (double)P.xm[pv] / 255.0;
-        const double ayim = (double)P.yim[pv] / 255.0, aym = (double)P.ym[pv] / 255.0;
-        const double bxim = (double)P.xim[pw] / 255.0, bxm = (double)P.xm[pw] / 255.0;
-        const double byim = (double)P.yim[pw] / 255.0, bym = (double)P.ym[pw] / 255.0;
+        const double axim = k255[P.xim[pv]], axm = k255[P.xm[pv]];     // parked as numerators in -255..255
+        const double ayim = k255[P.yim[pv]], aym = k255[P.ym[pv]];
+        const double bxim = k255[P.xim[pw]], bxm = k255[P.xm[pw]];
+        const double byim = k255[P.yim[pw]], bym = k255[P.ym[pw]];
         const double axfx = P.xfx[pv], axfy = P.xfy[pv], ayfx = P.yfx[pv], ayfy = P.yfy[pv];
         const double bxfx = P.xfx[pw], bxfy = P.xfy[pw], byfx = P.yfx[pw], byfy = P.yfy[pw];
         const double avx = P.vxfx[pv], avy = P.vyfy[pv], bvx = P.vxfx[pw], bvy = P.vyfy[pw];
@@ -603,16 +698,16 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure_edge(MeasureArgs a)
         acc[B_XVY] += axfy * bvy; acc[B_YVY] += ayfy * bvy; acc[B_VYX] += avy * bxfy; acc[B_VYY] += avy * byfy;
         acc[B_VYVY] += avy * bvy;
     }
-    d_block_reduce<B_NV, MEAS_NT>(acc, s_red, a.out + ((size_t)(N + e) * MEAS_VSPLIT) * MEAS_OUT);
+    d_block_reduce<B_NV, MEAS_NT>(acc, s_red, a.out + ((size_t)(N + e) * MEAS_VSPLIT_MAX) * MEAS_OUT);
 }
 
 // ---- job sums -> Hz, Hz components, dense HTH (device twin of the unpacking in KFState.update) -------
 // One thread per job; every entry of H is written by exactly one job (vertex jobs own the diagonal
 // 4x4 blocks, edge jobs the two mirrored off-diagonal ones), so plain stores suffice.  H must be zero.
 struct ScatterArgs {
-    const double *out;        // njobs * MEAS_OUT
+    const double *out;        // njobs * MEAS_VSPLIT_MAX * MEAS_OUT
     const int *edges;
-    int N, E;
+    int N, E, vsplit;
     double eZ, eJ, eM, d;
     double *H, *Hz, *Hzc;     // 4N x 4N, 4N, 4N x 4
 };
@@ -631,8 +726,8 @@ __global__ void k_hth_scatter(ScatterArgs a)
     if (job >= N + a.E) return;
     double o[MEAS_OUT];
     {
-        const double *src = a.out + (size_t)job * MEAS_VSPLIT * MEAS_OUT;
-        const int parts = job < N ? MEAS_VSPLIT : 1;
+        const double *src = a.out + (size_t)job * MEAS_VSPLIT_MAX * MEAS_OUT;
+        const int parts = job < N ? a.vsplit : 1;
         for (int k = 0; k < MEAS_OUT; k++) {
             double v = src[k];
             for (int q = 1; q < parts; q++) v += src[q * MEAS_OUT + k];

@@ -205,6 +205,9 @@ class Renderer:
         tok = DeviceCovariance(self, self._cov_serial)
         return tok.fetch() if fetch else tok
 
+    def tune(self, key, value):
+        _lib.check(_lib.lib().hm_ctx_tune(self._h, key.encode(), int(value)), "hm_ctx_tune")
+
     def cov_fetch(self):
         n4 = 4 * self.n
         W = np.empty((n4, n4))
