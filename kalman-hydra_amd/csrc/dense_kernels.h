@@ -500,6 +500,125 @@ __global__ __launch_bounds__(NT) void k_tri_solve(const double *__restrict__ L, 
     }
 }
 
+// ---- backward substitution L^T x = y for ONE right-hand side (the row that went through the
+// factorisation), one 1024-thread workgroup, software-pipelined over the 32-row blocks:
+//   wave 0 owns the serial chain -- with x_k known it applies L_{k,k-1}^T x_k to the block above
+//   and solves that block's 32x32 triangle (its column of the diagonal block in registers, the
+//   unknowns passed by v_readlane);
+//   waves 1..15 meanwhile subtract the contribution of x_k from all earlier entries of y (right-
+//   looking; two threads per entry, 16 coalesced loads of the block row of L in flight each) and
+//   fetch the diagonal and sub-diagonal blocks wave 0 needs next into LDS.
+// One barrier per block.
+__device__ __forceinline__ double d_back_triangle(double (*D)[DNB + 1], double val, int li)
+{
+    const double rd = d_rcp(D[li][li]);
+    // two halves of 16 columns: the rest of the workgroup's registers stay live across this call
+#pragma unroll
+    for (int hh = 1; hh >= 0; hh--) {
+        double dcol[DNB / 2];
+#pragma unroll
+        for (int j = 0; j < DNB / 2; j++) dcol[j] = D[hh * (DNB / 2) + j][li];
+#pragma unroll
+        for (int j = DNB / 2 - 1; j >= 0; j--) {
+            const int jj = hh * (DNB / 2) + j;
+            const double xj = d_readlane(val * rd, jj);
+            if (li == jj) val = xj;
+            else if (li < jj) val = val - dcol[j] * xj;
+        }
+    }
+    return val;
+}
+
+__global__ __launch_bounds__(1024) void k_back_row(const double *__restrict__ L, const double *__restrict__ Ld, int n,
+                                                   double *__restrict__ row)
+{
+    extern __shared__ double Y[];                 // nb * 32
+    __shared__ double Xb[2][DNB];                 // x of block k in Xb[k & 1]
+    __shared__ double Dg[2][DNB][DNB + 1];        // diagonal block k (identity padded) in Dg[k & 1]
+    __shared__ double Sg[2][DNB][DNB + 1];        // L_{k,k-1} in Sg[k & 1]
+    const int t = threadIdx.x;
+    const int nb = (n + DNB - 1) / DNB;
+    const int li = t & (DNB - 1);
+    constexpr int HR = DNB / 2;                   // rows per thread of a pair
+    // waves 1..15: thread pair (half 0 / 1) owns the entries c0 and c1 = c0 + 480 of y
+    const int e = t - 64, half = e & 1, c0 = e >> 1, c1 = c0 + 480;
+    // the rows [half*16, half*16+16) of block row k of L at column c; zero outside the bulk range
+    // of step k (columns < (k-1)*32) and below the matrix
+    auto load_rows = [&](int k, int c, double (&l)[HR]) {
+        const bool on = c < (k - 1) * DNB;
+        const int off = half * HR * n + c;        // one 32-bit lane offset; the row base below is uniform
+        const int rows = n - k * DNB - half * HR; // rows of this half inside the matrix
+#pragma unroll
+        for (int r = 0; r < HR; r++) {
+            const double *Lr = L + (size_t)(k * DNB + r) * n;
+            l[r] = (on && r < rows) ? Lr[off] : 0.0;
+        }
+    };
+    // entry q (0..1023) of the two blocks wave 0 needs at step k: diagonal block k-1 and L_{k,k-1}
+    auto fetch = [&](int k, int q, double &d, double &sg) {
+        d = 0.0; sg = 0.0;
+        if (k >= 1) {
+            d = Ld[(size_t)(k - 1) * DNB * DNB + q];
+            const int gr = k * DNB + q / DNB;
+            sg = gr < n ? L[(size_t)gr * n + (k - 1) * DNB + q % DNB] : 0.0;
+        }
+    };
+    auto put = [&](int k, int q, double d, double sg) {
+        if (k >= 1) { Dg[(k - 1) & 1][q / DNB][q % DNB] = d; Sg[k & 1][q / DNB][q % DNB] = sg; }
+    };
+    for (int i = t; i < nb * DNB; i += 1024) Y[i] = i < n ? row[i] : 0.0;
+    Dg[(nb - 1) & 1][t / DNB][t % DNB] = Ld[(size_t)(nb - 1) * DNB * DNB + t];
+    {
+        double d, sg;
+        fetch(nb - 1, t, d, sg);
+        put(nb - 1, t, d, sg);
+    }
+    __syncthreads();
+    if (t < 64) {
+        const double val = d_back_triangle(Dg[(nb - 1) & 1], Y[(nb - 1) * DNB + li], li);
+        if (t < DNB) { Xb[(nb - 1) & 1][li] = val; Y[(nb - 1) * DNB + li] = val; }
+    }
+    __syncthreads();
+    for (int kb = nb - 1; kb >= 1; kb--) {
+        const int i0 = kb * DNB;
+        const double *x = Xb[kb & 1];
+        if (t < 64) {
+            double v = Y[i0 - DNB + li];
+#pragma unroll 8
+            for (int r = 0; r < DNB; r++) v = v - Sg[kb & 1][r][li] * x[r];
+            const double val = d_back_triangle(Dg[(kb - 1) & 1], v, li);
+            if (t < DNB) { Xb[(kb - 1) & 1][li] = val; Y[i0 - DNB + li] = val; }
+        } else {
+            // all loads of the step are requested together: the two blocks wave 0 needs next and
+            // this thread's rows of block row kb (a second batch only while more than 480 entries
+            // of y are left)
+            const int cols = i0 - DNB;            // the block above is wave 0's
+            double d0, s0, d1 = 0.0, s1 = 0.0;
+            fetch(kb - 1, e, d0, s0);
+            if (e < 64) fetch(kb - 1, e + 960, d1, s1);
+            double cur[HR];
+            load_rows(kb, c0, cur);
+            double a0 = 0.0;
+#pragma unroll
+            for (int r = 0; r < HR; r++) a0 = a0 + cur[r] * x[half * HR + r];
+            a0 = a0 + __shfl_xor(a0, 1, 64);
+            if (half == 0 && c0 < cols) Y[c0] = Y[c0] - a0;
+            if (cols > 480) {
+                load_rows(kb, c1, cur);
+                double a1 = 0.0;
+#pragma unroll
+                for (int r = 0; r < HR; r++) a1 = a1 + cur[r] * x[half * HR + r];
+                a1 = a1 + __shfl_xor(a1, 1, 64);
+                if (half == 0 && c1 < cols) Y[c1] = Y[c1] - a1;
+            }
+            put(kb - 1, e, d0, s0);
+            if (e < 64) put(kb - 1, e + 960, d1, s1);
+        }
+        __syncthreads();
+    }
+    for (int i = t; i < n; i += 1024) row[i] = Y[i];
+}
+
 // ---- W = T^T T for lower-triangular T (= L^-1): the SPD inverse from the triangular inverse --------
 // One workgroup per 32x32 tile (I >= J) of W: W_IJ = sum over rows k >= 32 I of T[k, I-block]^T T[k, J-block].
 // Both mirror images are written (the host wants the full symmetric matrix).

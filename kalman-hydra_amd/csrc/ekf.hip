@@ -522,8 +522,7 @@ static void chol_inverse(hm_ctx *h, const double *L, const double *Ld, int n, do
 static void chol_backsolve_row(hm_ctx *h, double *A, const double *Ld, int n)
 {
     double *row = A + (size_t)hm_cdiv(n, DNB) * DNB * n;     // y^T, overwritten by x^T
-    hipLaunchKernelGGL((k_tri_solve<4, false, false, true, 1024>), dim3(1), dim3(1024), (size_t)n * 5 * sizeof(double),
-                       h->stream, A, Ld, n, row, (size_t)1, (size_t)n, 1);
+    hipLaunchKernelGGL(k_back_row, dim3(1), dim3(1024), (size_t)hm_cdiv(n, DNB) * DNB * sizeof(double), h->stream, A, Ld, n, row);
 }
 
 // one iteration's worth of launches of the update: system assembly, factorisation, solve.

@@ -61,9 +61,9 @@ stats = Statistics()
 # with a small CPU quota (a container, the GPU box) is slower than a handful of threads by
 # orders of magnitude, so the team is capped (HYDRA_MI_BLAS_THREADS overrides the cap).
 try:
-    from threadpoolctl import threadpool_limits as _threadpool_limits
+    from threadpoolctl import ThreadpoolController as _ThreadpoolController
 except ImportError:                                   # pragma: no cover
-    _threadpool_limits = None
+    _ThreadpoolController = None
 _BLAS_THREADS = int(os.environ.get("HYDRA_MI_BLAS_THREADS", "8"))
 
 
@@ -98,10 +98,22 @@ def _spd_inverse(A):
 
 
 class _blas_cap:
+    """Cap the BLAS / OpenMP pools for the host algebra of one filter step.  The pools are looked up
+    once (threadpoolctl scans the loaded libraries, ~0.5 ms); filters whose algebra runs on the
+    device (enabled=False) skip it altogether."""
+    _controller = None
+
+    def __init__(self, enabled=True):
+        self._ctx = None
+        self._enabled = enabled and _ThreadpoolController is not None
+
     def __enter__(self):
-        self._ctx = _threadpool_limits(limits=_BLAS_THREADS) if _threadpool_limits is not None else None
-        if self._ctx is not None:
-            self._ctx.__enter__()
+        if not self._enabled:
+            return
+        if _blas_cap._controller is None:
+            _blas_cap._controller = _ThreadpoolController()
+        self._ctx = _blas_cap._controller.limit(limits=_BLAS_THREADS)
+        self._ctx.__enter__()
 
     def __exit__(self, *a):
         if self._ctx is not None:
@@ -399,7 +411,7 @@ class KalmanFilter:
             self.state.renderer.update_frame(y_im, y_flow, y_m)
             y_flow_mask = MaskedFlow(y_flow, y_m) if maskflow is True else y_flow
             mask_host = y_m
-        with _blas_cap():
+        with _blas_cap(enabled=not hasattr(self.state.renderer, "update_run")):
             t0 = time.time()
             self.predict()
             t1 = time.time()
