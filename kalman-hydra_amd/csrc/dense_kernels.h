@@ -678,6 +678,32 @@ __global__ void k_vec_axpy(const double *__restrict__ a, const double *__restric
     if (i < n) out[i] = a[i] + s * b[i];
 }
 
+// The update system of one iteration in one pass over H (one workgroup per row of the augmented
+// array): A = invW0 + H, the right-hand side Hz - H (X0 - X) as row `rhs_row` of the block below the
+// matrix, zeros in the padding rows.
+__global__ __launch_bounds__(256) void k_assemble(const double *__restrict__ invW0, const double *__restrict__ H,
+                                                  const double *__restrict__ X0, const double *__restrict__ X,
+                                                  const double *__restrict__ Hz, double *__restrict__ A, int n, int rhs_row)
+{
+    __shared__ double s[4];
+    const int row = blockIdx.x;
+    if (row >= n) {
+        if (row != rhs_row)
+            for (int j = threadIdx.x; j < n; j += 256) A[(size_t)row * n + j] = 0.0;
+        return;
+    }
+    double acc = 0.0;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        const double h = H[(size_t)row * n + j];
+        A[(size_t)row * n + j] = invW0[(size_t)row * n + j] + h;
+        acc += h * (X0[j] + -1.0 * X[j]);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) A[(size_t)rhs_row * n + row] = Hz[row] - (((s[0] + s[1]) + s[2]) + s[3]);
+}
+
 // y = base - M x   (one workgroup per row, fixed-order reduction)
 __global__ __launch_bounds__(256) void k_rhs(const double *__restrict__ M, const double *__restrict__ x,
                                              const double *__restrict__ base, double *__restrict__ y, int n)

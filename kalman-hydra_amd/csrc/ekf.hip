@@ -29,7 +29,7 @@ struct hm_ctx {
     bool have_tex, have_obs, have_ref;
     // renders
     Targets ref, P, Q;
-    TriSetup *d_setup;
+    TriSetup *d_setup, *d_cfgs;
     double *d_X, *d_out, *d_partial;
     uint8_t *d_im8, *d_m8;
     std::vector<double> X0;          // state of the reference render
@@ -77,7 +77,7 @@ static int ctx_free(hm_ctx *h)
     if (!h) return HM_OK;
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_tri, h->d_star_off, h->d_star_tri, h->d_edges, h->d_uv, h->d_tex, h->d_yim, h->d_ym, h->d_yfx,
-                    h->d_yfy, h->d_yfxm, h->d_yfym, h->d_setup, h->d_X, h->d_out, h->d_partial, h->d_im8, h->d_m8,
+                    h->d_yfy, h->d_yfxm, h->d_yfym, h->d_setup, h->d_cfgs, h->d_X, h->d_out, h->d_partial, h->d_im8, h->d_m8,
                     h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_Ld[0], h->d_Ld[1], h->d_Wprior, h->d_gain, h->d_Awork, h->d_dx,
                     h->d_Wtmp, h->d_X0, h->d_Xn, h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk,
                     h->pool.hdr, h->pool.off, h->pool.xim, h->pool.xm, h->pool.yim, h->pool.ym, h->pool.xfx, h->pool.xfy,
@@ -140,7 +140,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->o_yim = h->o_ym = nullptr; h->o_yfx = h->o_yfy = nullptr;
     h->d_yim = h->d_ym = nullptr; h->d_yfx = h->d_yfy = h->d_yfxm = h->d_yfym = nullptr;
     h->ref = Targets{nullptr, nullptr, nullptr, nullptr}; h->P = h->ref; h->Q = h->ref;
-    h->d_setup = nullptr; h->d_X = h->d_out = h->d_partial = nullptr; h->d_im8 = h->d_m8 = nullptr;
+    h->d_setup = nullptr; h->d_cfgs = nullptr; h->d_X = h->d_out = h->d_partial = nullptr; h->d_im8 = h->d_m8 = nullptr;
     h->d_H = h->d_Hz = h->d_Hzc = h->d_invW0 = h->d_Af[0] = h->d_Af[1] = h->d_dx = h->d_Wtmp = nullptr;
     h->d_Wprior = h->d_gain = h->d_Awork = nullptr; h->d_Wres = nullptr; h->pin = nullptr; h->pin_n = 0;
     h->tri.assign(tri, tri + (size_t)3 * T);
@@ -171,6 +171,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_yfxm, n * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_yfym, n * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_setup, (size_t)T * sizeof(TriSetup));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_cfgs, (size_t)N * MEAS_NCFG * (EKF_MAX_STAR + 1) * sizeof(TriSetup));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_X, (size_t)4 * N * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_out, (size_t)h->njobs * MEAS_VSPLIT_MAX * MEAS_OUT * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_partial, (size_t)h->red_blocks * 4 * sizeof(double));
@@ -447,8 +448,9 @@ static int measure_dev(hm_ctx *h, const double *dX, bool ref_ready, double delta
     a.out = h->d_out;
     a.pool = h->pool;
     a.vsplit = h->vsplit;
+    a.cfgs = h->d_cfgs;
     hipLaunchKernelGGL(k_star_regions, dim3(h->N), dim3(64), 0, h->stream, a, h->d_area);
-    hipLaunchKernelGGL(k_region_offsets, dim3(1), dim3(1), 0, h->stream, h->d_area, h->N, h->pool);
+    hipLaunchKernelGGL(k_region_offsets, dim3(1), dim3(256), 0, h->stream, h->d_area, h->N, h->pool);
     hipLaunchKernelGGL(k_measure_vertex, dim3(h->N, h->vsplit), dim3(MEAS_NT), 0, h->stream, a);
     if (h->E > 0) hipLaunchKernelGGL(k_measure_edge, dim3(h->E), dim3(MEAS_NT), 0, h->stream, a);
     const size_t n4 = (size_t)4 * h->N;
@@ -530,16 +532,13 @@ static void chol_backsolve_row(hm_ctx *h, double *A, const double *Ld, int n)
 static double *solve_step(hm_ctx *h, int slot)
 {
     const int n4 = 4 * h->N;
-    hipLaunchKernelGGL(k_vec_axpy, dim3(hm_cdiv(n4, 256)), dim3(256), 0, h->stream, h->d_X0, h->d_X, -1.0, h->d_dx, n4);
     double *A = h->d_Awork;
-    const size_t nn = (size_t)n4 * n4;
-    hipLaunchKernelGGL(k_add_mat, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, h->d_invW0, h->d_H, A, nn);
-    // right-hand side Hz - H (X0 - X) as the first row of the block below the matrix; the rows in
-    // between and the rest of that block stay zero
-    const size_t pad_n = (size_t)aug_rows(n4) * n4 - nn;
-    (void)hipMemsetAsync(A + nn, 0, pad_n * sizeof(double), h->stream);
-    double *rhs_row = A + (size_t)hm_cdiv(n4, DNB) * DNB * n4;
-    hipLaunchKernelGGL(k_rhs, dim3(n4), dim3(256), 0, h->stream, h->d_H, h->d_dx, h->d_Hz, rhs_row, n4);
+    // A = invW0 + H; the right-hand side Hz - H (X0 - X) as the first row of the block below the
+    // matrix; the rows in between and the rest of that block zero
+    const int rhs_index = hm_cdiv(n4, DNB) * DNB;
+    double *rhs_row = A + (size_t)rhs_index * n4;
+    hipLaunchKernelGGL(k_assemble, dim3(aug_rows(n4)), dim3(256), 0, h->stream, h->d_invW0, h->d_H, h->d_X0, h->d_X,
+                       h->d_Hz, A, n4, rhs_index);
     chol_factor(h, A, h->d_Af[slot], h->d_Ld[slot], n4, true);
     chol_backsolve_row(h, h->d_Af[slot], h->d_Ld[slot], n4);
     return h->d_Af[slot] + (rhs_row - A);

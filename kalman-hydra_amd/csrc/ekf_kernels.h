@@ -488,6 +488,7 @@ struct MeasureArgs {
     double *out;              // njobs * MEAS_VSPLIT_MAX * MEAS_OUT doubles
     DPool pool;
     int vsplit;               // workgroups per vertex job (gridDim.y of k_measure_vertex)
+    TriSetup *cfgs;           // N x MEAS_NCFG x (EKF_MAX_STAR + 1): the star setups, written by k_star_regions
 };
 
 #define MEAS_NT 256
@@ -531,6 +532,15 @@ __global__ __launch_bounds__(64) void k_star_regions(MeasureArgs a, int *__restr
     const int nsv = a.topo.star_off[v + 1] - a.topo.star_off[v];
     d_vertex_cfgs(s_cfg, nsv, a.topo.star_tri + a.topo.star_off[v], m, a.X, v, a.delta, 64);
     __syncthreads();
+    {   // keep the setups (with the padding entry) for the measurement kernel
+        constexpr int TW = sizeof(TriSetup) / 4;
+        const int used = (nsv + (nsv & 1)) * TW;
+        for (int c = 0; c < MEAS_NCFG; c++) {
+            const int *src = (const int *)s_cfg[c];
+            int *dst = (int *)(a.cfgs + ((size_t)v * MEAS_NCFG + c) * (EKF_MAX_STAR + 1));
+            for (int i = threadIdx.x; i < used; i += 64) dst[i] = src[i];
+        }
+    }
     if (threadIdx.x != 0) return;
     int c0 = m.W, c1 = -1, r0 = m.H, r1 = -1;
     for (int cfg = 0; cfg < MEAS_NCFG; cfg++)
@@ -544,13 +554,35 @@ __global__ __launch_bounds__(64) void k_star_regions(MeasureArgs a, int *__restr
     area[v] = rw * rh;
 }
 
-__global__ void k_region_offsets(const int *__restrict__ area, int N, DPool pool)
+// exclusive prefix sum of the region areas (one workgroup, Hillis-Steele over chunks of 256)
+__global__ __launch_bounds__(256) void k_region_offsets(const int *__restrict__ area, int N, DPool pool)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    long long o = 0;
-    for (int v = 0; v < N; v++) { pool.off[v] = o; o += area[v]; }
-    pool.off[N] = o;
-    *pool.overflow = o > pool.cap ? 1 : 0;
+    __shared__ long long sc[256];
+    __shared__ long long carry;
+    const int t = threadIdx.x;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < N; b0 += 256) {
+        const int v = b0 + t;
+        const long long mine = v < N ? (long long)area[v] : 0;
+        sc[t] = mine;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const long long add = t >= o ? sc[t - o] : 0;
+            __syncthreads();
+            sc[t] += add;
+            __syncthreads();
+        }
+        const long long base = carry;
+        if (v < N) pool.off[v] = base + sc[t] - mine;
+        __syncthreads();
+        if (t == 255) carry = base + sc[255];
+        __syncthreads();
+    }
+    if (t == 0) {
+        pool.off[N] = carry;
+        *pool.overflow = carry > pool.cap ? 1 : 0;
+    }
 }
 
 // ---- pass 1: vertex jobs ----------------------------------------------------------------------------------
@@ -571,7 +603,15 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure_vertex(MeasureArgs a)
     const double *X = a.X;
     const double d = a.delta;
     const int nsv = a.topo.star_off[v + 1] - a.topo.star_off[v];
-    d_vertex_cfgs(s_cfg, nsv, a.topo.star_tri + a.topo.star_off[v], m, X, v, d, MEAS_NT);
+    {   // the star setups k_star_regions computed
+        constexpr int TW = sizeof(TriSetup) / 4;
+        const int used = (nsv + (nsv & 1)) * TW;
+        for (int c = 0; c < MEAS_NCFG; c++) {
+            const int *src = (const int *)(a.cfgs + ((size_t)v * MEAS_NCFG + c) * (EKF_MAX_STAR + 1));
+            int *dst = (int *)s_cfg[c];
+            for (int i = threadIdx.x; i < used; i += MEAS_NT) dst[i] = src[i];
+        }
+    }
     __syncthreads();
     const int c0 = a.pool.hdr[4 * v], r0 = a.pool.hdr[4 * v + 1], rw = a.pool.hdr[4 * v + 2], rh = a.pool.hdr[4 * v + 3];
     const long long base = a.pool.off[v];
