@@ -75,10 +75,14 @@ int hm_brox_set_omega(hm_brox_t h, float omega);
  * "sor_threads" = 256, 512 or 1024 threads per SOR workgroup, "graph" = 1/0 replay the launch
  * series of a calc call as a captured hipGraph (default 1) or launch kernel by kernel */
 int hm_brox_tune(hm_brox_t h, const char *key, int value);
+/* set-up work of the first calc call for n pairs (capturing its launch series as a graph) done ahead
+ * of time; optional */
+int hm_brox_prepare(hm_brox_t h, int n);
 
 /* HIP-event timing of the SOR launches of subsequent calc calls.
  * read: total milliseconds, launches, and pixel-iterations (sum over launches of
- * pixels * red-black iterations) since profiling was switched on or last read. */
+ * pixels * red-black iterations) since profiling was switched on or last read
+ * (switching it off stops the recording and keeps the totals for `read`). */
 int hm_brox_profile(hm_brox_t h, int enable);
 int hm_brox_profile_read(hm_brox_t h, double *sor_ms, long long *sor_launches,
                          double *sor_pixel_iterations);

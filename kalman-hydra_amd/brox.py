@@ -103,6 +103,10 @@ class BroxOpticalFlow:
     def set_omega(self, omega):
         _lib.check(_lib.lib().hm_brox_set_omega(self._h, omega), "hm_brox_set_omega")
 
+    def prepare(self, n):
+        """Do the set-up work of the first calc call for n pairs now (hm_brox_prepare)."""
+        _lib.check(_lib.lib().hm_brox_prepare(self._h, int(n)), "hm_brox_prepare")
+
     def tune(self, key, value):
         _lib.check(_lib.lib().hm_brox_tune(self._h, key.encode(), int(value)), "hm_brox_tune")
 

@@ -214,7 +214,12 @@ extern "C" int hm_brox_create(int device, int W, int H, int max_batch, float alp
     // padding columns are read (never used) by float2 loads: keep them finite.  The fill
     // goes on the handle's own stream: that stream is non-blocking, so a fill issued on the
     // null stream could still be running when the first calc starts.
-    e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    {   // throughput work: lowest priority, so that a tracker's short latency-bound launches on
+        // another stream are not queued behind whole flow batches
+        int prio_least = 0, prio_greatest = 0;
+        e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_least);
+    }
     if (e == hipSuccess) e = hipMemsetAsync(h->arena, 0, h->arena_floats * sizeof(float), h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_f0, B * W * H);
@@ -307,8 +312,10 @@ extern "C" int hm_brox_profile(hm_brox_t h, int enable)
     HM_ARG(h != nullptr, "hm_brox_profile: NULL handle");
     HM_HIP(hipSetDevice(h->device));
     h->prof = enable != 0;
-    h->ev_used = 0; h->prof_ms = 0; h->prof_pxit = 0; h->prof_launches = 0;
-    h->ev_pxit.clear();
+    if (enable) {                                  // switching off keeps what was recorded for hm_brox_profile_read
+        h->ev_used = 0; h->prof_ms = 0; h->prof_pxit = 0; h->prof_launches = 0;
+        h->ev_pxit.clear();
+    }
     return HM_OK;
 }
 
@@ -434,6 +441,31 @@ static int brox_run(hm_brox *h, int n, const uint8_t *d_f0, const uint8_t *d_f1,
     return HM_OK;
 }
 
+// the launch series of a calc call for n pairs as an instantiated graph (captured on first use)
+static int brox_graph(hm_brox *h, int n)
+{
+    hipGraphExec_t &exec = h->graphs[n - 1];
+    if (exec) return HM_OK;
+    hipGraph_t graph = nullptr;
+    HM_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    int rc = brox_run(h, n, h->d_f0, h->d_f1, h->d_ox, h->d_oy);
+    hipError_t e = hipStreamEndCapture(h->stream, &graph);
+    if (rc != HM_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) { hm_set_error("hm_brox: stream capture failed: %s", hipGetErrorString(e)); return HM_ERR_HIP; }
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) { exec = nullptr; hm_set_error("hm_brox: hipGraphInstantiate failed: %s", hipGetErrorString(e)); return HM_ERR_HIP; }
+    return HM_OK;
+}
+
+extern "C" int hm_brox_prepare(hm_brox_t h, int n)
+{
+    HM_ARG(h != nullptr, "hm_brox_prepare: NULL handle");
+    HM_ARG(n >= 1 && n <= h->B, "hm_brox_prepare: n=%d outside 1..max_batch=%d", n, h->B);
+    HM_HIP(hipSetDevice(h->device));
+    return h->use_graph ? brox_graph(h, n) : HM_OK;
+}
+
 extern "C" int hm_brox_calc_dev(hm_brox_t h, int n, const uint8_t *d_f0, const uint8_t *d_f1, float *d_ox, float *d_oy)
 {
     HM_ARG(h != nullptr, "hm_brox_calc_dev: NULL handle");
@@ -450,18 +482,9 @@ extern "C" int hm_brox_calc_dev(hm_brox_t h, int n, const uint8_t *d_f0, const u
         HM_HIP(hipMemcpyAsync(h->d_f0, d_f0, px, hipMemcpyDeviceToDevice, h->stream));
         HM_HIP(hipMemcpyAsync(h->d_f1, d_f1, px, hipMemcpyDeviceToDevice, h->stream));
     }
-    hipGraphExec_t &exec = h->graphs[n - 1];
-    if (!exec) {
-        hipGraph_t graph = nullptr;
-        HM_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-        int rc = brox_run(h, n, h->d_f0, h->d_f1, h->d_ox, h->d_oy);
-        hipError_t e = hipStreamEndCapture(h->stream, &graph);
-        if (rc != HM_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-        if (e != hipSuccess) { hm_set_error("hm_brox_calc_dev: stream capture failed: %s", hipGetErrorString(e)); return HM_ERR_HIP; }
-        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (e != hipSuccess) { exec = nullptr; hm_set_error("hm_brox_calc_dev: hipGraphInstantiate failed: %s", hipGetErrorString(e)); return HM_ERR_HIP; }
-    }
+    int rc = brox_graph(h, n);
+    if (rc) return rc;
+    hipGraphExec_t exec = h->graphs[n - 1];
     HM_HIP(hipGraphLaunch(exec, h->stream));
     if (!in_place) {
         HM_HIP(hipMemcpyAsync(d_ox, h->d_ox, px * sizeof(float), hipMemcpyDeviceToDevice, h->stream));

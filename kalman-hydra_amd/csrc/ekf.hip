@@ -162,7 +162,12 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     step(upload(&h->d_star_tri, flat.data(), flat.size()));
     step(upload(&h->d_edges, h->edges.data(), h->edges.size()));
     if (rc == HM_OK) {
-        hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        // The filter's launches are short and chained (the host waits on each iteration); a flow batch
+        // running beside them on another stream fills every CU.  Highest priority lets the small
+        // kernels in as soon as any workgroup slot frees up.
+        int prio_least = 0, prio_greatest = 0;
+        hipError_t e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_greatest);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_tex, n);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_yim, n);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_ym, n);
