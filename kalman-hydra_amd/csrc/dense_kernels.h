@@ -236,13 +236,100 @@ __device__ __forceinline__ void chol_block_factor(double (*W)[DNB + 1], double (
     }
 }
 
-// the first diagonal block: A_00 -> Ld[0]
-__global__ __launch_bounds__(256) void k_chol_first(const double *__restrict__ A, double *__restrict__ Ld, int n)
+// T = L^-1 of the factored 32x32 block D (LDS; rD = reciprocals of its diagonal), all 256 threads.
+// Recursive: the four 8x8 diagonal triangles by substitution (one column per thread), then the
+// off-diagonal blocks T21 = -T22 (L21 T11) at sizes 8 and 16.  With the inverse at hand the panel
+// solves of a step are plain products (MFMA) instead of 32-step substitution chains.
+__device__ __forceinline__ void chol_block_inverse(double (*D)[DNB + 1], const double *rD, double (*Tm)[DNB + 1],
+                                                   double (*Ms)[DNB / 2 + 1], int t)
+{
+    // 8x8 diagonal triangles: thread (g, i), t < 32, solves column i of triangle g by substitution;
+    // its part of D goes to registers first so that the chain has no LDS round trips.  The other
+    // threads clear the rest of T meanwhile.
+    if (t < DNB) {
+        const int g = t / 8, i = t % 8, b0 = 8 * g;
+        double dl[8][8], rd[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            rd[j] = rD[b0 + j];
+#pragma unroll
+            for (int m = 0; m < 8; m++)
+                if (m < j) dl[j][m] = D[b0 + j][b0 + m];
+        }
+        double col[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int m = 0; m < 8; m++)
+                if (m < j) acc = acc + dl[j][m] * col[m];          // col[m] = 0 for m < i
+            col[j] = j == i ? rd[j] : (j > i ? -acc * rd[j] : 0.0);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) Tm[b0 + j][b0 + i] = col[j];
+    } else {
+        for (int e = t - DNB; e < DNB * DNB; e += 256 - DNB) {
+            const int i = e / DNB, j = e % DNB;
+            if ((i >> 3) != (j >> 3)) Tm[i][j] = 0.0;
+        }
+    }
+    __syncthreads();
+    if (t < 128) {                                // size 8: M = L21 T11 for the two 16x16 diagonal blocks
+        const int h = t / 64, b0 = 16 * h, i = (t % 64) / 8, j = t % 8;
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < 8; m++) acc = acc + D[b0 + 8 + i][b0 + m] * Tm[b0 + m][b0 + j];
+        Ms[h * 8 + i][j] = acc;
+    }
+    __syncthreads();
+    if (t < 128) {                                //         T21 = -T22 M
+        const int h = t / 64, b0 = 16 * h, i = (t % 64) / 8, j = t % 8;
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < 8; m++) acc = acc + Tm[b0 + 8 + i][b0 + 8 + m] * Ms[h * 8 + m][j];
+        Tm[b0 + 8 + i][b0 + j] = -acc;
+    }
+    __syncthreads();
+    const int i16 = t / 16, j16 = t % 16;
+    {                                             // size 16: M = L21 T11
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < 16; m++) acc = acc + D[16 + i16][m] * Tm[m][j16];
+        Ms[i16][j16] = acc;                       // the size-8 values were consumed before the last barrier
+    }
+    __syncthreads();
+    {                                             //          T21 = -T22 M
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < 16; m++) acc = acc + Tm[16 + i16][16 + m] * Ms[m][j16];
+        Tm[16 + i16][j16] = -acc;
+    }
+    __syncthreads();
+}
+
+// One 16x16 tile of X Y^T for 32x32 blocks X, Y in LDS on the f64 matrix cores
+// (v_mfma_f64_16x16x4_f64, eight k-steps): wave wv computes tile (wv >> 1, wv & 1); element e of the
+// result sits at row 16 (wv >> 1) + (lane >> 4) + 4 e, column 16 (wv & 1) + (lane & 15).
+typedef double d4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ d4_t d_mfma_nt(double (*X)[DNB + 1], double (*Y)[DNB + 1], int wv, int lane)
+{
+    d4_t c = {0.0, 0.0, 0.0, 0.0};
+    const int i = 16 * (wv >> 1) + (lane & 15), j = 16 * (wv & 1) + (lane & 15), kq = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < DNB / 4; kk++)
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(X[i][4 * kk + kq], Y[j][4 * kk + kq], c, 0, 0, 0);
+    return c;
+}
+
+// the first diagonal block: A_00 -> Ld[0], its inverse -> Lt[0]
+__global__ __launch_bounds__(256) void k_chol_first(const double *__restrict__ A, double *__restrict__ Ld,
+                                                    double *__restrict__ Lt, int n)
 {
     __shared__ double W[DNB][DNB + 1];
     __shared__ double D[DNB][DNB + 1];
     __shared__ double rD[DNB];
     __shared__ double LS[DNB][5];
+    __shared__ double Ms[DNB / 2][DNB / 2 + 1];
     const int t = threadIdx.x;
     const int nd = min(DNB, n);
     for (int e = t; e < DNB * DNB; e += 256) {
@@ -253,116 +340,81 @@ __global__ __launch_bounds__(256) void k_chol_first(const double *__restrict__ A
     chol_block_factor(W, D, rD, LS, t);
     __syncthreads();
     for (int e = t; e < DNB * DNB; e += 256) Ld[e] = D[e / DNB][e % DNB];
+    chol_block_inverse(D, rD, W, Ms, t);
+    for (int e = t; e < DNB * DNB; e += 256) Lt[e] = W[e / DNB][e % DNB];
 }
 
+// Step k.  Workgroup (r, c), r >= c > k:  X_r = A_rk T^T, X_c = A_ck T^T with T = L_kk^-1 (Lt[k], from
+// the previous launch), A_rc -= X_r X_c^T -- three 32x32x32 products on the matrix cores; column
+// c = k+1 also stores X_r as L_rk; workgroup (k+1, k+1) goes on to factor its updated block into
+// Ld[k+1] and to invert the factor into Lt[k+1].
 __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, double *__restrict__ L, double *__restrict__ Ld,
-                                                   int n, int nrows, int nb, int k)
+                                                   double *__restrict__ Lt, int n, int nrows, int nb, int k)
 {
     const int r = k + 1 + blockIdx.y;
     const int c = k + 1 + blockIdx.x;             // c >= nb: no block to update, the panel row only
     const bool panel_only = c >= nb;
     if (!panel_only && c > r) return;
-    __shared__ double D[DNB][DNB + 1];            // L_kk, later the factor of block k+1
+    __shared__ double Ts[DNB][DNB + 1];           // T = L_kk^-1; later the factor of block k+1
+    __shared__ double Br[DNB][DNB + 1];           // A_rk, then X_r, then the updated block k+1
+    __shared__ double Bc[DNB][DNB + 1];           // A_ck, then X_c, then the inverse of the new factor
     __shared__ double rD[DNB];
-    __shared__ double Xr[DNB][DNB + 1];
-    __shared__ double Xc[DNB][DNB + 1];
     __shared__ double LS[DNB][5];
-    const int t = threadIdx.x;
+    __shared__ double Ms[DNB / 2][DNB / 2 + 1];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int d0 = k * DNB;
     const int nd = min(DNB, n - d0);
     const int r0 = r * DNB, c0 = c * DNB;
     const int nr = min(DNB, nrows - r0);
     const int nc = panel_only ? 0 : min(DNB, n - c0);
-    const bool two = !panel_only && c != r;       // a second panel row to solve
-    // panel rows: 8 threads per row, thread `part` owns the entries 8 q + part
-    const int row = t / 8, part = t % 8;
-    double x[2][4];
+    const bool two = !panel_only && c != r;
+    // coordinates of this thread's four elements of a product tile
+    const int mj = 16 * (wv & 1) + (lane & 15);
+    int mi[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int cc = 8 * q + part;
-        x[0][q] = (row < nr && cc < nd) ? A[(size_t)(r0 + row) * n + d0 + cc] : 0.0;
-        x[1][q] = (two && row < nc && cc < nd) ? A[(size_t)(c0 + row) * n + d0 + cc] : 0.0;
-    }
-    // the block the product will be subtracted from: requested now, needed after the solves
-    const int tj = t % DNB, ti = t / DNB;
+    for (int e = 0; e < 4; e++) mi[e] = 16 * (wv >> 1) + (lane >> 4) + 4 * e;
     double a[4];
-    if (!panel_only) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int i = ti + 8 * q;
-            a[q] = (i < nr && tj < nc) ? A[(size_t)(r0 + i) * n + c0 + tj] : 0.0;
-        }
-    }
+    for (int e = 0; e < 4; e++)
+        a[e] = (!panel_only && mi[e] < nr && mj < nc) ? A[(size_t)(r0 + mi[e]) * n + c0 + mj] : 0.0;
     for (int e = t; e < DNB * DNB; e += 256) {
         const int i = e / DNB, j = e % DNB;
-        const double v = Ld[(size_t)k * DNB * DNB + e];
-        D[i][j] = v;
-        if (i == j) rD[i] = d_rcp(v);
+        Ts[i][j] = Lt[(size_t)k * DNB * DNB + e];
+        Br[i][j] = (i < nr && j < nd) ? A[(size_t)(r0 + i) * n + d0 + j] : 0.0;
+        Bc[i][j] = (two && i < nc && j < nd) ? A[(size_t)(c0 + i) * n + d0 + j] : 0.0;
     }
     __syncthreads();
-    // X L_kk^T = A_.k for the two rows at once (independent chains): the 32 columns in four groups
-    // of 8 -- a private dot product over the finished columns, then the 8x8 triangle of the group
-    // with one 8-lane shuffle per column
+    const d4_t xr = d_mfma_nt(Br, Ts, wv, lane);
+    d4_t xc = xr;
+    if (two) xc = d_mfma_nt(Bc, Ts, wv, lane);
+    __syncthreads();                              // all reads of A_rk, A_ck done
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int j = 8 * q + part;
-        double s0 = x[0][q], s1 = x[1][q];
-        for (int cc = 0; cc < 8 * q; cc++) {
-            const double d = D[j][cc];
-            s0 = s0 - Xr[row][cc] * d;
-            s1 = s1 - Xc[row][cc] * d;
-        }
-#pragma unroll
-        for (int jj = 0; jj < 8; jj++) {
-            const int jc = 8 * q + jj;
-            const double y0 = __shfl(s0 * rD[jc], jj, 8);
-            const double y1 = __shfl(s1 * rD[jc], jj, 8);
-            if (part == jj) { s0 = y0; s1 = y1; }
-            else if (part > jj) { const double d = D[j][jc]; s0 = s0 - y0 * d; s1 = s1 - y1 * d; }
-        }
-        x[0][q] = s0;
-        Xr[row][j] = s0;
-        Xc[row][j] = two ? s1 : s0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();          // the 8 lanes of a row are in one wave
-    }
-    if (blockIdx.x == 0 && row < nr) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int cc = 8 * q + part;
-            if (cc < nd) L[(size_t)(r0 + row) * n + d0 + cc] = x[0][q];
-        }
+    for (int e = 0; e < 4; e++) {
+        Br[mi[e]][mj] = xr[e];
+        Bc[mi[e]][mj] = xc[e];
+        if (blockIdx.x == 0 && mi[e] < nr && mj < nd) L[(size_t)(r0 + mi[e]) * n + d0 + mj] = xr[e];
     }
     if (panel_only) return;
     __syncthreads();
-    // A_rc -= X_r X_c^T: thread (ti, tj) owns rows ti + 8 q of column tj
-    double s[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 8
-    for (int qq = 0; qq < DNB; qq++) {
-        const double cv = Xc[tj][qq];
-#pragma unroll
-        for (int q = 0; q < 4; q++) s[q] = s[q] + Xr[ti + 8 * q][qq] * cv;
-    }
+    const d4_t s = d_mfma_nt(Br, Bc, wv, lane);
     const bool diag = r == k + 1 && c == k + 1;
     if (!diag) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int i = ti + 8 * q;
-            if (i < nr && tj < nc) A[(size_t)(r0 + i) * n + c0 + tj] = a[q] - s[q];
-        }
+        for (int e = 0; e < 4; e++)
+            if (mi[e] < nr && mj < nc) A[(size_t)(r0 + mi[e]) * n + c0 + mj] = a[e] - s[e];
         return;
     }
-    // the next diagonal block: finish its update and factor it now
-    __syncthreads();                              // everyone is done reading Xr as the panel
+    // the next diagonal block: finish its update, factor it and invert the factor now
+    __syncthreads();                              // everyone is done reading X_r
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int i = ti + 8 * q;
-        Xr[i][tj] = (i < nc && tj <= i) ? a[q] - s[q] : (i == tj ? 1.0 : 0.0);
-    }
+    for (int e = 0; e < 4; e++)
+        Br[mi[e]][mj] = (mi[e] < nc && mj <= mi[e]) ? a[e] - s[e] : (mi[e] == mj ? 1.0 : 0.0);
     __syncthreads();
-    chol_block_factor(Xr, D, rD, LS, t);
+    chol_block_factor(Br, Ts, rD, LS, t);
     __syncthreads();
-    for (int e = t; e < DNB * DNB; e += 256) Ld[(size_t)(k + 1) * DNB * DNB + e] = D[e / DNB][e % DNB];
+    for (int e = t; e < DNB * DNB; e += 256) Ld[(size_t)(k + 1) * DNB * DNB + e] = Ts[e / DNB][e % DNB];
+    chol_block_inverse(Ts, rD, Bc, Ms, t);
+    for (int e = t; e < DNB * DNB; e += 256) Lt[(size_t)(k + 1) * DNB * DNB + e] = Bc[e / DNB][e % DNB];
 }
 
 // ---- triangular solves with the factor, a slab of CH right-hand sides per workgroup --------------

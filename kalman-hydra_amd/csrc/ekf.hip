@@ -34,7 +34,7 @@ struct hm_ctx {
     uint8_t *d_im8, *d_m8;
     std::vector<double> X0;          // state of the reference render
     // dense update on the device (n4 = 4N)
-    double *d_H, *d_Hz, *d_Hzc, *d_invW0, *d_Af[2], *d_Ld[2], *d_dx, *d_Wtmp, *d_X0, *d_Xn, *d_Wprior, *d_gain, *d_Awork;
+    double *d_H, *d_Hz, *d_Hzc, *d_invW0, *d_Af[2], *d_Ld[2], *d_dx, *d_Wtmp, *d_X0, *d_Xn, *d_Wprior, *d_gain, *d_Awork, *d_Lt;
     std::vector<double> upd_X0;      // prior mean given to hm_update_begin
     int upd_last, upd_prev;          // which d_Af holds the factor of the last / previous step (-1: none)
     double *d_Wres;                  // the covariance resident on the device (the result of the last
@@ -78,7 +78,7 @@ static int ctx_free(hm_ctx *h)
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_tri, h->d_star_off, h->d_star_tri, h->d_edges, h->d_uv, h->d_tex, h->d_yim, h->d_ym, h->d_yfx,
                     h->d_yfy, h->d_yfxm, h->d_yfym, h->d_setup, h->d_cfgs, h->d_X, h->d_out, h->d_partial, h->d_im8, h->d_m8,
-                    h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_Ld[0], h->d_Ld[1], h->d_Wprior, h->d_gain, h->d_Awork, h->d_dx,
+                    h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_Ld[0], h->d_Ld[1], h->d_Wprior, h->d_gain, h->d_Awork, h->d_Lt, h->d_dx,
                     h->d_Wtmp, h->d_X0, h->d_Xn, h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk,
                     h->pool.hdr, h->pool.off, h->pool.xim, h->pool.xm, h->pool.yim, h->pool.ym, h->pool.xfx, h->pool.xfy,
                     h->pool.yfx, h->pool.yfy, h->pool.vxfx, h->pool.vyfy, h->pool.overflow, h->d_area};
@@ -142,7 +142,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->ref = Targets{nullptr, nullptr, nullptr, nullptr}; h->P = h->ref; h->Q = h->ref;
     h->d_setup = nullptr; h->d_cfgs = nullptr; h->d_X = h->d_out = h->d_partial = nullptr; h->d_im8 = h->d_m8 = nullptr;
     h->d_H = h->d_Hz = h->d_Hzc = h->d_invW0 = h->d_Af[0] = h->d_Af[1] = h->d_dx = h->d_Wtmp = nullptr;
-    h->d_Wprior = h->d_gain = h->d_Awork = nullptr; h->d_Wres = nullptr; h->pin = nullptr; h->pin_n = 0;
+    h->d_Wprior = h->d_gain = h->d_Awork = h->d_Lt = nullptr; h->d_Wres = nullptr; h->pin = nullptr; h->pin_n = 0;
     h->tri.assign(tri, tri + (size_t)3 * T);
     h->d_Ld[0] = h->d_Ld[1] = nullptr; h->d_X0 = h->d_Xn = nullptr;
     memset(&h->pool, 0, sizeof h->pool); h->d_area = nullptr;
@@ -192,6 +192,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         const size_t ld_bytes = (size_t)hm_cdiv((int)n4, DNB) * DNB * DNB * sizeof(double);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Ld[0], ld_bytes);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Ld[1], ld_bytes);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Lt, ld_bytes);     // inverses of the diagonal blocks, live during a factorisation
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Wtmp, nn);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Hz, n4 * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Hzc, n4 * 4 * sizeof(double));
@@ -507,10 +508,10 @@ static void chol_factor(hm_ctx *h, double *A, double *L, double *Ld, int n, bool
     const int nb = hm_cdiv(n, DNB);
     const int nrows = with_rhs ? aug_rows(n) : n;
     const int nbr = hm_cdiv(nrows, DNB);
-    hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, h->stream, A, Ld, n);
+    hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, h->stream, A, Ld, h->d_Lt, n);
     for (int k = 0; k < nb; k++) {
         const int mr = nbr - k - 1, mc = std::max(nb - k - 1, 1);
-        if (mr > 0) hipLaunchKernelGGL(k_chol_step, dim3(mc, mr), dim3(256), 0, h->stream, A, L, Ld, n, nrows, nb, k);
+        if (mr > 0) hipLaunchKernelGGL(k_chol_step, dim3(mc, mr), dim3(256), 0, h->stream, A, L, Ld, h->d_Lt, n, nrows, nb, k);
     }
 }
 
