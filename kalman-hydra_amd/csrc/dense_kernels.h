@@ -672,44 +672,71 @@ __global__ __launch_bounds__(1024) void k_back_row(const double *__restrict__ L,
 }
 
 // ---- W = T^T T for lower-triangular T (= L^-1): the SPD inverse from the triangular inverse --------
-// One workgroup per 32x32 tile (I >= J) of W: W_IJ = sum over rows k >= 32 I of T[k, I-block]^T T[k, J-block].
-// Both mirror images are written (the host wants the full symmetric matrix).
+// One workgroup per 32x32 tile (I >= J) of W: W_IJ = sum over block rows k >= I of T_kI^T T_kJ, each
+// term one 32x32x32 product on the f64 matrix cores.  The blocks come from memory written by other
+// XCDs (~1.7 us away), so three steps' worth of them are kept in flight in registers; LDS is double
+// buffered, one barrier per step.  Both mirror images are written (the host wants the full matrix).
+__device__ __forceinline__ d4_t d_mfma_tn(double (*X)[DNB + 1], double (*Y)[DNB + 1], int wv, int lane, d4_t c)
+{
+    const int i = 16 * (wv >> 1) + (lane & 15), j = 16 * (wv & 1) + (lane & 15), kq = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < DNB / 4; kk++)
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(X[4 * kk + kq][i], Y[4 * kk + kq][j], c, 0, 0, 0);
+    return c;
+}
+
+#define TTT_PF 3
 __global__ __launch_bounds__(256) void k_ttt(const double *__restrict__ Tm, int n, double *__restrict__ W)
 {
     const int I = blockIdx.y, J = blockIdx.x;
     if (J > I) return;
-    __shared__ double TI[DNB][DNB + 1];
-    __shared__ double TJ[DNB][DNB + 1];
-    const int t = threadIdx.x;
+    __shared__ double TI[2][DNB][DNB + 1];
+    __shared__ double TJ[2][DNB][DNB + 1];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int i0 = I * DNB, j0 = J * DNB;
     const int ni = min(DNB, n - i0), nj = min(DNB, n - j0);
-    const int jj = t % DNB;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};         // outputs (ii = t/32 + 8 q, jj)
-    for (int k0 = i0; k0 < n; k0 += DNB) {
-        const int nk = min(DNB, n - k0);
-        for (int e = t; e < DNB * DNB; e += 256) {
-            int kk = e / DNB, c = e % DNB;
-            // T is lower triangular: entries right of the diagonal are not stored
-            TI[kk][c] = (kk < nk && c < ni && i0 + c <= k0 + kk) ? Tm[(size_t)(k0 + kk) * n + i0 + c] : 0.0;
-            TJ[kk][c] = (kk < nk && c < nj && j0 + c <= k0 + kk) ? Tm[(size_t)(k0 + kk) * n + j0 + c] : 0.0;
-        }
-        __syncthreads();
+    const int nsteps = (n - i0 + DNB - 1) / DNB;
+    double pi[TTT_PF][4], pj[TTT_PF][4];
+    // this thread's four entries of the two blocks of step s (zeros past the end; T is lower
+    // triangular: entries right of the diagonal are not stored)
+    auto fetch = [&](int s, double (&a)[4], double (&b)[4]) {
+        const int k0 = i0 + s * DNB;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int ii = t / DNB + 8 * q;
-            double s = acc[q];
-#pragma unroll 8
-            for (int kk = 0; kk < DNB; kk++) s = s + TI[kk][ii] * TJ[kk][jj];
-            acc[q] = s;
+            const int e = t + 256 * q, kk = e / DNB, c = e % DNB;
+            const bool row = s < nsteps && k0 + kk < n;
+            a[q] = (row && c < ni && i0 + c <= k0 + kk) ? Tm[(size_t)(k0 + kk) * n + i0 + c] : 0.0;
+            b[q] = (row && c < nj && j0 + c <= k0 + kk) ? Tm[(size_t)(k0 + kk) * n + j0 + c] : 0.0;
         }
-        __syncthreads();
-    }
+    };
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int ii = t / DNB + 8 * q;
+    for (int p = 0; p < TTT_PF; p++) fetch(p, pi[p], pj[p]);
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    for (int s0 = 0; s0 < nsteps; s0 += TTT_PF) {
+#pragma unroll
+        for (int p = 0; p < TTT_PF; p++) {
+            const int s = s0 + p;
+            if (s < nsteps) {
+                const int buf = s & 1;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int e = t + 256 * q;
+                    TI[buf][e / DNB][e % DNB] = pi[p][q];
+                    TJ[buf][e / DNB][e % DNB] = pj[p][q];
+                }
+                fetch(s + TTT_PF, pi[p], pj[p]);
+                __syncthreads();
+                acc = d_mfma_tn(TI[buf], TJ[buf], wv, lane, acc);
+            }
+        }
+    }
+    const int jj = 16 * (wv & 1) + (lane & 15);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int ii = 16 * (wv >> 1) + (lane >> 4) + 4 * e;
         if (ii < ni && jj < nj) {
-            W[(size_t)(i0 + ii) * n + j0 + jj] = acc[q];
-            W[(size_t)(j0 + jj) * n + i0 + ii] = acc[q];
+            W[(size_t)(i0 + ii) * n + j0 + jj] = acc[e];
+            W[(size_t)(j0 + jj) * n + i0 + ii] = acc[e];
         }
     }
 }
