@@ -1,17 +1,21 @@
 // Small dense f64 algebra of the EKF update on the device (gfx950): blocked Cholesky of the
-// 4N x 4N information matrix, triangular solves, SPD inverse.  Replaces the explicit
+// 4N x 4N information matrix, the solve with it, the SPD inverse.  Replaces the explicit
 // numpy.linalg.inv calls of reference kalman.py:753-754, 785-786, 797-799.
 //
-// Matrices are row-major with leading dimension n; the factor L overwrites the blocks below the
-// block diagonal in place, its 32x32 diagonal blocks go to a side array Ld (the diagonal blocks of
-// the matrix itself stay as they were: every workgroup of a panel launch reads them).  A matrix may carry extra rows
-// below row nb*32 (nb = ceil(n/32)): right-hand sides stored as ROWS.  The factorisation treats
-// them like any other block row, which turns them into (L^-1 b)^T -- the forward substitution of
-// a solve comes for free.
+// Matrices are row-major with leading dimension n.  A factorisation reads a working copy A (which
+// it destroys) and writes three things: the factor's blocks below the 32x32 block diagonal to an
+// array L of the same shape, its diagonal blocks to a side array Ld and their inverses to Lt (all
+// identity padded when n is not a multiple of 32).  A may carry extra rows below row nb*32
+// (nb = ceil(n/32)): right-hand sides stored as ROWS.  The factorisation treats them like any other
+// block row, which turns them into (L^-1 b)^T -- the forward substitution of a solve comes for
+// free; k_back_row finishes it.  32x32x32 block products run on the f64 matrix cores
+// (v_mfma_f64_16x16x4_f64); launches communicate through memory only, in a fixed order, so results
+// do not depend on workgroup scheduling.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #define DNB 32          // block size
+#define TTT_PF 3        // block products whose operands are in flight (k_ttt, k_tinv_level)
 
 // 1/d and 1/sqrt(d) from the hardware estimates plus two Newton steps (about 1 ulp).  The
 // factorisation has a column-by-column dependency chain; a correctly rounded divide or square
@@ -417,141 +421,6 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, doubl
     for (int e = t; e < DNB * DNB; e += 256) Lt[(size_t)(k + 1) * DNB * DNB + e] = Bc[e / DNB][e % DNB];
 }
 
-// ---- triangular solves with the factor, a slab of CH right-hand sides per workgroup --------------
-// Element (i, c) of the right-hand side / solution lives at B[i * sbi + c * sbc].
-//   FWD: L Y = B,   BWD: L^T X = Y   (both: the full solve of L L^T X = B)
-//   IDENT: the right-hand side is the identity (B is only written); with FWD alone this gives the
-//          lower-triangular inverse L^-1, whose column c is zero above row c -- the work starts there.
-// The slab lives in LDS for the whole substitution.  Per 32-row block: (a) all 256 threads subtract
-// the contribution of the rows already solved (a 32 x done x CH product, L streamed from memory),
-// (b) the diagonal block is staged in LDS and each wave solves the 32x32 triangle for its columns,
-// one row per lane, passing x_j between lanes by shuffle.  NT threads: the product of (a) is a chain
-// of memory latencies, more threads keep more loads in flight.
-template <int CH, bool IDENT, bool FWD, bool BWD, int NT>
-__global__ __launch_bounds__(NT) void k_tri_solve(const double *__restrict__ L, const double *__restrict__ Ld, int n,
-                                                  double *__restrict__ B,
-                                                   size_t sbi, size_t sbc, int ncols)
-{
-    extern __shared__ double Y[];                 // n x (CH + 1): odd row stride, conflict-free column reads
-    constexpr int YS = CH + 1;
-    __shared__ double T[DNB][CH + 1];
-    __shared__ double Dg[DNB][DNB + 1];
-    __shared__ double rDg[DNB];                   // reciprocals of the diagonal of the staged block
-    constexpr int PARTS = NT / DNB;               // partial sums per (row, column slab)
-    __shared__ double S[PARTS][DNB][CH + 1];
-    const int t = threadIdx.x;
-    const int lane = t & 63, wv = t >> 6;
-    const int col0 = blockIdx.x * CH;
-    const int nb = (n + DNB - 1) / DNB;
-    const int kb_first = (IDENT && FWD) ? col0 / DNB : 0;     // rows above are identically zero
-    const int j_first = kb_first * DNB;
-    for (int e = t; e < n * CH; e += NT) {
-        int i = e / CH, c = e % CH;
-        double v = 0.0;
-        if (col0 + c < ncols) v = IDENT ? (i == col0 + c ? 1.0 : 0.0) : B[(size_t)i * sbi + (size_t)(col0 + c) * sbc];
-        Y[i * YS + c] = v;
-    }
-    __syncthreads();
-    if (FWD) {
-        for (int kb = kb_first; kb < nb; kb++) {
-            const int i0 = kb * DNB, ni = min(DNB, n - i0);
-            for (int e = t; e < DNB * DNB; e += NT) {       // stage the diagonal block (identity padded)
-                int i = e / DNB, j = e % DNB;
-                const double v = Ld[(size_t)kb * DNB * DNB + e];      // diagonal blocks live in Ld (identity padded)
-                Dg[i][j] = v;
-                if (i == j) rDg[i] = 1.0 / v;
-            }
-            {
-                const int i = t / PARTS, part = t % PARTS;    // row i of the block, every PARTS-th j
-                double acc[CH];
-#pragma unroll
-                for (int c = 0; c < CH; c++) acc[c] = 0.0;
-                if (i < ni) {
-                    const double *Lrow = L + (size_t)(i0 + i) * n;
-#pragma unroll 4
-                    for (int j = j_first + part; j < i0; j += PARTS) {
-                        const double l = Lrow[j];
-#pragma unroll
-                        for (int c = 0; c < CH; c++) acc[c] = acc[c] + l * Y[j * YS + c];
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < CH; c++) S[part][i][c] = acc[c];
-            }
-            __syncthreads();
-            for (int e = t; e < DNB * CH; e += NT) {         // fixed-order sum of the partials
-                int i = e / CH, c = e % CH;
-                double v = 0.0;
-                for (int q = 0; q < PARTS; q++) v += S[q][i][c];
-                T[i][c] = (i < ni ? Y[(i0 + i) * YS + c] : 0.0) - v;
-            }
-            __syncthreads();
-            for (int c = wv; c < CH; c += NT / 64) {                // triangle: one row per lane, x_j by shuffle
-                const int i = lane & (DNB - 1);
-                double val = T[i][c];
-                for (int j = 0; j < DNB; j++) {
-                    const double xj = __shfl(val, j, 64) * rDg[j];
-                    if (i == j) val = xj;
-                    else if (i > j) val = val - Dg[i][j] * xj;
-                }
-                if (lane < ni) Y[(i0 + lane) * YS + c] = val;
-            }
-            __syncthreads();
-        }
-    }
-    if (BWD) {
-        for (int kb = nb - 1; kb >= 0; kb--) {
-            const int i0 = kb * DNB, ni = min(DNB, n - i0);
-            const int j0 = i0 + ni;
-            for (int e = t; e < DNB * DNB; e += NT) {
-                int i = e / DNB, j = e % DNB;
-                const double v = Ld[(size_t)kb * DNB * DNB + e];      // diagonal blocks live in Ld (identity padded)
-                Dg[i][j] = v;
-                if (i == j) rDg[i] = 1.0 / v;
-            }
-            {
-                const int i = t % DNB, part = t / DNB;        // lanes run along i: L[j][i0+i] is contiguous in i
-                double acc[CH];
-#pragma unroll
-                for (int c = 0; c < CH; c++) acc[c] = 0.0;
-                if (i < ni) {
-#pragma unroll 4
-                    for (int j = j0 + part; j < n; j += PARTS) {
-                        const double l = L[(size_t)j * n + i0 + i];
-#pragma unroll
-                        for (int c = 0; c < CH; c++) acc[c] = acc[c] + l * Y[j * YS + c];
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < CH; c++) S[part][i][c] = acc[c];
-            }
-            __syncthreads();
-            for (int e = t; e < DNB * CH; e += NT) {
-                int i = e / CH, c = e % CH;
-                double v = 0.0;
-                for (int q = 0; q < PARTS; q++) v += S[q][i][c];
-                T[i][c] = (i < ni ? Y[(i0 + i) * YS + c] : 0.0) - v;
-            }
-            __syncthreads();
-            for (int c = wv; c < CH; c += NT / 64) {
-                const int i = lane & (DNB - 1);
-                double val = T[i][c];
-                for (int j = DNB - 1; j >= 0; j--) {
-                    const double xj = __shfl(val, j, 64) * rDg[j];
-                    if (i == j) val = xj;
-                    else if (i < j) val = val - Dg[j][i] * xj;
-                }
-                if (lane < ni) Y[(i0 + lane) * YS + c] = val;
-            }
-            __syncthreads();
-        }
-    }
-    for (int e = t; e < n * CH; e += NT) {
-        int i = e / CH, c = e % CH;
-        if (col0 + c < ncols) B[(size_t)i * sbi + (size_t)(col0 + c) * sbc] = Y[i * YS + c];
-    }
-}
-
 // ---- backward substitution L^T x = y for ONE right-hand side (the row that went through the
 // factorisation), one 1024-thread workgroup, software-pipelined over the 32-row blocks:
 //   wave 0 owns the serial chain -- with x_k known it applies L_{k,k-1}^T x_k to the block above
@@ -671,6 +540,89 @@ __global__ __launch_bounds__(1024) void k_back_row(const double *__restrict__ L,
     for (int i = t; i < n; i += 1024) row[i] = Y[i];
 }
 
+// ---- T = L^-1 by recursive doubling ---------------------------------------------------------------
+// The factorisation leaves the inverses of the 32x32 diagonal blocks (Lt).  With T11 and T22 the
+// inverses of two neighbouring s x s diagonal parts, the block below the diagonal of the 2s x 2s
+// part is T21 = -T22 (L21 T11): two batched products per level, s = 32, 64, ... -- ten launches of
+// MFMA tile products for n = 804 instead of one long substitution per column slab.
+//   phase 0:  M  = L21 T11      (M: scratch, same coordinates as T21)
+//   phase 1:  T21 = -T22 M
+// One workgroup per 32x32 output tile; grid (sb, sb, pairs), sb = s / 32.
+__device__ __forceinline__ d4_t d_mfma_nn(double (*X)[DNB + 1], double (*Y)[DNB + 1], int wv, int lane, d4_t c)
+{
+    const int i = 16 * (wv >> 1) + (lane & 15), j = 16 * (wv & 1) + (lane & 15), kq = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < DNB / 4; kk++)
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(X[i][4 * kk + kq], Y[4 * kk + kq][j], c, 0, 0, 0);
+    return c;
+}
+
+__global__ __launch_bounds__(256) void k_tinv_base(const double *__restrict__ Lt, double *__restrict__ T, int n)
+{
+    const int b = blockIdx.x, t = threadIdx.x;
+    for (int e = t; e < DNB * DNB; e += 256) {
+        const int i = b * DNB + e / DNB, j = b * DNB + e % DNB;
+        if (i < n && j < n) T[(size_t)i * n + j] = Lt[(size_t)b * DNB * DNB + e];
+    }
+}
+
+template <int PHASE>
+__global__ __launch_bounds__(256) void k_tinv_level(const double *__restrict__ L, double *__restrict__ T,
+                                                    double *__restrict__ M, int n, int nb, int sb)
+{
+    const int b0 = 2 * sb * blockIdx.z, ib = blockIdx.y, jb = blockIdx.x;
+    const int bi = b0 + sb + ib, bj = b0 + jb;    // output tile (block row, block column)
+    if (bi >= nb) return;
+    __shared__ double Xs[2][DNB][DNB + 1];
+    __shared__ double Ys[2][DNB][DNB + 1];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const double *Xm = PHASE == 0 ? L : T;
+    const double *Ym = PHASE == 0 ? T : M;
+    double *Out = PHASE == 0 ? M : T;
+    const int k_lo = PHASE == 0 ? jb : 0;         // T11 is lower triangular: blocks k < jb are zero
+    const int nsteps = (PHASE == 0 ? sb - 1 : ib) - k_lo + 1;     // T22 likewise: k <= ib
+    const int kbase = (PHASE == 0 ? b0 : b0 + sb) + k_lo;         // block index of step 0 along the summed dimension
+    double px[TTT_PF][4], py[TTT_PF][4];
+    auto fetch = [&](int s, double (&a)[4], double (&b)[4]) {
+        const int kb = kbase + s;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int e = t + 256 * q, rr = e / DNB, cc = e % DNB;
+            const int xr = bi * DNB + rr, xc = kb * DNB + cc, yr = kb * DNB + rr, yc = bj * DNB + cc;
+            const bool on = s < nsteps;
+            a[q] = (on && xr < n && xc < n) ? Xm[(size_t)xr * n + xc] : 0.0;
+            b[q] = (on && yr < n && yc < n) ? Ym[(size_t)yr * n + yc] : 0.0;
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < TTT_PF; p++) fetch(p, px[p], py[p]);
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    for (int s0 = 0; s0 < nsteps; s0 += TTT_PF) {
+#pragma unroll
+        for (int p = 0; p < TTT_PF; p++) {
+            const int s = s0 + p;
+            if (s < nsteps) {
+                const int buf = s & 1;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int e = t + 256 * q;
+                    Xs[buf][e / DNB][e % DNB] = px[p][q];
+                    Ys[buf][e / DNB][e % DNB] = py[p][q];
+                }
+                fetch(s + TTT_PF, px[p], py[p]);
+                __syncthreads();
+                acc = d_mfma_nn(Xs[buf], Ys[buf], wv, lane, acc);
+            }
+        }
+    }
+    const int jj = bj * DNB + 16 * (wv & 1) + (lane & 15);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int ii = bi * DNB + 16 * (wv >> 1) + (lane >> 4) + 4 * e;
+        if (ii < n && jj < n) Out[(size_t)ii * n + jj] = PHASE == 0 ? acc[e] : -acc[e];
+    }
+}
+
 // ---- W = T^T T for lower-triangular T (= L^-1): the SPD inverse from the triangular inverse --------
 // One workgroup per 32x32 tile (I >= J) of W: W_IJ = sum over block rows k >= I of T_kI^T T_kJ, each
 // term one 32x32x32 product on the f64 matrix cores.  The blocks come from memory written by other
@@ -685,7 +637,6 @@ __device__ __forceinline__ d4_t d_mfma_tn(double (*X)[DNB + 1], double (*Y)[DNB 
     return c;
 }
 
-#define TTT_PF 3
 __global__ __launch_bounds__(256) void k_ttt(const double *__restrict__ Tm, int n, double *__restrict__ W)
 {
     const int I = blockIdx.y, J = blockIdx.x;

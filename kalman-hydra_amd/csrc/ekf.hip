@@ -34,7 +34,7 @@ struct hm_ctx {
     uint8_t *d_im8, *d_m8;
     std::vector<double> X0;          // state of the reference render
     // dense update on the device (n4 = 4N)
-    double *d_H, *d_Hz, *d_Hzc, *d_invW0, *d_Af[2], *d_Ld[2], *d_dx, *d_Wtmp, *d_X0, *d_Xn, *d_Wprior, *d_gain, *d_Awork, *d_Lt;
+    double *d_H, *d_Hz, *d_Hzc, *d_invW0, *d_Af[2], *d_Ld[2], *d_dx, *d_Wtmp, *d_X0, *d_Xn, *d_Wprior, *d_gain, *d_Awork, *d_Lt[2];
     std::vector<double> upd_X0;      // prior mean given to hm_update_begin
     int upd_last, upd_prev;          // which d_Af holds the factor of the last / previous step (-1: none)
     double *d_Wres;                  // the covariance resident on the device (the result of the last
@@ -78,7 +78,7 @@ static int ctx_free(hm_ctx *h)
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_tri, h->d_star_off, h->d_star_tri, h->d_edges, h->d_uv, h->d_tex, h->d_yim, h->d_ym, h->d_yfx,
                     h->d_yfy, h->d_yfxm, h->d_yfym, h->d_setup, h->d_cfgs, h->d_X, h->d_out, h->d_partial, h->d_im8, h->d_m8,
-                    h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_Ld[0], h->d_Ld[1], h->d_Wprior, h->d_gain, h->d_Awork, h->d_Lt, h->d_dx,
+                    h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_Ld[0], h->d_Ld[1], h->d_Wprior, h->d_gain, h->d_Awork, h->d_Lt[0], h->d_Lt[1], h->d_dx,
                     h->d_Wtmp, h->d_X0, h->d_Xn, h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk,
                     h->pool.hdr, h->pool.off, h->pool.xim, h->pool.xm, h->pool.yim, h->pool.ym, h->pool.xfx, h->pool.xfy,
                     h->pool.yfx, h->pool.yfy, h->pool.vxfx, h->pool.vyfy, h->pool.overflow, h->d_area};
@@ -142,7 +142,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->ref = Targets{nullptr, nullptr, nullptr, nullptr}; h->P = h->ref; h->Q = h->ref;
     h->d_setup = nullptr; h->d_cfgs = nullptr; h->d_X = h->d_out = h->d_partial = nullptr; h->d_im8 = h->d_m8 = nullptr;
     h->d_H = h->d_Hz = h->d_Hzc = h->d_invW0 = h->d_Af[0] = h->d_Af[1] = h->d_dx = h->d_Wtmp = nullptr;
-    h->d_Wprior = h->d_gain = h->d_Awork = h->d_Lt = nullptr; h->d_Wres = nullptr; h->pin = nullptr; h->pin_n = 0;
+    h->d_Wprior = h->d_gain = h->d_Awork = h->d_Lt[0] = h->d_Lt[1] = nullptr; h->d_Wres = nullptr; h->pin = nullptr; h->pin_n = 0;
     h->tri.assign(tri, tri + (size_t)3 * T);
     h->d_Ld[0] = h->d_Ld[1] = nullptr; h->d_X0 = h->d_Xn = nullptr;
     memset(&h->pool, 0, sizeof h->pool); h->d_area = nullptr;
@@ -192,7 +192,8 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         const size_t ld_bytes = (size_t)hm_cdiv((int)n4, DNB) * DNB * DNB * sizeof(double);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Ld[0], ld_bytes);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Ld[1], ld_bytes);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Lt, ld_bytes);     // inverses of the diagonal blocks, live during a factorisation
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Lt[0], ld_bytes);  // inverses of the factored diagonal blocks
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Lt[1], ld_bytes);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Wtmp, nn);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Hz, n4 * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Hzc, n4 * 4 * sizeof(double));
@@ -503,26 +504,30 @@ static int aug_rows(int n) { return hm_cdiv(n, DNB) * DNB + DNB; }
 
 // Cholesky of the n x n matrix in the working copy A (destroyed) into L / Ld; with_rhs: the
 // right-hand-side rows below the matrix go through the elimination too (dense_kernels.h)
-static void chol_factor(hm_ctx *h, double *A, double *L, double *Ld, int n, bool with_rhs)
+static void chol_factor(hm_ctx *h, double *A, double *L, double *Ld, double *Lt, int n, bool with_rhs)
 {
     const int nb = hm_cdiv(n, DNB);
     const int nrows = with_rhs ? aug_rows(n) : n;
     const int nbr = hm_cdiv(nrows, DNB);
-    hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, h->stream, A, Ld, h->d_Lt, n);
+    hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, h->stream, A, Ld, Lt, n);
     for (int k = 0; k < nb; k++) {
         const int mr = nbr - k - 1, mc = std::max(nb - k - 1, 1);
-        if (mr > 0) hipLaunchKernelGGL(k_chol_step, dim3(mc, mr), dim3(256), 0, h->stream, A, L, Ld, h->d_Lt, n, nrows, nb, k);
+        if (mr > 0) hipLaunchKernelGGL(k_chol_step, dim3(mc, mr), dim3(256), 0, h->stream, A, L, Ld, Lt, n, nrows, nb, k);
     }
 }
 
-#define INV_CH 4
-// SPD inverse from the factor: T = L^-1 (forward substitution of the identity, lower triangular),
-// then inv = T^T T.  `scratch` receives T.
-static void chol_inverse(hm_ctx *h, const double *L, const double *Ld, int n, double *scratch, double *out)
+// SPD inverse from the factor: T = L^-1 by recursive doubling from the inverted diagonal blocks Lt
+// (dense_kernels.h), then inv = T^T T.  `scratch` receives T; `out` serves as the scratch of the
+// doubling before it receives the result.
+static void chol_inverse(hm_ctx *h, const double *L, const double *Lt, int n, double *scratch, double *out)
 {
-    hipLaunchKernelGGL((k_tri_solve<INV_CH, true, true, false, 256>), dim3(hm_cdiv(n, INV_CH)), dim3(256),
-                       (size_t)n * (INV_CH + 1) * sizeof(double), h->stream, L, Ld, n, scratch, (size_t)n, (size_t)1, n);
     const int nb = hm_cdiv(n, DNB);
+    hipLaunchKernelGGL(k_tinv_base, dim3(nb), dim3(256), 0, h->stream, Lt, scratch, n);
+    for (int sb = 1; sb < nb; sb *= 2) {
+        const dim3 grid(sb, sb, hm_cdiv(nb, 2 * sb));
+        hipLaunchKernelGGL(k_tinv_level<0>, grid, dim3(256), 0, h->stream, L, scratch, out, n, nb, sb);
+        hipLaunchKernelGGL(k_tinv_level<1>, grid, dim3(256), 0, h->stream, L, scratch, out, n, nb, sb);
+    }
     hipLaunchKernelGGL(k_ttt, dim3(nb, nb), dim3(256), 0, h->stream, scratch, n, out);
 }
 
@@ -545,7 +550,7 @@ static double *solve_step(hm_ctx *h, int slot)
     double *rhs_row = A + (size_t)rhs_index * n4;
     hipLaunchKernelGGL(k_assemble, dim3(aug_rows(n4)), dim3(256), 0, h->stream, h->d_invW0, h->d_H, h->d_X0, h->d_X,
                        h->d_Hz, A, n4, rhs_index);
-    chol_factor(h, A, h->d_Af[slot], h->d_Ld[slot], n4, true);
+    chol_factor(h, A, h->d_Af[slot], h->d_Ld[slot], h->d_Lt[slot], n4, true);
     chol_backsolve_row(h, h->d_Af[slot], h->d_Ld[slot], n4);
     return h->d_Af[slot] + (rhs_row - A);
 }
@@ -559,19 +564,9 @@ extern "C" int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *
     }
     HM_HIP(hipSetDevice(h->device));
     const int n4 = 4 * h->N;
-    // the inverse keeps an n x 16 slab of doubles in LDS next to its static buffers: raise the
-    // dynamic-LDS cap of that kernel to what is left of the CU's 160 KiB
-    static size_t inv_lds_cap = 0;
-    if (inv_lds_cap == 0) {
-        hipFuncAttributes fa;
-        HM_HIP(hipFuncGetAttributes(&fa, (const void *)k_tri_solve<INV_CH, true, true, false, 256>));
-        const size_t cap = 160 * 1024 - fa.sharedSizeBytes - 1024;
-        HM_HIP(hipFuncSetAttribute((const void *)k_tri_solve<INV_CH, true, true, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)cap));
-        inv_lds_cap = cap;
-    }
-    HM_ARG((size_t)n4 * (INV_CH + 1) * sizeof(double) <= inv_lds_cap, "hm_update_begin: state dimension %d too large for "
-           "the on-device inverse (limit %d)", n4, (int)(inv_lds_cap / ((INV_CH + 1) * sizeof(double))));
+    // k_back_row keeps the right-hand side (one double per row, padded to whole blocks) in LDS
+    HM_ARG((size_t)hm_cdiv(n4, DNB) * DNB * sizeof(double) <= 64 * 1024, "hm_update_begin: state dimension %d too large for the "
+           "on-device solve (limit %d)", n4, 64 * 1024 / 8);
     // the prior stays in d_Wprior: it is the covariance to keep when no iterate is accepted
     const size_t nnb = (size_t)n4 * n4 * sizeof(double);
     if (W_prior)
@@ -580,8 +575,8 @@ extern "C" int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *
         HM_HIP(hipMemcpyAsync(h->d_Wprior, h->d_Wres, nnb, hipMemcpyDeviceToDevice, h->stream));
     HM_HIP(hipMemcpyAsync(h->d_Awork, h->d_Wprior, nnb, hipMemcpyDeviceToDevice, h->stream));
     h->d_Wres = h->d_Wprior;                     // d_Wtmp is scratch from here on
-    chol_factor(h, h->d_Awork, h->d_Af[0], h->d_Ld[0], n4, false);
-    chol_inverse(h, h->d_Af[0], h->d_Ld[0], n4, h->d_Wtmp, h->d_invW0);
+    chol_factor(h, h->d_Awork, h->d_Af[0], h->d_Ld[0], h->d_Lt[0], n4, false);
+    chol_inverse(h, h->d_Af[0], h->d_Lt[0], n4, h->d_Wtmp, h->d_invW0);
     HM_HIP(hipGetLastError());
     h->upd_X0.assign(X0, X0 + n4);
     HM_HIP(hipMemcpyAsync(h->d_X0, h->upd_X0.data(), (size_t)n4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -639,7 +634,7 @@ extern "C" int hm_update_cov(hm_ctx_t h, int which, double *W_out)
     } else {
         const int slot = which == 0 ? h->upd_last : h->upd_prev;
         if (slot < 0) { hm_set_error("hm_update_cov: no such step"); return HM_ERR_STATE; }
-        chol_inverse(h, h->d_Af[slot], h->d_Ld[slot], n4, h->d_Wtmp, h->d_H);      // d_H is free between steps
+        chol_inverse(h, h->d_Af[slot], h->d_Lt[slot], n4, h->d_Wtmp, h->d_H);      // d_H is free between steps
         HM_HIP(hipGetLastError());
         h->d_Wres = h->d_H;
     }
