@@ -2,6 +2,7 @@
 // Replaces cv::cuda::BroxOpticalFlow as called by processflow_gpu
 // (reference src/optical_flow_ext.cpp:294-331).
 #include "hm_common.h"
+#include <hip/hip_ext.h>
 #include "brox_kernels.h"
 #include <cmath>
 #include <cstdlib>
@@ -115,18 +116,21 @@ static SorPlan sor_plan(const Geo &g, int solver, int fuse, int threads)
     return p;
 }
 
-static void sor_launch(const SorPlan &p, SorArgs a, int n, hipStream_t s)
+// e0 / e1 (profiling): events that receive the start and stop time of the kernel itself
+// (hipExtLaunchKernelGGL), the duration a kernel trace reports -- events recorded around the launch
+// would add the command processor's dispatch latency (~4 us) to every launch
+static void sor_launch(const SorPlan &p, SorArgs a, int n, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
 {
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y;
     a.step_x = p.step_x; a.step_y = p.step_y;
     a.halo_x = p.halo_x; a.halo_y = p.halo_y;
     dim3 grid(p.tiles_x * p.tiles_y, 1, n);
     if (p.threads == 1024)
-        hipLaunchKernelGGL((k_sor<SOR_TW, SOR_TH, 1024>), grid, dim3(1024), 0, s, a, p.K);
+        hipExtLaunchKernelGGL((k_sor<SOR_TW, SOR_TH, 1024>), grid, dim3(1024), 0, s, e0, e1, 0, a, p.K);
     else if (p.threads == 512)
-        hipLaunchKernelGGL((k_sor<SOR_TW, SOR_TH, 512>), grid, dim3(512), 0, s, a, p.K);
+        hipExtLaunchKernelGGL((k_sor<SOR_TW, SOR_TH, 512>), grid, dim3(512), 0, s, e0, e1, 0, a, p.K);
     else
-        hipLaunchKernelGGL((k_sor<SOR_TW, SOR_TH, 256>), grid, dim3(256), 0, s, a, p.K);
+        hipExtLaunchKernelGGL((k_sor<SOR_TW, SOR_TH, 256>), grid, dim3(256), 0, s, e0, e1, 0, a, p.K);
 }
 
 // ---- handle ------------------------------------------------------------------------------
@@ -409,11 +413,10 @@ static int brox_run(hm_brox *h, int n, const uint8_t *d_f0, const uint8_t *d_f1,
                         h->ev.push_back(e0);
                         h->ev.push_back(e1);
                     }
-                    HM_HIP(hipEventRecord(h->ev[h->ev_used], s));
                 }
-                sor_launch(plan, a, n, s);
+                if (rec) sor_launch(plan, a, n, s, h->ev[h->ev_used], h->ev[h->ev_used + 1]);
+                else sor_launch(plan, a, n, s);
                 if (rec) {
-                    HM_HIP(hipEventRecord(h->ev[h->ev_used + 1], s));
                     h->ev_used += 2;
                     h->ev_pxit.push_back((double)g.w * g.h * n * plan.K);
                 }
