@@ -174,6 +174,10 @@ int hm_measure(hm_ctx_t h, const double *X, double deltaX, int masked,
  * A non-positive-definite system shows up as NaNs in `step`. */
 int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *X0);   /* W_prior NULL: the covariance
                                                                               resident on the device */
+/* queue the covariance half of the next hm_update_begin / hm_update_run(h, NULL, ...) -- factoring and
+ * inverting the covariance resident on the device -- and return; it does not need the predicted state,
+ * so it can run while the host predicts the state (hm_ms_newton) */
+int hm_update_prefactor(hm_ctx_t h);
 int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int masked, double *step, double *Hzc,
                    double err[4]);
 int hm_update_cov(hm_ctx_t h, int which, double *W_out);                     /* W_out NULL: stays on the device */

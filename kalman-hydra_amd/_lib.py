@@ -63,6 +63,7 @@ SIGNATURES = {
     "hm_update_begin": (ctypes.c_int, [c_vp, c_vp, c_vp]),
     "hm_update_step": (ctypes.c_int, [c_vp, c_vp, ctypes.c_double, ctypes.c_int, c_vp, c_vp, c_f64p]),
     "hm_update_cov": (ctypes.c_int, [c_vp, ctypes.c_int, c_vp]),
+    "hm_update_prefactor": (ctypes.c_int, [c_vp]),
     "hm_update_run": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                      ctypes.POINTER(ctypes.c_int), c_vp, c_vp, c_vp, c_vp]),
     "hm_cov_fetch": (ctypes.c_int, [c_vp, c_vp]),

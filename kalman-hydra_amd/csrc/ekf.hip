@@ -51,6 +51,7 @@ struct hm_ctx {
     double *d_sp_blk;
     size_t sp_cap;                   // capacity (springs) of the d_sp_* arrays
     bool upd_open;
+    bool prefactored;                // d_invW0 is the inverse of the resident covariance d_Wprior (hm_update_prefactor)
     std::vector<double> h_partial;
     int red_blocks;
     int vsplit;                      // workgroups per vertex job of the measurement (hm_ctx_tune)
@@ -147,7 +148,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->d_Ld[0] = h->d_Ld[1] = nullptr; h->d_X0 = h->d_Xn = nullptr;
     memset(&h->pool, 0, sizeof h->pool); h->d_area = nullptr;
     h->d_sp_off = h->d_sp_bar = h->d_sp_other = nullptr; h->d_sp_blk = nullptr; h->sp_cap = 0;
-    h->upd_last = h->upd_prev = -1; h->upd_open = false;
+    h->upd_last = h->upd_prev = -1; h->upd_open = false; h->prefactored = false;
     for (const auto &e : eset) { h->edges.push_back(e.first); h->edges.push_back(e.second); }
     h->E = (int)eset.size();
     h->njobs = N + h->E;
@@ -555,14 +556,9 @@ static double *solve_step(hm_ctx *h, int slot)
     return h->d_Af[slot] + (rhs_row - A);
 }
 
-extern "C" int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *X0)
+// the covariance half of hm_update_begin: the prior into d_Wprior, its factor, inv(W) into d_invW0
+static int prior_inverse(hm_ctx *h, const double *W_prior)
 {
-    HM_ARG(h && X0, "hm_update_begin: NULL argument");
-    if (!W_prior && !h->d_Wres) {
-        hm_set_error("hm_update_begin: no prior given and none resident on the device");
-        return HM_ERR_STATE;
-    }
-    HM_HIP(hipSetDevice(h->device));
     const int n4 = 4 * h->N;
     // k_back_row keeps the right-hand side (one double per row, padded to whole blocks) in LDS
     HM_ARG((size_t)hm_cdiv(n4, DNB) * DNB * sizeof(double) <= 64 * 1024, "hm_update_begin: state dimension %d too large for the "
@@ -578,6 +574,39 @@ extern "C" int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *
     chol_factor(h, h->d_Awork, h->d_Af[0], h->d_Ld[0], h->d_Lt[0], n4, false);
     chol_inverse(h, h->d_Af[0], h->d_Lt[0], n4, h->d_Wtmp, h->d_invW0);
     HM_HIP(hipGetLastError());
+    return HM_OK;
+}
+
+// Start the covariance half of the next hm_update_begin / hm_update_run(h, NULL, ...) now: the
+// factorisation and inversion of the covariance resident on the device are queued and the call
+// returns.  They need the predicted covariance only, not the predicted state, so a caller whose
+// state prediction runs on the host (hm_ms_newton) overlaps the two.
+extern "C" int hm_update_prefactor(hm_ctx_t h)
+{
+    HM_ARG(h != nullptr, "hm_update_prefactor: NULL handle");
+    if (!h->d_Wres) { hm_set_error("hm_update_prefactor: no covariance resident on the device"); return HM_ERR_STATE; }
+    HM_HIP(hipSetDevice(h->device));
+    int rc = prior_inverse(h, nullptr);
+    if (rc) return rc;
+    h->prefactored = true;
+    h->upd_open = false;                          // the factor slots are being reused
+    return HM_OK;
+}
+
+extern "C" int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *X0)
+{
+    HM_ARG(h && X0, "hm_update_begin: NULL argument");
+    if (!W_prior && !h->d_Wres) {
+        hm_set_error("hm_update_begin: no prior given and none resident on the device");
+        return HM_ERR_STATE;
+    }
+    HM_HIP(hipSetDevice(h->device));
+    const int n4 = 4 * h->N;
+    if (!(h->prefactored && !W_prior && h->d_Wres == h->d_Wprior)) {
+        int rc = prior_inverse(h, W_prior);
+        if (rc) return rc;
+    }
+    h->prefactored = false;
     h->upd_X0.assign(X0, X0 + n4);
     HM_HIP(hipMemcpyAsync(h->d_X0, h->upd_X0.data(), (size_t)n4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     h->upd_last = h->upd_prev = -1;
@@ -836,5 +865,6 @@ extern "C" int hm_cov_predict(hm_ctx_t h, const double *W_in, int n_bars, const 
     if (W_out) HM_HIP(hipMemcpyAsync(W_out, h->d_Wtmp, nn, hipMemcpyDeviceToHost, h->stream));
     if (W_out) HM_HIP(hipStreamSynchronize(h->stream));
     h->d_Wres = h->d_Wtmp;
+    h->prefactored = false;
     return HM_OK;
 }

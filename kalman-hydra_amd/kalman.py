@@ -690,10 +690,15 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
         self.orig_x = st.X.copy()
         # F = [[I, dt I], [dt/M dfdy, I]] at the state before the step (:856)
         if hasattr(st.renderer, "cov_predict"):
+            # the covariance half first: it is queued on the device (prediction, then the
+            # factorisation and inversion the update starts with) and runs while the host works
+            # through the Newton iterations of the state
             blocks = self._spring_blocks()
-            self._newton()
             st.W = st.renderer.cov_predict(st._W, self._bars, blocks, self.deltat, self.deltat / self.M, st.eps_F,
                                            fetch=False)
+            if self.fused_update and hasattr(st.renderer, "update_prefactor"):
+                st.renderer.update_prefactor(st._W)
+            self._newton()
         else:
             A = self._jacobian() * (self.deltat / self.M)
             self._newton()

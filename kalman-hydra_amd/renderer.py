@@ -226,6 +226,13 @@ class Renderer:
                                              float(eps_F), None), "hm_cov_predict")
         return self._cov_result(fetch)
 
+    def update_prefactor(self, W):
+        """hm_update_prefactor: queue the factorisation / inversion of the DeviceCovariance W now (it
+        does not need the predicted state); the next update_begin / update_run with W picks it up."""
+        if self._cov_arg(W, "update_prefactor") is not None:
+            raise TypeError("update_prefactor takes the DeviceCovariance resident on the device")
+        _lib.check(_lib.lib().hm_update_prefactor(self._h), "hm_update_prefactor")
+
     def update_begin(self, W_prior, X0):
         """Factor the prior covariance on the device and keep inv(W), X0 there (hm_update_begin).
         A DeviceCovariance is used where it is."""

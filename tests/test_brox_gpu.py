@@ -157,3 +157,31 @@ def test_errors_are_loud(hm):
         bf.calc(np.zeros((64, 64), np.float32), np.zeros((64, 64), np.float32))
     with pytest.raises(RuntimeError):
         bf.tune("sor_fuse", 3)        # 3 does not divide solver_iterations = 10
+
+
+def test_prepare_and_profile_totals(hm, oracle_brox):
+    """hm_brox_prepare captures the launch series ahead of the first call (same result); switching
+    the profile off keeps the recorded totals for profile_read."""
+    from hydra_mi import brox, synth
+    n = 80
+    f0, f1, _, _ = synth.warp_pair(n, "rotate", 1)
+    ru, rv = oracle_brox.calc(f0, f1)
+    bf = brox.BroxOpticalFlow(n, n, max_batch=2)
+    bf.prepare(1)
+    bf.prepare(2)
+    u, v = bf.calc(f0, f1)
+    assert np.array_equal(u, ru) and np.array_equal(v, rv)
+    with pytest.raises(RuntimeError):
+        bf.prepare(3)                 # beyond max_batch
+    bf.profile(True)
+    bf.calc(f0, f1)
+    bf.profile(False)
+    u2, v2 = bf.calc(f0, f1)          # a replayed graph: not recorded
+    ms, launches, pxit = bf.profile_read()
+    assert launches > 0 and ms > 0 and pxit > 0
+    assert np.array_equal(u2, ru) and np.array_equal(v2, rv)
+    per_call = launches
+    bf.profile(True)
+    bf.calc(f0, f1)
+    ms2, launches2, _ = bf.profile_read()
+    assert launches2 == per_call

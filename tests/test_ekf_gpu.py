@@ -400,3 +400,26 @@ def test_dense_update_is_deterministic_under_contention(hm):
         cov_busy = R.update_cov(0)
         bf.sync()
         assert np.array_equal(busy, quiet) and e_busy == e_quiet and np.array_equal(cov_busy, cov_quiet), trial
+
+
+def test_measure_split_changes_only_the_summation_order(hm):
+    """hm_ctx_tune("measure_split"): more or fewer workgroups per vertex give the same sums up to
+    the rounding of another summation order."""
+    dm, N, tex, R, meas = _setup(hm, 96, 9.0, seed=4)
+    rng = np.random.default_rng(12)
+    X = _state(dm, rng, pos_sigma=0.5)
+    y_im, flow, y_m = _observation(dm, meas, rng, 96)
+    st = _Flow()
+    st.X = X.reshape(-1, 1)
+    R.update_frame(y_im, flow, y_m)
+    Hz0, HTH0, Hzc0 = R.measure(st, y_im, flow, y_m)
+    for split in (1, 2, 7, 16):
+        R.tune("measure_split", split)
+        Hz, HTH, Hzc = R.measure(st, y_im, flow, y_m)
+        assert np.abs(Hz - Hz0).max() <= 1e-12 * np.abs(Hz0).max(), split
+        assert np.abs(HTH - HTH0).max() <= 1e-12 * np.abs(HTH0).max(), split
+        assert np.abs(Hzc - Hzc0).max() <= 1e-12 * np.abs(Hzc0).max(), split
+    with pytest.raises(RuntimeError):
+        R.tune("measure_split", 17)
+    with pytest.raises(RuntimeError):
+        R.tune("no_such_knob", 1)
