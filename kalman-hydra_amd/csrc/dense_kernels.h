@@ -188,10 +188,35 @@ __device__ __forceinline__ double d_readlane(double v, int lane)
 // four at a time; wave 0 factors a 32x4 strip in registers (row i in lane i, pivots and multipliers
 // passed by v_readlane: no LDS, no barrier on the column-to-column chain), then all four waves
 // apply the rank-4 update to the columns to the right.  16 barriers instead of 32.
+//
+// INV: the inverse T = L^-1 comes out of the same sweep -- the elimination applied to an identity
+// block (Tm must hold the identity on entry; L^-1 A = L^T, L^-1 I = T) -- one strip behind the
+// factorisation and off its critical path: while wave 0 factors strip g, wave 1 finishes the four
+// rows of T that belong to strip g-1 (lanes = columns); in the rank-4 phase the threads whose column
+// lies left of strip g-1 -- idle in the update of W, which only touches columns to the right --
+// apply the rank-4 update of strip g-1 to the rows of T below it.  With T at hand the panel solves
+// of a step are plain products (MFMA) instead of 32-step substitution chains.
+template <bool INV>
 __device__ __forceinline__ void chol_block_factor(double (*W)[DNB + 1], double (*D)[DNB + 1], double *rD,
-                                                  double (*LS)[5], int t)
+                                                  double (*Tm)[DNB + 1], double (*ES)[DNB + 1], int t)
 {
     const int ti = t / DNB, tc = t % DNB;
+    // rows p0 .. p0+3 of T from the finished strip at columns p0 (D, rD), column c per lane:
+    // e_jj = (e_jj - sum_{m<jj} L[p0+jj][p0+m] e_m) / L[p0+jj][p0+jj]
+    auto t_rows = [&](int p0, int c) {
+        double e[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) e[jj] = Tm[p0 + jj][c];
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            double acc = e[jj];
+#pragma unroll
+            for (int m = 0; m < jj; m++) acc = acc - D[p0 + jj][p0 + m] * e[m];
+            e[jj] = acc * rD[p0 + jj];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) { Tm[p0 + jj][c] = e[jj]; ES[jj][c] = e[jj]; }
+    };
 #pragma unroll
     for (int g = 0; g < DNB / 4; g++) {
         const int j0 = 4 * g;
@@ -215,100 +240,40 @@ __device__ __forceinline__ void chol_block_factor(double (*W)[DNB + 1], double (
                 for (int jj = 0; jj < 4; jj++) {
                     const double v = i >= j0 + jj ? w[jj] : 0.0;
                     D[i][j0 + jj] = v;
-                    LS[i][jj] = v;
+                }
+            }
+        } else if (INV && g > 0 && t < 64 + DNB) {
+            t_rows(j0 - 4, t - 64);
+        }
+        __syncthreads();
+        // Rank-4 phase, one code path for both jobs (a wave holds columns of either kind; two branches
+        // would run one after the other): a thread right of strip g updates its column of W with the
+        // strip's multipliers, a thread left of strip g-1 its column of T with those of strip g-1.
+        {
+            const bool upd_w = tc >= j0 + 4;
+            const bool upd_t = INV && g > 0 && tc < j0;
+            if (upd_w || upd_t) {
+                const int p0 = upd_w ? j0 : j0 - 4;                   // the strip whose multipliers are used
+                double (*M)[DNB + 1] = upd_w ? W : Tm;
+                const int first = upd_w ? tc : j0;                    // rows from here down are touched
+                double c[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) c[jj] = upd_w ? D[tc][p0 + jj] : ES[jj][tc];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int i = ti + 8 * q;
+                    if (i >= first) {
+                        double v = M[i][tc];
+#pragma unroll
+                        for (int jj = 0; jj < 4; jj++) v = v - D[i][p0 + jj] * c[jj];
+                        M[i][tc] = v;
+                    }
                 }
             }
         }
-        if (g == DNB / 4 - 1) break;
-        __syncthreads();
-        if (tc >= j0 + 4) {
-            const double c0 = LS[tc][0], c1 = LS[tc][1], c2 = LS[tc][2], c3 = LS[tc][3];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int i = ti + 8 * q;
-                if (i >= tc) {
-                    double v = W[i][tc];
-                    v = v - LS[i][0] * c0;
-                    v = v - LS[i][1] * c1;
-                    v = v - LS[i][2] * c2;
-                    v = v - LS[i][3] * c3;
-                    W[i][tc] = v;
-                }
-            }
-        }
         __syncthreads();
     }
-}
-
-// T = L^-1 of the factored 32x32 block D (LDS; rD = reciprocals of its diagonal), all 256 threads.
-// Recursive: the four 8x8 diagonal triangles by substitution (one column per thread), then the
-// off-diagonal blocks T21 = -T22 (L21 T11) at sizes 8 and 16.  With the inverse at hand the panel
-// solves of a step are plain products (MFMA) instead of 32-step substitution chains.
-__device__ __forceinline__ void chol_block_inverse(double (*D)[DNB + 1], const double *rD, double (*Tm)[DNB + 1],
-                                                   double (*Ms)[DNB / 2 + 1], int t)
-{
-    // 8x8 diagonal triangles: thread (g, i), t < 32, solves column i of triangle g by substitution;
-    // its part of D goes to registers first so that the chain has no LDS round trips.  The other
-    // threads clear the rest of T meanwhile.
-    if (t < DNB) {
-        const int g = t / 8, i = t % 8, b0 = 8 * g;
-        double dl[8][8], rd[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            rd[j] = rD[b0 + j];
-#pragma unroll
-            for (int m = 0; m < 8; m++)
-                if (m < j) dl[j][m] = D[b0 + j][b0 + m];
-        }
-        double col[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            double acc = 0.0;
-#pragma unroll
-            for (int m = 0; m < 8; m++)
-                if (m < j) acc = acc + dl[j][m] * col[m];          // col[m] = 0 for m < i
-            col[j] = j == i ? rd[j] : (j > i ? -acc * rd[j] : 0.0);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) Tm[b0 + j][b0 + i] = col[j];
-    } else {
-        for (int e = t - DNB; e < DNB * DNB; e += 256 - DNB) {
-            const int i = e / DNB, j = e % DNB;
-            if ((i >> 3) != (j >> 3)) Tm[i][j] = 0.0;
-        }
-    }
-    __syncthreads();
-    if (t < 128) {                                // size 8: M = L21 T11 for the two 16x16 diagonal blocks
-        const int h = t / 64, b0 = 16 * h, i = (t % 64) / 8, j = t % 8;
-        double acc = 0.0;
-#pragma unroll
-        for (int m = 0; m < 8; m++) acc = acc + D[b0 + 8 + i][b0 + m] * Tm[b0 + m][b0 + j];
-        Ms[h * 8 + i][j] = acc;
-    }
-    __syncthreads();
-    if (t < 128) {                                //         T21 = -T22 M
-        const int h = t / 64, b0 = 16 * h, i = (t % 64) / 8, j = t % 8;
-        double acc = 0.0;
-#pragma unroll
-        for (int m = 0; m < 8; m++) acc = acc + Tm[b0 + 8 + i][b0 + 8 + m] * Ms[h * 8 + m][j];
-        Tm[b0 + 8 + i][b0 + j] = -acc;
-    }
-    __syncthreads();
-    const int i16 = t / 16, j16 = t % 16;
-    {                                             // size 16: M = L21 T11
-        double acc = 0.0;
-#pragma unroll
-        for (int m = 0; m < 16; m++) acc = acc + D[16 + i16][m] * Tm[m][j16];
-        Ms[i16][j16] = acc;                       // the size-8 values were consumed before the last barrier
-    }
-    __syncthreads();
-    {                                             //          T21 = -T22 M
-        double acc = 0.0;
-#pragma unroll
-        for (int m = 0; m < 16; m++) acc = acc + Tm[16 + i16][16 + m] * Ms[m][j16];
-        Tm[16 + i16][j16] = -acc;
-    }
-    __syncthreads();
+    if (INV && t < DNB) t_rows(DNB - 4, t);        // the last strip's rows; nothing lies below them
 }
 
 // One 16x16 tile of X Y^T for 32x32 blocks X, Y in LDS on the f64 matrix cores
@@ -332,20 +297,22 @@ __global__ __launch_bounds__(256) void k_chol_first(const double *__restrict__ A
     __shared__ double W[DNB][DNB + 1];
     __shared__ double D[DNB][DNB + 1];
     __shared__ double rD[DNB];
-    __shared__ double LS[DNB][5];
-    __shared__ double Ms[DNB / 2][DNB / 2 + 1];
+    __shared__ double Tm[DNB][DNB + 1];
+    __shared__ double ES[4][DNB + 1];
     const int t = threadIdx.x;
     const int nd = min(DNB, n);
     for (int e = t; e < DNB * DNB; e += 256) {
         const int i = e / DNB, j = e % DNB;
         W[i][j] = (i < nd && j <= i) ? A[(size_t)i * n + j] : (i == j ? 1.0 : 0.0);
+        Tm[i][j] = i == j ? 1.0 : 0.0;
     }
     __syncthreads();
-    chol_block_factor(W, D, rD, LS, t);
+    chol_block_factor<true>(W, D, rD, Tm, ES, t);
     __syncthreads();
-    for (int e = t; e < DNB * DNB; e += 256) Ld[e] = D[e / DNB][e % DNB];
-    chol_block_inverse(D, rD, W, Ms, t);
-    for (int e = t; e < DNB * DNB; e += 256) Lt[e] = W[e / DNB][e % DNB];
+    for (int e = t; e < DNB * DNB; e += 256) {
+        Ld[e] = D[e / DNB][e % DNB];
+        Lt[e] = Tm[e / DNB][e % DNB];
+    }
 }
 
 // Step k.  Workgroup (r, c), r >= c > k:  X_r = A_rk T^T, X_c = A_ck T^T with T = L_kk^-1 (Lt[k], from
@@ -363,8 +330,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, doubl
     __shared__ double Br[DNB][DNB + 1];           // A_rk, then X_r, then the updated block k+1
     __shared__ double Bc[DNB][DNB + 1];           // A_ck, then X_c, then the inverse of the new factor
     __shared__ double rD[DNB];
-    __shared__ double LS[DNB][5];
-    __shared__ double Ms[DNB / 2][DNB / 2 + 1];
+    __shared__ double ES[4][DNB + 1];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int d0 = k * DNB;
     const int nd = min(DNB, n - d0);
@@ -411,14 +377,17 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, doubl
     // the next diagonal block: finish its update, factor it and invert the factor now
     __syncthreads();                              // everyone is done reading X_r
 #pragma unroll
-    for (int e = 0; e < 4; e++)
+    for (int e = 0; e < 4; e++) {
         Br[mi[e]][mj] = (mi[e] < nc && mj <= mi[e]) ? a[e] - s[e] : (mi[e] == mj ? 1.0 : 0.0);
+        Bc[mi[e]][mj] = mi[e] == mj ? 1.0 : 0.0;
+    }
     __syncthreads();
-    chol_block_factor(Br, Ts, rD, LS, t);
+    chol_block_factor<true>(Br, Ts, rD, Bc, ES, t);
     __syncthreads();
-    for (int e = t; e < DNB * DNB; e += 256) Ld[(size_t)(k + 1) * DNB * DNB + e] = Ts[e / DNB][e % DNB];
-    chol_block_inverse(Ts, rD, Bc, Ms, t);
-    for (int e = t; e < DNB * DNB; e += 256) Lt[(size_t)(k + 1) * DNB * DNB + e] = Bc[e / DNB][e % DNB];
+    for (int e = t; e < DNB * DNB; e += 256) {
+        Ld[(size_t)(k + 1) * DNB * DNB + e] = Ts[e / DNB][e % DNB];
+        Lt[(size_t)(k + 1) * DNB * DNB + e] = Bc[e / DNB][e % DNB];
+    }
 }
 
 // ---- backward substitution L^T x = y for ONE right-hand side (the row that went through the
