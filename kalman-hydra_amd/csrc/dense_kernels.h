@@ -420,7 +420,8 @@ __device__ __forceinline__ double d_back_triangle(double (*D)[DNB + 1], double v
 }
 
 __global__ __launch_bounds__(1024) void k_back_row(const double *__restrict__ L, const double *__restrict__ Ld, int n,
-                                                   double *__restrict__ row)
+                                                   double *__restrict__ row, const double *__restrict__ x0,
+                                                   double *__restrict__ xn)
 {
     extern __shared__ double Y[];                 // nb * 32
     __shared__ double Xb[2][DNB];                 // x of block k in Xb[k & 1]
@@ -506,7 +507,10 @@ __global__ __launch_bounds__(1024) void k_back_row(const double *__restrict__ L,
         }
         __syncthreads();
     }
-    for (int i = t; i < n; i += 1024) row[i] = Y[i];
+    for (int i = t; i < n; i += 1024) {
+        row[i] = Y[i];
+        if (xn) xn[i] = x0[i] + 1.0 * Y[i];       // the update's new iterate X0 + step
+    }
 }
 
 // ---- T = L^-1 by recursive doubling ---------------------------------------------------------------

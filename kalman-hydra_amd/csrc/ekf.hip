@@ -34,6 +34,8 @@ struct hm_ctx {
     uint8_t *d_im8, *d_m8;
     std::vector<double> X0;          // state of the reference render
     // dense update on the device (n4 = 4N)
+    double *d_HTH;                   // dense HTH of the last measurement: zero outside the J pattern (cleared once;
+                                     // every pattern entry is rewritten by every measurement), used for nothing else
     double *d_H, *d_Hz, *d_Hzc, *d_invW0, *d_Af[2], *d_Ld[2], *d_dx, *d_Wtmp, *d_X0, *d_Xn, *d_Wprior, *d_gain, *d_Awork, *d_Lt[2];
     std::vector<double> upd_X0;      // prior mean given to hm_update_begin
     int upd_last, upd_prev;          // which d_Af holds the factor of the last / previous step (-1: none)
@@ -79,7 +81,7 @@ static int ctx_free(hm_ctx *h)
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_tri, h->d_star_off, h->d_star_tri, h->d_edges, h->d_uv, h->d_tex, h->d_yim, h->d_ym, h->d_yfx,
                     h->d_yfy, h->d_yfxm, h->d_yfym, h->d_setup, h->d_cfgs, h->d_X, h->d_out, h->d_partial, h->d_im8, h->d_m8,
-                    h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_Ld[0], h->d_Ld[1], h->d_Wprior, h->d_gain, h->d_Awork, h->d_Lt[0], h->d_Lt[1], h->d_dx,
+                    h->d_HTH, h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_Ld[0], h->d_Ld[1], h->d_Wprior, h->d_gain, h->d_Awork, h->d_Lt[0], h->d_Lt[1], h->d_dx,
                     h->d_Wtmp, h->d_X0, h->d_Xn, h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk,
                     h->pool.hdr, h->pool.off, h->pool.xim, h->pool.xm, h->pool.yim, h->pool.ym, h->pool.xfx, h->pool.xfy,
                     h->pool.yfx, h->pool.yfy, h->pool.vxfx, h->pool.vyfy, h->pool.overflow, h->d_area};
@@ -142,6 +144,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->d_yim = h->d_ym = nullptr; h->d_yfx = h->d_yfy = h->d_yfxm = h->d_yfym = nullptr;
     h->ref = Targets{nullptr, nullptr, nullptr, nullptr}; h->P = h->ref; h->Q = h->ref;
     h->d_setup = nullptr; h->d_cfgs = nullptr; h->d_X = h->d_out = h->d_partial = nullptr; h->d_im8 = h->d_m8 = nullptr;
+    h->d_HTH = nullptr;
     h->d_H = h->d_Hz = h->d_Hzc = h->d_invW0 = h->d_Af[0] = h->d_Af[1] = h->d_dx = h->d_Wtmp = nullptr;
     h->d_Wprior = h->d_gain = h->d_Awork = h->d_Lt[0] = h->d_Lt[1] = nullptr; h->d_Wres = nullptr; h->pin = nullptr; h->pin_n = 0;
     h->tri.assign(tri, tri + (size_t)3 * T);
@@ -185,6 +188,8 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_m8, n);
         const size_t n4 = (size_t)4 * N, nn = n4 * n4 * sizeof(double);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_H, nn);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_HTH, nn);
+        if (e == hipSuccess) e = hipMemsetAsync(h->d_HTH, 0, nn, h->stream);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_invW0, nn);
         const size_t nn_aug = (size_t)(hm_cdiv((int)n4, DNB) * DNB + DNB) * n4 * sizeof(double);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Af[0], nn_aug);
@@ -461,10 +466,7 @@ static int measure_dev(hm_ctx *h, const double *dX, bool ref_ready, double delta
     hipLaunchKernelGGL(k_region_offsets, dim3(1), dim3(256), 0, h->stream, h->d_area, h->N, h->pool);
     hipLaunchKernelGGL(k_measure_vertex, dim3(h->N, h->vsplit), dim3(MEAS_NT), 0, h->stream, a);
     if (h->E > 0) hipLaunchKernelGGL(k_measure_edge, dim3(h->E), dim3(MEAS_NT), 0, h->stream, a);
-    const size_t n4 = (size_t)4 * h->N;
-    if (h->d_Wres == h->d_H) h->d_Wres = nullptr;    // d_H is about to be overwritten
-    HM_HIP(hipMemsetAsync(h->d_H, 0, n4 * n4 * sizeof(double), h->stream));
-    ScatterArgs s = {h->d_out, h->d_edges, h->N, h->E, h->vsplit, h->eps_Z, h->eps_J, h->eps_M, deltaX, h->d_H, h->d_Hz, h->d_Hzc};
+    ScatterArgs s = {h->d_out, h->d_edges, h->N, h->E, h->vsplit, h->eps_Z, h->eps_J, h->eps_M, deltaX, h->d_HTH, h->d_Hz, h->d_Hzc};
     hipLaunchKernelGGL(k_hth_scatter, dim3(hm_cdiv(h->njobs, 64)), dim3(64), 0, h->stream, s);
     HM_HIP(hipGetLastError());
     return HM_OK;
@@ -490,7 +492,7 @@ extern "C" int hm_measure(hm_ctx_t h, const double *X, double deltaX, int masked
     const size_t n4 = (size_t)4 * h->N;
     HM_HIP(hipMemcpyAsync(Hz, h->d_Hz, n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (Hzc) HM_HIP(hipMemcpyAsync(Hzc, h->d_Hzc, n4 * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HM_HIP(hipMemcpyAsync(HTH, h->d_H, n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HM_HIP(hipMemcpyAsync(HTH, h->d_HTH, n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     int ovf = 0;
     HM_HIP(hipMemcpyAsync(&ovf, h->pool.overflow, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HM_HIP(hipStreamSynchronize(h->stream));
@@ -533,10 +535,12 @@ static void chol_inverse(hm_ctx *h, const double *L, const double *Lt, int n, do
 }
 
 // backward substitution L^T x = y for the right-hand side that went through the factorisation as a row
-static void chol_backsolve_row(hm_ctx *h, double *A, const double *Ld, int n)
+// (x0, xn: if given, xn = x0 + x is written as well -- the new iterate of the update)
+static void chol_backsolve_row(hm_ctx *h, double *A, const double *Ld, int n, const double *x0, double *xn)
 {
     double *row = A + (size_t)hm_cdiv(n, DNB) * DNB * n;     // y^T, overwritten by x^T
-    hipLaunchKernelGGL(k_back_row, dim3(1), dim3(1024), (size_t)hm_cdiv(n, DNB) * DNB * sizeof(double), h->stream, A, Ld, n, row);
+    hipLaunchKernelGGL(k_back_row, dim3(1), dim3(1024), (size_t)hm_cdiv(n, DNB) * DNB * sizeof(double), h->stream, A, Ld, n, row,
+                       x0, xn);
 }
 
 // one iteration's worth of launches of the update: system assembly, factorisation, solve.
@@ -549,10 +553,10 @@ static double *solve_step(hm_ctx *h, int slot)
     // matrix; the rows in between and the rest of that block zero
     const int rhs_index = hm_cdiv(n4, DNB) * DNB;
     double *rhs_row = A + (size_t)rhs_index * n4;
-    hipLaunchKernelGGL(k_assemble, dim3(aug_rows(n4)), dim3(256), 0, h->stream, h->d_invW0, h->d_H, h->d_X0, h->d_X,
+    hipLaunchKernelGGL(k_assemble, dim3(aug_rows(n4)), dim3(256), 0, h->stream, h->d_invW0, h->d_HTH, h->d_X0, h->d_X,
                        h->d_Hz, A, n4, rhs_index);
     chol_factor(h, A, h->d_Af[slot], h->d_Ld[slot], h->d_Lt[slot], n4, true);
-    chol_backsolve_row(h, h->d_Af[slot], h->d_Ld[slot], n4);
+    chol_backsolve_row(h, h->d_Af[slot], h->d_Ld[slot], n4, h->d_X0, h->d_Xn);     // also d_Xn = X0 + step
     return h->d_Af[slot] + (rhs_row - A);
 }
 
@@ -635,7 +639,6 @@ extern "C" int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int ma
     HM_HIP(hipMemcpyAsync(&ovf, h->pool.overflow, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (err) {
         // Renderer.error of the new iterate X0 + step, without another host round trip
-        hipLaunchKernelGGL(k_vec_axpy, dim3(hm_cdiv(n4, 256)), dim3(256), 0, h->stream, h->d_X0, rhs_row, 1.0, h->d_Xn, n4);
         rc = render_dev(h, h->d_Xn, h->P);
         if (rc) return rc;
         hipLaunchKernelGGL(k_error, dim3(h->red_blocks), dim3(RED_NT), 0, h->stream, h->P, obs_of(h, masked),
@@ -663,7 +666,7 @@ extern "C" int hm_update_cov(hm_ctx_t h, int which, double *W_out)
     } else {
         const int slot = which == 0 ? h->upd_last : h->upd_prev;
         if (slot < 0) { hm_set_error("hm_update_cov: no such step"); return HM_ERR_STATE; }
-        chol_inverse(h, h->d_Af[slot], h->d_Lt[slot], n4, h->d_Wtmp, h->d_H);      // d_H is free between steps
+        chol_inverse(h, h->d_Af[slot], h->d_Lt[slot], n4, h->d_Wtmp, h->d_H);
         HM_HIP(hipGetLastError());
         h->d_Wres = h->d_H;
     }
@@ -716,7 +719,6 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
         const int slot = h->upd_last == 0 ? 1 : 0;
         double *rhs_row = solve_step(h, slot);
         // the new iterate, its render and Renderer.error (kalman.py:813)
-        hipLaunchKernelGGL(k_vec_axpy, dim3(hm_cdiv(n4, 256)), dim3(256), 0, h->stream, h->d_X0, rhs_row, 1.0, h->d_Xn, n4);
         rc = render_dev(h, h->d_Xn, h->P);
         if (rc) return rc;
         hipLaunchKernelGGL(k_error, dim3(h->red_blocks), dim3(RED_NT), 0, h->stream, h->P, obs_of(h, masked),

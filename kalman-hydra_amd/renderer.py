@@ -188,7 +188,6 @@ class Renderer:
         HTH = np.empty((n4, n4))
         _lib.check(_lib.lib().hm_measure(self._h, _lib.ptr(self._X(state)), float(deltaX), masked, _lib.ptr(Hz),
                                          _lib.ptr(Hzc), _lib.ptr(HTH)), "hm_measure")
-        self._cov_serial += 1                   # the resident covariance may have shared that buffer
         return Hz.reshape(-1, 1), HTH, Hzc
 
     # -- the dense update on the device (information form) --------------------------------------
@@ -273,7 +272,6 @@ class Renderer:
         _lib.check(_lib.lib().hm_update_step(self._h, _lib.ptr(self._X(state)), float(deltaX), masked,
                                              _lib.ptr(step), _lib.ptr(Hzc), err if want_error else None),
                    "hm_update_step")
-        self._cov_serial += 1                   # the measurement reuses the buffer of update_cov's result
         e = (int(err[0]), err[1], err[2], int(err[3])) if want_error else None
         return step.reshape(-1, 1), Hzc, e
 
