@@ -218,12 +218,7 @@ extern "C" int hm_brox_create(int device, int W, int H, int max_batch, float alp
     // padding columns are read (never used) by float2 loads: keep them finite.  The fill
     // goes on the handle's own stream: that stream is non-blocking, so a fill issued on the
     // null stream could still be running when the first calc starts.
-    {   // throughput work: lowest priority, so that a tracker's short latency-bound launches on
-        // another stream are not queued behind whole flow batches
-        int prio_least = 0, prio_greatest = 0;
-        e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_least);
-    }
+    e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMemsetAsync(h->arena, 0, h->arena_floats * sizeof(float), h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_f0, B * W * H);

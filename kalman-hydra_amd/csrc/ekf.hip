@@ -166,12 +166,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     step(upload(&h->d_star_tri, flat.data(), flat.size()));
     step(upload(&h->d_edges, h->edges.data(), h->edges.size()));
     if (rc == HM_OK) {
-        // The filter's launches are short and chained (the host waits on each iteration); a flow batch
-        // running beside them on another stream fills every CU.  Highest priority lets the small
-        // kernels in as soon as any workgroup slot frees up.
-        int prio_least = 0, prio_greatest = 0;
-        hipError_t e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_greatest);
+        hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_tex, n);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_yim, n);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_ym, n);
@@ -462,12 +457,12 @@ static int measure_dev(hm_ctx *h, const double *dX, bool ref_ready, double delta
     a.pool = h->pool;
     a.vsplit = h->vsplit;
     a.cfgs = h->d_cfgs;
-    hipLaunchKernelGGL(k_star_regions, dim3(h->N), dim3(64), 0, h->stream, a, h->d_area);
+    hipLaunchKernelGGL(k_star_regions, dim3(h->N), dim3(REGION_NT), 0, h->stream, a, h->d_area);
     hipLaunchKernelGGL(k_region_offsets, dim3(1), dim3(256), 0, h->stream, h->d_area, h->N, h->pool);
     hipLaunchKernelGGL(k_measure_vertex, dim3(h->N, h->vsplit), dim3(MEAS_NT), 0, h->stream, a);
     if (h->E > 0) hipLaunchKernelGGL(k_measure_edge, dim3(h->E), dim3(MEAS_NT), 0, h->stream, a);
     ScatterArgs s = {h->d_out, h->d_edges, h->N, h->E, h->vsplit, h->eps_Z, h->eps_J, h->eps_M, deltaX, h->d_HTH, h->d_Hz, h->d_Hzc};
-    hipLaunchKernelGGL(k_hth_scatter, dim3(hm_cdiv(h->njobs, 64)), dim3(64), 0, h->stream, s);
+    hipLaunchKernelGGL(k_hth_scatter, dim3(hm_cdiv(h->njobs, 4)), dim3(256), 0, h->stream, s);
     HM_HIP(hipGetLastError());
     return HM_OK;
 }

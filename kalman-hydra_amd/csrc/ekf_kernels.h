@@ -524,31 +524,45 @@ __device__ inline void d_vertex_cfgs(TriSetup (*cfg)[EKF_MAX_STAR + 1], int nsv,
 }
 
 // ---- pass 0: star regions and their places in the pool -------------------------------------------------
-__global__ __launch_bounds__(64) void k_star_regions(MeasureArgs a, int *__restrict__ area)
+// One wave per configuration (MEAS_NCFG waves per vertex): setups in parallel, then the bounding box
+// of the star over all configurations by a lane-parallel min/max.
+#define REGION_NT (64 * MEAS_NCFG)
+__global__ __launch_bounds__(REGION_NT) void k_star_regions(MeasureArgs a, int *__restrict__ area)
 {
     __shared__ TriSetup s_cfg[MEAS_NCFG][EKF_MAX_STAR + 1];
+    __shared__ int s_box[MEAS_NCFG][4];
     const Mesh &m = a.m;
     const int v = blockIdx.x;
     const int nsv = a.topo.star_off[v + 1] - a.topo.star_off[v];
-    d_vertex_cfgs(s_cfg, nsv, a.topo.star_tri + a.topo.star_off[v], m, a.X, v, a.delta, 64);
+    d_vertex_cfgs(s_cfg, nsv, a.topo.star_tri + a.topo.star_off[v], m, a.X, v, a.delta, REGION_NT);
     __syncthreads();
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     {   // keep the setups (with the padding entry) for the measurement kernel
         constexpr int TW = sizeof(TriSetup) / 4;
         const int used = (nsv + (nsv & 1)) * TW;
-        for (int c = 0; c < MEAS_NCFG; c++) {
-            const int *src = (const int *)s_cfg[c];
-            int *dst = (int *)(a.cfgs + ((size_t)v * MEAS_NCFG + c) * (EKF_MAX_STAR + 1));
-            for (int i = threadIdx.x; i < used; i += 64) dst[i] = src[i];
-        }
+        const int *src = (const int *)s_cfg[wv];
+        int *dst = (int *)(a.cfgs + ((size_t)v * MEAS_NCFG + wv) * (EKF_MAX_STAR + 1));
+        for (int i = lane; i < used; i += 64) dst[i] = src[i];
     }
+    {   // bounding box of this wave's configuration
+        int c0 = m.W, c1 = -1, r0 = m.H, r1 = -1;
+        if (lane < nsv) {
+            const TriSetup &s = s_cfg[wv][lane];
+            if (s.cmin <= s.cmax) { c0 = s.cmin; c1 = s.cmax; r0 = s.rmin; r1 = s.rmax; }
+        }
+        for (int o = 16; o > 0; o >>= 1) {          // EKF_MAX_STAR <= 32 lanes carry values
+            c0 = min(c0, __shfl_down(c0, o, 64)); c1 = max(c1, __shfl_down(c1, o, 64));
+            r0 = min(r0, __shfl_down(r0, o, 64)); r1 = max(r1, __shfl_down(r1, o, 64));
+        }
+        if (lane == 0) { s_box[wv][0] = c0; s_box[wv][1] = c1; s_box[wv][2] = r0; s_box[wv][3] = r1; }
+    }
+    __syncthreads();
     if (threadIdx.x != 0) return;
     int c0 = m.W, c1 = -1, r0 = m.H, r1 = -1;
-    for (int cfg = 0; cfg < MEAS_NCFG; cfg++)
-        for (int k = 0; k < nsv; k++) {
-            const TriSetup &s = s_cfg[cfg][k];
-            if (s.cmin > s.cmax) continue;
-            c0 = min(c0, s.cmin); c1 = max(c1, s.cmax); r0 = min(r0, s.rmin); r1 = max(r1, s.rmax);
-        }
+    for (int cfg = 0; cfg < MEAS_NCFG; cfg++) {
+        c0 = min(c0, s_box[cfg][0]); c1 = max(c1, s_box[cfg][1]);
+        r0 = min(r0, s_box[cfg][2]); r1 = max(r1, s_box[cfg][3]);
+    }
     const int rw = max(0, c1 - c0 + 1), rh = max(0, r1 - r0 + 1);
     a.pool.hdr[4 * v] = c0; a.pool.hdr[4 * v + 1] = r0; a.pool.hdr[4 * v + 2] = rw; a.pool.hdr[4 * v + 3] = rh;
     area[v] = rw * rh;
@@ -742,8 +756,9 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure_edge(MeasureArgs a)
 }
 
 // ---- job sums -> Hz, Hz components, dense HTH (device twin of the unpacking in KFState.update) -------
-// One thread per job; every entry of H is written by exactly one job (vertex jobs own the diagonal
-// 4x4 blocks, edge jobs the two mirrored off-diagonal ones), so plain stores suffice.  H must be zero.
+// Every entry of H is written by exactly one job (vertex jobs own the diagonal 4x4 blocks, edge jobs
+// the two mirrored off-diagonal ones), always the same set, so plain stores suffice and H has to be
+// zero outside that set only once.
 struct ScatterArgs {
     const double *out;        // njobs * MEAS_VSPLIT_MAX * MEAS_OUT
     const int *edges;
@@ -759,70 +774,85 @@ __device__ __forceinline__ void d_put(double *H, int n4, int p, int q, double va
     H[(size_t)q * n4 + p] = v;
 }
 
-__global__ void k_hth_scatter(ScatterArgs a)
+// One wave per job (four jobs per workgroup): lane k < MEAS_OUT adds up value k of the job's
+// partial sums (in order), then every entry the job owns is formed by a lane of its own -- the
+// divisions of a job run side by side instead of one after the other in a single thread.
+__global__ __launch_bounds__(256) void k_hth_scatter(ScatterArgs a)
 {
-    const int job = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double so[4][MEAS_OUT];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int job = blockIdx.x * 4 + wv;
     const int N = a.N, n4 = 4 * N;
-    if (job >= N + a.E) return;
-    double o[MEAS_OUT];
-    {
+    const bool on = job < N + a.E;
+    if (on && lane < MEAS_OUT) {
         const double *src = a.out + (size_t)job * MEAS_VSPLIT_MAX * MEAS_OUT;
         const int parts = job < N ? a.vsplit : 1;
-        for (int k = 0; k < MEAS_OUT; k++) {
-            double v = src[k];
-            for (int q = 1; q < parts; q++) v += src[q * MEAS_OUT + k];
-            o[k] = v;
-        }
+        double v = src[lane];
+        for (int q = 1; q < parts; q++) v += src[q * MEAS_OUT + lane];
+        so[wv][lane] = v;
     }
+    __syncthreads();
+    if (!on) return;
+    const double *o = so[wv];
     const double eZ = a.eZ, eJ = a.eJ, eM = a.eM, d = a.d;
 #define SUM4(s) ((((s)[0] / eZ + (s)[1] / eJ) + (s)[2] / eJ) + (s)[3] / eM)
     if (job < N) {
         const int v = job;
         const int idx[4] = {2 * v, 2 * v + 1, 2 * N + 2 * v, 2 * N + 2 * v + 1};
-        // central differences of jz (kalman.py:499-515); component sums carry the sign of jz_CPU
-        const double cp[4][4] = {{o[A_XP] / eZ, o[A_XP + 1] / eJ, -o[A_XP + 2] / eJ, o[A_XP + 3] / eM},
-                                 {o[A_YP] / eZ, o[A_YP + 1] / eJ, -o[A_YP + 2] / eJ, o[A_YP + 3] / eM},
-                                 {0.0, o[A_VXP] / eJ, 0.0, 0.0},
-                                 {0.0, 0.0, -o[A_VYP] / eJ, 0.0}};
-        const double cm[4][4] = {{o[A_XM] / eZ, o[A_XM + 1] / eJ, -o[A_XM + 2] / eJ, o[A_XM + 3] / eM},
-                                 {o[A_YM] / eZ, o[A_YM + 1] / eJ, -o[A_YM + 2] / eJ, o[A_YM + 3] / eM},
-                                 {0.0, o[A_VXM] / eJ, 0.0, 0.0},
-                                 {0.0, 0.0, -o[A_VYM] / eJ, 0.0}};
-        for (int k = 0; k < 4; k++) {
-            const double hp = ((cp[k][0] + cp[k][1]) + cp[k][2]) + cp[k][3];
-            const double hm_ = ((cm[k][0] + cm[k][1]) + cm[k][2]) + cm[k][3];
+        if (lane < 4) {
+            // central differences of jz (kalman.py:499-515); component sums carry the sign of jz_CPU
+            const int k = lane;
+            double cp[4], cm[4];
+            if (k < 2) {
+                const double *p = o + (k == 0 ? A_XP : A_YP), *q = o + (k == 0 ? A_XM : A_YM);
+                cp[0] = p[0] / eZ; cp[1] = p[1] / eJ; cp[2] = -p[2] / eJ; cp[3] = p[3] / eM;
+                cm[0] = q[0] / eZ; cm[1] = q[1] / eJ; cm[2] = -q[2] / eJ; cm[3] = q[3] / eM;
+            } else if (k == 2) {
+                cp[0] = 0.0; cp[1] = o[A_VXP] / eJ; cp[2] = 0.0; cp[3] = 0.0;
+                cm[0] = 0.0; cm[1] = o[A_VXM] / eJ; cm[2] = 0.0; cm[3] = 0.0;
+            } else {
+                cp[0] = 0.0; cp[1] = 0.0; cp[2] = -o[A_VYP] / eJ; cp[3] = 0.0;
+                cm[0] = 0.0; cm[1] = 0.0; cm[2] = -o[A_VYM] / eJ; cm[3] = 0.0;
+            }
+            const double hp = ((cp[0] + cp[1]) + cp[2]) + cp[3];
+            const double hm_ = ((cm[0] + cm[1]) + cm[2]) + cm[3];
             a.Hz[idx[k]] = (hp / d - hm_ / d) / 2;
-            for (int ch = 0; ch < 4; ch++) a.Hzc[(size_t)idx[k] * 4 + ch] = (cp[k][ch] / d - cm[k][ch] / d) / 2;
+            for (int ch = 0; ch < 4; ch++) a.Hzc[(size_t)idx[k] * 4 + ch] = (cp[ch] / d - cm[ch] / d) / 2;
+        } else if (lane >= 8 && lane < 17) {
+            const int ix = idx[0], iy = idx[1], ivx = idx[2], ivy = idx[3];
+            switch (lane - 8) {
+            case 0: d_put(a.H, n4, ix, ix, SUM4(o + A_XX), d); break;
+            case 1: d_put(a.H, n4, ix, iy, SUM4(o + A_XY), d); break;
+            case 2: d_put(a.H, n4, iy, iy, SUM4(o + A_YY), d); break;
+            case 3: d_put(a.H, n4, ix, ivx, o[A_XVX] / eJ, d); break;
+            case 4: d_put(a.H, n4, iy, ivx, o[A_YVX] / eJ, d); break;
+            case 5: d_put(a.H, n4, ix, ivy, o[A_XVY] / eJ, d); break;
+            case 6: d_put(a.H, n4, iy, ivy, o[A_YVY] / eJ, d); break;
+            case 7: d_put(a.H, n4, ivx, ivx, o[A_VXVX] / eJ, d); break;
+            default: d_put(a.H, n4, ivy, ivy, o[A_VYVY] / eJ, d); break;
+            }
         }
-        const int ix = idx[0], iy = idx[1], ivx = idx[2], ivy = idx[3];
-        d_put(a.H, n4, ix, ix, SUM4(o + A_XX), d);
-        d_put(a.H, n4, ix, iy, SUM4(o + A_XY), d);
-        d_put(a.H, n4, iy, iy, SUM4(o + A_YY), d);
-        d_put(a.H, n4, ix, ivx, o[A_XVX] / eJ, d);
-        d_put(a.H, n4, iy, ivx, o[A_YVX] / eJ, d);
-        d_put(a.H, n4, ix, ivy, o[A_XVY] / eJ, d);
-        d_put(a.H, n4, iy, ivy, o[A_YVY] / eJ, d);
-        d_put(a.H, n4, ivx, ivx, o[A_VXVX] / eJ, d);
-        d_put(a.H, n4, ivy, ivy, o[A_VYVY] / eJ, d);
-    } else {
+    } else if (lane < 14) {
         const int e = job - N;
         const int v = a.edges[2 * e], w = a.edges[2 * e + 1];
         const int vx_ = 2 * v, vy_ = 2 * v + 1, vvx = 2 * N + 2 * v, vvy = 2 * N + 2 * v + 1;
         const int wx_ = 2 * w, wy_ = 2 * w + 1, wvx = 2 * N + 2 * w, wvy = 2 * N + 2 * w + 1;
-        d_put(a.H, n4, vx_, wx_, SUM4(o + B_XX), d);
-        d_put(a.H, n4, vx_, wy_, SUM4(o + B_XY), d);
-        d_put(a.H, n4, vy_, wx_, SUM4(o + B_YX), d);
-        d_put(a.H, n4, vy_, wy_, SUM4(o + B_YY), d);
-        d_put(a.H, n4, vx_, wvx, o[B_XVX] / eJ, d);
-        d_put(a.H, n4, vy_, wvx, o[B_YVX] / eJ, d);
-        d_put(a.H, n4, vvx, wx_, o[B_VXX] / eJ, d);
-        d_put(a.H, n4, vvx, wy_, o[B_VXY] / eJ, d);
-        d_put(a.H, n4, vvx, wvx, o[B_VXVX] / eJ, d);
-        d_put(a.H, n4, vx_, wvy, o[B_XVY] / eJ, d);
-        d_put(a.H, n4, vy_, wvy, o[B_YVY] / eJ, d);
-        d_put(a.H, n4, vvy, wx_, o[B_VYX] / eJ, d);
-        d_put(a.H, n4, vvy, wy_, o[B_VYY] / eJ, d);
-        d_put(a.H, n4, vvy, wvy, o[B_VYVY] / eJ, d);
+        switch (lane) {
+        case 0: d_put(a.H, n4, vx_, wx_, SUM4(o + B_XX), d); break;
+        case 1: d_put(a.H, n4, vx_, wy_, SUM4(o + B_XY), d); break;
+        case 2: d_put(a.H, n4, vy_, wx_, SUM4(o + B_YX), d); break;
+        case 3: d_put(a.H, n4, vy_, wy_, SUM4(o + B_YY), d); break;
+        case 4: d_put(a.H, n4, vx_, wvx, o[B_XVX] / eJ, d); break;
+        case 5: d_put(a.H, n4, vy_, wvx, o[B_YVX] / eJ, d); break;
+        case 6: d_put(a.H, n4, vvx, wx_, o[B_VXX] / eJ, d); break;
+        case 7: d_put(a.H, n4, vvx, wy_, o[B_VXY] / eJ, d); break;
+        case 8: d_put(a.H, n4, vvx, wvx, o[B_VXVX] / eJ, d); break;
+        case 9: d_put(a.H, n4, vx_, wvy, o[B_XVY] / eJ, d); break;
+        case 10: d_put(a.H, n4, vy_, wvy, o[B_YVY] / eJ, d); break;
+        case 11: d_put(a.H, n4, vvy, wx_, o[B_VYX] / eJ, d); break;
+        case 12: d_put(a.H, n4, vvy, wy_, o[B_VYY] / eJ, d); break;
+        default: d_put(a.H, n4, vvy, wvy, o[B_VYVY] / eJ, d); break;
+        }
     }
 #undef SUM4
 }
