@@ -156,7 +156,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->E = (int)eset.size();
     h->njobs = N + h->E;
     h->red_blocks = 512;
-    h->vsplit = 3;
+    h->vsplit = 6;
     const size_t n = (size_t)W * H;
     int rc = HM_OK;
     auto step = [&](int r) { if (rc == HM_OK) rc = r; };
