@@ -723,10 +723,13 @@ __global__ __launch_bounds__(256) void k_rhs(const double *__restrict__ M, const
 
 
 // ---- end of one iteration of hm_update_run ---------------------------------------------------------------
-// res (host-visible) = [step (n) | the four error sums, partials added in index order | overflow flag].
-// One workgroup; the partials are staged in LDS so that the in-order sums do not wait on memory.
+// res (host-visible, coherent) = [step (n) | the four error sums, partials added in index order |
+// overflow flag | ticket].  One workgroup; the partials are staged in LDS so that the in-order sums do
+// not wait on memory.  The ticket is written last, after a system-scope fence: a host that sees it
+// sees the rest.
 __global__ __launch_bounds__(256) void k_iter_result(const double *__restrict__ step, int n, const double *__restrict__ partial,
-                                                     int nblocks, const int *__restrict__ overflow, double *__restrict__ res)
+                                                     int nblocks, const int *__restrict__ overflow, double *__restrict__ res,
+                                                     double ticket)
 {
     extern __shared__ double sp[];                // 4 * nblocks
     const int t = threadIdx.x;
@@ -739,6 +742,12 @@ __global__ __launch_bounds__(256) void k_iter_result(const double *__restrict__ 
         res[n + t] = s;
     } else if (t == 4) {
         res[n + 4] = (double)*overflow;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) {
+        *(volatile double *)(res + n + 5) = ticket;
+        __threadfence_system();
     }
 }
 

@@ -5,6 +5,8 @@
 #include "ekf_kernels.h"
 #include "dense_kernels.h"
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <set>
@@ -56,6 +58,7 @@ struct hm_ctx {
     bool prefactored;                // d_invW0 is the inverse of the resident covariance d_Wprior (hm_update_prefactor)
     std::vector<double> h_partial;
     int red_blocks;
+    long long run_ticket;            // sequence number of hm_update_run's per-iteration result blocks
     int vsplit;                      // workgroups per vertex job of the measurement (hm_ctx_tune)
 };
 
@@ -156,6 +159,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->E = (int)eset.size();
     h->njobs = N + h->E;
     h->red_blocks = 512;
+    h->run_ticket = 0;
     h->vsplit = 6;
     const size_t n = (size_t)W * H;
     int rc = HM_OK;
@@ -202,7 +206,8 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_gain, n4 * 3 * sizeof(double));
         // [step (n4) | four error sums | overflow flag] per iteration, then Hzc (n4 x 4) and the gains (3 x n4)
         h->pin_n = n4 + 8 + n4 * 4 + n4 * 3;
-        if (e == hipSuccess) e = hipHostMalloc((void **)&h->pin, h->pin_n * sizeof(double), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&h->pin, h->pin_n * sizeof(double), hipHostMallocCoherent);
+        if (e == hipSuccess) memset(h->pin, 0, h->pin_n * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_dx, n4 * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_X0, n4 * sizeof(double));
         // pool of parked difference images: the star regions overlap a few times; 16 frames' worth of
@@ -719,9 +724,24 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
         hipLaunchKernelGGL(k_error, dim3(h->red_blocks), dim3(RED_NT), 0, h->stream, h->P, obs_of(h, masked),
                            h->W * h->H, h->d_partial);
         hipLaunchKernelGGL(k_iter_result, dim3(1), dim3(256), (size_t)h->red_blocks * 4 * sizeof(double), h->stream, rhs_row, n4, h->d_partial,
-                           h->red_blocks, h->pool.overflow, res);
+                           h->red_blocks, h->pool.overflow, res, (double)(++h->run_ticket));
         HM_HIP(hipGetLastError());
-        HM_HIP(hipStreamSynchronize(h->stream));
+        // The result block carries a ticket that the kernel writes last (system-scope fence before it).
+        // Watching it costs a couple of microseconds against ~20 for waking up from a stream
+        // synchronisation, once per iteration; the synchronisation remains as the fallback.
+        {
+            const volatile double *ticket = res + n4 + 5;
+            const double want = (double)h->run_ticket;
+            const auto t_give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+            bool seen = false;
+            for (int spin = 0;; spin++) {
+                if (*ticket == want) { seen = true; break; }
+                __builtin_ia32_pause();
+                if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() > t_give_up) break;
+            }
+            if (!seen) HM_HIP(hipStreamSynchronize(h->stream));
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
         h->upd_prev = h->upd_last;
         h->upd_last = slot;
         niter++;
