@@ -205,9 +205,8 @@ def main():
 
     bf = brox.BroxOpticalFlow(n, n, max_batch=B, device=dev)
     bf.tune("sor_threads", 512)
-    for size in sorted({1, min(B, 4), B} | {((K - 1 - min(B, 4)) % B) or B}):     # series sizes of the schedule below
-        if 1 <= size <= B:
-            bf.prepare(size)
+    for size in range(1, B + 1):                  # any series size the schedule below may use
+        bf.prepare(size)
     flow0 = np.zeros((n, n, 2), np.float32)
     kf = kalman.IteratedMSKalmanFilter(dm, video[0], flow0, True, device=dev)
     N = kf.N
@@ -247,7 +246,7 @@ def main():
     def step(k, phase_end):
         """Frame k+1: flow of (k, k+1) -- computed for up to B consecutive pairs per launch series (they do
         not depend on the filter), the next series running on the GPU while the filter works through
-        this one (the very first series of a phase is a single pair: nothing to overlap it with) --
+        this one (series of 1, 2, 4, ... pairs at the start of a phase: nothing to overlap the first with) --
         then the EKF on frame k+1."""
         nonlocal t_flow, t_ekf, iters
         t0 = time.perf_counter()
@@ -260,7 +259,7 @@ def main():
             sched["ready"], sched["pending"] = sched["pending"], None
             lo, nxt = sched["ready"]
             if nxt < phase_end:        # ramp: what the GPU gets done beside the frames just made ready
-                sched["pending"] = launch(nxt, phase_end, sched["buf"] ^ 1, most=min(B, 4 * (nxt - lo)))
+                sched["pending"] = launch(nxt, phase_end, sched["buf"] ^ 1, most=min(B, 2 * (nxt - lo)))
         i = k - sched["ready"][0]
         cur = sched["buf"]
         t1 = time.perf_counter()
@@ -270,6 +269,9 @@ def main():
         t2 = time.perf_counter()
         t_flow += t1 - t0
         t_ekf += t2 - t1
+        if os.environ.get("HYDRA_MI_BENCH_TRACE"):
+            print("step %d: flow wait %.2f ms, filter %.2f ms (%d iterations), series ready %s pending %s"
+                  % (k, 1e3 * (t1 - t0), 1e3 * (t2 - t1), kf.niter, sched["ready"], sched["pending"]), file=sys.stderr)
         iters += kf.niter
 
     # per-launch HIP events cost more host time than the SOR launches they bracket, so they are
@@ -289,10 +291,11 @@ def main():
     t0 = time.perf_counter()
     # one flow series of the timed region is profiled (series: 1 pair, then B at a time): the first
     # full one, or the last if there is no full one
-    # series of the timed region: 1 pair, then 4, then B at a time
+    # series of the timed region: 1 pair, then 2, 4, ... up to B at a time (a series of n pairs takes
+    # about 7.5 + 0.65 (n - 1) ms here, a frame of the filter about 8 ms)
     starts, k_ = [], Wm
     while k_ < Wm + K:
-        size = 1 if not starts else min(B, 4 * starts[-1][1], Wm + K - k_)
+        size = 1 if not starts else min(B, 2 * starts[-1][1], Wm + K - k_)
         starts.append((k_, size))
         k_ += size
     full = [st for st in starts if st[1] == B]
