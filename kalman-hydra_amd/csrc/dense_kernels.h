@@ -35,147 +35,19 @@ __device__ __forceinline__ double d_rsqrt(double d)
     return r;
 }
 
-// ---- potrf, step k, part 1: factor the diagonal block, solve the panel below it ---------------
-// One 256-thread workgroup per block row r >= k (rows [32 r, 32 r + 32) of an array with
-// `nrows` rows).  Every workgroup factors the 32x32 diagonal block itself in LDS (11k flops,
-// cheaper than a launch boundary; the rank-1 update of each of the 32 steps is spread over all
-// threads).  Workgroup r == k stores the factor; the others solve X L_kk^T = A_rk for their rows
-// -- 8 threads per row -- and store X.
-__global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, double *__restrict__ Ld, int n, int nrows, int k)
-{
-    __shared__ double W[DNB][DNB + 1];            // working copy: column j keeps its unscaled values
-    __shared__ double D[DNB][DNB + 1];            // the factor L_kk
-    __shared__ double rD[DNB];                    // reciprocals of the diagonal of L_kk
-    const int t = threadIdx.x;
-    const int r = k + blockIdx.x;
-    const int d0 = k * DNB;
-    const int nd = min(DNB, n - d0);              // the last diagonal block may be short: pad with identity
-    // this workgroup's rows of the panel (8 threads per row, 4 entries each): requested now, needed
-    // only after the diagonal block has been factored
-    const int r0 = r * DNB;
-    const int nr = min(DNB, nrows - r0);
-    const int row = t / 8, part = t % 8;
-    double x[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int c = 8 * q + part;
-        x[q] = (r != k && row < nr && c < nd) ? A[(size_t)(r0 + row) * n + d0 + c] : 0.0;
-    }
-    for (int e = t; e < DNB * DNB; e += 256) {
-        int i = e / DNB, j = e % DNB;
-        W[i][j] = (i < nd && j < nd && j <= i) ? A[(size_t)(d0 + i) * n + d0 + j] : (i == j ? 1.0 : 0.0);
-        D[i][j] = 0.0;
-    }
-    __syncthreads();
-    // Right-looking elimination with ONE barrier per column: the rank-1 update uses the unscaled
-    // column and 1/w_jj, so it does not wait for the scaled column, which goes to a separate array.
-    // (A single-wave, barrier-free variant of this loop was measured slower: the rank-1 update is
-    // LDS-throughput bound and wants all four waves.)
-    const int ti = t / DNB, tc = t % DNB;         // 8 x 32 thread grid over (row, column)
-    for (int j = 0; j < DNB; j++) {
-        // every LDS read of the step is issued up front (the stores below may alias them as far as
-        // the compiler knows, which would otherwise serialise the four updates of a thread)
-        const double wjj = W[j][j];
-        const double wtj = W[tc][j];
-        double wa[4], wb[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            wa[q] = W[ti + 8 * q][j];
-            wb[q] = W[ti + 8 * q][tc];
-        }
-        const double rd = d_rcp(wjj);
-        if (tc > j) {
-            const double wcj = wtj * rd;
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (ti + 8 * q >= tc) W[ti + 8 * q][tc] = wb[q] - wa[q] * wcj;
-        }
-        if (t < DNB && t >= j) {
-            const double rs = d_rsqrt(wjj);
-            D[t][j] = (t == j) ? wjj * rs : wtj * rs;     // for t < 32: tc == t, so wtj = W[t][j]
-            if (t == j) rD[j] = rs;
-        }
-        __syncthreads();
-    }
-    if (r == k) {
-        // The factored block goes to the side array Ld, NOT back into A: the other workgroups of this
-        // launch read the unfactored block from A at their own pace.
-        for (int e = t; e < DNB * DNB; e += 256) Ld[(size_t)k * DNB * DNB + e] = D[e / DNB][e % DNB];
-        return;
-    }
-    // Rows of the panel: 8 threads per row (consecutive lanes of one wave), thread `part` owns the
-    // entries x[8 q + part].  The 32 columns are done in four groups of 8: for a group, every thread
-    // first subtracts the contribution of the finished columns to ITS entry (a private dot product
-    // over values parked in LDS, no reduction), then the 8x8 triangle of the group is solved with
-    // one 8-lane shuffle per column.
-    __shared__ double Xs[DNB][DNB + 1];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int j = 8 * q + part;
-        double sacc = x[q];
-        for (int c = 0; c < 8 * q; c++) sacc = sacc - Xs[row][c] * D[j][c];
-#pragma unroll
-        for (int jj = 0; jj < 8; jj++) {
-            const int jc = 8 * q + jj;                        // column being finished
-            const double xj = __shfl(sacc * rD[jc], jj, 8);   // from its owner, already scaled
-            if (part == jj) sacc = xj;
-            else if (part > jj) sacc = sacc - xj * D[j][jc];
-        }
-        x[q] = sacc;
-        Xs[row][j] = sacc;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();                      // the 8 lanes of a row are in one wave
-    }
-    if (row < nr) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int c = 8 * q + part;
-            if (c < nd) A[(size_t)(r0 + row) * n + d0 + c] = x[q];
-        }
-    }
-}
-
-// ---- potrf, step k, part 2: trailing update A_rc -= L_rk L_ck^T for r >= c > k -------------------
-// c runs over the block columns of the matrix (c < nb), r over all block rows including the
-// right-hand-side rows below the matrix.
-__global__ __launch_bounds__(256) void k_chol_update(double *__restrict__ A, int n, int nrows, int k)
-{
-    const int r = k + 1 + blockIdx.y, c = k + 1 + blockIdx.x;
-    if (c > r) return;
-    __shared__ double R[DNB][DNB + 1];
-    __shared__ double C[DNB][DNB + 1];
-    const int t = threadIdx.x;
-    const int r0 = r * DNB, c0 = c * DNB, d0 = k * DNB;
-    const int nr = min(DNB, nrows - r0), nc = min(DNB, n - c0);
-    for (int e = t; e < DNB * DNB; e += 256) {
-        int i = e / DNB, j = e % DNB;
-        R[i][j] = i < nr ? A[(size_t)(r0 + i) * n + d0 + j] : 0.0;
-        C[i][j] = i < nc ? A[(size_t)(c0 + i) * n + d0 + j] : 0.0;
-    }
-    __syncthreads();
-    const int j = t % DNB;                        // column inside the block
-    for (int i = t / DNB; i < DNB; i += 256 / DNB) {
-        if (i >= nr || j >= nc) continue;
-        double s = 0.0;
-#pragma unroll 8
-        for (int q = 0; q < DNB; q++) s = s + R[i][q] * C[j][q];
-        const size_t p = (size_t)(r0 + i) * n + c0 + j;
-        A[p] = A[p] - s;
-    }
-}
-
 // ---- potrf, one launch per block column -----------------------------------------------------------
 // The factorisation reads a working copy A and writes the factor to a separate array L (same
-// shape; blocks below the block diagonal) and the factored diagonal blocks to Ld.  Launch k
-// (k_chol_step) does everything that involves block column k and has no later dependency:
-//   workgroup (r, c), r >= c > k:  X_r = A_rk L_kk^-T and X_c = A_ck L_kk^-T (each workgroup solves
-//       the two small triangular systems it needs itself, from the raw panel in A and the factored
-//       diagonal block Ld[k] of the previous launch), then A_rc -= X_r X_c^T;
+// shape; blocks below the block diagonal), the factored diagonal blocks to Ld and their inverses
+// to Lt.  Launch k (k_chol_step) does everything that involves block column k and has no later
+// dependency:
+//   workgroup (r, c), r >= c > k:  X_r = A_rk T_k^T and X_c = A_ck T_k^T with T_k = L_kk^-1 (Lt[k], left
+//       by the previous launch; each workgroup forms the two panel blocks it needs itself, from the raw
+//       panel in A), then A_rc -= X_r X_c^T -- 32x32x32 products on the f64 matrix cores;
 //   workgroups of block column c = k+1 also store X_r as L_rk;
-//   workgroup (k+1, k+1) goes on to factor its updated block into Ld[k+1] -- the only part that
-//       is sequential across launches.
+//   workgroup (k+1, k+1) goes on to factor its updated block into Ld[k+1] and to invert the factor
+//       into Lt[k+1] -- the only part that is sequential across launches.
 // Nothing is written that another workgroup of the same launch reads (the panel stays raw in A),
-// so the result does not depend on workgroup scheduling.  Launches: nb instead of 2 nb.
+// so the result does not depend on workgroup scheduling.
 __device__ __forceinline__ double d_readlane(double v, int lane)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -666,21 +538,6 @@ __global__ __launch_bounds__(256) void k_ttt(const double *__restrict__ Tm, int 
 }
 
 // ---- assembly of the update system -----------------------------------------------------------------
-// A = invW0 + H (elementwise)
-__global__ void k_add_mat(const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out, size_t n)
-{
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = a[i] + b[i];
-}
-
-// out = a + s * b
-__global__ void k_vec_axpy(const double *__restrict__ a, const double *__restrict__ b, double s, double *__restrict__ out,
-                           int n)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = a[i] + s * b[i];
-}
-
 // The update system of one iteration in one pass over H (one workgroup per row of the augmented
 // array): A = invW0 + H, the right-hand side Hz - H (X0 - X) as row `rhs_row` of the block below the
 // matrix, zeros in the padding rows.
@@ -706,21 +563,6 @@ __global__ __launch_bounds__(256) void k_assemble(const double *__restrict__ inv
     __syncthreads();
     if (threadIdx.x == 0) A[(size_t)rhs_row * n + row] = Hz[row] - (((s[0] + s[1]) + s[2]) + s[3]);
 }
-
-// y = base - M x   (one workgroup per row, fixed-order reduction)
-__global__ __launch_bounds__(256) void k_rhs(const double *__restrict__ M, const double *__restrict__ x,
-                                             const double *__restrict__ base, double *__restrict__ y, int n)
-{
-    __shared__ double s[4];
-    const int row = blockIdx.x;
-    double acc = 0.0;
-    for (int j = threadIdx.x; j < n; j += 256) acc += M[(size_t)row * n + j] * x[j];
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) y[row] = base[row] - (((s[0] + s[1]) + s[2]) + s[3]);
-}
-
 
 // ---- end of one iteration of hm_update_run ---------------------------------------------------------------
 // res (host-visible, coherent) = [step (n) | the four error sums, partials added in index order |
