@@ -303,8 +303,8 @@ __global__ __launch_bounds__(1024) void k_back_row(const double *__restrict__ L,
     const int nb = (n + DNB - 1) / DNB;
     const int li = t & (DNB - 1);
     constexpr int HR = DNB / 2;                   // rows per thread of a pair
-    // waves 1..15: thread pair (half 0 / 1) owns the entries c0 and c1 = c0 + 480 of y
-    const int e = t - 64, half = e & 1, c0 = e >> 1, c1 = c0 + 480;
+    // waves 1..15: thread pair (half 0 / 1) owns the entries c0, c0 + 480, c0 + 960, ... of y
+    const int e = t - 64, half = e & 1, c0 = e >> 1;
     // the rows [half*16, half*16+16) of block row k of L at column c; zero outside the bulk range
     // of step k (columns < (k-1)*32) and below the matrix
     auto load_rows = [&](int k, int c, double (&l)[HR]) {
@@ -359,20 +359,14 @@ __global__ __launch_bounds__(1024) void k_back_row(const double *__restrict__ L,
             double d0, s0, d1 = 0.0, s1 = 0.0;
             fetch(kb - 1, e, d0, s0);
             if (e < 64) fetch(kb - 1, e + 960, d1, s1);
-            double cur[HR];
-            load_rows(kb, c0, cur);
-            double a0 = 0.0;
+            for (int c = c0; c < cols; c += 480) {            // one batch for up to 480 entries of y
+                double cur[HR];
+                load_rows(kb, c, cur);
+                double a0 = 0.0;
 #pragma unroll
-            for (int r = 0; r < HR; r++) a0 = a0 + cur[r] * x[half * HR + r];
-            a0 = a0 + __shfl_xor(a0, 1, 64);
-            if (half == 0 && c0 < cols) Y[c0] = Y[c0] - a0;
-            if (cols > 480) {
-                load_rows(kb, c1, cur);
-                double a1 = 0.0;
-#pragma unroll
-                for (int r = 0; r < HR; r++) a1 = a1 + cur[r] * x[half * HR + r];
-                a1 = a1 + __shfl_xor(a1, 1, 64);
-                if (half == 0 && c1 < cols) Y[c1] = Y[c1] - a1;
+                for (int r = 0; r < HR; r++) a0 = a0 + cur[r] * x[half * HR + r];
+                a0 = a0 + __shfl_xor(a0, 1, 64);
+                if (half == 0) Y[c] = Y[c] - a0;
             }
             put(kb - 1, e, d0, s0);
             if (e < 64) put(kb - 1, e + 960, d1, s1);
