@@ -126,23 +126,96 @@ struct WarpOut {
     float *Iz, *Ix, *Iy, *Ixz, *Iyz, *Ixx, *Ixy, *Iyy;
 };
 
-__global__ void k_warp(WarpIn in, WarpOut out, Geo g)
+// One 64x4 block.  The taps of a block's bilinear samples lie in a window only a little larger than
+// the block wherever the flow is smooth: the block finds the bounding box of its taps (LDS
+// min/max), stages that window of the six sampled fields in LDS with row-wise coalesced reads and
+// samples from there.  A block whose taps do not fit the window (a discontinuity, a very large
+// divergence) samples from memory directly -- same values, same arithmetic either way.
+#define WARP_WX 88            // 64 + 2 * 12
+#define WARP_WY 20            // 4 + 2 * 8
+__device__ __forceinline__ float d_bilin_win(const float (*win)[WARP_WX], int w, int h, int wx0, int wy0, float px, float py)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x;
-    int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= g.w || y >= g.h) return;
-    size_t off = (size_t)blockIdx.z * g.plane;
-    size_t p = off + y * g.pitch + x;
-    int w = g.w, h = g.h, pitch = g.pitch;
-    float px = (float)x + in.u[p], py = (float)y + in.v[p];
-    if (px < 0.0f || py < 0.0f || px > (float)(w - 1) || py > (float)(h - 1)) {
+    if (px < 0.0f) px = 0.0f;
+    if (py < 0.0f) py = 0.0f;
+    if (px > (float)(w - 1)) px = (float)(w - 1);
+    if (py > (float)(h - 1)) py = (float)(h - 1);
+    float fx0 = floorf(px), fy0 = floorf(py);
+    int x0 = (int)fx0, y0 = (int)fy0;
+    int x1 = x0 + 1 < w ? x0 + 1 : w - 1;
+    int y1 = y0 + 1 < h ? y0 + 1 : h - 1;
+    float ax = px - fx0, ay = py - fy0;
+    float a = win[y0 - wy0][x0 - wx0], b = win[y0 - wy0][x1 - wx0];
+    float c = win[y1 - wy0][x0 - wx0], d = win[y1 - wy0][x1 - wx0];
+    float top = (1.0f - ax) * a + ax * b;
+    float bot = (1.0f - ax) * c + ax * d;
+    return (1.0f - ay) * top + ay * bot;
+}
+
+__global__ __launch_bounds__(256) void k_warp(WarpIn in, WarpOut out, Geo g)
+{
+    __shared__ float win[6][WARP_WY][WARP_WX];
+    __shared__ int s_box[4];                      // min x, max x, min y, max y over the block's taps
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    const int w = g.w, h = g.h, pitch = g.pitch;
+    const size_t off = (size_t)blockIdx.z * g.plane;
+    const bool inside = x < w && y < h;
+    const size_t p = off + (inside ? y * pitch + x : 0);
+    float px = 0.0f, py = 0.0f;
+    bool sampled = false;
+    if (inside) {
+        px = (float)x + in.u[p];
+        py = (float)y + in.v[p];
+        sampled = !(px < 0.0f || py < 0.0f || px > (float)(w - 1) || py > (float)(h - 1));
+    }
+    if (tid == 0) { s_box[0] = w; s_box[1] = -1; s_box[2] = h; s_box[3] = -1; }
+    __syncthreads();
+    {
+        int bx0 = w, bx1 = -1, by0 = h, by1 = -1;
+        if (sampled) {
+            bx0 = (int)floorf(px); by0 = (int)floorf(py);
+            bx1 = bx0 + 1 < w ? bx0 + 1 : w - 1; by1 = by0 + 1 < h ? by0 + 1 : h - 1;
+        }
+        for (int o = 32; o > 0; o >>= 1) {          // per wave first: four LDS atomics per wave, not per thread
+            bx0 = min(bx0, __shfl_xor(bx0, o, 64)); bx1 = max(bx1, __shfl_xor(bx1, o, 64));
+            by0 = min(by0, __shfl_xor(by0, o, 64)); by1 = max(by1, __shfl_xor(by1, o, 64));
+        }
+        if ((tid & 63) == 0) {
+            atomicMin(&s_box[0], bx0); atomicMax(&s_box[1], bx1);
+            atomicMin(&s_box[2], by0); atomicMax(&s_box[3], by1);
+        }
+    }
+    __syncthreads();
+    const int wx0 = s_box[0], wx1 = s_box[1], wy0 = s_box[2], wy1 = s_box[3];
+    const bool staged = wx1 >= wx0 && wx1 - wx0 < WARP_WX && wy1 - wy0 < WARP_WY;
+    if (staged) {
+        const float *src[6] = {in.I1 + off, in.I1x + off, in.I1y + off, in.I1xx + off, in.I1xy + off, in.I1yy + off};
+        const int ww = wx1 - wx0 + 1, wh = wy1 - wy0 + 1;
+        for (int i = tid; i < ww * wh; i += 256) {
+            const int ly = i / ww, lx = i - ly * ww;
+            const int q = (wy0 + ly) * pitch + wx0 + lx;
+#pragma unroll
+            for (int f = 0; f < 6; f++) win[f][ly][lx] = src[f][q];
+        }
+    }
+    __syncthreads();
+    if (!inside) return;
+    if (!sampled) {
         out.Iz[p] = 0.0f; out.Ix[p] = 0.0f; out.Iy[p] = 0.0f; out.Ixz[p] = 0.0f; out.Iyz[p] = 0.0f;
         out.Ixx[p] = 0.0f; out.Ixy[p] = 0.0f; out.Iyy[p] = 0.0f;
         return;
     }
-    float i1 = d_bilin(in.I1 + off, w, h, pitch, px, py);
-    float ix = d_bilin(in.I1x + off, w, h, pitch, px, py);
-    float iy = d_bilin(in.I1y + off, w, h, pitch, px, py);
+    float i1, ix, iy;
+    if (staged) {
+        i1 = d_bilin_win(win[0], w, h, wx0, wy0, px, py);
+        ix = d_bilin_win(win[1], w, h, wx0, wy0, px, py);
+        iy = d_bilin_win(win[2], w, h, wx0, wy0, px, py);
+    } else {
+        i1 = d_bilin(in.I1 + off, w, h, pitch, px, py);
+        ix = d_bilin(in.I1x + off, w, h, pitch, px, py);
+        iy = d_bilin(in.I1y + off, w, h, pitch, px, py);
+    }
     out.Iz[p] = i1 - in.I0[p];
     out.Ix[p] = ix;
     out.Iy[p] = iy;
@@ -153,9 +226,15 @@ __global__ void k_warp(WarpIn in, WarpOut out, Geo g)
     }
     out.Ixz[p] = ix - in.Ix0[p];
     out.Iyz[p] = iy - in.Iy0[p];
-    out.Ixx[p] = d_bilin(in.I1xx + off, w, h, pitch, px, py);
-    out.Ixy[p] = d_bilin(in.I1xy + off, w, h, pitch, px, py);
-    out.Iyy[p] = d_bilin(in.I1yy + off, w, h, pitch, px, py);
+    if (staged) {
+        out.Ixx[p] = d_bilin_win(win[3], w, h, wx0, wy0, px, py);
+        out.Ixy[p] = d_bilin_win(win[4], w, h, wx0, wy0, px, py);
+        out.Iyy[p] = d_bilin_win(win[5], w, h, wx0, wy0, px, py);
+    } else {
+        out.Ixx[p] = d_bilin(in.I1xx + off, w, h, pitch, px, py);
+        out.Ixy[p] = d_bilin(in.I1xy + off, w, h, pitch, px, py);
+        out.Iyy[p] = d_bilin(in.I1yy + off, w, h, pitch, px, py);
+    }
 }
 
 // ---- linear system of one lagged-nonlinearity step ---------------------------------

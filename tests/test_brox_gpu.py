@@ -69,6 +69,28 @@ def test_warp_prepare(hm, oracle_brox, w, h):
         assert np.array_equal(g, r), name
 
 
+@pytest.mark.parametrize("kind", ["smooth", "rough", "jump", "outside"])
+def test_warp_window_and_direct_sampling_agree_with_oracle(hm, oracle_brox, kind):
+    """k_warp stages the window of a block's taps in LDS when it fits (smooth flow) and samples from
+    memory when it does not (rough flow, a discontinuity); either way bit-identical to the oracle."""
+    from hydra_mi import brox
+    w, h = 200, 150
+    f = list(_level_fields(oracle_brox, w, h, 50))
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    if kind == "smooth":
+        f[9] = (6.0 + 0.02 * xx).astype(np.float32); f[10] = (-4.0 + 0.03 * yy).astype(np.float32)
+    elif kind == "rough":
+        f[9] = _rand((h, w), 60, -40, 40); f[10] = _rand((h, w), 61, -40, 40)
+    elif kind == "jump":
+        f[9] = np.where(xx < 97, -7.5, 31.25).astype(np.float32); f[10] = np.where(yy < 70, 12.0, -9.0).astype(np.float32)
+    else:
+        f[9] = np.full((h, w), 500.0, np.float32); f[10] = np.zeros((h, w), np.float32)
+    got = brox.op_warp(*f)
+    ref = oracle_brox.warp(*f)
+    for name, g_, r_ in zip("Iz Ix Iy Ixz Iyz Ixx Ixy Iyy".split(), got, ref):
+        assert np.array_equal(g_, r_), (kind, name)
+
+
 @pytest.mark.parametrize("w,h", SIZES + [(300, 300)])
 @pytest.mark.parametrize("fuse", [0, 1, 2, 5, 105, 205])
 def test_sor(hm, oracle_brox, w, h, fuse):
