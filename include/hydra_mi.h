@@ -73,7 +73,9 @@ int hm_brox_set_omega(hm_brox_t h, float omega);
 /* launch tuning, never changes results: "sor_fuse" = red-black iterations fused
  * per SOR launch (0 = choose per level, else a divisor of solver_iterations),
  * "sor_threads" = 256, 512 or 1024 threads per SOR workgroup, "graph" = 1/0 replay the launch
- * series of a calc call as a captured hipGraph (default 1) or launch kernel by kernel */
+ * series of a calc call as a captured hipGraph (default 1) or launch kernel by kernel, "warp_window" =
+ * 1/0 the warp kernel stages its taps as an LDS window or reads them directly (default 0: measured
+ * faster, see brox_kernels.h) */
 int hm_brox_tune(hm_brox_t h, const char *key, int value);
 /* set-up work of the first calc call for n pairs (capturing its launch series as a graph) done ahead
  * of time; optional */
@@ -92,8 +94,9 @@ int hm_brox_profile_read(hm_brox_t h, double *sor_ms, long long *sor_launches,
 int hm_op_blur(const float *src, int w, int h, float scale_factor, float *dst);
 int hm_op_resample(const float *src, int ws, int hs, float *dst, int wd, int hd, float mul);
 int hm_op_deriv(const float *src, int w, int h, float *dx, float *dy);
-/* in: I0,Ix0,Iy0,I1,I1x,I1y,I1xx,I1xy,I1yy,u,v   out: Iz,Ix,Iy,Ixz,Iyz,Ixx,Ixy,Iyy */
-int hm_op_warp(const float *const in[11], int w, int h, float *const out[8]);
+/* in: I0,Ix0,Iy0,I1,I1x,I1y,I1xx,I1xy,I1yy,u,v   out: Iz,Ix,Iy,Ixz,Iyz,Ixx,Ixy,Iyy;
+ * window: 1 = the LDS-window variant of the kernel (hm_brox_tune "warp_window"), 0 = direct reads */
+int hm_op_warp(const float *const in[11], int w, int h, float *const out[8], int window);
 /* in: u,v,du,dv + the 8 warped fields   out: nu,nv,a12,idu,idv,sx,sy */
 int hm_op_prepare(const float *const in[12], int w, int h, float alpha, float gamma,
                   float *const out[7]);

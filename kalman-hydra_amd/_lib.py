@@ -43,7 +43,7 @@ SIGNATURES = {
     "hm_op_resample": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_float]),
     "hm_op_deriv": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
-    "hm_op_warp": (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_vp)]),
+    "hm_op_warp": (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_vp), ctypes.c_int]),
     "hm_op_prepare": (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                      ctypes.c_float, ctypes.POINTER(c_vp)]),
     "hm_op_sor": (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int,

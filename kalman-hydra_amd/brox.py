@@ -149,13 +149,14 @@ def op_deriv(img):
     return dx, dy
 
 
-def op_warp(*fields):
-    """fields = I0,Ix0,Iy0,I1,I1x,I1y,I1xx,I1xy,I1yy,u,v -> Iz,Ix,Iy,Ixz,Iyz,Ixx,Ixy,Iyy"""
+def op_warp(*fields, window=False):
+    """fields = I0,Ix0,Iy0,I1,I1x,I1y,I1xx,I1xy,I1yy,u,v -> Iz,Ix,Iy,Ixz,Iyz,Ixx,Ixy,Iyy
+    (window: the LDS-window variant of the kernel instead of direct reads)"""
     ins = [_f32(a) for a in fields]
     assert len(ins) == 11
     H, W = ins[0].shape
     outs = [np.empty((H, W), np.float32) for _ in range(8)]
-    _lib.check(_lib.lib().hm_op_warp(_lib.ptr_array(ins), W, H, _lib.ptr_array(outs)))
+    _lib.check(_lib.lib().hm_op_warp(_lib.ptr_array(ins), W, H, _lib.ptr_array(outs), 1 if window else 0))
     return outs
 
 

@@ -155,6 +155,7 @@ struct hm_brox {
     // microseconds instead of ~1100 kernel launches.  Dropped when a tuning knob changes.
     std::vector<hipGraphExec_t> graphs;   // index n-1
     bool use_graph;
+    bool warp_window;                     // k_warp stages its taps as an LDS window (hm_brox_tune)
     // profiling
     bool prof;
     std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -200,6 +201,7 @@ extern "C" int hm_brox_create(int device, int W, int H, int max_batch, float alp
     h->prof = false; h->ev_used = 0; h->prof_ms = 0; h->prof_pxit = 0; h->prof_launches = 0;
     h->graphs.assign(max_batch, nullptr);
     h->use_graph = true;
+    h->warp_window = false;
     make_levels(W, H, scale, outer, h->geo);
     h->taps = make_taps(scale);
 
@@ -285,6 +287,9 @@ extern "C" int hm_brox_tune(hm_brox_t h, const char *key, int value)
     } else if (!strcmp(key, "sor_threads")) {
         HM_ARG(value == 256 || value == 512 || value == 1024, "hm_brox_tune: sor_threads must be 256, 512 or 1024");
         h->sor_threads = value;
+    } else if (!strcmp(key, "warp_window")) {
+        HM_ARG(value == 0 || value == 1, "hm_brox_tune: warp_window must be 0 or 1");
+        h->warp_window = value != 0;
     } else if (!strcmp(key, "graph")) {
         HM_ARG(value == 0 || value == 1, "hm_brox_tune: graph must be 0 or 1");
         h->use_graph = value != 0;
@@ -380,7 +385,8 @@ static int brox_run(hm_brox *h, int n, const uint8_t *d_f0, const uint8_t *d_f1,
         hipLaunchKernelGGL(k_deriv, gr, kBlock2d, 0, s, h->I1y, (float *)nullptr, h->I1yy, g);
         WarpIn wi = {h->pyr0[k], h->Ix0, h->Iy0, h->pyr1[k], h->I1x, h->I1y, h->I1xx, h->I1xy, h->I1yy, u, v};
         WarpOut wo = {h->Iz, h->Ix, h->Iy, h->Ixz, h->Iyz, h->Ixx, h->Ixy, h->Iyy};
-        hipLaunchKernelGGL(k_warp, gr, kBlock2d, 0, s, wi, wo, g);
+        if (h->warp_window) hipLaunchKernelGGL((k_warp<true>), gr, kBlock2d, 0, s, wi, wo, g);
+        else hipLaunchKernelGGL((k_warp<false>), gr, kBlock2d, 0, s, wi, wo, g);
         int cur = 0;
         HM_HIP(hipMemsetAsync(h->du[0], 0, (size_t)g.plane * n * sizeof(float), s));
         HM_HIP(hipMemsetAsync(h->dv[0], 0, (size_t)g.plane * n * sizeof(float), s));
@@ -592,7 +598,7 @@ extern "C" int hm_op_deriv(const float *src, int w, int h, float *dx, float *dy)
     return HM_OK;
 }
 
-extern "C" int hm_op_warp(const float *const in[11], int w, int h, float *const out[8])
+extern "C" int hm_op_warp(const float *const in[11], int w, int h, float *const out[8], int window)
 {
     HM_ARG(in && out && w >= 1 && h >= 1, "hm_op_warp: bad argument");
     Geo g = make_geo(w, h);
@@ -603,7 +609,8 @@ extern "C" int hm_op_warp(const float *const in[11], int w, int h, float *const 
     for (int i = 0; i < 8; i++) { o[i] = sc.plane(g); OP_CHECK(o[i]); }
     WarpIn wi = {d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10]};
     WarpOut wo = {o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]};
-    hipLaunchKernelGGL(k_warp, grid2d(g, 1), kBlock2d, 0, 0, wi, wo, g);
+    if (window) hipLaunchKernelGGL((k_warp<true>), grid2d(g, 1), kBlock2d, 0, 0, wi, wo, g);
+    else hipLaunchKernelGGL((k_warp<false>), grid2d(g, 1), kBlock2d, 0, 0, wi, wo, g);
     HM_HIP(hipDeviceSynchronize());
     for (int i = 0; i < 8; i++) OP_CHECK(Scratch::down(g, o[i], out[i]));
     return HM_OK;

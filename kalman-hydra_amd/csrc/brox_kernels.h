@@ -126,13 +126,20 @@ struct WarpOut {
     float *Iz, *Ix, *Iy, *Ixz, *Iyz, *Ixx, *Ixy, *Iyy;
 };
 
-// One 64x4 block.  The taps of a block's bilinear samples lie in a window only a little larger than
-// the block wherever the flow is smooth: the block finds the bounding box of its taps (LDS
-// min/max), stages that window of the six sampled fields in LDS with row-wise coalesced reads and
-// samples from there.  A block whose taps do not fit the window (a discontinuity, a very large
-// divergence) samples from memory directly -- same values, same arithmetic either way.
-#define WARP_WX 88            // 64 + 2 * 12
-#define WARP_WY 20            // 4 + 2 * 8
+// One 64x4 block, two ways of getting at the taps (same values, same arithmetic):
+//   WINDOW = false: every thread reads its 2x2 taps from memory; neighbouring lanes share cache lines
+//       and the vector L1 serves the re-use.
+//   WINDOW = true: the taps of a block's samples lie in a window only a little larger than the block
+//       wherever the flow is smooth; the block finds the bounding box of its taps (wave min/max, then
+//       LDS atomics), stages that window of the six sampled fields in LDS with row-wise coalesced
+//       reads and samples from there.  A block whose taps do not fit (a discontinuity, a very large
+//       divergence) falls back to direct reads.
+// Measured at 8 x 1024^2 (profiles/): direct 126 us (5.0 TB/s of algorithmic traffic), window 173 us
+// with an 80x12 window and 280 us with 88x20 -- the staging costs two barriers and LDS space
+// (occupancy) and buys nothing the L1 does not already give.  Direct is the default
+// (hm_brox_tune "warp_window").
+#define WARP_WX 80            // 64 + 2 * 8
+#define WARP_WY 12            // 4 + 2 * 4
 __device__ __forceinline__ float d_bilin_win(const float (*win)[WARP_WX], int w, int h, int wx0, int wy0, float px, float py)
 {
     if (px < 0.0f) px = 0.0f;
@@ -151,9 +158,10 @@ __device__ __forceinline__ float d_bilin_win(const float (*win)[WARP_WX], int w,
     return (1.0f - ay) * top + ay * bot;
 }
 
+template <bool WINDOW>
 __global__ __launch_bounds__(256) void k_warp(WarpIn in, WarpOut out, Geo g)
 {
-    __shared__ float win[6][WARP_WY][WARP_WX];
+    __shared__ float win[WINDOW ? 6 : 1][WINDOW ? WARP_WY : 1][WARP_WX];
     __shared__ int s_box[4];                      // min x, max x, min y, max y over the block's taps
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
@@ -169,6 +177,9 @@ __global__ __launch_bounds__(256) void k_warp(WarpIn in, WarpOut out, Geo g)
         py = (float)y + in.v[p];
         sampled = !(px < 0.0f || py < 0.0f || px > (float)(w - 1) || py > (float)(h - 1));
     }
+    bool staged = false;
+    int wx0 = 0, wy0 = 0;
+    if (WINDOW) {
     if (tid == 0) { s_box[0] = w; s_box[1] = -1; s_box[2] = h; s_box[3] = -1; }
     __syncthreads();
     {
@@ -187,8 +198,9 @@ __global__ __launch_bounds__(256) void k_warp(WarpIn in, WarpOut out, Geo g)
         }
     }
     __syncthreads();
-    const int wx0 = s_box[0], wx1 = s_box[1], wy0 = s_box[2], wy1 = s_box[3];
-    const bool staged = wx1 >= wx0 && wx1 - wx0 < WARP_WX && wy1 - wy0 < WARP_WY;
+    const int wx1 = s_box[1], wy1 = s_box[3];
+    wx0 = s_box[0]; wy0 = s_box[2];
+    staged = wx1 >= wx0 && wx1 - wx0 < WARP_WX && wy1 - wy0 < WARP_WY;
     if (staged) {
         const float *src[6] = {in.I1 + off, in.I1x + off, in.I1y + off, in.I1xx + off, in.I1xy + off, in.I1yy + off};
         const int ww = wx1 - wx0 + 1, wh = wy1 - wy0 + 1;
@@ -196,10 +208,11 @@ __global__ __launch_bounds__(256) void k_warp(WarpIn in, WarpOut out, Geo g)
             const int ly = i / ww, lx = i - ly * ww;
             const int q = (wy0 + ly) * pitch + wx0 + lx;
 #pragma unroll
-            for (int f = 0; f < 6; f++) win[f][ly][lx] = src[f][q];
+            for (int f = 0; f < 6; f++) win[WINDOW ? f : 0][ly][lx] = src[f][q];
         }
     }
     __syncthreads();
+    }
     if (!inside) return;
     if (!sampled) {
         out.Iz[p] = 0.0f; out.Ix[p] = 0.0f; out.Iy[p] = 0.0f; out.Ixz[p] = 0.0f; out.Iyz[p] = 0.0f;
@@ -208,9 +221,9 @@ __global__ __launch_bounds__(256) void k_warp(WarpIn in, WarpOut out, Geo g)
     }
     float i1, ix, iy;
     if (staged) {
-        i1 = d_bilin_win(win[0], w, h, wx0, wy0, px, py);
-        ix = d_bilin_win(win[1], w, h, wx0, wy0, px, py);
-        iy = d_bilin_win(win[2], w, h, wx0, wy0, px, py);
+        i1 = d_bilin_win(win[WINDOW ? 0 : 0], w, h, wx0, wy0, px, py);
+        ix = d_bilin_win(win[WINDOW ? 1 : 0], w, h, wx0, wy0, px, py);
+        iy = d_bilin_win(win[WINDOW ? 2 : 0], w, h, wx0, wy0, px, py);
     } else {
         i1 = d_bilin(in.I1 + off, w, h, pitch, px, py);
         ix = d_bilin(in.I1x + off, w, h, pitch, px, py);
@@ -227,9 +240,9 @@ __global__ __launch_bounds__(256) void k_warp(WarpIn in, WarpOut out, Geo g)
     out.Ixz[p] = ix - in.Ix0[p];
     out.Iyz[p] = iy - in.Iy0[p];
     if (staged) {
-        out.Ixx[p] = d_bilin_win(win[3], w, h, wx0, wy0, px, py);
-        out.Ixy[p] = d_bilin_win(win[4], w, h, wx0, wy0, px, py);
-        out.Iyy[p] = d_bilin_win(win[5], w, h, wx0, wy0, px, py);
+        out.Ixx[p] = d_bilin_win(win[WINDOW ? 3 : 0], w, h, wx0, wy0, px, py);
+        out.Ixy[p] = d_bilin_win(win[WINDOW ? 4 : 0], w, h, wx0, wy0, px, py);
+        out.Iyy[p] = d_bilin_win(win[WINDOW ? 5 : 0], w, h, wx0, wy0, px, py);
     } else {
         out.Ixx[p] = d_bilin(in.I1xx + off, w, h, pitch, px, py);
         out.Ixy[p] = d_bilin(in.I1xy + off, w, h, pitch, px, py);

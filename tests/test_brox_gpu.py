@@ -71,8 +71,9 @@ def test_warp_prepare(hm, oracle_brox, w, h):
 
 @pytest.mark.parametrize("kind", ["smooth", "rough", "jump", "outside"])
 def test_warp_window_and_direct_sampling_agree_with_oracle(hm, oracle_brox, kind):
-    """k_warp stages the window of a block's taps in LDS when it fits (smooth flow) and samples from
-    memory when it does not (rough flow, a discontinuity); either way bit-identical to the oracle."""
+    """k_warp in both variants -- direct reads, and the window of a block's taps staged in LDS when it
+    fits (smooth flow) with the fall-back when it does not (rough flow, a discontinuity) -- is
+    bit-identical to the oracle."""
     from hydra_mi import brox
     w, h = 200, 150
     f = list(_level_fields(oracle_brox, w, h, 50))
@@ -85,10 +86,11 @@ def test_warp_window_and_direct_sampling_agree_with_oracle(hm, oracle_brox, kind
         f[9] = np.where(xx < 97, -7.5, 31.25).astype(np.float32); f[10] = np.where(yy < 70, 12.0, -9.0).astype(np.float32)
     else:
         f[9] = np.full((h, w), 500.0, np.float32); f[10] = np.zeros((h, w), np.float32)
-    got = brox.op_warp(*f)
     ref = oracle_brox.warp(*f)
-    for name, g_, r_ in zip("Iz Ix Iy Ixz Iyz Ixx Ixy Iyy".split(), got, ref):
-        assert np.array_equal(g_, r_), (kind, name)
+    for window in (False, True):
+        got = brox.op_warp(*f, window=window)
+        for name, g_, r_ in zip("Iz Ix Iy Ixz Iyz Ixx Ixy Iyy".split(), got, ref):
+            assert np.array_equal(g_, r_), (kind, window, name)
 
 
 @pytest.mark.parametrize("w,h", SIZES + [(300, 300)])
@@ -155,7 +157,7 @@ def test_calc_batch_and_tuning_do_not_change_results(hm, oracle_brox):
         ru, rv = oracle_brox.calc(F0[i], F1[i])
         assert np.array_equal(U[i], ru) and np.array_equal(V[i], rv)
     for key, val in [("sor_fuse", 1), ("sor_fuse", 2), ("sor_threads", 512), ("sor_fuse", 0), ("sor_threads", 1024), ("graph", 0),
-                     ("graph", 1)]:
+                     ("graph", 1), ("warp_window", 1), ("warp_window", 0)]:
         bf.tune(key, val)
         U2, V2 = bf.calc_batch(F0, F1)
         assert np.array_equal(U, U2) and np.array_equal(V, V2), (key, val)
