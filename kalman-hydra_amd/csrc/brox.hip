@@ -394,9 +394,8 @@ static int brox_run(hm_brox *h, int n, const uint8_t *d_f0, const uint8_t *d_f1,
         Coef co = {h->nu, h->nv, h->a12, h->idu, h->idv, h->sx, h->sy};
         for (int it = 0; it < h->inner; it++) {
             PrepIn pi = {u, v, h->du[cur], h->dv[cur], h->Iz, h->Ix, h->Iy, h->Ixz, h->Iyz, h->Ixx, h->Ixy, h->Iyy};
-            hipLaunchKernelGGL(k_diffusivity, dim3(hm_cdiv(g.w, DIFF_BX), hm_cdiv(g.h, DIFF_BY), n),
-                               dim3(DIFF_BX, DIFF_BY), 0, s, pi, co, g, h->alpha);
-            hipLaunchKernelGGL(k_system, gr, kBlock2d, 0, s, pi, co, g, h->gamma);
+            hipLaunchKernelGGL(k_prepare, dim3(hm_cdiv(g.w, PREP_BX), hm_cdiv(g.h, PREP_BY), n), dim3(PREP_BX, PREP_BY), 0, s,
+                               pi, co, g, h->alpha, h->gamma);
             for (int done = 0; done < h->solver; done += plan.K) {
                 SorArgs a;
                 a.du_in = h->du[cur]; a.dv_in = h->dv[cur];
@@ -627,9 +626,8 @@ extern "C" int hm_op_prepare(const float *const in[12], int w, int h, float alph
     for (int i = 0; i < 7; i++) { o[i] = sc.plane(g); OP_CHECK(o[i]); }
     PrepIn pi = {d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10], d[11]};
     Coef co = {o[0], o[1], o[2], o[3], o[4], o[5], o[6]};
-    hipLaunchKernelGGL(k_diffusivity, dim3(hm_cdiv(w, DIFF_BX), hm_cdiv(h, DIFF_BY), 1), dim3(DIFF_BX, DIFF_BY), 0, 0,
-                       pi, co, g, alpha);
-    hipLaunchKernelGGL(k_system, grid2d(g, 1), kBlock2d, 0, 0, pi, co, g, gamma);
+    hipLaunchKernelGGL(k_prepare, dim3(hm_cdiv(w, PREP_BX), hm_cdiv(h, PREP_BY), 1), dim3(PREP_BX, PREP_BY), 0, 0,
+                       pi, co, g, alpha, gamma);
     HM_HIP(hipDeviceSynchronize());
     for (int i = 0; i < 7; i++) OP_CHECK(Scratch::down(g, o[i], out[i]));
     return HM_OK;

@@ -260,61 +260,84 @@ struct Coef {
     float *nu, *nv, *a12, *idu, *idv, *sx, *sy;
 };
 
-// Stage 1: edge diffusivities of the smoothness term at the current u+du, v+dv.
-// One 64x4 block; U = u+du and V = v+dv of the block plus a 1-px ring are staged
-// in LDS once (every pixel is needed by up to 8 neighbouring edges).
-#define DIFF_BX 64
-#define DIFF_BY 4
-__global__ __launch_bounds__(DIFF_BX * DIFF_BY) void k_diffusivity(PrepIn in, Coef c, Geo g, float alpha)
+// One launch per lagged-nonlinearity step: the edge diffusivities of the smoothness term at the
+// current u+du, v+dv, then the 2x2 system of every pixel.  One 64x4 block; u, v, u+du and v+dv of the
+// block plus a 1-px ring are staged in LDS once (ring filled with clamped reads, so clamped
+// neighbours coincide with it); every thread computes the diffusivities of its own right and lower
+// edge, the block's first column / first row of threads also those of the edges towards the
+// neighbouring blocks (recomputed there with the same operations: the same bits), and the system is
+// assembled from LDS.  sx, sy are written for the SOR sweeps; nothing is re-read from memory.
+#define PREP_BX 64
+#define PREP_BY 4
+__device__ __forceinline__ float d_edge_x(const float (*sU)[PREP_BX + 2], const float (*sV)[PREP_BX + 2], int lx, int ly,
+                                          float alpha)
 {
-    __shared__ float sU[DIFF_BY + 2][DIFF_BX + 2];
-    __shared__ float sV[DIFF_BY + 2][DIFF_BX + 2];
-    const int w = g.w, h = g.h, pitch = g.pitch;
-    const size_t off = (size_t)blockIdx.z * g.plane;
-    const int bx0 = blockIdx.x * DIFF_BX, by0 = blockIdx.y * DIFF_BY;
-    const int tid = threadIdx.y * DIFF_BX + threadIdx.x;
-    for (int i = tid; i < (DIFF_BY + 2) * (DIFF_BX + 2); i += DIFF_BX * DIFF_BY) {
-        int ly = i / (DIFF_BX + 2), lx = i - ly * (DIFF_BX + 2);
-        int gx = d_clampi(bx0 + lx - 1, 0, w - 1), gy = d_clampi(by0 + ly - 1, 0, h - 1);
-        size_t p = off + gy * pitch + gx;
-        sU[ly][lx] = in.u[p] + in.du[p];
-        sV[ly][lx] = in.v[p] + in.dv[p];
-    }
-    __syncthreads();
-    int x = bx0 + threadIdx.x, y = by0 + threadIdx.y;
-    if (x >= w || y >= h) return;
-    // LDS coordinates of (x,y); clamped neighbours coincide with the ring because the
-    // ring itself was filled with clamped reads
-    int lx = threadIdx.x + 1, ly = threadIdx.y + 1;
-    size_t p = off + y * pitch + x;
-    float rsx = 0.0f, rsy = 0.0f;
-    if (x + 1 < w) {
-        float ux = sU[ly][lx + 1] - sU[ly][lx];
-        float vx = sV[ly][lx + 1] - sV[ly][lx];
-        float uy = 0.25f * ((sU[ly + 1][lx] - sU[ly - 1][lx]) + (sU[ly + 1][lx + 1] - sU[ly - 1][lx + 1]));
-        float vy = 0.25f * ((sV[ly + 1][lx] - sV[ly - 1][lx]) + (sV[ly + 1][lx + 1] - sV[ly - 1][lx + 1]));
-        rsx = alpha * d_psi(((ux * ux + uy * uy) + vx * vx) + vy * vy);
-    }
-    if (y + 1 < h) {
-        float uy = sU[ly + 1][lx] - sU[ly][lx];
-        float vy = sV[ly + 1][lx] - sV[ly][lx];
-        float ux = 0.25f * ((sU[ly][lx + 1] - sU[ly][lx - 1]) + (sU[ly + 1][lx + 1] - sU[ly + 1][lx - 1]));
-        float vx = 0.25f * ((sV[ly][lx + 1] - sV[ly][lx - 1]) + (sV[ly + 1][lx + 1] - sV[ly + 1][lx - 1]));
-        rsy = alpha * d_psi(((ux * ux + uy * uy) + vx * vx) + vy * vy);
-    }
-    c.sx[p] = rsx;
-    c.sy[p] = rsy;
+    float ux = sU[ly][lx + 1] - sU[ly][lx];
+    float vx = sV[ly][lx + 1] - sV[ly][lx];
+    float uy = 0.25f * ((sU[ly + 1][lx] - sU[ly - 1][lx]) + (sU[ly + 1][lx + 1] - sU[ly - 1][lx + 1]));
+    float vy = 0.25f * ((sV[ly + 1][lx] - sV[ly - 1][lx]) + (sV[ly + 1][lx + 1] - sV[ly - 1][lx + 1]));
+    return alpha * d_psi(((ux * ux + uy * uy) + vx * vx) + vy * vy);
+}
+__device__ __forceinline__ float d_edge_y(const float (*sU)[PREP_BX + 2], const float (*sV)[PREP_BX + 2], int lx, int ly,
+                                          float alpha)
+{
+    float uy = sU[ly + 1][lx] - sU[ly][lx];
+    float vy = sV[ly + 1][lx] - sV[ly][lx];
+    float ux = 0.25f * ((sU[ly][lx + 1] - sU[ly][lx - 1]) + (sU[ly + 1][lx + 1] - sU[ly + 1][lx - 1]));
+    float vx = 0.25f * ((sV[ly][lx + 1] - sV[ly][lx - 1]) + (sV[ly + 1][lx + 1] - sV[ly + 1][lx - 1]));
+    return alpha * d_psi(((ux * ux + uy * uy) + vx * vx) + vy * vy);
 }
 
-// Stage 2: data and gradient-constancy terms and the assembled 2x2-block system.
-__global__ void k_system(PrepIn in, Coef c, Geo g, float gamma)
+__global__ __launch_bounds__(PREP_BX * PREP_BY) void k_prepare(PrepIn in, Coef c, Geo g, float alpha, float gamma)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x;
-    int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= g.w || y >= g.h) return;
+    __shared__ float sU[PREP_BY + 2][PREP_BX + 2];      // u + du
+    __shared__ float sV[PREP_BY + 2][PREP_BX + 2];
+    __shared__ float su0[PREP_BY + 2][PREP_BX + 2];     // u
+    __shared__ float sv0[PREP_BY + 2][PREP_BX + 2];
+    __shared__ float sSX[PREP_BY][PREP_BX + 1];         // sx of columns bx0-1 .. bx0+63
+    __shared__ float sSY[PREP_BY + 1][PREP_BX];         // sy of rows by0-1 .. by0+3
     const int w = g.w, h = g.h, pitch = g.pitch;
     const size_t off = (size_t)blockIdx.z * g.plane;
+    const int bx0 = blockIdx.x * PREP_BX, by0 = blockIdx.y * PREP_BY;
+    const int tid = threadIdx.y * PREP_BX + threadIdx.x;
+    for (int i = tid; i < (PREP_BY + 2) * (PREP_BX + 2); i += PREP_BX * PREP_BY) {
+        int ly = i / (PREP_BX + 2), lx = i - ly * (PREP_BX + 2);
+        int gx = d_clampi(bx0 + lx - 1, 0, w - 1), gy = d_clampi(by0 + ly - 1, 0, h - 1);
+        size_t p = off + gy * pitch + gx;
+        const float uu = in.u[p], vv = in.v[p];
+        su0[ly][lx] = uu;
+        sv0[ly][lx] = vv;
+        sU[ly][lx] = uu + in.du[p];
+        sV[ly][lx] = vv + in.dv[p];
+    }
+    __syncthreads();
+    const int x = bx0 + threadIdx.x, y = by0 + threadIdx.y;
+    const int lx = threadIdx.x + 1, ly = threadIdx.y + 1;
+    const bool inside = x < w && y < h;
+    // diffusivities of the own right / lower edge (zero across the image border) ...
+    float rsx = 0.0f, rsy = 0.0f;
+    if (inside) {
+        if (x + 1 < w) rsx = d_edge_x(sU, sV, lx, ly, alpha);
+        if (y + 1 < h) rsy = d_edge_y(sU, sV, lx, ly, alpha);
+    }
+    sSX[threadIdx.y][threadIdx.x + 1] = rsx;
+    sSY[threadIdx.y + 1][threadIdx.x] = rsy;
+    // ... and of the edges towards the block on the left (first column of threads) and above (first row)
+    if (threadIdx.x == 0) {
+        float v = 0.0f;
+        if (bx0 > 0 && y < h) v = d_edge_x(sU, sV, 0, ly, alpha);      // pixel (bx0-1, y): x + 1 = bx0 < w
+        sSX[threadIdx.y][0] = v;
+    }
+    if (threadIdx.y == 0) {
+        float v = 0.0f;
+        if (by0 > 0 && x < w) v = d_edge_y(sU, sV, lx, 0, alpha);      // pixel (x, by0-1): y + 1 = by0 < h
+        sSY[0][threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (!inside) return;
     const size_t p = off + y * pitch + x;
+    c.sx[p] = rsx;
+    c.sy[p] = rsy;
     float ddu = in.du[p], ddv = in.dv[p];
     float ix = in.Ix[p], iy = in.Iy[p], iz = in.Iz[p];
     float ixx = in.Ixx[p], ixy = in.Ixy[p], iyy = in.Iyy[p], ixz = in.Ixz[p], iyz = in.Iyz[p];
@@ -328,13 +351,12 @@ __global__ void k_system(PrepIn in, Coef c, Geo g, float gamma)
     float A22 = pd * (iy * iy) + pg * (ixy * ixy + iyy * iyy);
     float b1 = -(pd * (ix * iz) + pg * (ixx * ixz + ixy * iyz));
     float b2 = -(pd * (iy * iz) + pg * (ixy * ixz + iyy * iyz));
-    float sl = x > 0 ? c.sx[p - 1] : 0.0f, sr = c.sx[p];
-    float st = y > 0 ? c.sy[p - pitch] : 0.0f, sb = c.sy[p];
-    size_t pl = x > 0 ? p - 1 : p, pr = x + 1 < w ? p + 1 : p;
-    size_t pt = y > 0 ? p - pitch : p, pb = y + 1 < h ? p + pitch : p;
-    float uc = in.u[p], vc = in.v[p];
-    float su = ((sl * (in.u[pl] - uc) + sr * (in.u[pr] - uc)) + st * (in.u[pt] - uc)) + sb * (in.u[pb] - uc);
-    float sv = ((sl * (in.v[pl] - vc) + sr * (in.v[pr] - vc)) + st * (in.v[pt] - vc)) + sb * (in.v[pb] - vc);
+    float sl = x > 0 ? sSX[threadIdx.y][threadIdx.x] : 0.0f, sr = rsx;
+    float st = y > 0 ? sSY[threadIdx.y][threadIdx.x] : 0.0f, sb = rsy;
+    // clamped neighbours of u, v: the ring holds them
+    float uc = su0[ly][lx], vc = sv0[ly][lx];
+    float su = ((sl * (su0[ly][lx - 1] - uc) + sr * (su0[ly][lx + 1] - uc)) + st * (su0[ly - 1][lx] - uc)) + sb * (su0[ly + 1][lx] - uc);
+    float sv = ((sl * (sv0[ly][lx - 1] - vc) + sr * (sv0[ly][lx + 1] - vc)) + st * (sv0[ly - 1][lx] - vc)) + sb * (sv0[ly + 1][lx] - vc);
     float ssum = ((sl + sr) + st) + sb;
     c.nu[p] = b1 + su;
     c.nv[p] = b2 + sv;

@@ -10,9 +10,8 @@ import csv, sys, collections
 PX = 8 * 1024 * 1024
 FLOW = {                       # kernel prefix -> (algorithmic bytes per pixel per launch, note)
     "void k_sor": (52.0 * 5, "52 B/px/iteration x 5 fused iterations"),
-    "k_system": (68.0, "12 fields read + 5 written"),
-    "k_diffusivity": (24.0, "u,v,du,dv read + 2 written"),
-    "k_warp": (76.0, "11 read + 8 written"),
+    "k_prepare": (76.0, "u,v,du,dv + 8 warped fields read, 7 written"),
+    "void k_warp": (76.0, "11 read + 8 written"),
     "k_deriv": (12.0, "1 read + 2 written"),
     "k_add": (24.0, "4 read + 2 written"),
 }
