@@ -4,11 +4,11 @@
 //
 // Matrices are row-major with leading dimension n.  A factorisation reads a working copy A (which
 // it destroys) and writes three things: the factor's blocks below the 32x32 block diagonal to an
-// array L of the same shape, its diagonal blocks to a side array Ld and their inverses to Lt (all
-// identity padded when n is not a multiple of 32).  A may carry extra rows below row nb*32
+// array L of the same shape and the inverses of its 32x32 diagonal blocks to a side array Lt
+// (identity padded when n is not a multiple of 32).  A may carry extra rows below row nb*32
 // (nb = ceil(n/32)): right-hand sides stored as ROWS.  The factorisation treats them like any other
 // block row, which turns them into (L^-1 b)^T -- the forward substitution of a solve comes for
-// free; k_back_row finishes it.  32x32x32 block products run on the f64 matrix cores
+// free; T = L^-1 (k_tinv_*) and x = T^T y (k_tvec) finish it.  32x32x32 block products run on the f64 matrix cores
 // (v_mfma_f64_16x16x4_f64); launches communicate through memory only, in a fixed order, so results
 // do not depend on workgroup scheduling.
 #pragma once
@@ -37,15 +37,14 @@ __device__ __forceinline__ double d_rsqrt(double d)
 
 // ---- potrf, one launch per block column -----------------------------------------------------------
 // The factorisation reads a working copy A and writes the factor to a separate array L (same
-// shape; blocks below the block diagonal), the factored diagonal blocks to Ld and their inverses
-// to Lt.  Launch k (k_chol_step) does everything that involves block column k and has no later
+// shape; blocks below the block diagonal) and the inverses of the factored diagonal blocks to Lt.  Launch k (k_chol_step) does everything that involves block column k and has no later
 // dependency:
 //   workgroup (r, c), r >= c > k:  X_r = A_rk T_k^T and X_c = A_ck T_k^T with T_k = L_kk^-1 (Lt[k], left
 //       by the previous launch; each workgroup forms the two panel blocks it needs itself, from the raw
 //       panel in A), then A_rc -= X_r X_c^T -- 32x32x32 products on the f64 matrix cores;
 //   workgroups of block column c = k+1 also store X_r as L_rk;
-//   workgroup (k+1, k+1) goes on to factor its updated block into Ld[k+1] and to invert the factor
-//       into Lt[k+1] -- the only part that is sequential across launches.
+//   workgroup (k+1, k+1) goes on to factor its updated block and to invert the factor into Lt[k+1]
+//       -- the only part that is sequential across launches.
 // Nothing is written that another workgroup of the same launch reads (the panel stays raw in A),
 // so the result does not depend on workgroup scheduling.
 __device__ __forceinline__ double d_readlane(double v, int lane)
@@ -162,9 +161,8 @@ __device__ __forceinline__ d4_t d_mfma_nt(double (*X)[DNB + 1], double (*Y)[DNB 
     return c;
 }
 
-// the first diagonal block: A_00 -> Ld[0], its inverse -> Lt[0]
-__global__ __launch_bounds__(256) void k_chol_first(const double *__restrict__ A, double *__restrict__ Ld,
-                                                    double *__restrict__ Lt, int n)
+// the first diagonal block: the inverse of the factor of A_00 -> Lt[0]
+__global__ __launch_bounds__(256) void k_chol_first(const double *__restrict__ A, double *__restrict__ Lt, int n)
 {
     __shared__ double W[DNB][DNB + 1];
     __shared__ double D[DNB][DNB + 1];
@@ -182,7 +180,6 @@ __global__ __launch_bounds__(256) void k_chol_first(const double *__restrict__ A
     chol_block_factor<true>(W, D, rD, Tm, ES, t);
     __syncthreads();
     for (int e = t; e < DNB * DNB; e += 256) {
-        Ld[e] = D[e / DNB][e % DNB];
         Lt[e] = Tm[e / DNB][e % DNB];
     }
 }
@@ -190,9 +187,9 @@ __global__ __launch_bounds__(256) void k_chol_first(const double *__restrict__ A
 // Step k.  Workgroup (r, c), r >= c > k:  X_r = A_rk T^T, X_c = A_ck T^T with T = L_kk^-1 (Lt[k], from
 // the previous launch), A_rc -= X_r X_c^T -- three 32x32x32 products on the matrix cores; column
 // c = k+1 also stores X_r as L_rk; workgroup (k+1, k+1) goes on to factor its updated block into
-// Ld[k+1] and to invert the factor into Lt[k+1].
-__global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, double *__restrict__ L, double *__restrict__ Ld,
-                                                   double *__restrict__ Lt, int n, int nrows, int nb, int k)
+// and to invert the factor into Lt[k+1].
+__global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, double *__restrict__ L, double *__restrict__ Lt,
+                                                   int n, int nrows, int nb, int k)
 {
     const int r = k + 1 + blockIdx.y;
     const int c = k + 1 + blockIdx.x;             // c >= nb: no block to update, the panel row only
@@ -257,125 +254,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, doubl
     chol_block_factor<true>(Br, Ts, rD, Bc, ES, t);
     __syncthreads();
     for (int e = t; e < DNB * DNB; e += 256) {
-        Ld[(size_t)(k + 1) * DNB * DNB + e] = Ts[e / DNB][e % DNB];
         Lt[(size_t)(k + 1) * DNB * DNB + e] = Bc[e / DNB][e % DNB];
-    }
-}
-
-// ---- backward substitution L^T x = y for ONE right-hand side (the row that went through the
-// factorisation), one 1024-thread workgroup, software-pipelined over the 32-row blocks:
-//   wave 0 owns the serial chain -- with x_k known it applies L_{k,k-1}^T x_k to the block above
-//   and solves that block's 32x32 triangle (its column of the diagonal block in registers, the
-//   unknowns passed by v_readlane);
-//   waves 1..15 meanwhile subtract the contribution of x_k from all earlier entries of y (right-
-//   looking; two threads per entry, 16 coalesced loads of the block row of L in flight each) and
-//   fetch the diagonal and sub-diagonal blocks wave 0 needs next into LDS.
-// One barrier per block.
-__device__ __forceinline__ double d_back_triangle(double (*D)[DNB + 1], double val, int li)
-{
-    const double rd = d_rcp(D[li][li]);
-    // two halves of 16 columns: the rest of the workgroup's registers stay live across this call
-#pragma unroll
-    for (int hh = 1; hh >= 0; hh--) {
-        double dcol[DNB / 2];
-#pragma unroll
-        for (int j = 0; j < DNB / 2; j++) dcol[j] = D[hh * (DNB / 2) + j][li];
-#pragma unroll
-        for (int j = DNB / 2 - 1; j >= 0; j--) {
-            const int jj = hh * (DNB / 2) + j;
-            const double xj = d_readlane(val * rd, jj);
-            if (li == jj) val = xj;
-            else if (li < jj) val = val - dcol[j] * xj;
-        }
-    }
-    return val;
-}
-
-__global__ __launch_bounds__(1024) void k_back_row(const double *__restrict__ L, const double *__restrict__ Ld, int n,
-                                                   double *__restrict__ row, const double *__restrict__ x0,
-                                                   double *__restrict__ xn)
-{
-    extern __shared__ double Y[];                 // nb * 32
-    __shared__ double Xb[2][DNB];                 // x of block k in Xb[k & 1]
-    __shared__ double Dg[2][DNB][DNB + 1];        // diagonal block k (identity padded) in Dg[k & 1]
-    __shared__ double Sg[2][DNB][DNB + 1];        // L_{k,k-1} in Sg[k & 1]
-    const int t = threadIdx.x;
-    const int nb = (n + DNB - 1) / DNB;
-    const int li = t & (DNB - 1);
-    constexpr int HR = DNB / 2;                   // rows per thread of a pair
-    // waves 1..15: thread pair (half 0 / 1) owns the entries c0, c0 + 480, c0 + 960, ... of y
-    const int e = t - 64, half = e & 1, c0 = e >> 1;
-    // the rows [half*16, half*16+16) of block row k of L at column c; zero outside the bulk range
-    // of step k (columns < (k-1)*32) and below the matrix
-    auto load_rows = [&](int k, int c, double (&l)[HR]) {
-        const bool on = c < (k - 1) * DNB;
-        const int off = half * HR * n + c;        // one 32-bit lane offset; the row base below is uniform
-        const int rows = n - k * DNB - half * HR; // rows of this half inside the matrix
-#pragma unroll
-        for (int r = 0; r < HR; r++) {
-            const double *Lr = L + (size_t)(k * DNB + r) * n;
-            l[r] = (on && r < rows) ? Lr[off] : 0.0;
-        }
-    };
-    // entry q (0..1023) of the two blocks wave 0 needs at step k: diagonal block k-1 and L_{k,k-1}
-    auto fetch = [&](int k, int q, double &d, double &sg) {
-        d = 0.0; sg = 0.0;
-        if (k >= 1) {
-            d = Ld[(size_t)(k - 1) * DNB * DNB + q];
-            const int gr = k * DNB + q / DNB;
-            sg = gr < n ? L[(size_t)gr * n + (k - 1) * DNB + q % DNB] : 0.0;
-        }
-    };
-    auto put = [&](int k, int q, double d, double sg) {
-        if (k >= 1) { Dg[(k - 1) & 1][q / DNB][q % DNB] = d; Sg[k & 1][q / DNB][q % DNB] = sg; }
-    };
-    for (int i = t; i < nb * DNB; i += 1024) Y[i] = i < n ? row[i] : 0.0;
-    Dg[(nb - 1) & 1][t / DNB][t % DNB] = Ld[(size_t)(nb - 1) * DNB * DNB + t];
-    {
-        double d, sg;
-        fetch(nb - 1, t, d, sg);
-        put(nb - 1, t, d, sg);
-    }
-    __syncthreads();
-    if (t < 64) {
-        const double val = d_back_triangle(Dg[(nb - 1) & 1], Y[(nb - 1) * DNB + li], li);
-        if (t < DNB) { Xb[(nb - 1) & 1][li] = val; Y[(nb - 1) * DNB + li] = val; }
-    }
-    __syncthreads();
-    for (int kb = nb - 1; kb >= 1; kb--) {
-        const int i0 = kb * DNB;
-        const double *x = Xb[kb & 1];
-        if (t < 64) {
-            double v = Y[i0 - DNB + li];
-#pragma unroll 8
-            for (int r = 0; r < DNB; r++) v = v - Sg[kb & 1][r][li] * x[r];
-            const double val = d_back_triangle(Dg[(kb - 1) & 1], v, li);
-            if (t < DNB) { Xb[(kb - 1) & 1][li] = val; Y[i0 - DNB + li] = val; }
-        } else {
-            // all loads of the step are requested together: the two blocks wave 0 needs next and
-            // this thread's rows of block row kb (a second batch only while more than 480 entries
-            // of y are left)
-            const int cols = i0 - DNB;            // the block above is wave 0's
-            double d0, s0, d1 = 0.0, s1 = 0.0;
-            fetch(kb - 1, e, d0, s0);
-            if (e < 64) fetch(kb - 1, e + 960, d1, s1);
-            for (int c = c0; c < cols; c += 480) {            // one batch for up to 480 entries of y
-                double cur[HR];
-                load_rows(kb, c, cur);
-                double a0 = 0.0;
-#pragma unroll
-                for (int r = 0; r < HR; r++) a0 = a0 + cur[r] * x[half * HR + r];
-                a0 = a0 + __shfl_xor(a0, 1, 64);
-                if (half == 0) Y[c] = Y[c] - a0;
-            }
-            put(kb - 1, e, d0, s0);
-            if (e < 64) put(kb - 1, e + 960, d1, s1);
-        }
-        __syncthreads();
-    }
-    for (int i = t; i < n; i += 1024) {
-        row[i] = Y[i];
-        if (xn) xn[i] = x0[i] + 1.0 * Y[i];       // the update's new iterate X0 + step
     }
 }
 
@@ -459,6 +338,35 @@ __global__ __launch_bounds__(256) void k_tinv_level(const double *__restrict__ L
     for (int e = 0; e < 4; e++) {
         const int ii = bi * DNB + 16 * (wv >> 1) + (lane >> 4) + 4 * e;
         if (ii < n && jj < n) Out[(size_t)ii * n + jj] = PHASE == 0 ? acc[e] : -acc[e];
+    }
+}
+
+// ---- x = T^T y: the second half of a solve with A = L L^T once T = L^-1 is at hand ---------------
+// y = L^-1 b is the right-hand-side row that went through the factorisation; x = A^-1 b = T^T y.
+// One 1024-thread workgroup per 32-column block J: thread (g, c) adds T[i][32 J + c] y[i] over the rows
+// i = 32 J + g, + 32, ... (rows of T: coalesced; at most n / 32 loads per thread, all in flight
+// together), the 32 partial sums per column are added in order.  x goes to xout (not onto y: other
+// workgroups still read it); if xn is given, xn = x0 + x is written as well (the update's new iterate).
+__global__ __launch_bounds__(1024) void k_tvec(const double *__restrict__ T, int n, const double *__restrict__ y,
+                                               double *__restrict__ xout, const double *__restrict__ x0,
+                                               double *__restrict__ xn)
+{
+    __shared__ double S[DNB][DNB + 1];
+    const int J = blockIdx.x, t = threadIdx.x, g = t / DNB, c = t % DNB;
+    const int col = J * DNB + c;
+    double acc = 0.0;
+    if (col < n) {
+#pragma unroll 8
+        for (int i = J * DNB + g; i < n; i += DNB) acc = acc + T[(size_t)i * n + col] * y[i];
+    }
+    S[g][c] = acc;
+    __syncthreads();
+    if (t < DNB && J * DNB + t < n) {
+        double v = 0.0;
+#pragma unroll 8
+        for (int q = 0; q < DNB; q++) v = v + S[q][t];
+        xout[J * DNB + t] = v;
+        if (xn) xn[J * DNB + t] = x0[J * DNB + t] + 1.0 * v;
     }
 }
 

@@ -38,7 +38,7 @@ struct hm_ctx {
     // dense update on the device (n4 = 4N)
     double *d_HTH;                   // dense HTH of the last measurement: zero outside the J pattern (cleared once;
                                      // every pattern entry is rewritten by every measurement), used for nothing else
-    double *d_H, *d_Hz, *d_Hzc, *d_invW0, *d_Af[2], *d_Ld[2], *d_Wtmp, *d_X0, *d_Xn, *d_Wprior, *d_gain, *d_Awork, *d_Lt[2];
+    double *d_H, *d_Hz, *d_Hzc, *d_invW0, *d_Af[2], *d_T[2], *d_step, *d_Wtmp, *d_X0, *d_Xn, *d_Wprior, *d_gain, *d_Awork, *d_Lt[2];
     std::vector<double> upd_X0;      // prior mean given to hm_update_begin
     int upd_last, upd_prev;          // which d_Af holds the factor of the last / previous step (-1: none)
     double *d_Wres;                  // the covariance resident on the device (the result of the last
@@ -85,7 +85,7 @@ static int ctx_free(hm_ctx *h)
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_tri, h->d_star_off, h->d_star_tri, h->d_edges, h->d_uv, h->d_tex, h->d_yim, h->d_ym, h->d_yfx,
                     h->d_yfy, h->d_yfxm, h->d_yfym, h->d_setup, h->d_cfgs, h->d_X, h->d_out, h->d_partial, h->d_im8, h->d_m8,
-                    h->d_HTH, h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_Ld[0], h->d_Ld[1], h->d_Wprior, h->d_gain, h->d_Awork, h->d_Lt[0], h->d_Lt[1],
+                    h->d_HTH, h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_T[0], h->d_T[1], h->d_step, h->d_Wprior, h->d_gain, h->d_Awork, h->d_Lt[0], h->d_Lt[1],
                     h->d_Wtmp, h->d_X0, h->d_Xn, h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk,
                     h->pool.hdr, h->pool.off, h->pool.xim, h->pool.xm, h->pool.yim, h->pool.ym, h->pool.xfx, h->pool.xfy,
                     h->pool.yfx, h->pool.yfy, h->pool.vxfx, h->pool.vyfy, h->pool.overflow, h->d_area};
@@ -154,7 +154,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->d_H = h->d_Hz = h->d_Hzc = h->d_invW0 = h->d_Af[0] = h->d_Af[1] = h->d_Wtmp = nullptr;
     h->d_Wprior = h->d_gain = h->d_Awork = h->d_Lt[0] = h->d_Lt[1] = nullptr; h->d_Wres = nullptr; h->pin = nullptr; h->pin_n = 0;
     h->tri.assign(tri, tri + (size_t)3 * T);
-    h->d_Ld[0] = h->d_Ld[1] = nullptr; h->d_X0 = h->d_Xn = nullptr;
+    h->d_T[0] = h->d_T[1] = h->d_step = nullptr; h->d_X0 = h->d_Xn = nullptr;
     memset(&h->pool, 0, sizeof h->pool); h->d_area = nullptr;
     h->d_sp_off = h->d_sp_bar = h->d_sp_other = nullptr; h->d_sp_blk = nullptr; h->sp_cap = 0;
     h->upd_last = h->upd_prev = -1; h->upd_open = false; h->prefactored = false;
@@ -199,8 +199,9 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Af[1], nn_aug);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Awork, nn_aug);
         const size_t ld_bytes = (size_t)hm_cdiv((int)n4, DNB) * DNB * DNB * sizeof(double);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Ld[0], ld_bytes);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Ld[1], ld_bytes);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_T[0], nn);       // L^-1 of the factor in the same slot
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_T[1], nn);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_step, n4 * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Lt[0], ld_bytes);  // inverses of the factored diagonal blocks
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Lt[1], ld_bytes);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Wtmp, nn);
@@ -508,46 +509,43 @@ extern "C" int hm_measure(hm_ctx_t h, const double *X, double deltaX, int masked
 // 32-row block whose first row carries the right-hand side (see dense_kernels.h).
 static int aug_rows(int n) { return hm_cdiv(n, DNB) * DNB + DNB; }
 
-// Cholesky of the n x n matrix in the working copy A (destroyed) into L / Ld; with_rhs: the
+// Cholesky of the n x n matrix in the working copy A (destroyed) into L / Lt; with_rhs: the
 // right-hand-side rows below the matrix go through the elimination too (dense_kernels.h)
-static void chol_factor(hm_ctx *h, double *A, double *L, double *Ld, double *Lt, int n, bool with_rhs)
+static void chol_factor(hm_ctx *h, double *A, double *L, double *Lt, int n, bool with_rhs)
 {
     const int nb = hm_cdiv(n, DNB);
     const int nrows = with_rhs ? aug_rows(n) : n;
     const int nbr = hm_cdiv(nrows, DNB);
-    hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, h->stream, A, Ld, Lt, n);
+    hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, h->stream, A, Lt, n);
     for (int k = 0; k < nb; k++) {
         const int mr = nbr - k - 1, mc = std::max(nb - k - 1, 1);
-        if (mr > 0) hipLaunchKernelGGL(k_chol_step, dim3(mc, mr), dim3(256), 0, h->stream, A, L, Ld, Lt, n, nrows, nb, k);
+        if (mr > 0) hipLaunchKernelGGL(k_chol_step, dim3(mc, mr), dim3(256), 0, h->stream, A, L, Lt, n, nrows, nb, k);
     }
 }
 
-// SPD inverse from the factor: T = L^-1 by recursive doubling from the inverted diagonal blocks Lt
-// (dense_kernels.h), then inv = T^T T.  `scratch` receives T; `out` serves as the scratch of the
-// doubling before it receives the result.
-static void chol_inverse(hm_ctx *h, const double *L, const double *Lt, int n, double *scratch, double *out)
+// T = L^-1 by recursive doubling from the inverted diagonal blocks Lt (dense_kernels.h); M: scratch
+static void chol_tinv(hm_ctx *h, const double *L, const double *Lt, int n, double *T, double *M)
 {
     const int nb = hm_cdiv(n, DNB);
-    hipLaunchKernelGGL(k_tinv_base, dim3(nb), dim3(256), 0, h->stream, Lt, scratch, n);
+    hipLaunchKernelGGL(k_tinv_base, dim3(nb), dim3(256), 0, h->stream, Lt, T, n);
     for (int sb = 1; sb < nb; sb *= 2) {
         const dim3 grid(sb, sb, hm_cdiv(nb, 2 * sb));
-        hipLaunchKernelGGL(k_tinv_level<0>, grid, dim3(256), 0, h->stream, L, scratch, out, n, nb, sb);
-        hipLaunchKernelGGL(k_tinv_level<1>, grid, dim3(256), 0, h->stream, L, scratch, out, n, nb, sb);
+        hipLaunchKernelGGL(k_tinv_level<0>, grid, dim3(256), 0, h->stream, L, T, M, n, nb, sb);
+        hipLaunchKernelGGL(k_tinv_level<1>, grid, dim3(256), 0, h->stream, L, T, M, n, nb, sb);
     }
+}
+
+// SPD inverse from the factor: T = L^-1, then inv = T^T T.  `scratch` receives T; `out` serves as the
+// scratch of the doubling before it receives the result.
+static void chol_inverse(hm_ctx *h, const double *L, const double *Lt, int n, double *scratch, double *out)
+{
+    chol_tinv(h, L, Lt, n, scratch, out);
+    const int nb = hm_cdiv(n, DNB);
     hipLaunchKernelGGL(k_ttt, dim3(nb, nb), dim3(256), 0, h->stream, scratch, n, out);
 }
 
-// backward substitution L^T x = y for the right-hand side that went through the factorisation as a row
-// (x0, xn: if given, xn = x0 + x is written as well -- the new iterate of the update)
-static void chol_backsolve_row(hm_ctx *h, double *A, const double *Ld, int n, const double *x0, double *xn)
-{
-    double *row = A + (size_t)hm_cdiv(n, DNB) * DNB * n;     // y^T, overwritten by x^T
-    hipLaunchKernelGGL(k_back_row, dim3(1), dim3(1024), (size_t)hm_cdiv(n, DNB) * DNB * sizeof(double), h->stream, A, Ld, n, row,
-                       x0, xn);
-}
-
 // one iteration's worth of launches of the update: system assembly, factorisation, solve.
-// d_X holds the iterate the measurement was taken at; the step ends up in the right-hand-side row.
+// d_X holds the iterate the measurement was taken at; returns the step (d_step).
 static double *solve_step(hm_ctx *h, int slot)
 {
     const int n4 = 4 * h->N;
@@ -558,9 +556,16 @@ static double *solve_step(hm_ctx *h, int slot)
     double *rhs_row = A + (size_t)rhs_index * n4;
     hipLaunchKernelGGL(k_assemble, dim3(aug_rows(n4)), dim3(256), 0, h->stream, h->d_invW0, h->d_HTH, h->d_X0, h->d_X,
                        h->d_Hz, A, n4, rhs_index);
-    chol_factor(h, A, h->d_Af[slot], h->d_Ld[slot], h->d_Lt[slot], n4, true);
-    chol_backsolve_row(h, h->d_Af[slot], h->d_Ld[slot], n4, h->d_X0, h->d_Xn);     // also d_Xn = X0 + step
-    return h->d_Af[slot] + (rhs_row - A);
+    chol_factor(h, A, h->d_Af[slot], h->d_Lt[slot], n4, true);
+    // y = L^-1 b came out of the factorisation as the extra row; x = T^T y with T = L^-1, which stays in
+    // the slot for hm_update_cov (inv = T^T T).  d_Wtmp is scratch between hm_update_begin and the
+    // next hm_cov_predict.
+    if (h->d_Wres == h->d_Wtmp) h->d_Wres = nullptr;          // a covariance predicted since hm_update_begin is lost
+    chol_tinv(h, h->d_Af[slot], h->d_Lt[slot], n4, h->d_T[slot], h->d_Wtmp);
+    const double *yrow = h->d_Af[slot] + (rhs_row - A);
+    hipLaunchKernelGGL(k_tvec, dim3(hm_cdiv(n4, DNB)), dim3(1024), 0, h->stream, h->d_T[slot], n4, yrow, h->d_step, h->d_X0,
+                       h->d_Xn);                              // also d_Xn = X0 + step
+    return h->d_step;
 }
 
 // the covariance half of hm_update_begin: the prior into d_Wprior, its factor, inv(W) into d_invW0
@@ -578,7 +583,7 @@ static int prior_inverse(hm_ctx *h, const double *W_prior)
         HM_HIP(hipMemcpyAsync(h->d_Wprior, h->d_Wres, nnb, hipMemcpyDeviceToDevice, h->stream));
     HM_HIP(hipMemcpyAsync(h->d_Awork, h->d_Wprior, nnb, hipMemcpyDeviceToDevice, h->stream));
     h->d_Wres = h->d_Wprior;                     // d_Wtmp is scratch from here on
-    chol_factor(h, h->d_Awork, h->d_Af[0], h->d_Ld[0], h->d_Lt[0], n4, false);
+    chol_factor(h, h->d_Awork, h->d_Af[0], h->d_Lt[0], n4, false);
     chol_inverse(h, h->d_Af[0], h->d_Lt[0], n4, h->d_Wtmp, h->d_invW0);
     HM_HIP(hipGetLastError());
     return HM_OK;
@@ -685,7 +690,10 @@ extern "C" int hm_update_cov(hm_ctx_t h, int which, double *W_out)
     } else {
         const int slot = which == 0 ? h->upd_last : h->upd_prev;
         if (slot < 0) { hm_set_error("hm_update_cov: no such step"); return HM_ERR_STATE; }
-        chol_inverse(h, h->d_Af[slot], h->d_Lt[slot], n4, h->d_Wtmp, h->d_H);
+        {   // T of this slot is there since its solve: inv = T^T T
+            const int nb = hm_cdiv(n4, DNB);
+            hipLaunchKernelGGL(k_ttt, dim3(nb, nb), dim3(256), 0, h->stream, h->d_T[slot], n4, h->d_H);
+        }
         HM_HIP(hipGetLastError());
         h->d_Wres = h->d_H;
     }
