@@ -572,9 +572,6 @@ static double *solve_step(hm_ctx *h, int slot)
 static int prior_inverse(hm_ctx *h, const double *W_prior)
 {
     const int n4 = 4 * h->N;
-    // k_back_row keeps the right-hand side (one double per row, padded to whole blocks) in LDS
-    HM_ARG((size_t)hm_cdiv(n4, DNB) * DNB * sizeof(double) <= 64 * 1024, "hm_update_begin: state dimension %d too large for the "
-           "on-device solve (limit %d)", n4, 64 * 1024 / 8);
     // the prior stays in d_Wprior: it is the covariance to keep when no iterate is accepted
     const size_t nnb = (size_t)n4 * n4 * sizeof(double);
     if (W_prior)
