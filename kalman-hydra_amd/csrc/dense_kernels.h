@@ -275,12 +275,45 @@ __device__ __forceinline__ d4_t d_mfma_nn(double (*X)[DNB + 1], double (*Y)[DNB 
     return c;
 }
 
-__global__ __launch_bounds__(256) void k_tinv_base(const double *__restrict__ Lt, double *__restrict__ T, int n)
+// The first level in one launch: workgroup p takes the diagonal blocks 2p and 2p+1 -- copies their
+// inverses from Lt into T and forms the block between them, T21 = -T22 (L21 T11), both products from
+// LDS.  (A last block without a partner is only copied.)
+__global__ __launch_bounds__(256) void k_tinv_first(const double *__restrict__ L, const double *__restrict__ Lt,
+                                                    double *__restrict__ T, int n, int nb)
 {
-    const int b = blockIdx.x, t = threadIdx.x;
+    __shared__ double A1[DNB][DNB + 1];           // T11, later M = L21 T11
+    __shared__ double A2[DNB][DNB + 1];           // T22
+    __shared__ double B[DNB][DNB + 1];            // L21
+    const int b0 = 2 * blockIdx.x, b1 = b0 + 1;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const bool pair = b1 < nb;
     for (int e = t; e < DNB * DNB; e += 256) {
-        const int i = b * DNB + e / DNB, j = b * DNB + e % DNB;
-        if (i < n && j < n) T[(size_t)i * n + j] = Lt[(size_t)b * DNB * DNB + e];
+        const int r = e / DNB, c = e % DNB;
+        const double t11 = Lt[(size_t)b0 * DNB * DNB + e];
+        A1[r][c] = t11;
+        if (b0 * DNB + r < n && b0 * DNB + c < n) T[(size_t)(b0 * DNB + r) * n + b0 * DNB + c] = t11;
+        if (pair) {
+            const double t22 = Lt[(size_t)b1 * DNB * DNB + e];
+            A2[r][c] = t22;
+            const int gr = b1 * DNB + r, gc = b1 * DNB + c;
+            if (gr < n && gc < n) T[(size_t)gr * n + gc] = t22;
+            B[r][c] = gr < n ? L[(size_t)gr * n + b0 * DNB + c] : 0.0;
+        }
+    }
+    if (!pair) return;
+    __syncthreads();
+    d4_t z = {0.0, 0.0, 0.0, 0.0};
+    const d4_t m = d_mfma_nn(B, A1, wv, lane, z);             // M = L21 T11
+    __syncthreads();                                          // all reads of T11 done
+    const int mj = 16 * (wv & 1) + (lane & 15);
+#pragma unroll
+    for (int e = 0; e < 4; e++) A1[16 * (wv >> 1) + (lane >> 4) + 4 * e][mj] = m[e];
+    __syncthreads();
+    const d4_t r = d_mfma_nn(A2, A1, wv, lane, z);            // T22 M
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int gr = b1 * DNB + 16 * (wv >> 1) + (lane >> 4) + 4 * e, gc = b0 * DNB + mj;
+        if (gr < n) T[(size_t)gr * n + gc] = -r[e];
     }
 }
 

@@ -527,8 +527,8 @@ static void chol_factor(hm_ctx *h, double *A, double *L, double *Lt, int n, bool
 static void chol_tinv(hm_ctx *h, const double *L, const double *Lt, int n, double *T, double *M)
 {
     const int nb = hm_cdiv(n, DNB);
-    hipLaunchKernelGGL(k_tinv_base, dim3(nb), dim3(256), 0, h->stream, Lt, T, n);
-    for (int sb = 1; sb < nb; sb *= 2) {
+    hipLaunchKernelGGL(k_tinv_first, dim3(hm_cdiv(nb, 2)), dim3(256), 0, h->stream, L, Lt, T, n, nb);
+    for (int sb = 2; sb < nb; sb *= 2) {
         const dim3 grid(sb, sb, hm_cdiv(nb, 2 * sb));
         hipLaunchKernelGGL(k_tinv_level<0>, grid, dim3(256), 0, h->stream, L, T, M, n, nb, sb);
         hipLaunchKernelGGL(k_tinv_level<1>, grid, dim3(256), 0, h->stream, L, T, M, n, nb, sb);
