@@ -153,6 +153,44 @@ def test_measure_equals_single_perturbation_operators(hm):
         assert R.j(st, 2.0, int(i), int(j)) == 0.0
 
 
+@pytest.mark.parametrize("case", ["outside", "folded", "blank", "saturated"])
+def test_measure_edge_cases_match_oracle(hm, case):
+    """The fused measurement where the rasteriser's corner cases matter: a mesh partly outside the
+    frame (clipped star boxes), folded triangles (overlap: additive blending, 8-bit saturation),
+    an empty observation (no mask, zero flow), a saturated texture."""
+    n = 48
+    dm, N, tex, R, meas = _setup(hm, n, 10.0, seed=14)
+    rng = np.random.default_rng(17)
+    X = _state(dm, rng, pos_sigma=0.5)
+    if case == "outside":
+        X[0:2 * N:2] -= 0.45 * n                  # x coordinates: a third of the mesh leaves the frame
+        X[1:2 * N:2] += 0.30 * n
+    elif case == "folded":
+        X = _state(dm, rng, pos_sigma=4.0)        # vertices jump across their neighbours
+    y_im, flow, y_m = _observation(dm, meas, rng, n)
+    if case == "blank":
+        y_im = np.zeros_like(y_im); y_m = np.zeros_like(y_m); flow = np.zeros_like(flow)
+    if case == "saturated":
+        from hydra_mi import renderer
+        tex = np.full((n, n), 255, np.uint8)
+        R = renderer.Renderer(dm, np.zeros((N, 2)), np.zeros((n, n, 2), np.float32), n, tex, True, 1e-3, 1.0, 1.0)
+        meas = ekf_ref.Measurement(N, dm.t, dm.p, tex, 1e-3, 1.0, 1.0)
+        X = _state(dm, rng, pos_sigma=3.0)        # overlaps of a white texture: sums beyond 255
+    st = _Flow()
+    st.X = X.reshape(-1, 1)
+    Hz, HTH, Hzc = R.measure(st, y_im, flow, y_m)
+    rHz, rHzc = ekf_ref.jacobian(meas, X, y_im, flow, y_m)
+    _, J = ekf_ref.adjacency(N, dm.t)
+    rHTH = ekf_ref.hessian_sparse(meas, X, J)
+    tol = lambda a: 1e-9 * max(np.abs(a).max(), 1e-300)
+    assert np.abs(Hz - rHz).max() <= tol(rHz)
+    assert np.abs(Hzc - rHzc).max() <= tol(rHzc)
+    assert np.abs(HTH - rHTH).max() <= tol(rHTH)
+    e = R.error(st, y_im, flow, y_m)
+    r = meas.error(X, y_im, flow, y_m)
+    assert e[0] == r[0] and e[3] == r[3]
+
+
 def test_masked_flow_path(hm):
     from hydra_mi.renderer import MaskedFlow
     n = 64
