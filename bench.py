@@ -205,8 +205,6 @@ def main():
 
     bf = brox.BroxOpticalFlow(n, n, max_batch=B, device=dev)
     bf.tune("sor_threads", 512)
-    for size in range(1, B + 1):                  # any series size the schedule below may use
-        bf.prepare(size)
     flow0 = np.zeros((n, n, 2), np.float32)
     kf = kalman.IteratedMSKalmanFilter(dm, video[0], flow0, True, device=dev)
     N = kf.N

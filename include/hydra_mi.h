@@ -73,7 +73,9 @@ int hm_brox_set_omega(hm_brox_t h, float omega);
 /* launch tuning, never changes results: "sor_fuse" = red-black iterations fused
  * per SOR launch (0 = choose per level, else a divisor of solver_iterations),
  * "sor_threads" = 256, 512 or 1024 threads per SOR workgroup, "graph" = 1/0 replay the launch
- * series of a calc call as a captured hipGraph (default 1) or launch kernel by kernel, "warp_window" =
+ * series of a calc call as a captured hipGraph or launch kernel by kernel (default 0: with ROCm 7.2
+ * replays were seen to produce garbage from the fifth launch of a graph on when the caller allocated
+ * device memory between calls -- tools/graph_debug.py; the direct launches are not affected), "warp_window" =
  * 1/0 the warp kernel stages its taps as an LDS window or reads them directly (default 0: measured
  * faster, see brox_kernels.h) */
 int hm_brox_tune(hm_brox_t h, const char *key, int value);

@@ -116,21 +116,32 @@ static SorPlan sor_plan(const Geo &g, int solver, int fuse, int threads)
     return p;
 }
 
-// e0 / e1 (profiling): events that receive the start and stop time of the kernel itself
-// (hipExtLaunchKernelGGL), the duration a kernel trace reports -- events recorded around the launch
-// would add the command processor's dispatch latency (~4 us) to every launch
+// e0 / e1 (profiling only): events that receive the start and stop time of the kernel itself
+// (hipExtLaunchKernelGGL) -- events recorded around the launch would add the command processor's
+// dispatch latency to every launch.  Without events the plain launch is used: the Ext launch must not
+// be captured into a graph (the captured node keeps pointers to the caller's argument storage instead
+// of a copy; replays then read whatever the host stack holds by then).
 static void sor_launch(const SorPlan &p, SorArgs a, int n, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
 {
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y;
     a.step_x = p.step_x; a.step_y = p.step_y;
     a.halo_x = p.halo_x; a.halo_y = p.halo_y;
     dim3 grid(p.tiles_x * p.tiles_y, 1, n);
+    if (e0 && e1) {
+        if (p.threads == 1024)
+            hipExtLaunchKernelGGL((k_sor<SOR_TW, SOR_TH, 1024>), grid, dim3(1024), 0, s, e0, e1, 0, a, p.K);
+        else if (p.threads == 512)
+            hipExtLaunchKernelGGL((k_sor<SOR_TW, SOR_TH, 512>), grid, dim3(512), 0, s, e0, e1, 0, a, p.K);
+        else
+            hipExtLaunchKernelGGL((k_sor<SOR_TW, SOR_TH, 256>), grid, dim3(256), 0, s, e0, e1, 0, a, p.K);
+        return;
+    }
     if (p.threads == 1024)
-        hipExtLaunchKernelGGL((k_sor<SOR_TW, SOR_TH, 1024>), grid, dim3(1024), 0, s, e0, e1, 0, a, p.K);
+        hipLaunchKernelGGL((k_sor<SOR_TW, SOR_TH, 1024>), grid, dim3(1024), 0, s, a, p.K);
     else if (p.threads == 512)
-        hipExtLaunchKernelGGL((k_sor<SOR_TW, SOR_TH, 512>), grid, dim3(512), 0, s, e0, e1, 0, a, p.K);
+        hipLaunchKernelGGL((k_sor<SOR_TW, SOR_TH, 512>), grid, dim3(512), 0, s, a, p.K);
     else
-        hipExtLaunchKernelGGL((k_sor<SOR_TW, SOR_TH, 256>), grid, dim3(256), 0, s, e0, e1, 0, a, p.K);
+        hipLaunchKernelGGL((k_sor<SOR_TW, SOR_TH, 256>), grid, dim3(256), 0, s, a, p.K);
 }
 
 // ---- handle ------------------------------------------------------------------------------
@@ -200,7 +211,7 @@ extern "C" int hm_brox_create(int device, int W, int H, int max_batch, float alp
     h->arena = nullptr; h->d_f0 = h->d_f1 = nullptr; h->d_ox = h->d_oy = nullptr; h->stream = nullptr;
     h->prof = false; h->ev_used = 0; h->prof_ms = 0; h->prof_pxit = 0; h->prof_launches = 0;
     h->graphs.assign(max_batch, nullptr);
-    h->use_graph = true;
+    h->use_graph = false;                         // see hm_brox_tune "graph" in the header: off by default
     h->warp_window = false;
     make_levels(W, H, scale, outer, h->geo);
     h->taps = make_taps(scale);

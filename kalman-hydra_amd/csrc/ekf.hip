@@ -55,7 +55,6 @@ struct hm_ctx {
     double *d_sp_blk;
     size_t sp_cap;                   // capacity (springs) of the d_sp_* arrays
     bool upd_open;
-    hipGraphExec_t pre_graph[3];     // hm_update_prefactor's launch series, one per possible home of the covariance
     bool prefactored;                // d_invW0 is the inverse of the resident covariance d_Wprior (hm_update_prefactor)
     std::vector<double> h_partial;
     int red_blocks;
@@ -95,8 +94,6 @@ static int ctx_free(hm_ctx *h)
     free_targets(h->P);
     free_targets(h->Q);
     if (h->pin) (void)hipHostFree(h->pin);
-    for (hipGraphExec_t g : h->pre_graph)
-        if (g) (void)hipGraphExecDestroy(g);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return HM_OK;
@@ -158,7 +155,6 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     memset(&h->pool, 0, sizeof h->pool); h->d_area = nullptr;
     h->d_sp_off = h->d_sp_bar = h->d_sp_other = nullptr; h->d_sp_blk = nullptr; h->sp_cap = 0;
     h->upd_last = h->upd_prev = -1; h->upd_open = false; h->prefactored = false;
-    h->pre_graph[0] = h->pre_graph[1] = h->pre_graph[2] = nullptr;
     for (const auto &e : eset) { h->edges.push_back(e.first); h->edges.push_back(e.second); }
     h->E = (int)eset.size();
     h->njobs = N + h->E;
@@ -595,24 +591,10 @@ extern "C" int hm_update_prefactor(hm_ctx_t h)
     HM_ARG(h != nullptr, "hm_update_prefactor: NULL handle");
     if (!h->d_Wres) { hm_set_error("hm_update_prefactor: no covariance resident on the device"); return HM_ERR_STATE; }
     HM_HIP(hipSetDevice(h->device));
-    // ~45 launches with fixed arguments: replayed as a graph (one per buffer the covariance may live
-    // in), so that the host gets on with the state prediction after one call
-    const int which = h->d_Wres == h->d_Wtmp ? 0 : (h->d_Wres == h->d_H ? 1 : 2);
-    if (!h->pre_graph[which]) {
-        hipGraph_t graph = nullptr;
-        HM_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-        double *keep = h->d_Wres;
-        int rc = prior_inverse(h, nullptr);
-        hipError_t e = hipStreamEndCapture(h->stream, &graph);
-        h->d_Wres = keep;                          // prior_inverse moved it; the replay below does so again
-        if (rc != HM_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-        if (e != hipSuccess) { hm_set_error("hm_update_prefactor: stream capture failed: %s", hipGetErrorString(e)); return HM_ERR_HIP; }
-        e = hipGraphInstantiate(&h->pre_graph[which], graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (e != hipSuccess) { h->pre_graph[which] = nullptr; hm_set_error("hm_update_prefactor: hipGraphInstantiate failed: %s", hipGetErrorString(e)); return HM_ERR_HIP; }
-    }
-    HM_HIP(hipGraphLaunch(h->pre_graph[which], h->stream));
-    h->d_Wres = h->d_Wprior;
+    // (launched one by one: replaying this series as a hipGraph saved 0.08 ms of host time per frame, but
+    // graph replays proved unreliable next to allocations by the caller -- see hm_brox_tune "graph")
+    int rc = prior_inverse(h, nullptr);
+    if (rc) return rc;
     h->prefactored = true;
     h->upd_open = false;                          // the factor slots are being reused
     return HM_OK;

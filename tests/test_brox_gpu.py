@@ -209,3 +209,30 @@ def test_prepare_and_profile_totals(hm, oracle_brox):
     bf.calc(f0, f1)
     ms2, launches2, _ = bf.profile_read()
     assert launches2 == per_call
+
+
+def test_repeated_series_with_caller_reallocating_buffers(hm):
+    """A caller that allocates fresh device buffers for every series (a new video each time): the
+    flows must not depend on how often the handle has been used or where the buffers live.  (Replayed
+    hipGraphs failed exactly this from the fifth launch on; the default path launches directly.)"""
+    torch = pytest.importorskip("torch")
+    from hydra_mi import brox, synth
+    n, B = 256, 4
+    pairs = [synth.warp_pair(n, name, s) for s, name in enumerate(["warp", "rotate", "translate_leftup", "warp", "rotate"])]
+    F0 = np.stack([p[0] for p in pairs[:B]]); F1 = np.stack([p[1] for p in pairs[:B]])
+    bf = brox.BroxOpticalFlow(n, n, max_batch=B)
+    first = None
+    for it in range(4):
+        d0 = torch.from_numpy(F0).cuda(); d1 = torch.from_numpy(F1).cuda()
+        U = torch.empty((2, B, n, n), dtype=torch.float32, device="cuda"); V = torch.empty_like(U)
+        torch.cuda.synchronize()
+        for rep in range(2):
+            bf.calc_dev(B, d0.data_ptr(), d1.data_ptr(), U[rep].data_ptr(), V[rep].data_ptr())
+        bf.sync()
+        got = (U.cpu().numpy(), V.cpu().numpy())
+        assert np.isfinite(got[0]).all() and np.isfinite(got[1]).all(), it
+        assert np.array_equal(got[0][0], got[0][1]) and np.array_equal(got[1][0], got[1][1]), it
+        if first is None:
+            first = got
+        assert np.array_equal(got[0], first[0]) and np.array_equal(got[1], first[1]), it
+        keep = (d0, d1, U, V) if it % 2 == 0 else None        # vary what is freed in between
