@@ -336,7 +336,8 @@ def main():
                          "launches": sor_launches, "profiled": "one flow series (%d pairs) of the timed region" % prof_pairs, "avg_launch_us": 1e3 * sor_ms / max(1, sor_launches),
                          "bytes_per_pixel_iteration": SOR_BYTES_PER_PIXEL_ITERATION},
         }
-        if not args.no_cpu_baseline and world == 1:         # a reported baseline, timed at N = 1 only
+        out["cpu_baseline"] = None                           # a reported baseline, timed at N = 1 only
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, video, masks, dm, max(1.0, iters / K))
         print(json.dumps(out), flush=True)
     if world > 1:
