@@ -159,6 +159,9 @@ def main():
                     help="video = the headline metric (flow + EKF per frame); flowbatch = BASELINE config 5: "
                          "independent frame pairs sharded over the GPUs, one gather of the flows at the end")
     ap.add_argument("--pairs-per-gpu", type=int, default=32)
+    ap.add_argument("--videos-per-gpu", type=int, default=1,
+                    help="video workload: independent videos tracked concurrently on each GPU, one thread each "
+                         "(default 1: the configuration the metric is quoted on)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real run); gloo only to rehearse several ranks on one GPU")
     args = ap.parse_args()
@@ -193,122 +196,156 @@ def main():
     K, Wm = args.steps, args.warmup
     if args.workload == "flowbatch":
         return flowbatch(args, rank, world, dev, coll_dev)
-    frames = K + Wm + 1
-    video, masks, centre, radius = make_video(n, frames, seed=rank)
-    dm = mesh.disk_mesh(centre[0], centre[1], radius - 1.0, args.h0 * n)
-    d_video = torch.from_numpy(video).cuda()
-    d_masks = torch.from_numpy(masks).cuda()
-    B = max(1, args.flow_batch)
-    d_u = torch.empty((2, B, n, n), dtype=torch.float32, device="cuda")      # double-buffered flow planes
-    d_v = torch.empty_like(d_u)
-    torch.cuda.synchronize()
-
-    bf = brox.BroxOpticalFlow(n, n, max_batch=B, device=dev)
-    bf.tune("sor_threads", 512)
-    flow0 = np.zeros((n, n, 2), np.float32)
-    kf = kalman.IteratedMSKalmanFilter(dm, video[0], flow0, True, device=dev)
-    N = kf.N
-
-    t_flow = t_ekf = 0.0
-    iters = 0
-    # frame pairs [lo, hi) of `ready` have their flow in buffer `buf`; `pending` is being computed
-    # on the flow handle's own stream while the filter works on `ready`
-    sched = {"ready": (0, 0), "buf": 0, "pending": None, "profile_from": None}
-
     import threading
+    B = max(1, args.flow_batch)
+    V = max(1, args.videos_per_gpu)
 
-    def launch(k, phase_end, buf, most=None):
-        """Queue the flow of the pairs [k, k+nb) on the flow handle's stream.  The calls are made from a
-        helper thread (ctypes drops the GIL): the profiled series is launched kernel by kernel with an
-        event pair around every SOR launch, several milliseconds of host time that the filter's
-        thread does not have to spend."""
-        nb = min(B if most is None else most, phase_end - k)
+    class Track:
+        """One video: its frames and flow planes in HBM, a flow handle, a filter, and the schedule that
+        computes the flow of the next frames while the filter works on the current ones."""
 
-        def work():
-            if sched["profile_from"] == k:
-                bf.profile(True)
-            elif sched["profile_from"] is not None and k > sched["profile_from"]:
-                bf.profile(False)              # totals stay readable (hm_brox_profile_read)
-            bf.calc_dev(nb, d_video[k].data_ptr(), d_video[k + 1].data_ptr(), d_u[buf].data_ptr(), d_v[buf].data_ptr())
-        th = threading.Thread(target=work)
-        th.start()
-        sched["thread"] = th
-        return (k, k + nb)
+        def __init__(self, seed):
+            frames = K + Wm + 1
+            self.video, self.masks, centre, radius = make_video(n, frames, seed=seed)
+            self.dm = mesh.disk_mesh(centre[0], centre[1], radius - 1.0, args.h0 * n)
+            self.d_video = torch.from_numpy(self.video).cuda()
+            self.d_masks = torch.from_numpy(self.masks).cuda()
+            self.d_u = torch.empty((2, B, n, n), dtype=torch.float32, device="cuda")      # double-buffered flow planes
+            self.d_v = torch.empty_like(self.d_u)
+            torch.cuda.synchronize()
+            self.bf = brox.BroxOpticalFlow(n, n, max_batch=B, device=dev)
+            self.bf.tune("sor_threads", 512)
+            self.kf = kalman.IteratedMSKalmanFilter(self.dm, self.video[0], np.zeros((n, n, 2), np.float32), True, device=dev)
+            self.t_flow = self.t_ekf = 0.0
+            self.iters = 0
+            # frame pairs [lo, hi) of `ready` have their flow in buffer `buf`; `pending` is being computed
+            # on the flow handle's own stream while the filter works on `ready`
+            self.sched = {"ready": (0, 0), "buf": 0, "pending": None, "profile_from": None, "thread": None}
 
-    def flow_sync():
-        if sched.get("thread") is not None:
-            sched["thread"].join()
-            sched["thread"] = None
-        bf.sync()
+        def launch(self, k, phase_end, buf, most=None):
+            """Queue the flow of the pairs [k, k+nb) on the flow handle's stream.  The calls are made from a
+            helper thread (ctypes drops the GIL): a series is ~900 launches (the profiled one with an event
+            pair for every SOR launch on top), several milliseconds of host time that the filter's thread
+            does not have to spend."""
+            nb = min(B if most is None else most, phase_end - k)
+            bf, sched = self.bf, self.sched
 
-    def step(k, phase_end):
-        """Frame k+1: flow of (k, k+1) -- computed for up to B consecutive pairs per launch series (they do
-        not depend on the filter), the next series running on the GPU while the filter works through
-        this one (series of 1, 2, 4, ... pairs at the start of a phase: nothing to overlap the first with) --
-        then the EKF on frame k+1."""
-        nonlocal t_flow, t_ekf, iters
-        t0 = time.perf_counter()
-        if k >= sched["ready"][1]:
-            if sched["pending"] is not None and sched["pending"][0] == k:
-                sched["buf"] ^= 1
-            else:                      # start of a phase: one pair only, so that the filter can start
-                sched["pending"] = launch(k, phase_end, sched["buf"], most=1)
-            flow_sync()
-            sched["ready"], sched["pending"] = sched["pending"], None
-            lo, nxt = sched["ready"]
-            if nxt < phase_end:        # ramp: what the GPU gets done beside the frames just made ready
-                sched["pending"] = launch(nxt, phase_end, sched["buf"] ^ 1, most=min(B, 2 * (nxt - lo)))
-        i = k - sched["ready"][0]
-        cur = sched["buf"]
-        t1 = time.perf_counter()
-        obs = DeviceObservation(d_video[k + 1].data_ptr(), d_u[cur, i].data_ptr(), d_v[cur, i].data_ptr(),
-                                d_masks[k + 1].data_ptr(), y_m_host=masks[k + 1])
-        kf.compute(obs, None, None)
-        t2 = time.perf_counter()
-        t_flow += t1 - t0
-        t_ekf += t2 - t1
-        if os.environ.get("HYDRA_MI_BENCH_TRACE"):
-            print("step %d: flow wait %.2f ms, filter %.2f ms (%d iterations), series ready %s pending %s"
-                  % (k, 1e3 * (t1 - t0), 1e3 * (t2 - t1), kf.niter, sched["ready"], sched["pending"]), file=sys.stderr)
-        iters += kf.niter
+            def work():
+                if sched["profile_from"] == k:
+                    bf.profile(True)
+                elif sched["profile_from"] is not None and k > sched["profile_from"]:
+                    bf.profile(False)              # totals stay readable (hm_brox_profile_read)
+                bf.calc_dev(nb, self.d_video[k].data_ptr(), self.d_video[k + 1].data_ptr(), self.d_u[buf].data_ptr(),
+                            self.d_v[buf].data_ptr())
+            th = threading.Thread(target=work)
+            th.start()
+            sched["thread"] = th
+            return (k, k + nb)
 
-    # per-launch HIP events cost more host time than the SOR launches they bracket, so they are
-    # recorded for ONE step of the timed region (the last), not for all of them
-    bf.profile(True)
-    for k in range(Wm):
-        step(k, Wm)
-    bf.profile_read()
-    bf.profile(False)
-    t_flow = t_ekf = 0.0
-    iters = 0
-    kf.predtime = kf.updatetime = kf.projecttime = 0.0
+        def flow_sync(self):
+            if self.sched["thread"] is not None:
+                self.sched["thread"].join()
+                self.sched["thread"] = None
+            self.bf.sync()
 
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    # one flow series of the timed region is profiled (series: 1 pair, then B at a time): the first
-    # full one, or the last if there is no full one
+        def step(self, k, phase_end):
+            """Frame k+1: flow of (k, k+1) -- computed for up to B consecutive pairs per launch series (they do
+            not depend on the filter), the next series running on the GPU while the filter works through
+            this one (series of 1, 2, 4, ... pairs at the start of a phase: nothing to overlap the first with) --
+            then the EKF on frame k+1."""
+            sched = self.sched
+            t0 = time.perf_counter()
+            if k >= sched["ready"][1]:
+                if sched["pending"] is not None and sched["pending"][0] == k:
+                    sched["buf"] ^= 1
+                else:                      # start of a phase: one pair only, so that the filter can start
+                    sched["pending"] = self.launch(k, phase_end, sched["buf"], most=1)
+                self.flow_sync()
+                sched["ready"], sched["pending"] = sched["pending"], None
+                lo, nxt = sched["ready"]
+                if nxt < phase_end:        # ramp: what the GPU gets done beside the frames just made ready
+                    sched["pending"] = self.launch(nxt, phase_end, sched["buf"] ^ 1, most=min(B, 2 * (nxt - lo)))
+            i = k - sched["ready"][0]
+            cur = sched["buf"]
+            t1 = time.perf_counter()
+            obs = DeviceObservation(self.d_video[k + 1].data_ptr(), self.d_u[cur, i].data_ptr(), self.d_v[cur, i].data_ptr(),
+                                    self.d_masks[k + 1].data_ptr(), y_m_host=self.masks[k + 1])
+            self.kf.compute(obs, None, None)
+            t2 = time.perf_counter()
+            self.t_flow += t1 - t0
+            self.t_ekf += t2 - t1
+            if os.environ.get("HYDRA_MI_BENCH_TRACE"):
+                print("step %d: flow wait %.2f ms, filter %.2f ms (%d iterations), series ready %s pending %s"
+                      % (k, 1e3 * (t1 - t0), 1e3 * (t2 - t1), self.kf.niter, sched["ready"], sched["pending"]), file=sys.stderr)
+            self.iters += self.kf.niter
+
+        def warmup(self):
+            self.bf.profile(True)
+            for k in range(Wm):
+                self.step(k, Wm)
+            self.bf.profile_read()
+            self.bf.profile(False)
+            self.t_flow = self.t_ekf = 0.0
+            self.iters = 0
+            self.kf.predtime = self.kf.updatetime = self.kf.projecttime = 0.0
+
+        def timed(self):
+            for k in range(Wm, Wm + K):
+                self.step(k, Wm + K)
+
+    # the videos of this rank: seeds rank * V .. rank * V + V - 1 (one video per GPU unless --videos-per-gpu)
+    tracks = [Track(rank * V + i) for i in range(V)]
+    for tr in tracks:
+        tr.warmup()
     # series of the timed region: 1 pair, then 2, 4, ... up to B at a time (a series of n pairs takes
-    # about 7.5 + 0.65 (n - 1) ms here, a frame of the filter about 8 ms)
+    # about 7.5 + 0.65 (n - 1) ms here, a frame of the filter about 8 ms); one of them is profiled (kernel
+    # start/stop events for every SOR launch): the first full one, or the last if there is no full one
     starts, k_ = [], Wm
     while k_ < Wm + K:
         size = 1 if not starts else min(B, 2 * starts[-1][1], Wm + K - k_)
         starts.append((k_, size))
         k_ += size
     full = [st for st in starts if st[1] == B]
-    sched["profile_from"], prof_pairs = full[0] if full else starts[-1]
-    for k in range(Wm, Wm + K):
-        step(k, Wm + K)
-    state = torch.from_numpy(kf.state.X.reshape(-1).copy()).to(coll_dev)
+    tracks[0].sched["profile_from"], prof_pairs = full[0] if full else starts[-1]
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if V == 1:
+        tracks[0].timed()
+    else:                               # independent trackers, one thread each (the long calls drop the GIL)
+        failures = []
+
+        def run(tr):
+            try:
+                tr.timed()
+            except Exception as exc:    # noqa: BLE001 -- reported below: the bench must not hang on a dead thread
+                failures.append(repr(exc))
+        threads = [threading.Thread(target=run, args=(tr,)) for tr in tracks]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        if failures:
+            raise SystemExit("a tracker failed: %s" % failures[0])
+    state = torch.from_numpy(np.concatenate([tr.kf.state.X.reshape(-1) for tr in tracks])).to(coll_dev)
     if world > 1:                       # the batch path's only exchange: gather the tracked states
         gathered = [torch.empty_like(state) for _ in range(world)]
         dist.all_gather(gathered, state)
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    flow_sync()
-    sor_ms, sor_launches, sor_pxit = bf.profile_read()
+    for tr in tracks:
+        tr.flow_sync()
+    sor_ms, sor_launches, sor_pxit = tracks[0].bf.profile_read()
+    kf, video, masks, dm = tracks[0].kf, tracks[0].video, tracks[0].masks, tracks[0].dm
+    N = kf.N
+    t_flow = sum(tr.t_flow for tr in tracks) / V
+    t_ekf = sum(tr.t_ekf for tr in tracks) / V
+    iters = sum(tr.iters for tr in tracks) / V
+    predtime = sum(tr.kf.predtime for tr in tracks) / V
+    updatetime = sum(tr.kf.updatetime for tr in tracks) / V
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
@@ -320,14 +357,15 @@ def main():
         out = {
             "metric": "frames/sec (Brox flow + EKF update) at 1024^2" if n == 1024 else
                       "frames/sec (Brox flow + EKF update) at %d^2" % n,
-            "value": world * K / elapsed, "unit": "frames/sec", "n_gpus": world, "steps": K, "warmup": Wm,
+            "value": world * V * K / elapsed, "unit": "frames/sec", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (flow, renders) / f64 (EKF sums and state)", "data": "synthetic",
-            "config": {"workload": "%dx%d video, %d-vertex mesh (%d triangles), one video per GPU; Brox defaults "
+            "config": {"workload": "%dx%d video, %d-vertex mesh (%d triangles), %s per GPU; Brox defaults "
                                    "alpha .197 gamma 50 scale .8 inner 10 outer 77 solver 10; IteratedMSKalmanFilter "
-                                   "defaults" % (n, n, N, kf.state.NT), "frames_per_gpu": K, "flow_batch": B, "parallelism": "videos x%d" % world},
+                                   "defaults" % (n, n, N, kf.state.NT, "one video" if V == 1 else "%d concurrent videos" % V),
+                       "frames_per_gpu": K * V, "videos_per_gpu": V, "flow_batch": B, "parallelism": "videos x%d" % (world * V)},
             "breakdown_ms_per_step": {"brox_flow": 1e3 * t_flow / K, "ekf_compute": 1e3 * t_ekf / K,
-                                      "ekf_predict": 1e3 * kf.predtime / K, "ekf_update": 1e3 * kf.updatetime / K,
+                                      "ekf_predict": 1e3 * predtime / K, "ekf_update": 1e3 * updatetime / K,
                                       "iekf_iterations": iters / K},
             "roofline": {"bound": "hbm", "kernel": "k_sor", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
