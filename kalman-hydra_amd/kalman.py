@@ -777,60 +777,52 @@ def _inside(y_m, p):
     return ok & (m[ys, xs] > 0.5) & (m[ys, xs + 1] > 0.5) & (m[ys + 1, xs] > 0.5) & (m[ys + 1, xs + 1] > 0.5)
 
 
-def _mask_distance(y_m, window=12):
+def _mask_distance(y_m):
     """Signed distance to the object outline: positive outside the mask, negative inside,
     sampled bilinearly (see projectmask).
 
-    The Euclidean distance transform of a whole 1024^2 mask costs tens of milliseconds per
-    frame, and only the few vertices near the outline ever ask.  The distance of a pixel is
-    therefore taken from the transform of a (2*window+1)^2 crop around the query whenever that
-    is provably the same number (the nearest pixel of the other kind lies inside the crop, i.e.
-    |d| < distance to the crop border); otherwise from the transform of the whole mask."""
-    from scipy import ndimage
+    The numbers are those of the Euclidean distance transform of the mask (distance of an
+    object pixel to the nearest background pixel and vice versa), but the transform of a whole
+    1024^2 frame costs ~0.2 s on the host and only a few vertices ever ask.  The nearest pixel of
+    the other kind is always one that touches the outline (has a 4-neighbour of the other kind),
+    so the outline pixels of either kind go into two k-d trees (a few thousand points) and the
+    four pixels around each query look their distance up there: the same sqrt(integer) values,
+    at a cost that does not depend on how far the mesh has drifted from the object."""
+    from scipy.spatial import cKDTree
     m = np.asarray(y_m) > 0.5
     H, W = m.shape
-    full = []
-
-    def full_dist():
-        if not full:
-            full.append(ndimage.distance_transform_edt(~m) - ndimage.distance_transform_edt(m))
-        return full[0]
-
-    if not m.any():
+    mu = m.view(np.uint8)
+    dx = mu[:, 1:] ^ mu[:, :-1]
+    dy = mu[1:, :] ^ mu[:-1, :]
+    edge = np.zeros((H, W), np.uint8)
+    edge[:, 1:] |= dx
+    edge[:, :-1] |= dx
+    edge[1:, :] |= dy
+    edge[:-1, :] |= dy
+    flat = np.flatnonzero(edge)
+    if flat.size == 0:                    # blank or full mask: no outline to be pulled to
         return lambda p: np.zeros(len(np.atleast_2d(p)))
-
-    def local(px, py):
-        """Exact signed distances of the 2x2 pixels whose top-left is (px, py), or None."""
-        x0, x1 = max(0, px - window), min(W, px + 2 + window)
-        y0, y1 = max(0, py - window), min(H, py + 2 + window)
-        c = m[y0:y1, x0:x1]
-        if c.all() or not c.any():
-            return None
-        d = ndimage.distance_transform_edt(~c) - ndimage.distance_transform_edt(c)
-        out = np.empty((2, 2))
-        for j in range(2):
-            for i in range(2):
-                yy, xx = min(max(py + j, 0), H - 1), min(max(px + i, 0), W - 1)
-                v = d[yy - y0, xx - x0]
-                # distance from the pixel to the crop border, ignoring borders that are image borders
-                room = min(xx - x0 if x0 > 0 else 1e9, x1 - 1 - xx if x1 < W else 1e9,
-                           yy - y0 if y0 > 0 else 1e9, y1 - 1 - yy if y1 < H else 1e9)
-                if abs(v) >= room:
-                    return None
-                out[j, i] = v
-        return out
+    ys, xs = np.divmod(flat, W)
+    obj = m.ravel()[flat]
+    pts = np.column_stack((xs, ys)).astype(np.float64)
+    tree_obj, tree_bg = cKDTree(pts[obj]), cKDTree(pts[~obj])
 
     def fd(p):
         p = np.atleast_2d(np.asarray(p, np.float64))
-        out = np.empty(len(p))
-        for k, (x, y) in enumerate(p):
-            xc, yc = min(max(x, 0.0), W - 1.0), min(max(y, 0.0), H - 1.0)      # mode="nearest"
-            px, py = int(np.floor(xc)), int(np.floor(yc))
-            q = local(px, py)
-            if q is None:
-                out[k] = ndimage.map_coordinates(full_dist(), [[y], [x]], order=1, mode="nearest")[0]
-                continue
-            ax, ay = xc - px, yc - py
-            out[k] = (1 - ay) * ((1 - ax) * q[0, 0] + ax * q[0, 1]) + ay * ((1 - ax) * q[1, 0] + ax * q[1, 1])
-        return out
+        xc, yc = np.clip(p[:, 0], 0.0, W - 1.0), np.clip(p[:, 1], 0.0, H - 1.0)     # mode="nearest"
+        px, py = np.floor(xc).astype(np.int64), np.floor(yc).astype(np.int64)
+        q = np.empty((2, 2, len(p)))
+        for j in range(2):
+            for i in range(2):
+                xx, yy = np.minimum(px + i, W - 1), np.minimum(py + j, H - 1)
+                pix = np.column_stack((xx, yy)).astype(np.float64)
+                inside = m[yy, xx]
+                d = np.empty(len(p))
+                if inside.any():
+                    d[inside] = -tree_bg.query(pix[inside])[0]
+                if not inside.all():
+                    d[~inside] = tree_obj.query(pix[~inside])[0]
+                q[j, i] = d
+        ax, ay = xc - px, yc - py
+        return (1 - ay) * ((1 - ax) * q[0, 0] + ax * q[0, 1]) + ay * ((1 - ax) * q[1, 0] + ax * q[1, 1])
     return fd

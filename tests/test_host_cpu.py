@@ -227,6 +227,28 @@ def test_projectmask_pulls_outliers_back(hm):
     assert kf.state.X[0, 0] > X0[0, 0] - 1.5 and kf.state.X[8, 0] > 0     # pulled back, velocity follows
 
 
+def test_mask_distance_equals_whole_frame_transform(hm):
+    """_mask_distance answers from the outline pixels only; the numbers are those of the distance
+    transform of the whole mask, near the outline, far from it and for queries off the frame."""
+    from scipy import ndimage
+    from hydra_mi import kalman
+    rng = np.random.default_rng(5)
+    H, W = 90, 120
+    yy, xx = np.mgrid[:H, :W]
+    m = (((xx - 50) ** 2 + (yy - 40) ** 2 < 20 ** 2) | ((xx > 95) & (yy < 30))).astype(np.uint8)   # touches the border
+    m[38:43, 48:53] = 0                                                                        # and has a hole
+    full = ndimage.distance_transform_edt(m == 0) - ndimage.distance_transform_edt(m > 0)
+    p = np.column_stack((rng.uniform(-8, W + 8, 500), rng.uniform(-8, H + 8, 500)))
+    p[:20] = np.round(p[:20])                                                                  # on pixel centres
+    want = ndimage.map_coordinates(full, [p[:, 1], p[:, 0]], order=1, mode="nearest")
+    got = kalman._mask_distance(m)(p)
+    assert np.allclose(got, want, rtol=0, atol=1e-12)
+    on = (p[:20, 0] >= 0) & (p[:20, 0] <= W - 1) & (p[:20, 1] >= 0) & (p[:20, 1] <= H - 1)
+    assert np.array_equal(got[:20][on], full[p[:20, 1].astype(int)[on], p[:20, 0].astype(int)[on]])
+    for blank in (np.zeros_like(m), np.ones_like(m)):
+        assert np.array_equal(kalman._mask_distance(blank)(p), np.zeros(len(p)))
+
+
 # ---- sharding over ranks (gloo, world_size 2) ---------------------------------------------------
 def _worker(rank, world, port, out):
     import torch
