@@ -151,6 +151,17 @@ int hm_jz(hm_ctx_t h, const double *Xp, int masked, double *jz, double jzc[4]);
 /* j (cuda.py:982-1010): renders X + dX e_i and X + dX e_j and reduces the products
  * of their differences to the reference render */
 int hm_j(hm_ctx_t h, const double *X, double deltaX, int i, int j, double *out);
+/* KalmanFilter.projectmask (kalman.py:724-742): every vertex whose signed
+ * distance d to the object outline exceeds 1 px takes 10 steps
+ * p -= d g/|g|^2 (g: forward differences of 0.1 px; d and the set of vertices
+ * are those before the first step) and its displacement is added to its
+ * velocity.  The reference's distance comes from OpenCV contours
+ * (imgproc.py:175-248, not on this path); here it is the Euclidean distance
+ * transform of the mask sampled bilinearly, evaluated exactly from the outline
+ * pixels.  y_m: W*H host mask (object where > 0), or NULL = the mask of the
+ * observation in place.  X (4N) is updated in place; *moved (may be NULL) =
+ * number of vertices that were outside. */
+int hm_project_mask(hm_ctx_t h, const uint8_t *y_m, double *X, int *moved);
 /* Renderer.error (renderer.py:485-501): SSE per channel of render(X) against the
  * observation, with the 8-bit wrap-around the reference's uint8 arithmetic has
  * for the image and mask terms.  err = e_im, e_fx, e_fy, e_m; fx/fy (may be NULL)

@@ -4,6 +4,7 @@
 #include "hm_common.h"
 #include "ekf_kernels.h"
 #include "dense_kernels.h"
+#include "project_kernels.h"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -60,6 +61,9 @@ struct hm_ctx {
     int red_blocks;
     long long run_ticket;            // sequence number of hm_update_run's per-iteration result blocks
     int vsplit;                      // workgroups per vertex job of the measurement (hm_ctx_tune)
+    int2 *d_outline;                 // hm_project_mask: outline pixels (W*H), counters, uploaded mask; allocated on first use
+    int *d_outline_cnt;
+    uint8_t *d_pm_mask;
 };
 
 static int alloc_targets(Targets &t, size_t n)
@@ -87,7 +91,8 @@ static int ctx_free(hm_ctx *h)
                     h->d_HTH, h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_T[0], h->d_T[1], h->d_step, h->d_Wprior, h->d_gain, h->d_Awork, h->d_Lt[0], h->d_Lt[1],
                     h->d_Wtmp, h->d_X0, h->d_Xn, h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk,
                     h->pool.hdr, h->pool.off, h->pool.xim, h->pool.xm, h->pool.yim, h->pool.ym, h->pool.xfx, h->pool.xfy,
-                    h->pool.yfx, h->pool.yfy, h->pool.vxfx, h->pool.vyfy, h->pool.overflow, h->d_area};
+                    h->pool.yfx, h->pool.yfy, h->pool.vxfx, h->pool.vyfy, h->pool.overflow, h->d_area,
+                    h->d_outline, h->d_outline_cnt, h->d_pm_mask};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     free_targets(h->ref);
@@ -151,6 +156,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->d_H = h->d_Hz = h->d_Hzc = h->d_invW0 = h->d_Af[0] = h->d_Af[1] = h->d_Wtmp = nullptr;
     h->d_Wprior = h->d_gain = h->d_Awork = h->d_Lt[0] = h->d_Lt[1] = nullptr; h->d_Wres = nullptr; h->pin = nullptr; h->pin_n = 0;
     h->tri.assign(tri, tri + (size_t)3 * T);
+    h->d_outline = nullptr; h->d_outline_cnt = nullptr; h->d_pm_mask = nullptr;
     h->d_T[0] = h->d_T[1] = h->d_step = nullptr; h->d_X0 = h->d_Xn = nullptr;
     memset(&h->pool, 0, sizeof h->pool); h->d_area = nullptr;
     h->d_sp_off = h->d_sp_bar = h->d_sp_other = nullptr; h->d_sp_blk = nullptr; h->sp_cap = 0;
@@ -680,6 +686,43 @@ extern "C" int hm_update_cov(hm_ctx_t h, int which, double *W_out)
         HM_HIP(hipMemcpyAsync(W_out, h->d_Wres, (size_t)n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HM_HIP(hipStreamSynchronize(h->stream));
     }
+    return HM_OK;
+}
+
+// KalmanFilter.projectmask (kalman.py:724-742): vertices more than 1 px outside the object are
+// walked back onto its outline, their displacement is added to their velocity.  y_m: a W*H host
+// mask (object where > 0), or NULL for the mask of the observation in place.  X (4N) is updated in
+// place; *moved (may be NULL) receives the number of vertices that were outside.
+extern "C" int hm_project_mask(hm_ctx_t h, const uint8_t *y_m, double *X, int *moved)
+{
+    HM_ARG(h && X, "hm_project_mask: NULL argument");
+    if (!y_m) { NEED_OBS(h, "hm_project_mask"); }
+    HM_HIP(hipSetDevice(h->device));
+    const size_t n = (size_t)h->W * h->H;
+    if (!h->d_outline) {
+        HM_HIP(hipMalloc((void **)&h->d_outline, n * sizeof(int2)));
+        HM_HIP(hipMalloc((void **)&h->d_outline_cnt, 4 * sizeof(int)));
+    }
+    const uint8_t *mask = h->o_ym;
+    if (y_m) {
+        if (!h->d_pm_mask) HM_HIP(hipMalloc((void **)&h->d_pm_mask, n));
+        HM_HIP(hipMemcpyAsync(h->d_pm_mask, y_m, n, hipMemcpyHostToDevice, h->stream));
+        mask = h->d_pm_mask;
+    }
+    const size_t xb = (size_t)4 * h->N * sizeof(double);
+    HM_HIP(hipMemsetAsync(h->d_outline_cnt, 0, 4 * sizeof(int), h->stream));
+    HM_HIP(hipMemcpyAsync(h->d_X, X, xb, hipMemcpyHostToDevice, h->stream));
+    Outline o = {h->d_outline, h->d_outline_cnt, (int)n};
+    hipLaunchKernelGGL(k_outline, dim3(hm_cdiv(h->W, 64), hm_cdiv(h->H, OUTLINE_NT / 64)), dim3(OUTLINE_NT), 0, h->stream,
+                       mask, h->W, h->H, o);
+    ProjArgs a = {mask, h->W, h->H, h->N, o, h->d_X};
+    hipLaunchKernelGGL(k_project_mask, dim3(h->N), dim3(PROJ_NT), 0, h->stream, a);
+    HM_HIP(hipGetLastError());
+    int cnt[4] = {0, 0, 0, 0};
+    HM_HIP(hipMemcpyAsync(cnt, h->d_outline_cnt, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
+    HM_HIP(hipMemcpyAsync(X, h->d_X, xb, hipMemcpyDeviceToHost, h->stream));
+    HM_HIP(hipStreamSynchronize(h->stream));
+    if (moved) *moved = cnt[2];
     return HM_OK;
 }
 

@@ -405,17 +405,16 @@ class KalmanFilter:
         if isinstance(y_im, DeviceObservation):
             obs = y_im
             self.state.renderer.set_observation_dev(obs)
-            y_flow, y_m, mask_host = obs.raw, obs, obs.y_m_host
+            y_flow, y_m = obs.raw, obs
             y_flow_mask = obs.masked if maskflow is True else obs.raw
         else:
             self.state.renderer.update_frame(y_im, y_flow, y_m)
             y_flow_mask = MaskedFlow(y_flow, y_m) if maskflow is True else y_flow
-            mask_host = y_m
         with _blas_cap(enabled=not hasattr(self.state.renderer, "update_run")):
             t0 = time.time()
             self.predict()
             t1 = time.time()
-            self.projectmask(mask_host)
+            self.projectmask(y_m)
             t2 = time.time()
             self.update(y_im, y_flow_mask, y_m)
             t3 = time.time()
@@ -446,9 +445,17 @@ class KalmanFilter:
         The reference takes the signed distance from OpenCV contours (imgproc.py:175-248,
         outside this path); here it is the Euclidean distance transform of the mask, sampled
         bilinearly.  Steps, step size and the stale d / index set follow the reference."""
-        p = self.state.vertices()
         if y_m is None:
             return
+        r = self.state.renderer
+        if hasattr(r, "project_mask"):    # the same walk on the device (hm_project_mask)
+            X, moved = r.project_mask(self.state.X, None if isinstance(y_m, DeviceObservation) else y_m)
+            if moved:
+                self.state.X = X
+            return
+        if isinstance(y_m, DeviceObservation):
+            y_m = y_m.y_m_host
+        p = self.state.vertices()
         near = ~_inside(y_m, p)           # vertices whose four surrounding pixels are not all object
         if not near.any():
             return                        # d <= 0 everywhere: nothing to project

@@ -207,6 +207,22 @@ class Renderer:
     def tune(self, key, value):
         _lib.check(_lib.lib().hm_ctx_tune(self._h, key.encode(), int(value)), "hm_ctx_tune")
 
+    def project_mask(self, X, y_m=None):
+        """KalmanFilter.projectmask (kalman.py:724-742) on the device -> (X projected, number of
+        vertices that were outside).  y_m: host mask, or None for the mask of the observation in place."""
+        Xp = np.array(X, np.float64).reshape(-1)
+        if Xp.shape[0] != 4 * self.n:
+            raise ValueError("state of %d entries for a mesh of %d vertices" % (Xp.shape[0], self.n))
+        mask = None
+        if y_m is not None:
+            mask = np.ascontiguousarray(np.asarray(y_m) > 0.5).view(np.uint8)
+            if mask.shape != (self.ny, self.nx):
+                raise ValueError("mask of shape %r for frames of %r" % (mask.shape, (self.ny, self.nx)))
+        moved = ctypes.c_int(0)
+        _lib.check(_lib.lib().hm_project_mask(self._h, _lib.ptr(mask), _lib.ptr(Xp), ctypes.byref(moved)),
+                   "hm_project_mask")
+        return Xp.reshape(np.shape(X)), moved.value
+
     def cov_fetch(self):
         n4 = 4 * self.n
         W = np.empty((n4, n4))

@@ -366,7 +366,15 @@ def project_mask(X, N, y_m, steps=10, ddeps=1e-1):
     if not m.any():
         return X
     dist = ndimage.distance_transform_edt(~m) - ndimage.distance_transform_edt(m)
-    fd = lambda q: ndimage.map_coordinates(dist, [q[:, 1], q[:, 0]], order=1, mode="nearest")
+    H, W = m.shape
+
+    def fd(q):      # bilinear, coordinates clamped to the frame (map_coordinates order=1 mode="nearest", spelt out)
+        xc, yc = np.clip(q[:, 0], 0.0, W - 1.0), np.clip(q[:, 1], 0.0, H - 1.0)
+        px, py = np.floor(xc).astype(int), np.floor(yc).astype(int)
+        px1, py1 = np.minimum(px + 1, W - 1), np.minimum(py + 1, H - 1)
+        ax, ay = xc - px, yc - py
+        return ((1 - ay) * ((1 - ax) * dist[py, px] + ax * dist[py, px1])
+                + ay * ((1 - ax) * dist[py1, px] + ax * dist[py1, px1]))
     p = X[:2 * N].reshape(-1, 2).copy()
     p0 = p.copy()
     d = fd(p)

@@ -463,3 +463,77 @@ def test_measure_split_changes_only_the_summation_order(hm):
         R.tune("measure_split", 17)
     with pytest.raises(RuntimeError):
         R.tune("no_such_knob", 1)
+
+
+# ---- projectmask on the device (hm_project_mask) against oracle/ekf_ref.project_mask ---------------
+def _project_masks(n):
+    yy, xx = np.mgrid[:n, :n]
+    disk = ((xx - 0.5 * n) ** 2 + (yy - 0.45 * n) ** 2 < (0.3 * n) ** 2).astype(np.uint8)
+    holed = disk.copy()
+    holed[int(0.4 * n):int(0.5 * n), int(0.45 * n):int(0.55 * n)] = 0
+    edge = np.zeros((n, n), np.uint8)
+    edge[:n // 2, n // 3:] = 1                                      # touches two frame borders
+    specks = disk.copy()
+    specks[3, 5] = 1                                                # single far pixel
+    specks[n - 2, n - 2] = 1
+    return {"disk": disk, "holed": holed, "edge": edge, "specks": specks}
+
+
+@pytest.mark.parametrize("kind", ["disk", "holed", "edge", "specks"])
+def test_project_mask_matches_oracle(hm, kind):
+    n = 96
+    dm, N, tex, R, meas = _setup(hm, n, 9.0)
+    mask = _project_masks(n)[kind]
+    rng = np.random.default_rng(3)
+    for trial, spread in enumerate((0.5, 4.0, 15.0, 60.0)):
+        X = _state(dm, rng, pos_sigma=spread)
+        if trial == 3:
+            X[0:2] = (-7.3, 5.1)                                    # off the frame
+            X[2:4] = (n + 11.0, n + 2.5)
+            X[4:6] = (17.0, 33.0)                                   # on a pixel centre
+        want = ekf_ref.project_mask(X, N, mask)[:, 0]
+        got, moved = R.project_mask(X, mask)
+        assert got.shape == X.shape
+        inside_before = int((np.abs(want - X)[:2 * N].reshape(-1, 2).max(axis=1) > 0).sum())
+        assert moved >= inside_before                               # moved counts d > 1, some of which may step by 0
+        # same operations in the same order on exact integer distances: the same f64 numbers, also where
+        # a vanishing gradient throws a vertex far away (the walk is the reference's, kalman.py:731-739)
+        assert np.array_equal(got, want), (kind, trial, np.abs(got - want).max())
+
+
+def test_project_mask_resident_observation_and_blank(hm):
+    n = 64
+    dm, N, tex, R, meas = _setup(hm, n)
+    rng = np.random.default_rng(4)
+    y_im, flow, y_m = _observation(dm, meas, rng, n)
+    X = _state(dm, rng, pos_sigma=5.0)
+    with pytest.raises(RuntimeError):
+        R.project_mask(X)                                           # no observation yet
+    R.update_frame(y_im, flow, y_m)
+    got, moved = R.project_mask(X)                                  # the observation's mask, already on the device
+    want = ekf_ref.project_mask(X, N, y_m)[:, 0]
+    assert moved > 0 and np.array_equal(got, want)
+    again, moved2 = R.project_mask(X, y_m)
+    assert moved2 == moved and np.array_equal(again, got)
+    for blank in (np.zeros((n, n), np.uint8), np.ones((n, n), np.uint8)):
+        same, moved = R.project_mask(X, blank)
+        assert moved == 0 and np.array_equal(same, X)
+    with pytest.raises(ValueError):
+        R.project_mask(X, np.zeros((n, n + 1), np.uint8))
+    with pytest.raises(ValueError):
+        R.project_mask(X[:-1], y_m)
+
+
+def test_filter_projectmask_uses_the_device_and_matches_host_walk(hm):
+    from hydra_mi import kalman
+    n = 64
+    dm, N, tex, R, meas = _setup(hm, n)
+    kf = kalman.KalmanFilter(dm, tex, np.zeros((n, n, 2), np.float32), True)
+    rng = np.random.default_rng(6)
+    y_im, flow, y_m = _observation(dm, meas, rng, n)
+    kf.state.X[:2 * N, 0] += rng.normal(0, 4.0, 2 * N)
+    X0 = kf.state.X.copy()
+    kf.projectmask(y_m)
+    want = ekf_ref.project_mask(X0, N, y_m)
+    assert kf.state.X.shape == X0.shape and np.array_equal(kf.state.X, want)
+    assert not np.array_equal(kf.state.X, X0)

@@ -31,7 +31,7 @@ for k in range(nf):
     kf.orig_x = kf.state.X.copy(); kf._newton(); t = tick("newton", t)
     kf.state.W = R.cov_predict(kf.state._W, kf._bars, blocks, kf.deltat, kf.deltat / kf.M, kf.state.eps_F, fetch=False); t = tick("cov_predict", t)
     kf.pred_x = kf.state.X.copy()
-    kf.projectmask(obs.y_m_host); t = tick("projectmask", t)
+    kf.projectmask(obs); t = tick("projectmask", t)
     kf.update(obs, obs.masked, obs); t = tick("update", t)
     e = kf.error(obs, obs.raw, obs); t = tick("error", t)
     iters += kf.niter
