@@ -24,10 +24,10 @@ struct TriSetup {              // one triangle in one configuration
     // ec + (1 if a zero edge value counts as inside, the top-left rule): E is a whole number, so
     // "E > 0 or (E == 0 and top-left)" is the single comparison ea*c + eb*r + ecb > 0
     double ecb[3];
+    int cmin, cmax, rmin, rmax;  // pixel bounding box (inclusive), empty if cmin > cmax (16-byte aligned: one scalar load)
     int tl[3];                 // 1 if a zero edge value counts as inside (top-left edge)
     float inv;                 // 1 / (2 area)
     int i0, i1, i2;            // vertex ids after orientation normalisation
-    int cmin, cmax, rmin, rmax;  // pixel bounding box (inclusive), empty if cmin > cmax
     // attributes of the three vertices in that order: texture coordinates (pixels of the initial
     // frame) and the two velocity render attributes vx, -vy.  Kept here so that a covered pixel
     // needs no dependent global loads besides its texel.
@@ -363,13 +363,14 @@ struct StarVel {
     float fxp, fxm, fyp, fym;
 };
 
-// The star's setups are padded to an even count with an empty one (d_star_setups); two triangles are
-// tested per round, branch-free, so that the LDS reads of both are in flight together -- the walk
-// over the star is a chain of LDS latencies otherwise.
+// The setups are the same for every lane (scalar loads when cfg is a read-only kernel argument), and
+// so is the 8x8 tile (tc0, tr0) the wave works on: a triangle whose bounding box misses the tile is
+// skipped by a scalar branch -- about two thirds of the star's triangles at ~48 px edge length -- and
+// costs no vector instruction.  (The box contains every covered pixel, so the result is the same.)
 template <bool VEL>
-__device__ __forceinline__ StarVal d_star_eval(const TriSetup *__restrict__ cfg, int ns, int c, int r, const Mesh &m,
-                                               int v, float vxp, float vxm, float nvyp, float nvym, StarVel &vel,
-                                               StarTex &q)
+__device__ __forceinline__ StarVal d_star_eval(const TriSetup *__restrict__ cfg, int ns, int c, int r, int tc0, int tr0,
+                                               const Mesh &m, int v, float vxp, float vxm, float nvyp, float nvym,
+                                               StarVel &vel, StarTex &q)
 {
     StarVal s = {0, 0, 0.0f, 0.0f};
     q.t0 = -1; q.t1 = -1;
@@ -395,10 +396,11 @@ __device__ __forceinline__ StarVal d_star_eval(const TriSetup *__restrict__ cfg,
             vel.fym = vel.fym + d_lerp(v0 ? nvym : b0, v1 ? nvym : b1, v2 ? nvym : b2, l1, l2);
         }
     };
-    for (int k = 0; k < ns; k += 2) {
-        const bool in0 = d_tri_cover(cfg[k], dc, dr), in1 = d_tri_cover(cfg[k + 1], dc, dr);
-        if (in0) add(cfg[k]);
-        if (in1) add(cfg[k + 1]);
+    for (int k = 0; k < ns; k++) {
+        const TriSetup &t = cfg[k];
+        const int cmin = t.cmin, cmax = t.cmax, rmin = t.rmin, rmax = t.rmax;
+        if ((cmax < tc0) | (cmin > tc0 + 7) | (rmax < tr0) | (rmin > tr0 + 7)) continue;
+        if (d_tri_cover(t, dc, dr)) add(t);
     }
     return s;
 }
@@ -604,9 +606,8 @@ __global__ __launch_bounds__(256) void k_region_offsets(const int *__restrict__ 
 // workgroups per vertex; a perturbation of vertex v changes the render only inside the triangles
 // around v (its star), so every sum runs over the bounding box of that star; the perturbed renders
 // are never materialised.  The forward difference images are parked in the pool for pass 2.
-__global__ __launch_bounds__(MEAS_NT) void k_measure_vertex(MeasureArgs a)
+__global__ __launch_bounds__(MEAS_NT) void k_measure_vertex(MeasureArgs a, const TriSetup *__restrict__ cfgs)
 {
-    __shared__ TriSetup s_cfg[MEAS_NCFG][EKF_MAX_STAR + 1];
     __shared__ double s_red[(MEAS_NT / 64) * MEAS_OUT];
     __shared__ double s_k255[511];
     const double *k255 = s_k255 + 255;
@@ -617,15 +618,13 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure_vertex(MeasureArgs a)
     const double *X = a.X;
     const double d = a.delta;
     const int nsv = a.topo.star_off[v + 1] - a.topo.star_off[v];
-    {   // the star setups k_star_regions computed
-        constexpr int TW = sizeof(TriSetup) / 4;
-        const int used = (nsv + (nsv & 1)) * TW;
-        for (int c = 0; c < MEAS_NCFG; c++) {
-            const int *src = (const int *)(a.cfgs + ((size_t)v * MEAS_NCFG + c) * (EKF_MAX_STAR + 1));
-            int *dst = (int *)s_cfg[c];
-            for (int i = threadIdx.x; i < used; i += MEAS_NT) dst[i] = src[i];
-        }
-    }
+    // The star setups k_star_regions computed (cfgs == a.cfgs, as a read-only kernel argument): the same
+    // for every lane, so they are read with scalar loads into SGPRs where the edge functions take them
+    // as operands -- staged in LDS, their broadcast reads (12 doubles per triangle and configuration,
+    // per tile) kept the LDS pipe busier than the vector ALUs.
+    const TriSetup *__restrict__ s_cfg[MEAS_NCFG];
+#pragma unroll
+    for (int c = 0; c < MEAS_NCFG; c++) s_cfg[c] = cfgs + ((size_t)v * MEAS_NCFG + c) * (EKF_MAX_STAR + 1);
     __syncthreads();
     const int c0 = a.pool.hdr[4 * v], r0 = a.pool.hdr[4 * v + 1], rw = a.pool.hdr[4 * v + 2], rh = a.pool.hdr[4 * v + 3];
     const long long base = a.pool.off[v];
@@ -651,13 +650,13 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure_vertex(MeasureArgs a)
         const long long pp = base + i;
         StarVel vel, none;
         StarTex q0, q1, q2, q3, q4;
-        StarVal sref = d_star_eval<true>(s_cfg[0], nsv, c, r, m, v, (float)(X[2 * N + 2 * v] + d),
+        StarVal sref = d_star_eval<true>(s_cfg[0], nsv, c, r, tc0, tr0, m, v, (float)(X[2 * N + 2 * v] + d),
                                          (float)(X[2 * N + 2 * v] - d), (float)(-(X[2 * N + 2 * v + 1] + d)),
                                          (float)(-(X[2 * N + 2 * v + 1] - d)), vel, q0);
-        StarVal sxp = d_star_eval<false>(s_cfg[1], nsv, c, r, m, v, 0, 0, 0, 0, none, q1);
-        StarVal sxm = d_star_eval<false>(s_cfg[2], nsv, c, r, m, v, 0, 0, 0, 0, none, q2);
-        StarVal syp = d_star_eval<false>(s_cfg[3], nsv, c, r, m, v, 0, 0, 0, 0, none, q3);
-        StarVal sym = d_star_eval<false>(s_cfg[4], nsv, c, r, m, v, 0, 0, 0, 0, none, q4);
+        StarVal sxp = d_star_eval<false>(s_cfg[1], nsv, c, r, tc0, tr0, m, v, 0, 0, 0, 0, none, q1);
+        StarVal sxm = d_star_eval<false>(s_cfg[2], nsv, c, r, tc0, tr0, m, v, 0, 0, 0, 0, none, q2);
+        StarVal syp = d_star_eval<false>(s_cfg[3], nsv, c, r, tc0, tr0, m, v, 0, 0, 0, 0, none, q3);
+        StarVal sym = d_star_eval<false>(s_cfg[4], nsv, c, r, tc0, tr0, m, v, 0, 0, 0, 0, none, q4);
         {   // all texels at once
             const int e0 = d_star_texels(m.tex, q0), e1 = d_star_texels(m.tex, q1), e2 = d_star_texels(m.tex, q2);
             const int e3 = d_star_texels(m.tex, q3), e4 = d_star_texels(m.tex, q4);
