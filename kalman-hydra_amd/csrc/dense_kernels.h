@@ -30,8 +30,9 @@ __device__ __forceinline__ double d_rcp(double d)
 __device__ __forceinline__ double d_rsqrt(double d)
 {
     double r = __builtin_amdgcn_rsq(d);
-    r = r * fma(-0.5 * d * r, r, 1.5);
-    r = r * fma(-0.5 * d * r, r, 1.5);
+    const double hd = -0.5 * d;
+    r = fma(r, fma(hd * r, r, 0.5), r);
+    r = fma(r, fma(hd * r, r, 0.5), r);
     return r;
 }
 
@@ -43,8 +44,8 @@ __device__ __forceinline__ double d_rsqrt(double d)
 //       by the previous launch; each workgroup forms the two panel blocks it needs itself, from the raw
 //       panel in A), then A_rc -= X_r X_c^T -- 32x32x32 products on the f64 matrix cores;
 //   workgroups of block column c = k+1 also store X_r as L_rk;
-//   workgroup (k+1, k+1) goes on to factor its updated block and to invert the factor into Lt[k+1]
-//       -- the only part that is sequential across launches.
+//   workgroup (k+1, k+1) goes on to turn its updated block into the inverse of its factor, Lt[k+1]
+//       (chol32_tinv_wave) -- the only part that is sequential across launches.
 // Nothing is written that another workgroup of the same launch reads (the panel stays raw in A),
 // so the result does not depend on workgroup scheduling.
 __device__ __forceinline__ double d_readlane(double v, int lane)
@@ -54,103 +55,117 @@ __device__ __forceinline__ double d_readlane(double v, int lane)
     return __hiloint2double(hi, lo);
 }
 
-// Cholesky of the 32x32 block whose lower triangle is in W (LDS, identity padded); the factor goes to
-// D (upper triangle zero), the reciprocals of its diagonal to rD.  Two-level: the columns are taken
-// four at a time; wave 0 factors a 32x4 strip in registers (row i in lane i, pivots and multipliers
-// passed by v_readlane: no LDS, no barrier on the column-to-column chain), then all four waves
-// apply the rank-4 update to the columns to the right.  16 barriers instead of 32.
-//
-// INV: the inverse T = L^-1 comes out of the same sweep -- the elimination applied to an identity
-// block (Tm must hold the identity on entry; L^-1 A = L^T, L^-1 I = T) -- one strip behind the
-// factorisation and off its critical path: while wave 0 factors strip g, wave 1 finishes the four
-// rows of T that belong to strip g-1 (lanes = columns); in the rank-4 phase the threads whose column
-// lies left of strip g-1 -- idle in the update of W, which only touches columns to the right --
-// apply the rank-4 update of strip g-1 to the rows of T below it.  With T at hand the panel solves
-// of a step are plain products (MFMA) instead of 32-step substitution chains.
-template <bool INV>
-__device__ __forceinline__ void chol_block_factor(double (*W)[DNB + 1], double (*D)[DNB + 1], double *rD,
-                                                  double (*Tm)[DNB + 1], double (*ES)[DNB + 1], int t)
+// ---- the 32x32 diagonal block: T = chol(B)^-1 in the registers of one wave ---------------------------
+// The only part of the factorisation that is sequential across launches, so it is kept short: no
+// LDS, no barrier, no substitution.  B (symmetric, both triangles, identity padded) and T (identity on
+// entry) are held as 2x2 tiles of 16x16 in the accumulator layout of v_mfma_f64_16x16x4_f64 (element e
+// of a lane: row 16R + (lane >> 4) + 4e, column 16C + (lane & 15)) and forward elimination is applied
+// to [B | I], four columns at a time -- it ends as [L^T | L^-1].  Strip g (columns j = 4g .. j+3):
+//   P = B[j:j+4, j:j+4] is broadcast (v_readlane) and every lane forms T44 = chol(P)^-1, a 4x4 job;
+//   U = T44 [B | T][j:j+4, :] -- the pivot rows are accumulator element g & 3 of the tiles in tile row
+//       g >> 2, which is exactly the B-operand layout (k = lane >> 4), and T44 padded to 16x4 is the
+//       A operand: one MFMA per column tile, whose element 0 is U, again in B-operand layout;
+//   rows below: [B | T][r, :] -= X[r, :] U with X[r, :] = B[r, j:j+4] T44^T = U[:, r]^T (symmetry): the A
+//       operand of row tile R is the very register that holds U for column tile R;
+//   rows j .. j+3 of T are final: U's T half.
+// 48 MFMAs and eight 4x4 factorisations instead of 32 column steps with 16 barriers: 3.5 us instead of 6.1.
+typedef double d4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ d4_t d_mfma4(double a, double b, d4_t c)
 {
-    const int ti = t / DNB, tc = t % DNB;
-    // rows p0 .. p0+3 of T from the finished strip at columns p0 (D, rD), column c per lane:
-    // e_jj = (e_jj - sum_{m<jj} L[p0+jj][p0+m] e_m) / L[p0+jj][p0+jj]
-    auto t_rows = [&](int p0, int c) {
-        double e[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; jj++) e[jj] = Tm[p0 + jj][c];
-#pragma unroll
-        for (int jj = 0; jj < 4; jj++) {
-            double acc = e[jj];
-#pragma unroll
-            for (int m = 0; m < jj; m++) acc = acc - D[p0 + jj][p0 + m] * e[m];
-            e[jj] = acc * rD[p0 + jj];
-        }
-#pragma unroll
-        for (int jj = 0; jj < 4; jj++) { Tm[p0 + jj][c] = e[jj]; ES[jj][c] = e[jj]; }
-    };
-#pragma unroll
-    for (int g = 0; g < DNB / 4; g++) {
-        const int j0 = 4 * g;
-        if (t < 64) {
-            const int i = t & (DNB - 1);          // lanes 32..63 mirror 0..31 and do not store
-            double w[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; jj++) w[jj] = W[i][j0 + jj];
-#pragma unroll
-            for (int jj = 0; jj < 4; jj++) {
-                const double piv = d_readlane(w[jj], j0 + jj);
-                const double rs = d_rsqrt(piv);
-                const double l = w[jj] * rs;       // lane j0+jj: piv / sqrt(piv) = sqrt(piv)
-                if (t == j0 + jj) rD[j0 + jj] = rs;
-#pragma unroll
-                for (int j2 = jj + 1; j2 < 4; j2++) w[j2] = w[j2] - l * d_readlane(l, j0 + j2);
-                w[jj] = l;
-            }
-            if (t < DNB) {
-#pragma unroll
-                for (int jj = 0; jj < 4; jj++) {
-                    const double v = i >= j0 + jj ? w[jj] : 0.0;
-                    D[i][j0 + jj] = v;
-                }
-            }
-        } else if (INV && g > 0 && t < 64 + DNB) {
-            t_rows(j0 - 4, t - 64);
-        }
-        __syncthreads();
-        // Rank-4 phase, one code path for both jobs (a wave holds columns of either kind; two branches
-        // would run one after the other): a thread right of strip g updates its column of W with the
-        // strip's multipliers, a thread left of strip g-1 its column of T with those of strip g-1.
-        {
-            const bool upd_w = tc >= j0 + 4;
-            const bool upd_t = INV && g > 0 && tc < j0;
-            if (upd_w || upd_t) {
-                const int p0 = upd_w ? j0 : j0 - 4;                   // the strip whose multipliers are used
-                double (*M)[DNB + 1] = upd_w ? W : Tm;
-                const int first = upd_w ? tc : j0;                    // rows from here down are touched
-                double c[4];
-#pragma unroll
-                for (int jj = 0; jj < 4; jj++) c[jj] = upd_w ? D[tc][p0 + jj] : ES[jj][tc];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int i = ti + 8 * q;
-                    if (i >= first) {
-                        double v = M[i][tc];
-#pragma unroll
-                        for (int jj = 0; jj < 4; jj++) v = v - D[i][p0 + jj] * c[jj];
-                        M[i][tc] = v;
-                    }
-                }
-            }
-        }
-        __syncthreads();
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+template <int G>
+__device__ __forceinline__ void chol32_strip(d4_t (&b)[2][2], d4_t (&t)[2][2], int lane)
+{
+    constexpr int j = 4 * G, RJ = G >> 2, E = G & 3, JJ = j & 15;
+    // P[a][c] sits in lane 16 a + JJ + c of accumulator element E of tile (RJ, RJ)
+    const double pv = b[RJ][RJ][E];
+    const double p00 = d_readlane(pv, JJ);
+    const double p10 = d_readlane(pv, 16 + JJ), p11 = d_readlane(pv, 16 + JJ + 1);
+    const double p20 = d_readlane(pv, 32 + JJ), p21 = d_readlane(pv, 32 + JJ + 1), p22 = d_readlane(pv, 32 + JJ + 2);
+    const double p30 = d_readlane(pv, 48 + JJ), p31 = d_readlane(pv, 48 + JJ + 1), p32 = d_readlane(pv, 48 + JJ + 2),
+                 p33 = d_readlane(pv, 48 + JJ + 3);
+    // L44 = chol(P) (l = p / sqrt(p) on the diagonal is never needed, only the reciprocals r); fused
+    // multiply-adds throughout: this is the chain every launch of the factorisation waits for
+    const double r0 = d_rsqrt(p00);
+    const double l10 = p10 * r0, l20 = p20 * r0, l30 = p30 * r0;
+    const double r1 = d_rsqrt(fma(-l10, l10, p11));
+    const double l21 = fma(-l20, l10, p21) * r1, l31 = fma(-l30, l10, p31) * r1;
+    const double r2 = d_rsqrt(fma(-l21, l21, fma(-l20, l20, p22)));
+    const double l32 = fma(-l31, l21, fma(-l30, l20, p32)) * r2;
+    const double r3 = d_rsqrt(fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, p33))));
+    // T44 = L44^-1
+    double t10 = -(l10 * r0) * r1;
+    double t20 = -fma(l21, t10, l20 * r0) * r2, t21 = -(l21 * r1) * r2;
+    double t30 = -fma(l32, t20, fma(l31, t10, l30 * r0)) * r3, t31 = -fma(l32, t21, l31 * r1) * r3, t32 = -(l32 * r2) * r3;
+    // (the 4x4 job is the same in every lane and stays so: without this the compiler sinks each entry into
+    // the lanes that select it below and the wave walks through the branches one after the other)
+    asm volatile("" : "+v"(t10), "+v"(t20), "+v"(t21), "+v"(t30), "+v"(t31), "+v"(t32));
+    // A operand: lane holds T44[a][kq], a = lane & 15 (rows 4..15: zero), kq = lane >> 4
+    const int a = lane & 15, kq = lane >> 4;
+    const int idx = a < 4 ? 4 * a + kq : 16;
+    double ta = 0.0;                               // a flat chain of selects (v_cndmask), no control flow
+    ta = idx == 0 ? r0 : ta;
+    ta = idx == 4 ? t10 : ta; ta = idx == 5 ? r1 : ta;
+    ta = idx == 8 ? t20 : ta; ta = idx == 9 ? t21 : ta; ta = idx == 10 ? r2 : ta;
+    ta = idx == 12 ? t30 : ta; ta = idx == 13 ? t31 : ta; ta = idx == 14 ? t32 : ta; ta = idx == 15 ? r3 : ta;
+    const d4_t z = {0.0, 0.0, 0.0, 0.0};
+    // which tiles still matter: rows / columns >= j + 4 of B, columns <= j + 3 of T
+    constexpr bool live0 = j + 4 <= 15, live1 = j + 4 <= 31;      // tile row / column 0, 1 of B
+    constexpr bool tcol1 = j >= 16;                                // T has entries in column tile 1
+    double uB0 = 0.0, uB1 = 0.0, uT0, uT1 = 0.0;
+    if (live0) uB0 = d_mfma4(ta, b[RJ][0][E], z)[0];
+    if (live1) uB1 = d_mfma4(ta, b[RJ][1][E], z)[0];
+    uT0 = d_mfma4(ta, t[RJ][0][E], z)[0];
+    if (tcol1) uT1 = d_mfma4(ta, t[RJ][1][E], z)[0];
+    if (live0) {
+        const double xa = a >= j + 4 ? -uB0 : 0.0;
+        b[0][0] = d_mfma4(xa, uB0, b[0][0]);
+        b[0][1] = d_mfma4(xa, uB1, b[0][1]);
+        t[0][0] = d_mfma4(xa, uT0, t[0][0]);
+        if (tcol1) t[0][1] = d_mfma4(xa, uT1, t[0][1]);
     }
-    if (INV && t < DNB) t_rows(DNB - 4, t);        // the last strip's rows; nothing lies below them
+    if (live1) {
+        const double xa = 16 + a >= j + 4 ? -uB1 : 0.0;
+        if (live0) b[1][0] = d_mfma4(xa, uB0, b[1][0]);
+        b[1][1] = d_mfma4(xa, uB1, b[1][1]);
+        t[1][0] = d_mfma4(xa, uT0, t[1][0]);
+        if (tcol1) t[1][1] = d_mfma4(xa, uT1, t[1][1]);
+    }
+    t[RJ][0][E] = uT0;
+    if (tcol1) t[RJ][1][E] = uT1;
+}
+
+// One wave: B from LDS (W, full symmetric block, identity padded) -> T = chol(B)^-1 to global memory
+// (row-major 32x32 at `out`)
+__device__ __forceinline__ void chol32_tinv_wave(double (*W)[DNB + 1], double *__restrict__ out, int lane)
+{
+    d4_t b[2][2], t[2][2];
+    const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+    for (int R = 0; R < 2; R++)
+#pragma unroll
+        for (int C = 0; C < 2; C++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int i = 16 * R + lr + 4 * e, jc = 16 * C + lc;
+                b[R][C][e] = W[i][jc];
+                t[R][C][e] = i == jc ? 1.0 : 0.0;
+            }
+    chol32_strip<0>(b, t, lane); chol32_strip<1>(b, t, lane); chol32_strip<2>(b, t, lane); chol32_strip<3>(b, t, lane);
+    chol32_strip<4>(b, t, lane); chol32_strip<5>(b, t, lane); chol32_strip<6>(b, t, lane); chol32_strip<7>(b, t, lane);
+#pragma unroll
+    for (int R = 0; R < 2; R++)
+#pragma unroll
+        for (int C = 0; C < 2; C++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) out[(16 * R + lr + 4 * e) * DNB + 16 * C + lc] = t[R][C][e];
 }
 
 // One 16x16 tile of X Y^T for 32x32 blocks X, Y in LDS on the f64 matrix cores
 // (v_mfma_f64_16x16x4_f64, eight k-steps): wave wv computes tile (wv >> 1, wv & 1); element e of the
 // result sits at row 16 (wv >> 1) + (lane >> 4) + 4 e, column 16 (wv & 1) + (lane & 15).
-typedef double d4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ d4_t d_mfma_nt(double (*X)[DNB + 1], double (*Y)[DNB + 1], int wv, int lane)
 {
     d4_t c = {0.0, 0.0, 0.0, 0.0};
@@ -162,26 +177,17 @@ __device__ __forceinline__ d4_t d_mfma_nt(double (*X)[DNB + 1], double (*Y)[DNB 
 }
 
 // the first diagonal block: the inverse of the factor of A_00 -> Lt[0]
-__global__ __launch_bounds__(256) void k_chol_first(const double *__restrict__ A, double *__restrict__ Lt, int n)
+__global__ __launch_bounds__(64) void k_chol_first(const double *__restrict__ A, double *__restrict__ Lt, int n)
 {
     __shared__ double W[DNB][DNB + 1];
-    __shared__ double D[DNB][DNB + 1];
-    __shared__ double rD[DNB];
-    __shared__ double Tm[DNB][DNB + 1];
-    __shared__ double ES[4][DNB + 1];
     const int t = threadIdx.x;
     const int nd = min(DNB, n);
-    for (int e = t; e < DNB * DNB; e += 256) {
+    for (int e = t; e < DNB * DNB; e += 64) {
         const int i = e / DNB, j = e % DNB;
-        W[i][j] = (i < nd && j <= i) ? A[(size_t)i * n + j] : (i == j ? 1.0 : 0.0);
-        Tm[i][j] = i == j ? 1.0 : 0.0;
+        W[i][j] = (i < nd && j < nd) ? A[(size_t)i * n + j] : (i == j ? 1.0 : 0.0);
     }
     __syncthreads();
-    chol_block_factor<true>(W, D, rD, Tm, ES, t);
-    __syncthreads();
-    for (int e = t; e < DNB * DNB; e += 256) {
-        Lt[e] = Tm[e / DNB][e % DNB];
-    }
+    chol32_tinv_wave(W, Lt, t);
 }
 
 // Step k.  Workgroup (r, c), r >= c > k:  X_r = A_rk T^T, X_c = A_ck T^T with T = L_kk^-1 (Lt[k], from
@@ -198,8 +204,6 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, doubl
     __shared__ double Ts[DNB][DNB + 1];           // T = L_kk^-1; later the factor of block k+1
     __shared__ double Br[DNB][DNB + 1];           // A_rk, then X_r, then the updated block k+1
     __shared__ double Bc[DNB][DNB + 1];           // A_ck, then X_c, then the inverse of the new factor
-    __shared__ double rD[DNB];
-    __shared__ double ES[4][DNB + 1];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int d0 = k * DNB;
     const int nd = min(DNB, n - d0);
@@ -243,19 +247,14 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, doubl
             if (mi[e] < nr && mj < nc) A[(size_t)(r0 + mi[e]) * n + c0 + mj] = a[e] - s[e];
         return;
     }
-    // the next diagonal block: finish its update, factor it and invert the factor now
+    // the next diagonal block: finish its update (the whole symmetric block), then wave 0 alone turns it
+    // into the inverse of its factor
     __syncthreads();                              // everyone is done reading X_r
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-        Br[mi[e]][mj] = (mi[e] < nc && mj <= mi[e]) ? a[e] - s[e] : (mi[e] == mj ? 1.0 : 0.0);
-        Bc[mi[e]][mj] = mi[e] == mj ? 1.0 : 0.0;
-    }
+    for (int e = 0; e < 4; e++) Br[mi[e]][mj] = (mi[e] < nc && mj < nc) ? a[e] - s[e] : (mi[e] == mj ? 1.0 : 0.0);
     __syncthreads();
-    chol_block_factor<true>(Br, Ts, rD, Bc, ES, t);
-    __syncthreads();
-    for (int e = t; e < DNB * DNB; e += 256) {
-        Lt[(size_t)(k + 1) * DNB * DNB + e] = Bc[e / DNB][e % DNB];
-    }
+    if (wv != 0) return;
+    chol32_tinv_wave(Br, Lt + (size_t)(k + 1) * DNB * DNB, lane);
 }
 
 // ---- T = L^-1 by recursive doubling ---------------------------------------------------------------

@@ -519,7 +519,7 @@ static void chol_factor(hm_ctx *h, double *A, double *L, double *Lt, int n, bool
     const int nb = hm_cdiv(n, DNB);
     const int nrows = with_rhs ? aug_rows(n) : n;
     const int nbr = hm_cdiv(nrows, DNB);
-    hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, h->stream, A, Lt, n);
+    hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(64), 0, h->stream, A, Lt, n);
     for (int k = 0; k < nb; k++) {
         const int mr = nbr - k - 1, mc = std::max(nb - k - 1, 1);
         if (mr > 0) hipLaunchKernelGGL(k_chol_step, dim3(mc, mr), dim3(256), 0, h->stream, A, L, Lt, n, nrows, nb, k);
