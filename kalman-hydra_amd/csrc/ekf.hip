@@ -166,7 +166,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->njobs = N + h->E;
     h->red_blocks = 512;
     h->run_ticket = 0;
-    h->vsplit = 6;
+    h->vsplit = 5;
     const size_t n = (size_t)W * H;
     int rc = HM_OK;
     auto step = [&](int r) { if (rc == HM_OK) rc = r; };
@@ -467,6 +467,7 @@ static int measure_dev(hm_ctx *h, const double *dX, bool ref_ready, double delta
     a.out = h->d_out;
     a.pool = h->pool;
     a.vsplit = h->vsplit;
+    a.iZ = 1.0 / h->eps_Z; a.iJ = 1.0 / h->eps_J; a.iM = 1.0 / h->eps_M;
     a.cfgs = h->d_cfgs;
     hipLaunchKernelGGL(k_star_regions, dim3(h->N), dim3(REGION_NT), 0, h->stream, a, h->d_area);
     hipLaunchKernelGGL(k_region_offsets, dim3(1), dim3(256), 0, h->stream, h->d_area, h->N, h->pool);

@@ -490,22 +490,26 @@ struct MeasureArgs {
     double *out;              // njobs * MEAS_VSPLIT_MAX * MEAS_OUT doubles
     DPool pool;
     int vsplit;               // workgroups per vertex job (gridDim.y of k_measure_vertex)
+    double iZ, iJ, iM;        // 1 / eps_Z, 1 / eps_J, 1 / eps_M
     TriSetup *cfgs;           // N x MEAS_NCFG x (EKF_MAX_STAR + 1): the star setups, written by k_star_regions
 };
 
 #define MEAS_NT 256
 #define MEAS_OUT 40
 #define MEAS_VSPLIT_MAX 16     // most workgroups per vertex job (their partial sums are added in order)
-// vertex job output layout (doubles): only the non-zero terms are accumulated
+// vertex job output layout (doubles): only the non-zero terms are accumulated, and only in the
+// combinations KFState.update uses -- 19 sums per thread instead of 38 keep the kernel under 128
+// VGPRs (four waves per SIMD):
 enum {
-    // jz sums: plus then minus; x and y have 4 channels, vx only fx, vy only fy
-    A_XP = 0, A_YP = 4, A_VXP = 8, A_VYP = 9, A_XM = 10, A_YM = 14, A_VXM = 18, A_VYM = 19,
-    // self block of HTH (forward differences): per channel sums
-    A_XX = 20, A_XY = 24, A_YY = 28,      // 4 channels each
-    A_XVX = 32, A_YVX = 33,               // fx channel
-    A_XVY = 34, A_YVY = 35,               // fy channel
-    A_VXVX = 36, A_VYVY = 37,
-    A_NV = 38
+    // jz, plus minus minus (the central difference of kalman.py:499-515 is linear in the sums): x and y
+    // per channel (Hzc wants the components), vx only has an fx term, vy only an fy term
+    A_X = 0, A_Y = 4, A_VX = 8, A_VY = 9,
+    // self block of HTH (forward differences): the four channels already weighted by 1/eps and added
+    A_XX = 10, A_XY = 11, A_YY = 12,
+    A_XVX = 13, A_YVX = 14,               // fx channel only (not weighted)
+    A_XVY = 15, A_YVY = 16,               // fy channel only
+    A_VXVX = 17, A_VYVY = 18,
+    A_NV = 19
 };
 enum {
     // edge job (v,w): D_v,a * D_w,b
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(256) void k_region_offsets(const int *__restrict__ 
 // workgroups per vertex; a perturbation of vertex v changes the render only inside the triangles
 // around v (its star), so every sum runs over the bounding box of that star; the perturbed renders
 // are never materialised.  The forward difference images are parked in the pool for pass 2.
-__global__ __launch_bounds__(MEAS_NT) void k_measure_vertex(MeasureArgs a, const TriSetup *__restrict__ cfgs)
+__global__ __launch_bounds__(MEAS_NT, 4) void k_measure_vertex(MeasureArgs a, const TriSetup *__restrict__ cfgs)
 {
     __shared__ double s_red[(MEAS_NT / 64) * MEAS_OUT];
     __shared__ double s_k255[511];
@@ -683,22 +687,26 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure_vertex(MeasureArgs a, const
         const double z = k255[(int)a.obs.yim[p] - rim];
         const double zm = d_q255(k255, 255 * (int)a.obs.ym[p] - rm);
         const double zfx = (double)(a.obs.yfx[p] - rfx), zfy = (double)(a.obs.yfy[p] + rfy);
-        acc[A_XP + 0] = fma(dxp.im, z, acc[A_XP + 0]); acc[A_XP + 1] = fma((double)dxp.fx, zfx, acc[A_XP + 1]); acc[A_XP + 2] = fma((double)dxp.fy, zfy, acc[A_XP + 2]); acc[A_XP + 3] = fma(dxp.m, zm, acc[A_XP + 3]);
-        acc[A_YP + 0] = fma(dyp.im, z, acc[A_YP + 0]); acc[A_YP + 1] = fma((double)dyp.fx, zfx, acc[A_YP + 1]); acc[A_YP + 2] = fma((double)dyp.fy, zfy, acc[A_YP + 2]); acc[A_YP + 3] = fma(dyp.m, zm, acc[A_YP + 3]);
-        acc[A_XM + 0] = fma(dxm.im, z, acc[A_XM + 0]); acc[A_XM + 1] = fma((double)dxm.fx, zfx, acc[A_XM + 1]); acc[A_XM + 2] = fma((double)dxm.fy, zfy, acc[A_XM + 2]); acc[A_XM + 3] = fma(dxm.m, zm, acc[A_XM + 3]);
-        acc[A_YM + 0] = fma(dym.im, z, acc[A_YM + 0]); acc[A_YM + 1] = fma((double)dym.fx, zfx, acc[A_YM + 1]); acc[A_YM + 2] = fma((double)dym.fy, zfy, acc[A_YM + 2]); acc[A_YM + 3] = fma(dym.m, zm, acc[A_YM + 3]);
-        acc[A_VXP] = fma((double)dvxp.fx, zfx, acc[A_VXP]); acc[A_VXM] = fma((double)dvxm.fx, zfx, acc[A_VXM]);
-        acc[A_VYP] = fma((double)dvyp.fy, zfy, acc[A_VYP]); acc[A_VYM] = fma((double)dvym.fy, zfy, acc[A_VYM]);
-        // HTH diagonal block (forward differences, cuda.py:993-996)
-        acc[A_XX + 0] = fma(dxp.im, dxp.im, acc[A_XX + 0]); acc[A_XX + 1] = fma((double)dxp.fx, (double)dxp.fx, acc[A_XX + 1]);
-        acc[A_XX + 2] = fma((double)dxp.fy, (double)dxp.fy, acc[A_XX + 2]); acc[A_XX + 3] = fma(dxp.m, dxp.m, acc[A_XX + 3]);
-        acc[A_XY + 0] = fma(dxp.im, dyp.im, acc[A_XY + 0]); acc[A_XY + 1] = fma((double)dxp.fx, (double)dyp.fx, acc[A_XY + 1]);
-        acc[A_XY + 2] = fma((double)dxp.fy, (double)dyp.fy, acc[A_XY + 2]); acc[A_XY + 3] = fma(dxp.m, dyp.m, acc[A_XY + 3]);
-        acc[A_YY + 0] = fma(dyp.im, dyp.im, acc[A_YY + 0]); acc[A_YY + 1] = fma((double)dyp.fx, (double)dyp.fx, acc[A_YY + 1]);
-        acc[A_YY + 2] = fma((double)dyp.fy, (double)dyp.fy, acc[A_YY + 2]); acc[A_YY + 3] = fma(dyp.m, dyp.m, acc[A_YY + 3]);
-        acc[A_XVX] = fma((double)dxp.fx, (double)dvxp.fx, acc[A_XVX]); acc[A_YVX] = fma((double)dyp.fx, (double)dvxp.fx, acc[A_YVX]);
-        acc[A_XVY] = fma((double)dxp.fy, (double)dvyp.fy, acc[A_XVY]); acc[A_YVY] = fma((double)dyp.fy, (double)dvyp.fy, acc[A_YVY]);
-        acc[A_VXVX] = fma((double)dvxp.fx, (double)dvxp.fx, acc[A_VXVX]); acc[A_VYVY] = fma((double)dvyp.fy, (double)dvyp.fy, acc[A_VYVY]);
+        {   // jz: z . (D+ - D-) per channel
+            acc[A_X + 0] = fma(dxp.im - dxm.im, z, acc[A_X + 0]); acc[A_X + 1] = fma((double)dxp.fx - (double)dxm.fx, zfx, acc[A_X + 1]);
+            acc[A_X + 2] = fma((double)dxp.fy - (double)dxm.fy, zfy, acc[A_X + 2]); acc[A_X + 3] = fma(dxp.m - dxm.m, zm, acc[A_X + 3]);
+            acc[A_Y + 0] = fma(dyp.im - dym.im, z, acc[A_Y + 0]); acc[A_Y + 1] = fma((double)dyp.fx - (double)dym.fx, zfx, acc[A_Y + 1]);
+            acc[A_Y + 2] = fma((double)dyp.fy - (double)dym.fy, zfy, acc[A_Y + 2]); acc[A_Y + 3] = fma(dyp.m - dym.m, zm, acc[A_Y + 3]);
+            acc[A_VX] = fma((double)dvxp.fx - (double)dvxm.fx, zfx, acc[A_VX]);
+            acc[A_VY] = fma((double)dvyp.fy - (double)dvym.fy, zfy, acc[A_VY]);
+        }
+        {   // HTH diagonal block (forward differences, cuda.py:993-996): sum over channels of D_a D_b / eps
+            const double xi = dxp.im, xf = (double)dxp.fx, xg = (double)dxp.fy, xm = dxp.m;
+            const double yi = dyp.im, yf = (double)dyp.fx, yg = (double)dyp.fy, ym = dyp.m;
+            const double wxi = xi * a.iZ, wxf = xf * a.iJ, wxg = xg * a.iJ, wxm = xm * a.iM;
+            acc[A_XX] = fma(wxm, xm, fma(wxg, xg, fma(wxf, xf, fma(wxi, xi, acc[A_XX]))));
+            acc[A_XY] = fma(wxm, ym, fma(wxg, yg, fma(wxf, yf, fma(wxi, yi, acc[A_XY]))));
+            acc[A_YY] = fma(ym * a.iM, ym, fma(yg * a.iJ, yg, fma(yf * a.iJ, yf, fma(yi * a.iZ, yi, acc[A_YY]))));
+            const double vf = (double)dvxp.fx, vg = (double)dvyp.fy;
+            acc[A_XVX] = fma(xf, vf, acc[A_XVX]); acc[A_YVX] = fma(yf, vf, acc[A_YVX]);
+            acc[A_XVY] = fma(xg, vg, acc[A_XVY]); acc[A_YVY] = fma(yg, vg, acc[A_YVY]);
+            acc[A_VXVX] = fma(vf, vf, acc[A_VXVX]); acc[A_VYVY] = fma(vg, vg, acc[A_VYVY]);
+        }
         if (park) {
             a.pool.xim[pp] = (short)d_i255(dxp.im); a.pool.xm[pp] = (short)d_i255(dxp.m);
             a.pool.yim[pp] = (short)d_i255(dyp.im); a.pool.ym[pp] = (short)d_i255(dyp.m);
@@ -802,28 +810,23 @@ __global__ __launch_bounds__(256) void k_hth_scatter(ScatterArgs a)
         if (lane < 4) {
             // central differences of jz (kalman.py:499-515); component sums carry the sign of jz_CPU
             const int k = lane;
-            double cp[4], cm[4];
+            double c[4] = {0.0, 0.0, 0.0, 0.0};
             if (k < 2) {
-                const double *p = o + (k == 0 ? A_XP : A_YP), *q = o + (k == 0 ? A_XM : A_YM);
-                cp[0] = p[0] / eZ; cp[1] = p[1] / eJ; cp[2] = -p[2] / eJ; cp[3] = p[3] / eM;
-                cm[0] = q[0] / eZ; cm[1] = q[1] / eJ; cm[2] = -q[2] / eJ; cm[3] = q[3] / eM;
+                const double *p = o + (k == 0 ? A_X : A_Y);
+                c[0] = p[0] / eZ; c[1] = p[1] / eJ; c[2] = -p[2] / eJ; c[3] = p[3] / eM;
             } else if (k == 2) {
-                cp[0] = 0.0; cp[1] = o[A_VXP] / eJ; cp[2] = 0.0; cp[3] = 0.0;
-                cm[0] = 0.0; cm[1] = o[A_VXM] / eJ; cm[2] = 0.0; cm[3] = 0.0;
+                c[1] = o[A_VX] / eJ;
             } else {
-                cp[0] = 0.0; cp[1] = 0.0; cp[2] = -o[A_VYP] / eJ; cp[3] = 0.0;
-                cm[0] = 0.0; cm[1] = 0.0; cm[2] = -o[A_VYM] / eJ; cm[3] = 0.0;
+                c[2] = -o[A_VY] / eJ;
             }
-            const double hp = ((cp[0] + cp[1]) + cp[2]) + cp[3];
-            const double hm_ = ((cm[0] + cm[1]) + cm[2]) + cm[3];
-            a.Hz[idx[k]] = (hp / d - hm_ / d) / 2;
-            for (int ch = 0; ch < 4; ch++) a.Hzc[(size_t)idx[k] * 4 + ch] = (cp[ch] / d - cm[ch] / d) / 2;
+            a.Hz[idx[k]] = (((c[0] + c[1]) + c[2]) + c[3]) / d / 2;
+            for (int ch = 0; ch < 4; ch++) a.Hzc[(size_t)idx[k] * 4 + ch] = c[ch] / d / 2;
         } else if (lane >= 8 && lane < 17) {
             const int ix = idx[0], iy = idx[1], ivx = idx[2], ivy = idx[3];
             switch (lane - 8) {
-            case 0: d_put(a.H, n4, ix, ix, SUM4(o + A_XX), d); break;
-            case 1: d_put(a.H, n4, ix, iy, SUM4(o + A_XY), d); break;
-            case 2: d_put(a.H, n4, iy, iy, SUM4(o + A_YY), d); break;
+            case 0: d_put(a.H, n4, ix, ix, o[A_XX], d); break;
+            case 1: d_put(a.H, n4, ix, iy, o[A_XY], d); break;
+            case 2: d_put(a.H, n4, iy, iy, o[A_YY], d); break;
             case 3: d_put(a.H, n4, ix, ivx, o[A_XVX] / eJ, d); break;
             case 4: d_put(a.H, n4, iy, ivx, o[A_YVX] / eJ, d); break;
             case 5: d_put(a.H, n4, ix, ivy, o[A_XVY] / eJ, d); break;
