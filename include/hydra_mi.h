@@ -226,8 +226,9 @@ int hm_ms_newton(int n_vertices, int n_bars, const int32_t *bars, const double *
  * W_out (NULL: not copied) and kept on the device for hm_update_begin / hm_update_run(h, NULL, ...). */
 int hm_cov_predict(hm_ctx_t h, const double *W_in, int n_bars, const int32_t *bars, const double *blocks,
                    double a, double s, double eps_F, double *W_out);
-/* tuning knob: "measure_split" = workgroups per vertex of the measurement kernel (1..16, default 5);
- * the sums change in their last bits with it (another summation order) */
+/* tuning knobs: "measure_split" = workgroups per vertex job of the measurement (1..16, default 5),
+ * "edge_split" = workgroups per mesh-edge job (1..16, default 2); the sums change in their last
+ * bits with them (another summation order) */
 int hm_ctx_tune(hm_ctx_t h, const char *key, int value);
 int hm_ctx_sync(hm_ctx_t h);
 void *hm_ctx_stream(hm_ctx_t h);

@@ -60,7 +60,7 @@ struct hm_ctx {
     std::vector<double> h_partial;
     int red_blocks;
     long long run_ticket;            // sequence number of hm_update_run's per-iteration result blocks
-    int vsplit;                      // workgroups per vertex job of the measurement (hm_ctx_tune)
+    int vsplit, esplit;              // workgroups per vertex / per edge job of the measurement (hm_ctx_tune)
     int2 *d_outline;                 // hm_project_mask: outline pixels (W*H), counters, uploaded mask; allocated on first use
     int *d_outline_cnt;
     uint8_t *d_pm_mask;
@@ -167,6 +167,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->red_blocks = 512;
     h->run_ticket = 0;
     h->vsplit = 5;
+    h->esplit = 2;
     const size_t n = (size_t)W * H;
     int rc = HM_OK;
     auto step = [&](int r) { if (rc == HM_OK) rc = r; };
@@ -256,6 +257,9 @@ extern "C" int hm_ctx_tune(hm_ctx_t h, const char *key, int value)
     if (!strcmp(key, "measure_split")) {
         HM_ARG(value >= 1 && value <= MEAS_VSPLIT_MAX, "hm_ctx_tune: measure_split must be in 1..%d", MEAS_VSPLIT_MAX);
         h->vsplit = value;
+    } else if (!strcmp(key, "edge_split")) {
+        HM_ARG(value >= 1 && value <= MEAS_VSPLIT_MAX, "hm_ctx_tune: edge_split must be in 1..%d", MEAS_VSPLIT_MAX);
+        h->esplit = value;
     } else {
         hm_set_error("hm_ctx_tune: unknown key '%s'", key);
         return HM_ERR_ARG;
@@ -467,14 +471,15 @@ static int measure_dev(hm_ctx *h, const double *dX, bool ref_ready, double delta
     a.out = h->d_out;
     a.pool = h->pool;
     a.vsplit = h->vsplit;
+    a.esplit = h->esplit;
     a.iZ = 1.0 / h->eps_Z; a.iJ = 1.0 / h->eps_J; a.iM = 1.0 / h->eps_M;
     a.cfgs = h->d_cfgs;
     hipLaunchKernelGGL(k_star_regions, dim3(h->N), dim3(REGION_NT), 0, h->stream, a, h->d_area);
     hipLaunchKernelGGL(k_region_offsets, dim3(1), dim3(256), 0, h->stream, h->d_area, h->N, h->pool);
     hipLaunchKernelGGL(k_measure_vertex, dim3(h->N, h->vsplit), dim3(MEAS_NT), 0, h->stream, a,
                        (const TriSetup *)h->d_cfgs);
-    if (h->E > 0) hipLaunchKernelGGL(k_measure_edge, dim3(h->E), dim3(MEAS_NT), 0, h->stream, a);
-    ScatterArgs s = {h->d_out, h->d_edges, h->N, h->E, h->vsplit, h->eps_Z, h->eps_J, h->eps_M, deltaX, h->d_HTH, h->d_Hz, h->d_Hzc};
+    if (h->E > 0) hipLaunchKernelGGL(k_measure_edge, dim3(h->E, h->esplit), dim3(MEAS_NT), 0, h->stream, a);
+    ScatterArgs s = {h->d_out, h->d_edges, h->N, h->E, h->vsplit, h->esplit, h->eps_Z, h->eps_J, h->eps_M, deltaX, h->d_HTH, h->d_Hz, h->d_Hzc};
     hipLaunchKernelGGL(k_hth_scatter, dim3(hm_cdiv(h->njobs, 4)), dim3(256), 0, h->stream, s);
     HM_HIP(hipGetLastError());
     return HM_OK;

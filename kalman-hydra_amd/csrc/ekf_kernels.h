@@ -490,6 +490,7 @@ struct MeasureArgs {
     double *out;              // njobs * MEAS_VSPLIT_MAX * MEAS_OUT doubles
     DPool pool;
     int vsplit;               // workgroups per vertex job (gridDim.y of k_measure_vertex)
+    int esplit;               // workgroups per edge job (gridDim.y of k_measure_edge)
     double iZ, iJ, iM;        // 1 / eps_Z, 1 / eps_J, 1 / eps_M
     TriSetup *cfgs;           // N x MEAS_NCFG x (EKF_MAX_STAR + 1): the star setups, written by k_star_regions
 };
@@ -513,10 +514,10 @@ enum {
 };
 enum {
     // edge job (v,w): D_v,a * D_w,b
-    B_XX = 0, B_XY = 4, B_YX = 8, B_YY = 12,       // geometry x geometry, 4 channels each
-    B_XVX = 16, B_YVX = 17, B_VXX = 18, B_VXY = 19, B_VXVX = 20,   // fx channel
-    B_XVY = 21, B_YVY = 22, B_VYX = 23, B_VYY = 24, B_VYVY = 25,   // fy channel
-    B_NV = 26
+    B_XX = 0, B_XY = 1, B_YX = 2, B_YY = 3,        // geometry x geometry: channels weighted by 1/eps and added
+    B_XVX = 4, B_YVX = 5, B_VXX = 6, B_VXY = 7, B_VXVX = 8,        // fx channel (not weighted)
+    B_XVY = 9, B_YVY = 10, B_VYX = 11, B_VYY = 12, B_VYVY = 13,    // fy channel
+    B_NV = 14
 };
 
 #define MEAS_NCFG 5            // reference, +x, -x, +y, -y of the vertex
@@ -740,10 +741,18 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure_edge(MeasureArgs a)
 #pragma unroll
     for (int k = 0; k < B_NV; k++) acc[k] = 0.0;
     const DPool &P = a.pool;
-    for (int i = threadIdx.x; i < npx; i += MEAS_NT) {
-        const int r = r0 + i / rw, c = c0 + i % rw;
+    // the job's pixels are dealt to the threads of its gridDim.y workgroups round robin; row and column
+    // advance with the stride (no division per pixel)
+    const int nthr = MEAS_NT * gridDim.y, first = blockIdx.y * MEAS_NT + threadIdx.x;
+    const int rwd = rw > 0 ? rw : 1;
+    const int dr = nthr / rwd, dc = nthr % rwd;
+    int r = r0 + first / rwd, c = c0 + first % rwd;
+    const double iZ = a.iZ, iJ = a.iJ, iM = a.iM;
+    for (int i = first; i < npx; i += nthr) {
         const long long pv = bv + (long long)(r - hv[1]) * hv[2] + (c - hv[0]);
         const long long pw = bw + (long long)(r - hw[1]) * hw[2] + (c - hw[0]);
+        r += dr; c += dc;
+        if (c > c1) { c -= rw; r++; }
         const double axim = k255[P.xim[pv]], axm = k255[P.xm[pv]];     // parked as numerators in -255..255
         const double ayim = k255[P.yim[pv]], aym = k255[P.ym[pv]];
         const double bxim = k255[P.xim[pw]], bxm = k255[P.xm[pw]];
@@ -751,16 +760,20 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure_edge(MeasureArgs a)
         const double axfx = P.xfx[pv], axfy = P.xfy[pv], ayfx = P.yfx[pv], ayfy = P.yfy[pv];
         const double bxfx = P.xfx[pw], bxfy = P.xfy[pw], byfx = P.yfx[pw], byfy = P.yfy[pw];
         const double avx = P.vxfx[pv], avy = P.vyfy[pv], bvx = P.vxfx[pw], bvy = P.vyfy[pw];
-        acc[B_XX + 0] += axim * bxim; acc[B_XX + 1] += axfx * bxfx; acc[B_XX + 2] += axfy * bxfy; acc[B_XX + 3] += axm * bxm;
-        acc[B_XY + 0] += axim * byim; acc[B_XY + 1] += axfx * byfx; acc[B_XY + 2] += axfy * byfy; acc[B_XY + 3] += axm * bym;
-        acc[B_YX + 0] += ayim * bxim; acc[B_YX + 1] += ayfx * bxfx; acc[B_YX + 2] += ayfy * bxfy; acc[B_YX + 3] += aym * bxm;
-        acc[B_YY + 0] += ayim * byim; acc[B_YY + 1] += ayfx * byfx; acc[B_YY + 2] += ayfy * byfy; acc[B_YY + 3] += aym * bym;
-        acc[B_XVX] += axfx * bvx; acc[B_YVX] += ayfx * bvx; acc[B_VXX] += avx * bxfx; acc[B_VXY] += avx * byfx;
-        acc[B_VXVX] += avx * bvx;
-        acc[B_XVY] += axfy * bvy; acc[B_YVY] += ayfy * bvy; acc[B_VYX] += avy * bxfy; acc[B_VYY] += avy * byfy;
-        acc[B_VYVY] += avy * bvy;
+        const double wxi = axim * iZ, wxf = axfx * iJ, wxg = axfy * iJ, wxm = axm * iM;    // D_v,x / eps
+        const double wyi = ayim * iZ, wyf = ayfx * iJ, wyg = ayfy * iJ, wym = aym * iM;    // D_v,y / eps
+        acc[B_XX] = fma(wxm, bxm, fma(wxg, bxfy, fma(wxf, bxfx, fma(wxi, bxim, acc[B_XX]))));
+        acc[B_XY] = fma(wxm, bym, fma(wxg, byfy, fma(wxf, byfx, fma(wxi, byim, acc[B_XY]))));
+        acc[B_YX] = fma(wym, bxm, fma(wyg, bxfy, fma(wyf, bxfx, fma(wyi, bxim, acc[B_YX]))));
+        acc[B_YY] = fma(wym, bym, fma(wyg, byfy, fma(wyf, byfx, fma(wyi, byim, acc[B_YY]))));
+        acc[B_XVX] = fma(axfx, bvx, acc[B_XVX]); acc[B_YVX] = fma(ayfx, bvx, acc[B_YVX]);
+        acc[B_VXX] = fma(avx, bxfx, acc[B_VXX]); acc[B_VXY] = fma(avx, byfx, acc[B_VXY]);
+        acc[B_VXVX] = fma(avx, bvx, acc[B_VXVX]);
+        acc[B_XVY] = fma(axfy, bvy, acc[B_XVY]); acc[B_YVY] = fma(ayfy, bvy, acc[B_YVY]);
+        acc[B_VYX] = fma(avy, bxfy, acc[B_VYX]); acc[B_VYY] = fma(avy, byfy, acc[B_VYY]);
+        acc[B_VYVY] = fma(avy, bvy, acc[B_VYVY]);
     }
-    d_block_reduce<B_NV, MEAS_NT>(acc, s_red, a.out + ((size_t)(N + e) * MEAS_VSPLIT_MAX) * MEAS_OUT);
+    d_block_reduce<B_NV, MEAS_NT>(acc, s_red, a.out + ((size_t)(N + e) * MEAS_VSPLIT_MAX + blockIdx.y) * MEAS_OUT);
 }
 
 // ---- job sums -> Hz, Hz components, dense HTH (device twin of the unpacking in KFState.update) -------
@@ -770,7 +783,7 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure_edge(MeasureArgs a)
 struct ScatterArgs {
     const double *out;        // njobs * MEAS_VSPLIT_MAX * MEAS_OUT
     const int *edges;
-    int N, E, vsplit;
+    int N, E, vsplit, esplit;
     double eZ, eJ, eM, d;
     double *H, *Hz, *Hzc;     // 4N x 4N, 4N, 4N x 4
 };
@@ -794,7 +807,7 @@ __global__ __launch_bounds__(256) void k_hth_scatter(ScatterArgs a)
     const bool on = job < N + a.E;
     if (on && lane < MEAS_OUT) {
         const double *src = a.out + (size_t)job * MEAS_VSPLIT_MAX * MEAS_OUT;
-        const int parts = job < N ? a.vsplit : 1;
+        const int parts = job < N ? a.vsplit : a.esplit;
         double v = src[lane];
         for (int q = 1; q < parts; q++) v += src[q * MEAS_OUT + lane];
         so[wv][lane] = v;
@@ -803,7 +816,6 @@ __global__ __launch_bounds__(256) void k_hth_scatter(ScatterArgs a)
     if (!on) return;
     const double *o = so[wv];
     const double eZ = a.eZ, eJ = a.eJ, eM = a.eM, d = a.d;
-#define SUM4(s) ((((s)[0] / eZ + (s)[1] / eJ) + (s)[2] / eJ) + (s)[3] / eM)
     if (job < N) {
         const int v = job;
         const int idx[4] = {2 * v, 2 * v + 1, 2 * N + 2 * v, 2 * N + 2 * v + 1};
@@ -841,10 +853,10 @@ __global__ __launch_bounds__(256) void k_hth_scatter(ScatterArgs a)
         const int vx_ = 2 * v, vy_ = 2 * v + 1, vvx = 2 * N + 2 * v, vvy = 2 * N + 2 * v + 1;
         const int wx_ = 2 * w, wy_ = 2 * w + 1, wvx = 2 * N + 2 * w, wvy = 2 * N + 2 * w + 1;
         switch (lane) {
-        case 0: d_put(a.H, n4, vx_, wx_, SUM4(o + B_XX), d); break;
-        case 1: d_put(a.H, n4, vx_, wy_, SUM4(o + B_XY), d); break;
-        case 2: d_put(a.H, n4, vy_, wx_, SUM4(o + B_YX), d); break;
-        case 3: d_put(a.H, n4, vy_, wy_, SUM4(o + B_YY), d); break;
+        case 0: d_put(a.H, n4, vx_, wx_, o[B_XX], d); break;
+        case 1: d_put(a.H, n4, vx_, wy_, o[B_XY], d); break;
+        case 2: d_put(a.H, n4, vy_, wx_, o[B_YX], d); break;
+        case 3: d_put(a.H, n4, vy_, wy_, o[B_YY], d); break;
         case 4: d_put(a.H, n4, vx_, wvx, o[B_XVX] / eJ, d); break;
         case 5: d_put(a.H, n4, vy_, wvx, o[B_YVX] / eJ, d); break;
         case 6: d_put(a.H, n4, vvx, wx_, o[B_VXX] / eJ, d); break;
@@ -857,5 +869,4 @@ __global__ __launch_bounds__(256) void k_hth_scatter(ScatterArgs a)
         default: d_put(a.H, n4, vvy, wvy, o[B_VYVY] / eJ, d); break;
         }
     }
-#undef SUM4
 }

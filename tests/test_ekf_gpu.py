@@ -459,8 +459,16 @@ def test_measure_split_changes_only_the_summation_order(hm):
         assert np.abs(Hz - Hz0).max() <= 1e-12 * np.abs(Hz0).max(), split
         assert np.abs(HTH - HTH0).max() <= 1e-12 * np.abs(HTH0).max(), split
         assert np.abs(Hzc - Hzc0).max() <= 1e-12 * np.abs(Hzc0).max(), split
+    R.tune("measure_split", 5)
+    for split in (1, 3, 16):
+        R.tune("edge_split", split)
+        Hz, HTH, Hzc = R.measure(st, y_im, flow, y_m)
+        assert np.array_equal(Hz, Hz0) and np.array_equal(Hzc, Hzc0), split      # vertex jobs: untouched
+        assert np.abs(HTH - HTH0).max() <= 1e-12 * np.abs(HTH0).max(), split
     with pytest.raises(RuntimeError):
         R.tune("measure_split", 17)
+    with pytest.raises(RuntimeError):
+        R.tune("edge_split", 0)
     with pytest.raises(RuntimeError):
         R.tune("no_such_knob", 1)
 

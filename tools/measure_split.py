@@ -15,6 +15,8 @@ du = torch.empty((n, n), dtype=torch.float32, device="cuda"); dvv = torch.empty_
 bf = brox.BroxOpticalFlow(n, n)
 kf = kalman.IteratedMSKalmanFilter(dm, video[0], np.zeros((n, n, 2), np.float32), True)
 kf.state.renderer.tune("measure_split", split)
+if len(sys.argv) > 2:
+    kf.state.renderer.tune("edge_split", int(sys.argv[2]))
 for k in range(4):
     bf.calc_dev(1, dv[k].data_ptr(), dv[k + 1].data_ptr(), du.data_ptr(), dvv.data_ptr()); bf.sync()
     obs = DeviceObservation(dv[k + 1].data_ptr(), du.data_ptr(), dvv.data_ptr(), dmk[k + 1].data_ptr(), y_m_host=masks[k + 1])
