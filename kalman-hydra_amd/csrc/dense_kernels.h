@@ -474,13 +474,26 @@ __global__ __launch_bounds__(256) void k_ttt(const double *__restrict__ Tm, int 
 // ---- assembly of the update system -----------------------------------------------------------------
 // The update system of one iteration in one pass over H (one workgroup per row of the augmented
 // array): A = invW0 + H, the right-hand side Hz - H (X0 - X) as row `rhs_row` of the block below the
-// matrix, zeros in the padding rows.
+// matrix, zeros in the padding rows.  One more workgroup (the last) does what k_chol_first would do in a
+// launch of its own: it forms the first diagonal block itself and leaves the inverse of its factor in Lt[0].
 __global__ __launch_bounds__(256) void k_assemble(const double *__restrict__ invW0, const double *__restrict__ H,
                                                   const double *__restrict__ X0, const double *__restrict__ X,
-                                                  const double *__restrict__ Hz, double *__restrict__ A, int n, int rhs_row)
+                                                  const double *__restrict__ Hz, double *__restrict__ A, int n, int rhs_row,
+                                                  double *__restrict__ Lt)
 {
     __shared__ double s[4];
     const int row = blockIdx.x;
+    if (row == (int)gridDim.x - 1) {
+        __shared__ double W[DNB][DNB + 1];
+        const int nd = min(DNB, n);
+        for (int e = threadIdx.x; e < DNB * DNB; e += 256) {
+            const int i = e / DNB, j = e % DNB;
+            W[i][j] = (i < nd && j < nd) ? invW0[(size_t)i * n + j] + H[(size_t)i * n + j] : (i == j ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) chol32_tinv_wave(W, Lt, threadIdx.x);
+        return;
+    }
     if (row >= n) {
         if (row != rhs_row)
             for (int j = threadIdx.x; j < n; j += 256) A[(size_t)row * n + j] = 0.0;

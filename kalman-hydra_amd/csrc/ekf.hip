@@ -90,7 +90,7 @@ static int ctx_free(hm_ctx *h)
                     h->d_yfy, h->d_yfxm, h->d_yfym, h->d_setup, h->d_cfgs, h->d_X, h->d_out, h->d_partial, h->d_im8, h->d_m8,
                     h->d_HTH, h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_T[0], h->d_T[1], h->d_step, h->d_Wprior, h->d_gain, h->d_Awork, h->d_Lt[0], h->d_Lt[1],
                     h->d_Wtmp, h->d_X0, h->d_Xn, h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk,
-                    h->pool.hdr, h->pool.off, h->pool.xim, h->pool.xm, h->pool.yim, h->pool.ym, h->pool.xfx, h->pool.xfy,
+                    h->pool.hdr, h->pool.xim, h->pool.xm, h->pool.yim, h->pool.ym, h->pool.xfx, h->pool.xfy,
                     h->pool.yfx, h->pool.yfy, h->pool.vxfx, h->pool.vyfy, h->pool.overflow, h->d_area,
                     h->d_outline, h->d_outline_cnt, h->d_pm_mask};
     for (void *p : ptrs)
@@ -222,9 +222,9 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         h->pool.cap = (long long)16 * W * H;
         const size_t pc = (size_t)h->pool.cap;
         if (e == hipSuccess) e = hipMalloc((void **)&h->pool.hdr, (size_t)4 * N * sizeof(int));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->pool.off, (size_t)(N + 1) * sizeof(long long));
         if (e == hipSuccess) e = hipMalloc((void **)&h->pool.overflow, sizeof(int));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_area, (size_t)N * sizeof(int));
+        h->pool.area = h->d_area;
         short **sp[] = {&h->pool.xim, &h->pool.xm, &h->pool.yim, &h->pool.ym};
         for (short **q : sp)
             if (e == hipSuccess) e = hipMalloc((void **)q, pc * sizeof(short));
@@ -455,13 +455,37 @@ extern "C" int hm_error(hm_ctx_t h, const double *X, int masked, double err[4], 
 
 // render X as the reference, run the fused perturb-and-reduce kernel, unpack into d_H / d_Hz / d_Hzc
 // the measurement at the device-resident state dX, whose render is (ref_ready) or is to be put in h->ref
-static int measure_dev(hm_ctx *h, const double *dX, bool ref_ready, double deltaX, int masked)
+static void measure_args(hm_ctx *h, const double *dX, double deltaX, int masked, MeasureArgs &a);
+
+// the star regions and triangle setups of the measurement at dX (the first launch of measure_dev, which a
+// caller that knows the next state early may issue ahead: it reads nothing but the state)
+static void measure_regions(hm_ctx *h, const double *dX, double deltaX)
+{
+    MeasureArgs a;
+    measure_args(h, dX, deltaX, 0, a);
+    hipLaunchKernelGGL(k_star_regions, dim3(h->N), dim3(REGION_NT), 0, h->stream, a, h->d_area);
+}
+
+static int measure_dev(hm_ctx *h, const double *dX, bool ref_ready, double deltaX, int masked, bool regions_ready = false)
 {
     if (!ref_ready) {
         int rc = render_dev(h, dX, h->ref);
         if (rc) return rc;
     }
     MeasureArgs a;
+    measure_args(h, dX, deltaX, masked, a);
+    if (!regions_ready) hipLaunchKernelGGL(k_star_regions, dim3(h->N), dim3(REGION_NT), 0, h->stream, a, h->d_area);
+    hipLaunchKernelGGL(k_measure_vertex, dim3(h->N, h->vsplit), dim3(MEAS_NT), 0, h->stream, a,
+                       (const TriSetup *)h->d_cfgs);
+    if (h->E > 0) hipLaunchKernelGGL(k_measure_edge, dim3(h->E, h->esplit), dim3(MEAS_NT), 0, h->stream, a);
+    ScatterArgs s = {h->d_out, h->d_edges, h->N, h->E, h->vsplit, h->esplit, h->eps_Z, h->eps_J, h->eps_M, deltaX, h->d_HTH, h->d_Hz, h->d_Hzc};
+    hipLaunchKernelGGL(k_hth_scatter, dim3(hm_cdiv(h->njobs, 4)), dim3(256), 0, h->stream, s);
+    HM_HIP(hipGetLastError());
+    return HM_OK;
+}
+
+static void measure_args(hm_ctx *h, const double *dX, double deltaX, int masked, MeasureArgs &a)
+{
     a.m = Mesh{h->W, h->H, h->N, h->T, h->d_tri, h->d_uv, h->d_tex};
     a.topo = StarTopo{h->d_star_off, h->d_star_tri, h->d_edges, h->E};
     a.ref = h->ref;
@@ -474,15 +498,6 @@ static int measure_dev(hm_ctx *h, const double *dX, bool ref_ready, double delta
     a.esplit = h->esplit;
     a.iZ = 1.0 / h->eps_Z; a.iJ = 1.0 / h->eps_J; a.iM = 1.0 / h->eps_M;
     a.cfgs = h->d_cfgs;
-    hipLaunchKernelGGL(k_star_regions, dim3(h->N), dim3(REGION_NT), 0, h->stream, a, h->d_area);
-    hipLaunchKernelGGL(k_region_offsets, dim3(1), dim3(256), 0, h->stream, h->d_area, h->N, h->pool);
-    hipLaunchKernelGGL(k_measure_vertex, dim3(h->N, h->vsplit), dim3(MEAS_NT), 0, h->stream, a,
-                       (const TriSetup *)h->d_cfgs);
-    if (h->E > 0) hipLaunchKernelGGL(k_measure_edge, dim3(h->E, h->esplit), dim3(MEAS_NT), 0, h->stream, a);
-    ScatterArgs s = {h->d_out, h->d_edges, h->N, h->E, h->vsplit, h->esplit, h->eps_Z, h->eps_J, h->eps_M, deltaX, h->d_HTH, h->d_Hz, h->d_Hzc};
-    hipLaunchKernelGGL(k_hth_scatter, dim3(hm_cdiv(h->njobs, 4)), dim3(256), 0, h->stream, s);
-    HM_HIP(hipGetLastError());
-    return HM_OK;
 }
 
 static int measure_on_device(hm_ctx *h, const double *X, double deltaX, int masked)
@@ -520,12 +535,13 @@ static int aug_rows(int n) { return hm_cdiv(n, DNB) * DNB + DNB; }
 
 // Cholesky of the n x n matrix in the working copy A (destroyed) into L / Lt; with_rhs: the
 // right-hand-side rows below the matrix go through the elimination too (dense_kernels.h)
-static void chol_factor(hm_ctx *h, double *A, double *L, double *Lt, int n, bool with_rhs)
+// first_done: Lt[0] is there already (k_assemble)
+static void chol_factor(hm_ctx *h, double *A, double *L, double *Lt, int n, bool with_rhs, bool first_done = false)
 {
     const int nb = hm_cdiv(n, DNB);
     const int nrows = with_rhs ? aug_rows(n) : n;
     const int nbr = hm_cdiv(nrows, DNB);
-    hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(64), 0, h->stream, A, Lt, n);
+    if (!first_done) hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(64), 0, h->stream, A, Lt, n);
     for (int k = 0; k < nb; k++) {
         const int mr = nbr - k - 1, mc = std::max(nb - k - 1, 1);
         if (mr > 0) hipLaunchKernelGGL(k_chol_step, dim3(mc, mr), dim3(256), 0, h->stream, A, L, Lt, n, nrows, nb, k);
@@ -563,9 +579,9 @@ static double *solve_step(hm_ctx *h, int slot)
     // matrix; the rows in between and the rest of that block zero
     const int rhs_index = hm_cdiv(n4, DNB) * DNB;
     double *rhs_row = A + (size_t)rhs_index * n4;
-    hipLaunchKernelGGL(k_assemble, dim3(aug_rows(n4)), dim3(256), 0, h->stream, h->d_invW0, h->d_HTH, h->d_X0, h->d_X,
-                       h->d_Hz, A, n4, rhs_index);
-    chol_factor(h, A, h->d_Af[slot], h->d_Lt[slot], n4, true);
+    hipLaunchKernelGGL(k_assemble, dim3(aug_rows(n4) + 1), dim3(256), 0, h->stream, h->d_invW0, h->d_HTH, h->d_X0, h->d_X,
+                       h->d_Hz, A, n4, rhs_index, h->d_Lt[slot]);
+    chol_factor(h, A, h->d_Af[slot], h->d_Lt[slot], n4, true, true);
     // y = L^-1 b came out of the factorisation as the extra row; x = T^T y with T = L^-1, which stays in
     // the slot for hm_update_cov (inv = T^T T).  d_Wtmp is scratch between hm_update_begin and the
     // next hm_cov_predict.
@@ -765,10 +781,10 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
     HM_HIP(hipMemcpyAsync(h->d_X, h->d_X0, (size_t)n4 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     double *res = h->pin, *pin_hzc = h->pin + n4 + 8, *pin_gain = pin_hzc + (size_t)n4 * 4;
     int niter = 0, accepted = 0;
-    bool reverted = false, conv = false, ref_ready = false;
+    bool reverted = false, conv = false, ref_ready = false, regions_ahead = false;
     double eold = 0.0;
     for (int it = 0; it < max_iter; it++) {
-        rc = measure_dev(h, h->d_X, ref_ready, deltaX, masked);
+        rc = measure_dev(h, h->d_X, ref_ready, deltaX, masked, regions_ahead);
         if (rc) return rc;
         h->X0 = Xcur;                              // the state of the reference render (hm_jz / hm_j)
         h->have_ref = true;
@@ -781,6 +797,10 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
                            h->W * h->H, h->d_partial);
         hipLaunchKernelGGL(k_iter_result, dim3(1), dim3(256), (size_t)h->red_blocks * 4 * sizeof(double), h->stream, rhs_row, n4, h->d_partial,
                            h->red_blocks, h->pool.overflow, res, (double)(++h->run_ticket));
+        // the star regions of the next measurement (it needs the new iterate only) run while the host looks
+        // at this iteration's result; wasted when the loop ends here
+        regions_ahead = it + 1 < max_iter;
+        if (regions_ahead) measure_regions(h, h->d_Xn, deltaX);
         HM_HIP(hipGetLastError());
         // The result block carries a ticket that the kernel writes last (system-scope fence before it).
         // Watching it costs a couple of microseconds against ~20 for waking up from a stream

@@ -473,7 +473,7 @@ __device__ inline void d_star_setups(TriSetup *dst, int ns, const int *tris, con
 // integers in 1/255 units, flow as f32) and the flow channel of the two velocity perturbations.
 struct DPool {
     int *hdr;                 // N x 4: c0, r0, rw, rh of the region
-    long long *off;           // N + 1 pixel offsets (exclusive prefix sum of the areas)
+    const int *area;          // N region areas (k_star_regions); a region's offset is the sum of those before it
     short *xim, *xm, *yim, *ym;
     float *xfx, *xfy, *yfx, *yfy, *vxfx, *vyfy;
     long long cap;            // pixels in the pool
@@ -575,35 +575,28 @@ __global__ __launch_bounds__(REGION_NT) void k_star_regions(MeasureArgs a, int *
     area[v] = rw * rh;
 }
 
-// exclusive prefix sum of the region areas (one workgroup, Hillis-Steele over chunks of 256)
-__global__ __launch_bounds__(256) void k_region_offsets(const int *__restrict__ area, int N, DPool pool)
+// Places in the pool: the region of vertex v starts at pixel offset sum_{u < v} area[u].  Every
+// workgroup adds that up for itself (a few hundred integers from L2, exact in any order) rather than
+// waiting for a scan kernel between k_star_regions and the jobs; `tot` = all areas, for the capacity check.
+template <int NT>
+__device__ inline void d_region_sums(const int *__restrict__ area, int N, int v, int w, long long &bv, long long &bw,
+                                     long long &tot, long long *s /* [NT / 64][3] */)
 {
-    __shared__ long long sc[256];
-    __shared__ long long carry;
-    const int t = threadIdx.x;
-    if (t == 0) carry = 0;
+    long long a = 0, b = 0, c = 0;
+    for (int i = threadIdx.x; i < N; i += NT) {
+        const long long x = area[i];
+        c += x;
+        if (i < v) a += x;
+        if (i < w) b += x;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); c += __shfl_down(c, o, 64);
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { s[wv * 3] = a; s[wv * 3 + 1] = b; s[wv * 3 + 2] = c; }
     __syncthreads();
-    for (int b0 = 0; b0 < N; b0 += 256) {
-        const int v = b0 + t;
-        const long long mine = v < N ? (long long)area[v] : 0;
-        sc[t] = mine;
-        __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) {
-            const long long add = t >= o ? sc[t - o] : 0;
-            __syncthreads();
-            sc[t] += add;
-            __syncthreads();
-        }
-        const long long base = carry;
-        if (v < N) pool.off[v] = base + sc[t] - mine;
-        __syncthreads();
-        if (t == 255) carry = base + sc[255];
-        __syncthreads();
-    }
-    if (t == 0) {
-        pool.off[N] = carry;
-        *pool.overflow = carry > pool.cap ? 1 : 0;
-    }
+    bv = 0; bw = 0; tot = 0;
+    for (int k = 0; k < NT / 64; k++) { bv += s[k * 3]; bw += s[k * 3 + 1]; tot += s[k * 3 + 2]; }
 }
 
 // ---- pass 1: vertex jobs ----------------------------------------------------------------------------------
@@ -632,8 +625,11 @@ __global__ __launch_bounds__(MEAS_NT, 4) void k_measure_vertex(MeasureArgs a, co
     for (int c = 0; c < MEAS_NCFG; c++) s_cfg[c] = cfgs + ((size_t)v * MEAS_NCFG + c) * (EKF_MAX_STAR + 1);
     __syncthreads();
     const int c0 = a.pool.hdr[4 * v], r0 = a.pool.hdr[4 * v + 1], rw = a.pool.hdr[4 * v + 2], rh = a.pool.hdr[4 * v + 3];
-    const long long base = a.pool.off[v];
-    const bool park = *a.pool.overflow == 0;
+    __shared__ long long s_sum[(MEAS_NT / 64) * 3];
+    long long base, unused, total;
+    d_region_sums<MEAS_NT>(a.pool.area, N, v, 0, base, unused, total, s_sum);
+    const bool park = total <= a.pool.cap;
+    if (v == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.pool.overflow = park ? 0 : 1;
     double acc[A_NV];
 #pragma unroll
     for (int k = 0; k < A_NV; k++) acc[k] = 0.0;
@@ -736,7 +732,9 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure_edge(MeasureArgs a)
     const int c1 = min(hv[0] + hv[2], hw[0] + hw[2]) - 1, r1 = min(hv[1] + hv[3], hw[1] + hw[3]) - 1;
     const int rw = c1 - c0 + 1, rh = r1 - r0 + 1;
     const int npx = (rw > 0 && rh > 0) ? rw * rh : 0;
-    const long long bv = a.pool.off[v], bw = a.pool.off[w];
+    __shared__ long long s_sum[(MEAS_NT / 64) * 3];
+    long long bv, bw, total;
+    d_region_sums<MEAS_NT>(a.pool.area, N, v, w, bv, bw, total, s_sum);
     double acc[B_NV];
 #pragma unroll
     for (int k = 0; k < B_NV; k++) acc[k] = 0.0;
