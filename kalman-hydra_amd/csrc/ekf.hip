@@ -33,6 +33,7 @@ struct hm_ctx {
     // renders
     Targets ref, P, Q;
     TriSetup *d_setup, *d_cfgs;
+    int4 *d_ubox;
     double *d_X, *d_out, *d_partial;
     uint8_t *d_im8, *d_m8;
     std::vector<double> X0;          // state of the reference render
@@ -87,7 +88,7 @@ static int ctx_free(hm_ctx *h)
     if (!h) return HM_OK;
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_tri, h->d_star_off, h->d_star_tri, h->d_edges, h->d_uv, h->d_tex, h->d_yim, h->d_ym, h->d_yfx,
-                    h->d_yfy, h->d_yfxm, h->d_yfym, h->d_setup, h->d_cfgs, h->d_X, h->d_out, h->d_partial, h->d_im8, h->d_m8,
+                    h->d_yfy, h->d_yfxm, h->d_yfym, h->d_setup, h->d_cfgs, h->d_ubox, h->d_X, h->d_out, h->d_partial, h->d_im8, h->d_m8,
                     h->d_HTH, h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_T[0], h->d_T[1], h->d_step, h->d_Wprior, h->d_gain, h->d_Awork, h->d_Lt[0], h->d_Lt[1],
                     h->d_Wtmp, h->d_X0, h->d_Xn, h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk,
                     h->pool.hdr, h->pool.xim, h->pool.xm, h->pool.yim, h->pool.ym, h->pool.xfx, h->pool.xfy,
@@ -151,7 +152,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->o_yim = h->o_ym = nullptr; h->o_yfx = h->o_yfy = nullptr;
     h->d_yim = h->d_ym = nullptr; h->d_yfx = h->d_yfy = h->d_yfxm = h->d_yfym = nullptr;
     h->ref = Targets{nullptr, nullptr, nullptr, nullptr}; h->P = h->ref; h->Q = h->ref;
-    h->d_setup = nullptr; h->d_cfgs = nullptr; h->d_X = h->d_out = h->d_partial = nullptr; h->d_im8 = h->d_m8 = nullptr;
+    h->d_setup = nullptr; h->d_cfgs = nullptr; h->d_ubox = nullptr; h->d_X = h->d_out = h->d_partial = nullptr; h->d_im8 = h->d_m8 = nullptr;
     h->d_HTH = nullptr;
     h->d_H = h->d_Hz = h->d_Hzc = h->d_invW0 = h->d_Af[0] = h->d_Af[1] = h->d_Wtmp = nullptr;
     h->d_Wprior = h->d_gain = h->d_Awork = h->d_Lt[0] = h->d_Lt[1] = nullptr; h->d_Wres = nullptr; h->pin = nullptr; h->pin_n = 0;
@@ -187,6 +188,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_yfym, n * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_setup, (size_t)T * sizeof(TriSetup));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_cfgs, (size_t)N * MEAS_NCFG * (EKF_MAX_STAR + 1) * sizeof(TriSetup));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_ubox, (size_t)N * UBOX_STRIDE * sizeof(int4));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_X, (size_t)4 * N * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_out, (size_t)h->njobs * MEAS_VSPLIT_MAX * MEAS_OUT * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_partial, (size_t)h->red_blocks * 4 * sizeof(double));
@@ -476,7 +478,7 @@ static int measure_dev(hm_ctx *h, const double *dX, bool ref_ready, double delta
     measure_args(h, dX, deltaX, masked, a);
     if (!regions_ready) hipLaunchKernelGGL(k_star_regions, dim3(h->N), dim3(REGION_NT), 0, h->stream, a, h->d_area);
     hipLaunchKernelGGL(k_measure_vertex, dim3(h->N, h->vsplit), dim3(MEAS_NT), 0, h->stream, a,
-                       (const TriSetup *)h->d_cfgs);
+                       (const TriSetup *)h->d_cfgs, (const int4 *)h->d_ubox);
     if (h->E > 0) hipLaunchKernelGGL(k_measure_edge, dim3(h->E, h->esplit), dim3(MEAS_NT), 0, h->stream, a);
     ScatterArgs s = {h->d_out, h->d_edges, h->N, h->E, h->vsplit, h->esplit, h->eps_Z, h->eps_J, h->eps_M, deltaX, h->d_HTH, h->d_Hz, h->d_Hzc};
     hipLaunchKernelGGL(k_hth_scatter, dim3(hm_cdiv(h->njobs, 4)), dim3(256), 0, h->stream, s);
@@ -498,6 +500,7 @@ static void measure_args(hm_ctx *h, const double *dX, double deltaX, int masked,
     a.esplit = h->esplit;
     a.iZ = 1.0 / h->eps_Z; a.iJ = 1.0 / h->eps_J; a.iM = 1.0 / h->eps_M;
     a.cfgs = h->d_cfgs;
+    a.ubox = h->d_ubox;
 }
 
 static int measure_on_device(hm_ctx *h, const double *X, double deltaX, int masked)

@@ -364,11 +364,13 @@ struct StarVel {
 };
 
 // The setups are the same for every lane (scalar loads when cfg is a read-only kernel argument), and
-// so is the 8x8 tile (tc0, tr0) the wave works on: a triangle whose bounding box misses the tile is
-// skipped by a scalar branch -- about two thirds of the star's triangles at ~48 px edge length -- and
-// costs no vector instruction.  (The box contains every covered pixel, so the result is the same.)
+// so is the 8x8 tile the wave works on: `mask` has a bit for every triangle of the star whose
+// bounding box -- over all five configurations, k_star_regions keeps that union -- meets the tile, one
+// scalar test per triangle and tile.  About two thirds of the star's triangles at ~48 px edge length
+// drop out and cost no vector instruction.  (The box contains every covered pixel, so the result is
+// the same; the triangles are still taken in ascending order.)
 template <bool VEL>
-__device__ __forceinline__ StarVal d_star_eval(const TriSetup *__restrict__ cfg, int ns, int c, int r, int tc0, int tr0,
+__device__ __forceinline__ StarVal d_star_eval(const TriSetup *__restrict__ cfg, unsigned mask, int c, int r,
                                                const Mesh &m, int v, float vxp, float vxm, float nvyp, float nvym,
                                                StarVel &vel, StarTex &q)
 {
@@ -396,10 +398,8 @@ __device__ __forceinline__ StarVal d_star_eval(const TriSetup *__restrict__ cfg,
             vel.fym = vel.fym + d_lerp(v0 ? nvym : b0, v1 ? nvym : b1, v2 ? nvym : b2, l1, l2);
         }
     };
-    for (int k = 0; k < ns; k++) {
-        const TriSetup &t = cfg[k];
-        const int cmin = t.cmin, cmax = t.cmax, rmin = t.rmin, rmax = t.rmax;
-        if ((cmax < tc0) | (cmin > tc0 + 7) | (rmax < tr0) | (rmin > tr0 + 7)) continue;
+    for (unsigned mm = mask; mm != 0; mm &= mm - 1) {
+        const TriSetup &t = cfg[__builtin_ctz(mm)];
         if (d_tri_cover(t, dc, dr)) add(t);
     }
     return s;
@@ -493,6 +493,7 @@ struct MeasureArgs {
     int esplit;               // workgroups per edge job (gridDim.y of k_measure_edge)
     double iZ, iJ, iM;        // 1 / eps_Z, 1 / eps_J, 1 / eps_M
     TriSetup *cfgs;           // N x MEAS_NCFG x (EKF_MAX_STAR + 1): the star setups, written by k_star_regions
+    int4 *ubox;               // N x UBOX_STRIDE: per triangle of the star, its pixel box over all configurations
 };
 
 #define MEAS_NT 256
@@ -521,6 +522,7 @@ enum {
 };
 
 #define MEAS_NCFG 5            // reference, +x, -x, +y, -y of the vertex
+#define UBOX_STRIDE (EKF_MAX_STAR + 4)
 
 __device__ inline void d_vertex_cfgs(TriSetup (*cfg)[EKF_MAX_STAR + 1], int nsv, const int *trv, const Mesh &m,
                                      const double *X, int v, double d, int nthreads)
@@ -550,6 +552,17 @@ __global__ __launch_bounds__(REGION_NT) void k_star_regions(MeasureArgs a, int *
         const int *src = (const int *)s_cfg[wv];
         int *dst = (int *)(a.cfgs + ((size_t)v * MEAS_NCFG + wv) * (EKF_MAX_STAR + 1));
         for (int i = lane; i < used; i += 64) dst[i] = src[i];
+    }
+    if (wv == 0 && lane < UBOX_STRIDE) {   // box of triangle `lane` over all configurations (cmin, cmax, rmin, rmax)
+        int4 u = make_int4(1, 0, 1, 0);
+        if (lane < nsv)
+            for (int cfg = 0; cfg < MEAS_NCFG; cfg++) {
+                const TriSetup &s = s_cfg[cfg][lane];
+                if (s.cmin > s.cmax) continue;
+                if (u.x > u.y) u = make_int4(s.cmin, s.cmax, s.rmin, s.rmax);
+                else u = make_int4(min(u.x, s.cmin), max(u.y, s.cmax), min(u.z, s.rmin), max(u.w, s.rmax));
+            }
+        a.ubox[(size_t)v * UBOX_STRIDE + lane] = u;
     }
     {   // bounding box of this wave's configuration
         int c0 = m.W, c1 = -1, r0 = m.H, r1 = -1;
@@ -604,7 +617,8 @@ __device__ inline void d_region_sums(const int *__restrict__ area, int N, int v,
 // workgroups per vertex; a perturbation of vertex v changes the render only inside the triangles
 // around v (its star), so every sum runs over the bounding box of that star; the perturbed renders
 // are never materialised.  The forward difference images are parked in the pool for pass 2.
-__global__ __launch_bounds__(MEAS_NT, 4) void k_measure_vertex(MeasureArgs a, const TriSetup *__restrict__ cfgs)
+__global__ __launch_bounds__(MEAS_NT, 4) void k_measure_vertex(MeasureArgs a, const TriSetup *__restrict__ cfgs,
+                                                                const int4 *__restrict__ ubox)
 {
     __shared__ double s_red[(MEAS_NT / 64) * MEAS_OUT];
     __shared__ double s_k255[511];
@@ -643,6 +657,11 @@ __global__ __launch_bounds__(MEAS_NT, 4) void k_measure_vertex(MeasureArgs a, co
     for (int tile = blockIdx.y * (MEAS_NT / 64) + wave; tile < ntiles; tile += nwaves) {
         const int tr0 = r0 + 8 * (tile / ntx), tc0 = c0 + 8 * (tile % ntx);
         const int r = tr0 + ly, c = tc0 + lx;
+        unsigned mask = 0;                         // the triangles of the star that can reach this tile
+        for (int k = 0; k < nsv; k++) {
+            const int4 b = ubox[(size_t)v * UBOX_STRIDE + k];
+            if (!((b.y < tc0) | (b.x > tc0 + 7) | (b.w < tr0) | (b.z > tr0 + 7))) mask |= 1u << k;
+        }
         if (r >= r0 + rh || c >= c0 + rw) continue;
         const int i = (r - r0) * rw + (c - c0);
         const int p = r * W + c;
@@ -651,13 +670,13 @@ __global__ __launch_bounds__(MEAS_NT, 4) void k_measure_vertex(MeasureArgs a, co
         const long long pp = base + i;
         StarVel vel, none;
         StarTex q0, q1, q2, q3, q4;
-        StarVal sref = d_star_eval<true>(s_cfg[0], nsv, c, r, tc0, tr0, m, v, (float)(X[2 * N + 2 * v] + d),
+        StarVal sref = d_star_eval<true>(s_cfg[0], mask, c, r, m, v, (float)(X[2 * N + 2 * v] + d),
                                          (float)(X[2 * N + 2 * v] - d), (float)(-(X[2 * N + 2 * v + 1] + d)),
                                          (float)(-(X[2 * N + 2 * v + 1] - d)), vel, q0);
-        StarVal sxp = d_star_eval<false>(s_cfg[1], nsv, c, r, tc0, tr0, m, v, 0, 0, 0, 0, none, q1);
-        StarVal sxm = d_star_eval<false>(s_cfg[2], nsv, c, r, tc0, tr0, m, v, 0, 0, 0, 0, none, q2);
-        StarVal syp = d_star_eval<false>(s_cfg[3], nsv, c, r, tc0, tr0, m, v, 0, 0, 0, 0, none, q3);
-        StarVal sym = d_star_eval<false>(s_cfg[4], nsv, c, r, tc0, tr0, m, v, 0, 0, 0, 0, none, q4);
+        StarVal sxp = d_star_eval<false>(s_cfg[1], mask, c, r, m, v, 0, 0, 0, 0, none, q1);
+        StarVal sxm = d_star_eval<false>(s_cfg[2], mask, c, r, m, v, 0, 0, 0, 0, none, q2);
+        StarVal syp = d_star_eval<false>(s_cfg[3], mask, c, r, m, v, 0, 0, 0, 0, none, q3);
+        StarVal sym = d_star_eval<false>(s_cfg[4], mask, c, r, m, v, 0, 0, 0, 0, none, q4);
         {   // all texels at once
             const int e0 = d_star_texels(m.tex, q0), e1 = d_star_texels(m.tex, q1), e2 = d_star_texels(m.tex, q2);
             const int e3 = d_star_texels(m.tex, q3), e4 = d_star_texels(m.tex, q4);
