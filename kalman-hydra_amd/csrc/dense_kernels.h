@@ -8,14 +8,15 @@
 // (identity padded when n is not a multiple of 32).  A may carry extra rows below row nb*32
 // (nb = ceil(n/32)): right-hand sides stored as ROWS.  The factorisation treats them like any other
 // block row, which turns them into (L^-1 b)^T -- the forward substitution of a solve comes for
-// free; T = L^-1 (k_tinv_*) and x = T^T y (k_tvec) finish it.  32x32x32 block products run on the f64 matrix cores
+// free; T = L^-1 comes out of the same launches (the elimination applied to an identity as well) and
+// x = T^T y (k_tvec) finishes it.  32x32x32 block products run on the f64 matrix cores
 // (v_mfma_f64_16x16x4_f64); launches communicate through memory only, in a fixed order, so results
 // do not depend on workgroup scheduling.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #define DNB 32          // block size
-#define TTT_PF 3        // block products whose operands are in flight (k_ttt, k_tinv_level)
+#define TTT_PF 3        // block products whose operands are in flight (k_ttt)
 
 // 1/d and 1/sqrt(d) from the hardware estimates plus two Newton steps (about 1 ulp).  The
 // factorisation has a column-by-column dependency chain; a correctly rounded divide or square
@@ -176,6 +177,16 @@ __device__ __forceinline__ d4_t d_mfma_nt(double (*X)[DNB + 1], double (*Y)[DNB 
     return c;
 }
 
+// the same for X Y
+__device__ __forceinline__ d4_t d_mfma_nn(double (*X)[DNB + 1], double (*Y)[DNB + 1], int wv, int lane, d4_t c)
+{
+    const int i = 16 * (wv >> 1) + (lane & 15), j = 16 * (wv & 1) + (lane & 15), kq = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < DNB / 4; kk++)
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(X[i][4 * kk + kq], Y[4 * kk + kq][j], c, 0, 0, 0);
+    return c;
+}
+
 // the first diagonal block: the inverse of the factor of A_00 -> Lt[0]
 __global__ __launch_bounds__(64) void k_chol_first(const double *__restrict__ A, double *__restrict__ Lt, int n)
 {
@@ -194,16 +205,70 @@ __global__ __launch_bounds__(64) void k_chol_first(const double *__restrict__ A,
 // the previous launch), A_rc -= X_r X_c^T -- three 32x32x32 products on the matrix cores; column
 // c = k+1 also stores X_r as L_rk; workgroup (k+1, k+1) goes on to factor its updated block into
 // and to invert the factor into Lt[k+1].
+//
+// The inverse of the whole factor comes out of the same launches: the elimination is applied to an
+// identity as well ([A | I] -> [L^T | L^-1], what chol32_tinv_wave does inside a block, here block by
+// block).  M holds the right half while it is worked on, Tinv receives its finished rows:
+//   workgroups (r, j), k < r < nb, j <= k (grid columns mc ..):   M_rj -= X_r (T_k M_kj)
+//   workgroups (j), j <= k (the extra grid row):                   Tinv_kj = T_k M_kj
+// with M_kk = I and M_rj = 0 before its first update (step j), so neither array needs clearing.  These
+// workgroups are as independent as the others and shorter than the diagonal one: the steps get no
+// longer, and the ten launches of a separate inversion are gone.
 __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, double *__restrict__ L, double *__restrict__ Lt,
-                                                   int n, int nrows, int nb, int k)
+                                                   double *__restrict__ Tinv, double *__restrict__ M,
+                                                   int n, int nrows, int nb, int k, int mc)
 {
+    __shared__ double Ts[DNB][DNB + 1];           // T = L_kk^-1
+    __shared__ double Br[DNB][DNB + 1];           // A_rk, then X_r, then the updated block k+1
+    __shared__ double Bc[DNB][DNB + 1];           // A_ck, then X_c (M_kj, then T_k M_kj in the inverse's workgroups)
+    if (blockIdx.y == gridDim.y - 1 || (int)blockIdx.x >= mc) {
+        const bool fin = blockIdx.y == gridDim.y - 1;             // finish row k of the inverse
+        const int j = fin ? (int)blockIdx.x : (int)blockIdx.x - mc;
+        const int r = k + 1 + blockIdx.y;
+        if (j > k || (!fin && r >= nb)) return;
+        const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+        const int d0 = k * DNB, j0 = j * DNB, r0 = r * DNB;
+        const int nd = min(DNB, n - d0), nr = fin ? 0 : min(DNB, n - r0);
+        const int mj = 16 * (wv & 1) + (lane & 15);
+        int mi[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) mi[e] = 16 * (wv >> 1) + (lane >> 4) + 4 * e;
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        if (!fin && j < k) {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (mi[e] < nr) a[e] = M[(size_t)(r0 + mi[e]) * n + j0 + mj];
+        }
+        for (int e = t; e < DNB * DNB; e += 256) {
+            const int i = e / DNB, c = e % DNB;
+            Ts[i][c] = Lt[(size_t)k * DNB * DNB + e];
+            Bc[i][c] = j == k ? (i == c ? 1.0 : 0.0) : (i < nd ? M[(size_t)(d0 + i) * n + j0 + c] : 0.0);
+            if (!fin) Br[i][c] = (i < nr && c < nd) ? A[(size_t)(r0 + i) * n + d0 + c] : 0.0;
+        }
+        __syncthreads();
+        const d4_t z = {0.0, 0.0, 0.0, 0.0};
+        const d4_t u = d_mfma_nn(Ts, Bc, wv, lane, z);            // T_k M_kj
+        if (fin) {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (mi[e] < nd && j0 + mj < n) Tinv[(size_t)(d0 + mi[e]) * n + j0 + mj] = u[e];
+            return;
+        }
+        const d4_t xr = d_mfma_nt(Br, Ts, wv, lane);              // X_r = A_rk T_k^T
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; e++) { Br[mi[e]][mj] = xr[e]; Bc[mi[e]][mj] = u[e]; }
+        __syncthreads();
+        const d4_t s = d_mfma_nn(Br, Bc, wv, lane, z);
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (mi[e] < nr) M[(size_t)(r0 + mi[e]) * n + j0 + mj] = a[e] - s[e];
+        return;
+    }
     const int r = k + 1 + blockIdx.y;
     const int c = k + 1 + blockIdx.x;             // c >= nb: no block to update, the panel row only
     const bool panel_only = c >= nb;
     if (!panel_only && c > r) return;
-    __shared__ double Ts[DNB][DNB + 1];           // T = L_kk^-1; later the factor of block k+1
-    __shared__ double Br[DNB][DNB + 1];           // A_rk, then X_r, then the updated block k+1
-    __shared__ double Bc[DNB][DNB + 1];           // A_ck, then X_c, then the inverse of the new factor
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int d0 = k * DNB;
     const int nd = min(DNB, n - d0);
@@ -255,122 +320,6 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, doubl
     __syncthreads();
     if (wv != 0) return;
     chol32_tinv_wave(Br, Lt + (size_t)(k + 1) * DNB * DNB, lane);
-}
-
-// ---- T = L^-1 by recursive doubling ---------------------------------------------------------------
-// The factorisation leaves the inverses of the 32x32 diagonal blocks (Lt).  With T11 and T22 the
-// inverses of two neighbouring s x s diagonal parts, the block below the diagonal of the 2s x 2s
-// part is T21 = -T22 (L21 T11): two batched products per level, s = 32, 64, ... -- ten launches of
-// MFMA tile products for n = 804 instead of one long substitution per column slab.
-//   phase 0:  M  = L21 T11      (M: scratch, same coordinates as T21)
-//   phase 1:  T21 = -T22 M
-// One workgroup per 32x32 output tile; grid (sb, sb, pairs), sb = s / 32.
-__device__ __forceinline__ d4_t d_mfma_nn(double (*X)[DNB + 1], double (*Y)[DNB + 1], int wv, int lane, d4_t c)
-{
-    const int i = 16 * (wv >> 1) + (lane & 15), j = 16 * (wv & 1) + (lane & 15), kq = lane >> 4;
-#pragma unroll
-    for (int kk = 0; kk < DNB / 4; kk++)
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(X[i][4 * kk + kq], Y[4 * kk + kq][j], c, 0, 0, 0);
-    return c;
-}
-
-// The first level in one launch: workgroup p takes the diagonal blocks 2p and 2p+1 -- copies their
-// inverses from Lt into T and forms the block between them, T21 = -T22 (L21 T11), both products from
-// LDS.  (A last block without a partner is only copied.)
-__global__ __launch_bounds__(256) void k_tinv_first(const double *__restrict__ L, const double *__restrict__ Lt,
-                                                    double *__restrict__ T, int n, int nb)
-{
-    __shared__ double A1[DNB][DNB + 1];           // T11, later M = L21 T11
-    __shared__ double A2[DNB][DNB + 1];           // T22
-    __shared__ double B[DNB][DNB + 1];            // L21
-    const int b0 = 2 * blockIdx.x, b1 = b0 + 1;
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const bool pair = b1 < nb;
-    for (int e = t; e < DNB * DNB; e += 256) {
-        const int r = e / DNB, c = e % DNB;
-        const double t11 = Lt[(size_t)b0 * DNB * DNB + e];
-        A1[r][c] = t11;
-        if (b0 * DNB + r < n && b0 * DNB + c < n) T[(size_t)(b0 * DNB + r) * n + b0 * DNB + c] = t11;
-        if (pair) {
-            const double t22 = Lt[(size_t)b1 * DNB * DNB + e];
-            A2[r][c] = t22;
-            const int gr = b1 * DNB + r, gc = b1 * DNB + c;
-            if (gr < n && gc < n) T[(size_t)gr * n + gc] = t22;
-            B[r][c] = gr < n ? L[(size_t)gr * n + b0 * DNB + c] : 0.0;
-        }
-    }
-    if (!pair) return;
-    __syncthreads();
-    d4_t z = {0.0, 0.0, 0.0, 0.0};
-    const d4_t m = d_mfma_nn(B, A1, wv, lane, z);             // M = L21 T11
-    __syncthreads();                                          // all reads of T11 done
-    const int mj = 16 * (wv & 1) + (lane & 15);
-#pragma unroll
-    for (int e = 0; e < 4; e++) A1[16 * (wv >> 1) + (lane >> 4) + 4 * e][mj] = m[e];
-    __syncthreads();
-    const d4_t r = d_mfma_nn(A2, A1, wv, lane, z);            // T22 M
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-        const int gr = b1 * DNB + 16 * (wv >> 1) + (lane >> 4) + 4 * e, gc = b0 * DNB + mj;
-        if (gr < n) T[(size_t)gr * n + gc] = -r[e];
-    }
-}
-
-template <int PHASE>
-__global__ __launch_bounds__(256) void k_tinv_level(const double *__restrict__ L, double *__restrict__ T,
-                                                    double *__restrict__ M, int n, int nb, int sb)
-{
-    const int b0 = 2 * sb * blockIdx.z, ib = blockIdx.y, jb = blockIdx.x;
-    const int bi = b0 + sb + ib, bj = b0 + jb;    // output tile (block row, block column)
-    if (bi >= nb) return;
-    __shared__ double Xs[2][DNB][DNB + 1];
-    __shared__ double Ys[2][DNB][DNB + 1];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const double *Xm = PHASE == 0 ? L : T;
-    const double *Ym = PHASE == 0 ? T : M;
-    double *Out = PHASE == 0 ? M : T;
-    const int k_lo = PHASE == 0 ? jb : 0;         // T11 is lower triangular: blocks k < jb are zero
-    const int nsteps = (PHASE == 0 ? sb - 1 : ib) - k_lo + 1;     // T22 likewise: k <= ib
-    const int kbase = (PHASE == 0 ? b0 : b0 + sb) + k_lo;         // block index of step 0 along the summed dimension
-    double px[TTT_PF][4], py[TTT_PF][4];
-    auto fetch = [&](int s, double (&a)[4], double (&b)[4]) {
-        const int kb = kbase + s;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int e = t + 256 * q, rr = e / DNB, cc = e % DNB;
-            const int xr = bi * DNB + rr, xc = kb * DNB + cc, yr = kb * DNB + rr, yc = bj * DNB + cc;
-            const bool on = s < nsteps;
-            a[q] = (on && xr < n && xc < n) ? Xm[(size_t)xr * n + xc] : 0.0;
-            b[q] = (on && yr < n && yc < n) ? Ym[(size_t)yr * n + yc] : 0.0;
-        }
-    };
-#pragma unroll
-    for (int p = 0; p < TTT_PF; p++) fetch(p, px[p], py[p]);
-    d4_t acc = {0.0, 0.0, 0.0, 0.0};
-    for (int s0 = 0; s0 < nsteps; s0 += TTT_PF) {
-#pragma unroll
-        for (int p = 0; p < TTT_PF; p++) {
-            const int s = s0 + p;
-            if (s < nsteps) {
-                const int buf = s & 1;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int e = t + 256 * q;
-                    Xs[buf][e / DNB][e % DNB] = px[p][q];
-                    Ys[buf][e / DNB][e % DNB] = py[p][q];
-                }
-                fetch(s + TTT_PF, px[p], py[p]);
-                __syncthreads();
-                acc = d_mfma_nn(Xs[buf], Ys[buf], wv, lane, acc);
-            }
-        }
-    }
-    const int jj = bj * DNB + 16 * (wv & 1) + (lane & 15);
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-        const int ii = bi * DNB + 16 * (wv >> 1) + (lane >> 4) + 4 * e;
-        if (ii < n && jj < n) Out[(size_t)ii * n + jj] = PHASE == 0 ? acc[e] : -acc[e];
-    }
 }
 
 // ---- x = T^T y: the second half of a solve with A = L L^T once T = L^-1 is at hand ---------------

@@ -536,10 +536,12 @@ extern "C" int hm_measure(hm_ctx_t h, const double *X, double deltaX, int masked
 // 32-row block whose first row carries the right-hand side (see dense_kernels.h).
 static int aug_rows(int n) { return hm_cdiv(n, DNB) * DNB + DNB; }
 
-// Cholesky of the n x n matrix in the working copy A (destroyed) into L / Lt; with_rhs: the
-// right-hand-side rows below the matrix go through the elimination too (dense_kernels.h)
+// Cholesky of the n x n matrix in the working copy A (destroyed) into L / Lt, and the inverse of the
+// factor into T (M: n x n scratch) -- both from the same launches; with_rhs: the right-hand-side rows
+// below the matrix go through the elimination too (dense_kernels.h)
 // first_done: Lt[0] is there already (k_assemble)
-static void chol_factor(hm_ctx *h, double *A, double *L, double *Lt, int n, bool with_rhs, bool first_done = false)
+static void chol_factor(hm_ctx *h, double *A, double *L, double *Lt, double *T, double *M, int n, bool with_rhs,
+                        bool first_done = false)
 {
     const int nb = hm_cdiv(n, DNB);
     const int nrows = with_rhs ? aug_rows(n) : n;
@@ -547,29 +549,17 @@ static void chol_factor(hm_ctx *h, double *A, double *L, double *Lt, int n, bool
     if (!first_done) hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(64), 0, h->stream, A, Lt, n);
     for (int k = 0; k < nb; k++) {
         const int mr = nbr - k - 1, mc = std::max(nb - k - 1, 1);
-        if (mr > 0) hipLaunchKernelGGL(k_chol_step, dim3(mc, mr), dim3(256), 0, h->stream, A, L, Lt, n, nrows, nb, k);
+        // grid: mr block rows below the diagonal (update of A in columns < mc, of the inverse in the k+1
+        // columns after them) and one more row that finishes row k of the inverse
+        hipLaunchKernelGGL(k_chol_step, dim3(mc + k + 1, mr + 1), dim3(256), 0, h->stream, A, L, Lt, T, M, n, nrows, nb, k, mc);
     }
 }
 
-// T = L^-1 by recursive doubling from the inverted diagonal blocks Lt (dense_kernels.h); M: scratch
-static void chol_tinv(hm_ctx *h, const double *L, const double *Lt, int n, double *T, double *M)
+// SPD inverse from the inverse T = L^-1 of the factor: inv = T^T T
+static void chol_inverse(hm_ctx *h, int n, const double *T, double *out)
 {
     const int nb = hm_cdiv(n, DNB);
-    hipLaunchKernelGGL(k_tinv_first, dim3(hm_cdiv(nb, 2)), dim3(256), 0, h->stream, L, Lt, T, n, nb);
-    for (int sb = 2; sb < nb; sb *= 2) {
-        const dim3 grid(sb, sb, hm_cdiv(nb, 2 * sb));
-        hipLaunchKernelGGL(k_tinv_level<0>, grid, dim3(256), 0, h->stream, L, T, M, n, nb, sb);
-        hipLaunchKernelGGL(k_tinv_level<1>, grid, dim3(256), 0, h->stream, L, T, M, n, nb, sb);
-    }
-}
-
-// SPD inverse from the factor: T = L^-1, then inv = T^T T.  `scratch` receives T; `out` serves as the
-// scratch of the doubling before it receives the result.
-static void chol_inverse(hm_ctx *h, const double *L, const double *Lt, int n, double *scratch, double *out)
-{
-    chol_tinv(h, L, Lt, n, scratch, out);
-    const int nb = hm_cdiv(n, DNB);
-    hipLaunchKernelGGL(k_ttt, dim3(nb, nb), dim3(256), 0, h->stream, scratch, n, out);
+    hipLaunchKernelGGL(k_ttt, dim3(nb, nb), dim3(256), 0, h->stream, T, n, out);
 }
 
 // one iteration's worth of launches of the update: system assembly, factorisation, solve.
@@ -584,12 +574,11 @@ static double *solve_step(hm_ctx *h, int slot)
     double *rhs_row = A + (size_t)rhs_index * n4;
     hipLaunchKernelGGL(k_assemble, dim3(aug_rows(n4) + 1), dim3(256), 0, h->stream, h->d_invW0, h->d_HTH, h->d_X0, h->d_X,
                        h->d_Hz, A, n4, rhs_index, h->d_Lt[slot]);
-    chol_factor(h, A, h->d_Af[slot], h->d_Lt[slot], n4, true, true);
-    // y = L^-1 b came out of the factorisation as the extra row; x = T^T y with T = L^-1, which stays in
-    // the slot for hm_update_cov (inv = T^T T).  d_Wtmp is scratch between hm_update_begin and the
-    // next hm_cov_predict.
     if (h->d_Wres == h->d_Wtmp) h->d_Wres = nullptr;          // a covariance predicted since hm_update_begin is lost
-    chol_tinv(h, h->d_Af[slot], h->d_Lt[slot], n4, h->d_T[slot], h->d_Wtmp);
+    chol_factor(h, A, h->d_Af[slot], h->d_Lt[slot], h->d_T[slot], h->d_Wtmp, n4, true, true);
+    // y = L^-1 b came out of the factorisation as the extra row and T = L^-1 with it (d_Wtmp was the
+    // scratch: it is free between hm_update_begin and the next hm_cov_predict); x = T^T y.  T stays in the
+    // slot for hm_update_cov (inv = T^T T).
     const double *yrow = h->d_Af[slot] + (rhs_row - A);
     hipLaunchKernelGGL(k_tvec, dim3(hm_cdiv(n4, DNB)), dim3(1024), 0, h->stream, h->d_T[slot], n4, yrow, h->d_step, h->d_X0,
                        h->d_Xn);                              // also d_Xn = X0 + step
@@ -608,8 +597,8 @@ static int prior_inverse(hm_ctx *h, const double *W_prior)
         HM_HIP(hipMemcpyAsync(h->d_Wprior, h->d_Wres, nnb, hipMemcpyDeviceToDevice, h->stream));
     HM_HIP(hipMemcpyAsync(h->d_Awork, h->d_Wprior, nnb, hipMemcpyDeviceToDevice, h->stream));
     h->d_Wres = h->d_Wprior;                     // d_Wtmp is scratch from here on
-    chol_factor(h, h->d_Awork, h->d_Af[0], h->d_Lt[0], n4, false);
-    chol_inverse(h, h->d_Af[0], h->d_Lt[0], n4, h->d_Wtmp, h->d_invW0);
+    chol_factor(h, h->d_Awork, h->d_Af[0], h->d_Lt[0], h->d_Wtmp, h->d_invW0, n4, false);    // T in d_Wtmp
+    chol_inverse(h, n4, h->d_Wtmp, h->d_invW0);
     HM_HIP(hipGetLastError());
     return HM_OK;
 }

@@ -250,7 +250,8 @@ def test_state_errors_are_loud(hm):
 
 # the last case has more than 248 vertices: 4N > 992, i.e. more than two column batches in k_back_row and a
 # block count that is not a power of two for the recursive inverse
-@pytest.mark.parametrize("n,h0", [(64, 11.0), (96, 9.0), (160, 8.0), (256, 8.5)])
+# 4N = 72, 200, 632, 1380 and 160, 108, 308: last block of 8, 8, 24, 4 and 32 (none), 12, 20 rows
+@pytest.mark.parametrize("n,h0", [(64, 11.0), (96, 9.0), (160, 8.0), (256, 8.5), (64, 7.0), (96, 13.0), (128, 9.5)])
 def test_device_dense_update_matches_host_algebra(hm, n, h0):
     """hm_update_begin/_step/_cov (blocked Cholesky on the device) against numpy on the host:
     step = (inv(W) + HTH)^-1 (Hz - HTH (X0 - X)), cov = (inv(W) + HTH)^-1."""
@@ -286,6 +287,32 @@ def test_device_dense_update_matches_host_algebra(hm, n, h0):
     assert np.linalg.norm(step2 - ref2) <= 1e-9 * np.linalg.norm(ref2)
     assert np.linalg.norm(R.update_cov(1) - np.linalg.inv(A)) <= 1e-9 * np.linalg.norm(np.linalg.inv(A))
     assert np.linalg.norm(R.update_cov(0) - np.linalg.inv(A2)) <= 1e-9 * np.linalg.norm(np.linalg.inv(A2))
+
+
+def test_device_dense_update_single_block(hm):
+    """4N = 16: the whole system is one (partial) 32x32 block."""
+    from hydra_mi import mesh, renderer
+    n = 64
+    dm = mesh.square4_mesh(14, 44)
+    tex = (np.arange(n * n).reshape(n, n) * 7 % 251).astype(np.uint8)
+    R = renderer.Renderer(dm, np.zeros((4, 2)), np.zeros((n, n, 2), np.float32), n, tex, True, 1e-3, 1.0, 1.0)
+    meas = ekf_ref.Measurement(4, dm.t, dm.p, tex, 1e-3, 1.0, 1.0)
+    rng = np.random.default_rng(2)
+    X = _state(dm, rng, pos_sigma=0.4)
+    X0 = X + rng.normal(0, 0.3, X.size)
+    y_im, flow, y_m = _observation(dm, meas, rng, n)
+    M = rng.normal(size=(16, 16))
+    W = np.eye(16) * 0.5 + 0.05 * (M @ M.T) / 16
+    st = _Flow()
+    st.X = X.reshape(-1, 1)
+    Hz, HTH, Hzc = R.measure(st, y_im, flow, y_m)
+    R.update_begin(W, X0)
+    step, _, _ = R.update_step(st, y_im, flow, y_m)
+    A = np.linalg.inv(W) + HTH
+    ref = np.linalg.solve(A, Hz - HTH @ (X0 - X).reshape(-1, 1))
+    assert np.linalg.norm(step - ref) <= 1e-9 * np.linalg.norm(ref)
+    assert np.linalg.norm(R.update_cov(0) - np.linalg.inv(A)) <= 1e-9 * np.linalg.norm(np.linalg.inv(A))
+    assert np.linalg.norm(R.update_cov(-1) - W) <= 1e-9 * np.linalg.norm(W)
 
 
 def test_plain_kalman_filter_update_on_device(hm):
