@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstring>
 #include <set>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -62,6 +63,10 @@ struct hm_ctx {
     int red_blocks;
     long long run_ticket;            // sequence number of hm_update_run's per-iteration result blocks
     int vsplit, esplit;              // workgroups per vertex / per edge job of the measurement (hm_ctx_tune)
+    std::thread worker;              // hm_update_prefactor queues its launches from here while the caller predicts the state
+    bool worker_active;
+    int worker_rc;
+    char worker_err[512];
     int2 *d_outline;                 // hm_project_mask: outline pixels (W*H), counters, uploaded mask; allocated on first use
     int *d_outline_cnt;
     uint8_t *d_pm_mask;
@@ -83,9 +88,28 @@ static void free_targets(Targets &t)
     if (t.cnt) (void)hipFree(t.cnt);
 }
 
+// Every entry point waits for the launches hm_update_prefactor is still queueing (one handle = one
+// stream = one thread at a time, as far as the device can tell) and reports their failure, if any.
+static int ctx_join(hm_ctx *h)
+{
+    if (!h || !h->worker_active) return HM_OK;
+    h->worker.join();
+    h->worker_active = false;
+    if (h->worker_rc != HM_OK) {
+        const int rc = h->worker_rc;
+        h->worker_rc = HM_OK;
+        h->prefactored = false;
+        hm_set_error("%s", h->worker_err);
+        return rc;
+    }
+    return HM_OK;
+}
+#define HM_JOIN(h) do { int _j = ctx_join(h); if (_j) return _j; } while (0)
+
 static int ctx_free(hm_ctx *h)
 {
     if (!h) return HM_OK;
+    (void)ctx_join(h);
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_tri, h->d_star_off, h->d_star_tri, h->d_edges, h->d_uv, h->d_tex, h->d_yim, h->d_ym, h->d_yfx,
                     h->d_yfy, h->d_yfxm, h->d_yfym, h->d_setup, h->d_cfgs, h->d_ubox, h->d_X, h->d_out, h->d_partial, h->d_im8, h->d_m8,
@@ -158,6 +182,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->d_Wprior = h->d_gain = h->d_Awork = h->d_Lt[0] = h->d_Lt[1] = nullptr; h->d_Wres = nullptr; h->pin = nullptr; h->pin_n = 0;
     h->tri.assign(tri, tri + (size_t)3 * T);
     h->d_outline = nullptr; h->d_outline_cnt = nullptr; h->d_pm_mask = nullptr;
+    h->worker_active = false; h->worker_rc = HM_OK; h->worker_err[0] = 0;
     h->d_T[0] = h->d_T[1] = h->d_step = nullptr; h->d_X0 = h->d_Xn = nullptr;
     memset(&h->pool, 0, sizeof h->pool); h->d_area = nullptr;
     h->d_sp_off = h->d_sp_bar = h->d_sp_other = nullptr; h->d_sp_blk = nullptr; h->sp_cap = 0;
@@ -256,6 +281,7 @@ extern "C" int hm_ctx_destroy(hm_ctx_t h) { return ctx_free(h); }
 extern "C" int hm_ctx_tune(hm_ctx_t h, const char *key, int value)
 {
     HM_ARG(h != nullptr && key != nullptr, "hm_ctx_tune: NULL argument");
+    HM_JOIN(h);
     if (!strcmp(key, "measure_split")) {
         HM_ARG(value >= 1 && value <= MEAS_VSPLIT_MAX, "hm_ctx_tune: measure_split must be in 1..%d", MEAS_VSPLIT_MAX);
         h->vsplit = value;
@@ -268,10 +294,15 @@ extern "C" int hm_ctx_tune(hm_ctx_t h, const char *key, int value)
     }
     return HM_OK;
 }
-extern "C" void *hm_ctx_stream(hm_ctx_t h) { return h ? (void *)h->stream : nullptr; }
+extern "C" void *hm_ctx_stream(hm_ctx_t h)
+{
+    (void)ctx_join(h);
+    return h ? (void *)h->stream : nullptr;
+}
 extern "C" int hm_ctx_sync(hm_ctx_t h)
 {
     HM_ARG(h != nullptr, "hm_ctx_sync: NULL handle");
+    HM_JOIN(h);
     HM_HIP(hipSetDevice(h->device));
     HM_HIP(hipStreamSynchronize(h->stream));
     return HM_OK;
@@ -280,6 +311,7 @@ extern "C" int hm_ctx_sync(hm_ctx_t h)
 extern "C" int hm_set_texture(hm_ctx_t h, const uint8_t *tex)
 {
     HM_ARG(h && tex, "hm_set_texture: NULL argument");
+    HM_JOIN(h);
     HM_HIP(hipSetDevice(h->device));
     HM_HIP(hipMemcpyAsync(h->d_tex, tex, (size_t)h->W * h->H, hipMemcpyHostToDevice, h->stream));
     HM_HIP(hipStreamSynchronize(h->stream));
@@ -301,6 +333,7 @@ extern "C" int hm_set_observation(hm_ctx_t h, const uint8_t *y_im, const float *
                                   const uint8_t *y_m)
 {
     HM_ARG(h && y_im && y_fx && y_fy && y_m, "hm_set_observation: NULL argument");
+    HM_JOIN(h);
     HM_HIP(hipSetDevice(h->device));
     const size_t n = (size_t)h->W * h->H;
     HM_HIP(hipMemcpyAsync(h->d_yim, y_im, n, hipMemcpyHostToDevice, h->stream));
@@ -318,6 +351,7 @@ extern "C" int hm_set_observation_dev(hm_ctx_t h, const uint8_t *d_y_im, const f
                                       const uint8_t *d_y_m)
 {
     HM_ARG(h && d_y_im && d_y_fx && d_y_fy && d_y_m, "hm_set_observation_dev: NULL argument");
+    HM_JOIN(h);
     HM_HIP(hipSetDevice(h->device));
     h->o_yim = d_y_im; h->o_ym = d_y_m; h->o_yfx = d_y_fx; h->o_yfy = d_y_fy;
     return finish_observation(h);
@@ -351,6 +385,7 @@ static int render_into(hm_ctx *h, const double *X, Targets t)
 extern "C" int hm_render(hm_ctx_t h, const double *X, uint8_t *im, float *fx, float *fy, uint8_t *mk)
 {
     HM_ARG(h && X, "hm_render: NULL argument");
+    HM_JOIN(h);
     NEED_TEX(h, "hm_render");
     HM_HIP(hipSetDevice(h->device));
     int rc = render_into(h, X, h->P);
@@ -374,6 +409,7 @@ static Obs obs_of(hm_ctx *h, int masked)
 extern "C" int hm_initjacobian(hm_ctx_t h, const double *X, int masked)
 {
     HM_ARG(h && X, "hm_initjacobian: NULL argument");
+    HM_JOIN(h);
     (void)masked;
     NEED_TEX(h, "hm_initjacobian");
     NEED_OBS(h, "hm_initjacobian");
@@ -401,6 +437,7 @@ static int collect4(hm_ctx *h, double s[4])
 extern "C" int hm_jz(hm_ctx_t h, const double *Xp, int masked, double *jz, double jzc[4])
 {
     HM_ARG(h && Xp, "hm_jz: NULL argument");
+    HM_JOIN(h);
     NEED_REF(h, "hm_jz");
     HM_HIP(hipSetDevice(h->device));
     int rc = render_into(h, Xp, h->P);
@@ -419,6 +456,7 @@ extern "C" int hm_jz(hm_ctx_t h, const double *Xp, int masked, double *jz, doubl
 extern "C" int hm_j(hm_ctx_t h, const double *X, double deltaX, int i, int j, double *out)
 {
     HM_ARG(h && X && out, "hm_j: NULL argument");
+    HM_JOIN(h);
     HM_ARG(i >= 0 && i < 4 * h->N && j >= 0 && j < 4 * h->N, "hm_j: state index outside 0..%d", 4 * h->N - 1);
     NEED_REF(h, "hm_j");
     HM_HIP(hipSetDevice(h->device));
@@ -442,6 +480,7 @@ extern "C" int hm_j(hm_ctx_t h, const double *X, double deltaX, int i, int j, do
 extern "C" int hm_error(hm_ctx_t h, const double *X, int masked, double err[4], float *fx, float *fy)
 {
     HM_ARG(h && X && err, "hm_error: NULL argument");
+    HM_JOIN(h);
     NEED_TEX(h, "hm_error");
     NEED_OBS(h, "hm_error");
     HM_HIP(hipSetDevice(h->device));
@@ -514,6 +553,7 @@ static int measure_on_device(hm_ctx *h, const double *X, double deltaX, int mask
 extern "C" int hm_measure(hm_ctx_t h, const double *X, double deltaX, int masked, double *Hz, double *Hzc, double *HTH)
 {
     HM_ARG(h && X && Hz && HTH, "hm_measure: NULL argument");
+    HM_JOIN(h);
     HM_ARG(deltaX > 0, "hm_measure: deltaX must be positive");
     NEED_TEX(h, "hm_measure");
     NEED_OBS(h, "hm_measure");
@@ -610,20 +650,32 @@ static int prior_inverse(hm_ctx *h, const double *W_prior)
 extern "C" int hm_update_prefactor(hm_ctx_t h)
 {
     HM_ARG(h != nullptr, "hm_update_prefactor: NULL handle");
+    HM_JOIN(h);
     if (!h->d_Wres) { hm_set_error("hm_update_prefactor: no covariance resident on the device"); return HM_ERR_STATE; }
     HM_HIP(hipSetDevice(h->device));
     // (launched one by one: replaying this series as a hipGraph saved 0.08 ms of host time per frame, but
     // graph replays proved unreliable next to allocations by the caller -- see hm_brox_tune "graph")
-    int rc = prior_inverse(h, nullptr);
-    if (rc) return rc;
-    h->prefactored = true;
-    h->upd_open = false;                          // the factor slots are being reused
+    // Queueing the ~30 launches takes the host about as long as the state prediction the caller does
+    // next (hm_ms_newton): a helper thread does it, and whatever is called next on this handle joins it.
+    h->worker_active = true;
+    h->worker = std::thread([h]() {
+        int rc = hipSetDevice(h->device) == hipSuccess ? HM_OK : HM_ERR_HIP;
+        if (rc == HM_OK) rc = prior_inverse(h, nullptr);
+        if (rc == HM_OK) {
+            h->prefactored = true;
+            h->upd_open = false;                  // the factor slots are being reused
+        } else {
+            snprintf(h->worker_err, sizeof h->worker_err, "hm_update_prefactor: %s", hm_last_error());
+        }
+        h->worker_rc = rc;
+    });
     return HM_OK;
 }
 
 extern "C" int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *X0)
 {
     HM_ARG(h && X0, "hm_update_begin: NULL argument");
+    HM_JOIN(h);
     if (!W_prior && !h->d_Wres) {
         hm_set_error("hm_update_begin: no prior given and none resident on the device");
         return HM_ERR_STATE;
@@ -646,6 +698,7 @@ extern "C" int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int ma
                               double err[4])
 {
     HM_ARG(h && X && step, "hm_update_step: NULL argument");
+    HM_JOIN(h);
     HM_ARG(deltaX > 0, "hm_update_step: deltaX must be positive");
     if (!h->upd_open) { hm_set_error("hm_update_step: hm_update_begin has not been called"); return HM_ERR_STATE; }
     NEED_TEX(h, "hm_update_step");
@@ -681,6 +734,7 @@ extern "C" int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int ma
 extern "C" int hm_update_cov(hm_ctx_t h, int which, double *W_out)
 {
     HM_ARG(h != nullptr, "hm_update_cov: NULL handle");
+    HM_JOIN(h);
     HM_ARG(which >= -1 && which <= 1, "hm_update_cov: which must be 0 (last step), 1 (the step before) or -1 (the prior)");
     if (!h->upd_open) { hm_set_error("hm_update_cov: hm_update_begin has not been called"); return HM_ERR_STATE; }
     HM_HIP(hipSetDevice(h->device));
@@ -711,6 +765,7 @@ extern "C" int hm_update_cov(hm_ctx_t h, int which, double *W_out)
 extern "C" int hm_project_mask(hm_ctx_t h, const uint8_t *y_m, double *X, int *moved)
 {
     HM_ARG(h && X, "hm_project_mask: NULL argument");
+    HM_JOIN(h);
     if (!y_m) { NEED_OBS(h, "hm_project_mask"); }
     HM_HIP(hipSetDevice(h->device));
     const size_t n = (size_t)h->W * h->H;
@@ -746,6 +801,7 @@ extern "C" int hm_project_mask(hm_ctx_t h, const uint8_t *y_m, double *X, int *m
 extern "C" int hm_cov_fetch(hm_ctx_t h, double *W_out)
 {
     HM_ARG(h && W_out, "hm_cov_fetch: NULL argument");
+    HM_JOIN(h);
     if (!h->d_Wres) { hm_set_error("hm_cov_fetch: no covariance resident on the device"); return HM_ERR_STATE; }
     HM_HIP(hipSetDevice(h->device));
     const size_t n4 = (size_t)4 * h->N;
@@ -763,6 +819,7 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
                              double reltol, int info[4], double *errs, double *Hzc, double *gains, double *W_out)
 {
     HM_ARG(h && X && info, "hm_update_run: NULL argument");
+    HM_JOIN(h);
     HM_ARG(deltaX > 0 && max_iter >= 0, "hm_update_run: deltaX must be positive, max_iter >= 0");
     NEED_TEX(h, "hm_update_run");
     NEED_OBS(h, "hm_update_run");
@@ -890,6 +947,7 @@ extern "C" int hm_cov_predict(hm_ctx_t h, const double *W_in, int n_bars, const 
                               double a, double s, double eps_F, double *W_out)
 {
     HM_ARG(h && n_bars >= 0 && (n_bars == 0 || (bars && blocks)), "hm_cov_predict: bad argument");
+    HM_JOIN(h);
     if (!W_in && !h->d_Wres) {
         hm_set_error("hm_cov_predict: no covariance given and none resident on the device");
         return HM_ERR_STATE;
