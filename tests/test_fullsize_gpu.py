@@ -1,0 +1,120 @@
+"""Parity at BASELINE.json's full sizes (1024^2 frames, ~200-vertex mesh): the flow against the C
+oracle (it finishes a 1024^2 pair in seconds), the EKF through properties that do not need the
+oracle's one-render-per-perturbation loops at that size -- the fused measurement against the
+product's own fine-grained operators (a full-frame render per perturbation, a different code
+path), symmetry and sparsity of HTH, and the information-form identity of the update."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+N_FULL = 1024
+
+
+def test_brox_full_size_pair_matches_oracle(hm, oracle_brox):
+    from hydra_mi import brox, synth
+    f0, f1, tu, tv = synth.warp_pair(N_FULL, "translate_leftup_stretch", 3)          # a BASELINE config 5 pair
+    bf = brox.BroxOpticalFlow(N_FULL, N_FULL, max_batch=2)
+    assert bf.levels() == oracle_brox.levels(N_FULL, N_FULL)
+    u, v = bf.calc(f0, f1)
+    ru, rv = oracle_brox.calc(f0, f1)
+    assert np.sqrt((u - ru) ** 2 + (v - rv) ** 2).max() <= 1e-4                        # the contract
+    assert np.array_equal(u, ru) and np.array_equal(v, rv)                            # what is achieved
+    b = N_FULL // 8
+    assert np.sqrt((u - tu) ** 2 + (v - tv) ** 2)[b:-b, b:-b].mean() < 0.25            # and it is the flow
+    # a series of pairs gives each pair the numbers it gets alone
+    g0, g1, _, _ = synth.warp_pair(N_FULL, "rotate", 4)
+    ub, vb = bf.calc_batch(np.stack((f0, g0)), np.stack((f1, g1)))
+    assert np.array_equal(ub[0], u) and np.array_equal(vb[0], v)
+    u2, v2 = bf.calc(g0, g1)
+    assert np.array_equal(ub[1], u2) and np.array_equal(vb[1], v2)
+
+
+def _scene():
+    from hydra_mi import mesh, renderer, synth
+    n = N_FULL
+    video, masks, c, r = synth.disk_video(n, 2, "translate_leftup", 0)
+    dm = mesh.disk_mesh(c[0], c[1], r - 1.0, 0.047 * n)                                # the bench's mesh: 201 vertices
+    N = dm.size()
+    R = renderer.Renderer(dm, np.zeros((N, 2)), np.zeros((n, n, 2), np.float32), n, video[0], True, 1e-3, 1.0, 1.0)
+    rng = np.random.default_rng(1)
+    flow = np.zeros((n, n, 2), np.float32) - 2.5 + rng.normal(0, 0.05, (n, n, 2)).astype(np.float32)
+    X = np.concatenate((dm.p.reshape(-1) + rng.normal(0, 0.4, 2 * N), rng.normal(-2.5, 0.3, 2 * N)))
+    return dm, N, R, video[1], flow, masks[1], X
+
+
+class _S:
+    pass
+
+
+def test_measure_full_size_against_fine_grained_operators(hm):
+    dm, N, R, y_im, flow, y_m, X = _scene()
+    assert 180 <= N <= 220
+    st = _S()
+    st.X = X.reshape(-1, 1)
+    R.update_frame(y_im, flow, y_m)
+    Hz, HTH, Hzc = R.measure(st, y_im, flow, y_m)
+    n4 = 4 * N
+    assert np.array_equal(HTH, HTH.T) and np.all(np.diag(HTH) >= 0)
+    # sparsity: non-adjacent vertices have disjoint supports (kalman.py:202-205)
+    adj = np.eye(N, dtype=bool)
+    for a, b, c in dm.t:
+        adj[a, b] = adj[b, a] = adj[a, c] = adj[c, a] = adj[b, c] = adj[c, b] = True
+    J = np.kron(np.ones((2, 2), bool), np.kron(adj, np.ones((2, 2), bool)))
+    assert not HTH[~J].any() and np.abs(HTH[J]).max() > 0
+    assert np.allclose(Hzc.sum(axis=1), Hz[:, 0], rtol=1e-12, atol=1e-9 * np.abs(Hz).max())
+    # the fused star kernel against one full-frame render per perturbation (hm_jz / hm_j)
+    R.update_vertex_buffer(X[:2 * N].reshape(-1, 2), X[2 * N:].reshape(-1, 2))
+    R.initjacobian(y_im, flow, y_m)
+    rng = np.random.default_rng(5)
+    for p in rng.choice(n4, 6, replace=False):
+        s = _S()
+        Xp, Xm = X.copy(), X.copy()
+        Xp[p] += 2.0
+        Xm[p] -= 2.0
+        s.X = Xp.reshape(-1, 1)
+        jp, _ = R.jz(s)
+        s.X = Xm.reshape(-1, 1)
+        jm, _ = R.jz(s)
+        ref = (jp - jm) / 4.0
+        assert abs(Hz[p, 0] - ref) <= 1e-9 * max(1.0, abs(ref), np.abs(Hz).max() * 1e-3), p
+    st.X = X.reshape(-1, 1)
+    v, w = int(dm.t[7][0]), int(dm.t[7][1])                                           # an adjacent pair
+    far = int(np.flatnonzero(~adj[v])[0])
+    for (i, j) in [(2 * v, 2 * v), (2 * v, 2 * v + 1), (2 * v, 2 * w + 1), (2 * v + 1, 2 * N + 2 * w),
+                   (2 * N + 2 * v, 2 * N + 2 * v), (2 * v, 2 * far)]:
+        ref = R.j(st, 2.0, i, j) / 2.0 / 2.0                                          # kalman.py:598
+        assert abs(HTH[i, j] - ref) <= 1e-9 * max(1.0, abs(ref)), (i, j)
+
+
+def test_update_full_size_information_identity(hm):
+    """One iteration of the update from X0: W1 = inv(inv(W0) + HTH(X0)), X1 = X0 + W1 Hz(X0)
+    (kalman.py:785-799 with X = X0)."""
+    dm, N, R, y_im, flow, y_m, X0 = _scene()
+    n4 = 4 * N
+    rng = np.random.default_rng(9)
+    M = rng.normal(size=(n4, n4))
+    W0 = np.eye(n4) * 0.5 + 0.05 * (M @ M.T) / n4
+    st = _S()
+    st.X = X0.reshape(-1, 1)
+    R.update_frame(y_im, flow, y_m)
+    Hz, HTH, Hzc = R.measure(st, y_im, flow, y_m)
+    X1, info, errs, Hzc1, gains, tok = R.update_run(W0, X0, y_im, flow, y_m, 1, 1e-4)
+    assert info["niter"] == 1 and errs.shape == (1, 4) and np.array_equal(Hzc1, Hzc)
+    W1 = tok.fetch()
+    assert np.abs(W1 - W1.T).max() <= 1e-12 * np.abs(W1).max()
+    A = np.linalg.inv(W0) + HTH
+    assert np.linalg.norm(W1 @ A - np.eye(n4)) <= 1e-8
+    if not info["reverted"]:
+        step = np.linalg.solve(A, Hz)
+        assert np.linalg.norm(X1.reshape(-1, 1) - X0.reshape(-1, 1) - step) <= 1e-9 * np.linalg.norm(step)
+        e = R.error(_state_of(X1), y_im, flow, y_m)
+        assert e[0] == int(errs[0][0]) and e[3] == int(errs[0][3]) and abs(e[1] - errs[0][1]) <= 1e-12 * e[1]
+    # gains (kalman.py:828-830)
+    assert np.allclose(gains[0], W1 @ Hzc[:, 0], rtol=1e-9, atol=1e-12)
+    assert np.allclose(gains[1], W1 @ (Hzc[:, 1] + Hzc[:, 2]), rtol=1e-9, atol=1e-12)
+
+
+def _state_of(X):
+    s = _S()
+    s.X = np.asarray(X).reshape(-1, 1)
+    return s
