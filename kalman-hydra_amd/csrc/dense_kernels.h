@@ -18,16 +18,9 @@
 #define DNB 32          // block size
 #define TTT_PF 3        // block products whose operands are in flight (k_ttt)
 
-// 1/d and 1/sqrt(d) from the hardware estimates plus two Newton steps (about 1 ulp).  The
-// factorisation has a column-by-column dependency chain; a correctly rounded divide or square
-// root (a few hundred cycles each in f64) would sit on it 32 times per block.
-__device__ __forceinline__ double d_rcp(double d)
-{
-    double r = __builtin_amdgcn_rcp(d);
-    r = fma(fma(-d, r, 1.0), r, r);
-    r = fma(fma(-d, r, 1.0), r, r);
-    return r;
-}
+// 1/sqrt(d) from the hardware estimate plus two Newton steps (about 1 ulp).  The factorisation has a
+// column-by-column dependency chain; a correctly rounded square root and divide (a few hundred
+// cycles each in f64) would sit on it 32 times per block.
 __device__ __forceinline__ double d_rsqrt(double d)
 {
     double r = __builtin_amdgcn_rsq(d);
