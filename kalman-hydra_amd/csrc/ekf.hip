@@ -106,6 +106,19 @@ static int ctx_join(hm_ctx *h)
 }
 #define HM_JOIN(h) do { int _j = ctx_join(h); if (_j) return _j; } while (0)
 
+// Wait for the stream: poll it for a while (a few microseconds of latency) before falling back on
+// hipStreamSynchronize, whose wake-up costs ~20 us -- three of those per frame on the compute() path.
+static hipError_t stream_wait(hipStream_t s)
+{
+    const auto t_give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+    for (int spin = 0;; spin++) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        __builtin_ia32_pause();
+        if ((spin & 255) == 255 && std::chrono::steady_clock::now() > t_give_up) return hipStreamSynchronize(s);
+    }
+}
+
 static int ctx_free(hm_ctx *h)
 {
     if (!h) return HM_OK;
@@ -427,7 +440,7 @@ static int collect4(hm_ctx *h, double s[4])
 {
     HM_HIP(hipMemcpyAsync(h->h_partial.data(), h->d_partial, (size_t)h->red_blocks * 4 * sizeof(double),
                           hipMemcpyDeviceToHost, h->stream));
-    HM_HIP(hipStreamSynchronize(h->stream));
+    HM_HIP(stream_wait(h->stream));
     for (int k = 0; k < 4; k++) s[k] = 0.0;
     for (int b = 0; b < h->red_blocks; b++)
         for (int k = 0; k < 4; k++) s[k] += h->h_partial[(size_t)4 * b + k];
@@ -753,7 +766,7 @@ extern "C" int hm_update_cov(hm_ctx_t h, int which, double *W_out)
     }
     if (W_out) {
         HM_HIP(hipMemcpyAsync(W_out, h->d_Wres, (size_t)n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HM_HIP(hipStreamSynchronize(h->stream));
+        HM_HIP(stream_wait(h->stream));
     }
     return HM_OK;
 }
@@ -791,7 +804,7 @@ extern "C" int hm_project_mask(hm_ctx_t h, const uint8_t *y_m, double *X, int *m
     int cnt[4] = {0, 0, 0, 0};
     HM_HIP(hipMemcpyAsync(cnt, h->d_outline_cnt, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
     HM_HIP(hipMemcpyAsync(X, h->d_X, xb, hipMemcpyDeviceToHost, h->stream));
-    HM_HIP(hipStreamSynchronize(h->stream));
+    HM_HIP(stream_wait(h->stream));
     if (moved) *moved = cnt[2];
     return HM_OK;
 }
@@ -923,7 +936,7 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
     }
     if (W_out) HM_HIP(hipMemcpyAsync(W_out, h->d_Wres, (size_t)n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HM_HIP(hipGetLastError());
-    HM_HIP(hipStreamSynchronize(h->stream));
+    HM_HIP(stream_wait(h->stream));
     if (niter > 0) {
         if (Hzc) memcpy(Hzc, pin_hzc, (size_t)n4 * 4 * sizeof(double));
         if (gains) memcpy(gains, pin_gain, (size_t)n4 * 3 * sizeof(double));
@@ -956,7 +969,7 @@ extern "C" int hm_cov_predict(hm_ctx_t h, const double *W_in, int n_bars, const 
     const int N = h->N, n4 = 4 * N;
     const size_t nn = (size_t)n4 * n4 * sizeof(double);
     std::vector<int> &off = h->sp_h_off, &bar = h->sp_h_bar, &other = h->sp_h_other;   // live until the copies ran
-    HM_HIP(hipStreamSynchronize(h->stream));      // ... of the previous call
+    HM_HIP(stream_wait(h->stream));      // ... of the previous call
     off.assign(N + 1, 0);
     for (int i = 0; i < n_bars; i++) {
         HM_ARG(bars[2 * i] >= 0 && bars[2 * i] < N && bars[2 * i + 1] >= 0 && bars[2 * i + 1] < N,
@@ -1006,7 +1019,7 @@ extern "C" int hm_cov_predict(hm_ctx_t h, const double *W_in, int n_bars, const 
     hipLaunchKernelGGL(k_pft_cols, dim3(hm_cdiv(n4, 256), N), dim3(256), 0, h->stream, P, h->d_Wtmp, N, tp, a, s, eps_F);
     HM_HIP(hipGetLastError());
     if (W_out) HM_HIP(hipMemcpyAsync(W_out, h->d_Wtmp, nn, hipMemcpyDeviceToHost, h->stream));
-    if (W_out) HM_HIP(hipStreamSynchronize(h->stream));
+    if (W_out) HM_HIP(stream_wait(h->stream));
     h->d_Wres = h->d_Wtmp;
     h->prefactored = false;
     return HM_OK;
