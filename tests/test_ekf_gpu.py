@@ -418,6 +418,29 @@ def test_fused_update_equals_stepwise_loop(hm, stress):
         assert np.allclose(a.mv, b.mv, rtol=1e-9, atol=1e-12)
 
 
+def test_update_with_indefinite_covariance_fails_loudly_and_recovers(hm):
+    """A prior that is not positive definite (or not finite) has no Cholesky factor: the update reports
+    it (HM_ERR_NUMERIC -> FloatingPointError) instead of returning numbers, and the handle stays usable."""
+    n = 64
+    dm, N, tex, R, meas = _setup(hm, n)
+    rng = np.random.default_rng(8)
+    X = _state(dm, rng, pos_sigma=0.3)
+    y_im, flow, y_m = _observation(dm, meas, rng, n)
+    n4 = 4 * N
+    R.update_frame(y_im, flow, y_m)
+    good = np.eye(n4) * 0.5
+    bad = good.copy()
+    bad[5, 5] = -1.0
+    with pytest.raises(FloatingPointError):
+        R.update_run(bad, X, y_im, flow, y_m, 3, 1e-4)
+    nan = good.copy()
+    nan[n4 - 1, n4 - 1] = np.nan
+    with pytest.raises(FloatingPointError):
+        R.update_run(nan, X, y_im, flow, y_m, 3, 1e-4)
+    Xk, info, errs, Hzc, gains, tok = R.update_run(good, X, y_im, flow, y_m, 3, 1e-4)
+    assert info["niter"] >= 1 and np.all(np.isfinite(Xk)) and np.all(np.isfinite(tok.fetch()))
+
+
 def test_update_run_without_iterations_keeps_the_prior(hm):
     dm, N, tex, R, meas = _setup(hm, 64, 9.0, seed=5)
     rng = np.random.default_rng(2)
