@@ -604,7 +604,7 @@ static void chol_factor(hm_ctx *h, double *A, double *L, double *Lt, double *T, 
         const int mr = nbr - k - 1, mc = std::max(nb - k - 1, 1);
         // grid: mr block rows below the diagonal (update of A in columns < mc, of the inverse in the k+1
         // columns after them) and one more row that finishes row k of the inverse
-        hipLaunchKernelGGL(k_chol_step, dim3(mc + k + 1, mr + 1), dim3(256), 0, h->stream, A, L, Lt, T, M, n, nrows, nb, k, mc);
+        hipLaunchKernelGGL(k_chol_step, dim3((mc + k + 1) * (mr + 1)), dim3(256), 0, h->stream, A, L, Lt, T, M, n, nrows, nb, k, mc, mc + k + 1, mr + 1);
     }
 }
 
