@@ -21,6 +21,7 @@ def tick(name, t0):
     t1 = time.perf_counter(); T[name] = T.get(name, 0.0) + (t1 - t0); return t1
 R = kf.state.renderer
 iters = 0
+nits = 0
 for k in range(nf):
     obs = DeviceObservation(dv[k + 1].data_ptr(), U[k].data_ptr(), V[k].data_ptr(), dmk[k + 1].data_ptr(), y_m_host=masks[k + 1])
     if k == 2:
@@ -35,8 +36,9 @@ for k in range(nf):
     kf.update(obs, obs.masked, obs); t = tick("update", t)
     e = kf.error(obs, obs.raw, obs); t = tick("error", t)
     iters += kf.niter
+    nits = nits + kf.newton_iterations if k >= 2 else 0
 tot = time.perf_counter() - tstart
 m = nf - 2
-print("frames", m, "ms/frame", 1e3 * tot / m, "iters/frame", iters / m)
+print("newton iterations/frame", nits / m); print("frames", m, "ms/frame", 1e3 * tot / m, "iters/frame", iters / m)
 for k_, v in T.items():
     print("%-14s %8.3f ms/frame" % (k_, 1e3 * v / m))
