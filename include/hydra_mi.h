@@ -36,6 +36,15 @@ const char *hm_version(void);
 /* number of visible HIP devices, or a negative error code */
 int hm_device_count(void);
 
+/* Device buffers for callers that keep frames / flow planes resident in HBM between calls (the
+ * *_dev entry points below; the in-process flow -> EKF pipeline).  Counterpart of the reference's
+ * cv::cuda::GpuMat uploads (src/optical_flow_ext.cpp:296-299) and gpuarray.to_gpu
+ * (cuda_multi.py:760-790).  upload / download are synchronous. */
+int hm_dev_alloc(int device, uint64_t bytes, void **out);
+int hm_dev_free(int device, void *ptr);
+int hm_dev_upload(int device, void *dst, const void *src, uint64_t bytes);
+int hm_dev_download(int device, void *dst, const void *src, uint64_t bytes);
+
 /* ------------------------------------------------------------------------
  * Brox optical flow.  Replaces cv::cuda::BroxOpticalFlow as used by
  * processflow_gpu (src/optical_flow_ext.cpp:294-331).

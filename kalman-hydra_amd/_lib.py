@@ -24,6 +24,10 @@ SIGNATURES = {
     "hm_last_error": (ctypes.c_char_p, []),
     "hm_version": (ctypes.c_char_p, []),
     "hm_device_count": (ctypes.c_int, []),
+    "hm_dev_alloc": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(c_vp)]),
+    "hm_dev_free": (ctypes.c_int, [ctypes.c_int, c_vp]),
+    "hm_dev_upload": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, ctypes.c_uint64]),
+    "hm_dev_download": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, ctypes.c_uint64]),
     "hm_brox_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                       ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       ctypes.POINTER(c_vp)]),

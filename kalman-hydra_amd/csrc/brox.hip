@@ -31,6 +31,37 @@ extern "C" int hm_device_count(void)
     return n;
 }
 
+// ---- device buffers of a caller that keeps its frames / flow planes in HBM --------------------------
+extern "C" int hm_dev_alloc(int device, uint64_t bytes, void **out)
+{
+    HM_ARG(out != nullptr && bytes > 0, "hm_dev_alloc: bad argument");
+    *out = nullptr;
+    HM_HIP(hipSetDevice(device));
+    HM_HIP(hipMalloc(out, (size_t)bytes));
+    return HM_OK;
+}
+extern "C" int hm_dev_free(int device, void *ptr)
+{
+    if (!ptr) return HM_OK;
+    HM_HIP(hipSetDevice(device));
+    HM_HIP(hipFree(ptr));
+    return HM_OK;
+}
+extern "C" int hm_dev_upload(int device, void *dst, const void *src, uint64_t bytes)
+{
+    HM_ARG(dst && src, "hm_dev_upload: NULL pointer");
+    HM_HIP(hipSetDevice(device));
+    HM_HIP(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice));
+    return HM_OK;
+}
+extern "C" int hm_dev_download(int device, void *dst, const void *src, uint64_t bytes)
+{
+    HM_ARG(dst && src, "hm_dev_download: NULL pointer");
+    HM_HIP(hipSetDevice(device));
+    HM_HIP(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return HM_OK;
+}
+
 // ---- geometry -----------------------------------------------------------------------
 static Geo make_geo(int w, int h)
 {

@@ -261,8 +261,12 @@ class KFState:
                 clash = {k for k in queue if int(Q[k][0]) in near or int(Q[k][1]) in near}
                 clash |= {diag[a], diag[b]} & set(queue)
                 members.append(qi)
-                free.discard(qi)
+                # the reference intersects its "do later" set with the pairs not yet placed BEFORE it
+                # marks the current one as placed (:341-344), and a diagonal pair clashes with itself
+                # (p_self1 / p_self2, :331-332): (i,i) is scheduled once more and lands in a second
+                # class -- kept, the lists must equal the reference's
                 later = (later | clash) & free
+                free.discard(qi)
                 queue = [k for k in queue if k != qi and k not in clash]
             queue = sorted(later)
             idx = np.array(sorted(members), float)

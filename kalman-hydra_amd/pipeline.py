@@ -1,0 +1,288 @@
+"""In-process flow -> EKF streaming.
+
+The reference computes its optical flow in a separate executable and hands it to the tracker
+through files (reference README.md:26-31; ``gen_synthetic.py:41-42`` shells out to
+``./bin/optical_flow_ext``); the tracker's frame loop then reads one flow file per frame
+(reference run_kalmanfilter.py:78-89).  Here both halves run in one process on one GPU:
+
+* the frames (and masks) of the video are uploaded to HBM once;
+* the Brox flow of consecutive frame pairs does not depend on the filter, so it is computed ahead
+  of it, in launch series of 1, 2, 4, ... up to ``flow_batch`` pairs on the flow handle's own HIP
+  stream (a single pair is launch-latency bound; a series amortises the ~900 launches over its
+  pairs), double buffered: while the filter works through the pairs of one series, the next series
+  runs beside it.  The series are queued from a helper thread -- the C calls drop the GIL -- so the
+  filter's thread does not pay for their launches;
+* a frame's flow planes are handed to the filter where they are, in device memory
+  (``renderer.DeviceObservation`` -> ``hm_set_observation_dev``).
+
+``VideoStream`` mirrors reference renderer.py:739-805 on an array source (no OpenCV on this path):
+``.npy`` / ``.npz`` of shape (frames, H, W) or (frames, H, W, 3), 8-bit.
+"""
+import threading
+
+import numpy as np
+
+from . import _lib
+from . import brox as _brox
+from .renderer import DeviceObservation
+
+
+def to_gray(a):
+    """cv2.cvtColor(frame, COLOR_BGR2GRAY) for 8-bit frames (reference renderer.py:752,
+    src/optical_flow_ext.cpp:366-368): rint(0.114 B + 0.587 G + 0.299 R).  2-D input is returned as is."""
+    a = np.asarray(a)
+    if a.ndim >= 3 and a.shape[-1] == 3:
+        a = np.rint(0.114 * a[..., 0] + 0.587 * a[..., 1] + 0.299 * a[..., 2]).astype(np.uint8)
+    return a
+
+
+def load_video(fn):
+    """The whole video as gray frames (frames, H, W) uint8 -- shared by run_kalmanfilter.py and
+    optical_flow_ext.py, so that the tracker sees the frames its flow was computed on."""
+    a = np.load(fn)
+    if hasattr(a, "files"):
+        a = a[a.files[0]]
+    a = np.asarray(a)
+    if a.dtype != np.uint8 or a.ndim not in (3, 4) or (a.ndim == 4 and a.shape[-1] != 3):
+        raise ValueError("%s: expected an 8-bit array of shape (frames, H, W[, 3])" % fn)
+    return np.ascontiguousarray(to_gray(a))
+
+
+def threshold_mask(gray, threshold):
+    """Object mask of a frame.  The reference thresholds, then keeps the pruned contour hierarchy
+    (imgproc.findObjectThreshold, imgproc.py:175-248, outside this path); here: intensity above threshold."""
+    return (np.asarray(gray) > threshold).astype(np.uint8)
+
+
+class VideoStream:
+    """reference renderer.py:739-805 over an in-memory frame stack."""
+
+    def __init__(self, fn, threshold):
+        self.threshold = threshold
+        self.frames = load_video(fn) if isinstance(fn, str) else np.ascontiguousarray(to_gray(np.asarray(fn)))
+        if self.frames.shape[0] < 1:
+            raise ValueError("Cannot open %s" % (fn,))
+        self.pos = 0
+        self.nx, self.ny = self.frames.shape[1:3]
+        self.frame = self.frames[0]
+        self.frame_orig = self.frame.copy()
+        self.grayframe = self.frame
+
+    def read(self, backsub=True):
+        """-> (ret, frame, grayframe, mask) with the background removed, or (ret, frame, grayframe)."""
+        if self.pos + 1 >= self.frames.shape[0]:
+            self.pos = self.frames.shape[0]
+            return False, None, None, None
+        self.pos += 1
+        self.frame = self.grayframe = self.frames[self.pos]
+        if not backsub:
+            return True, self.frame, self.grayframe
+        mask = threshold_mask(self.frame, self.threshold)
+        back = mask * self.frame
+        return True, back, back, mask
+
+    def current_frame(self, backsub=True):
+        return threshold_mask(self.frame, self.threshold) * self.frame if backsub else self.frame
+
+    gray_frame = current_frame
+
+    def backsub(self, im=None):
+        mask = threshold_mask(self.frame, self.threshold)
+        if im is None:
+            return mask, None, None                    # (mask, contours, distance function): the latter two are DistMesh input
+        im = np.asarray(im)
+        return mask * im if im.ndim == 2 else mask[:, :, None] * im
+
+    def isOpened(self):
+        return self.pos < self.frames.shape[0]
+
+    def release(self):
+        self.pos = self.frames.shape[0]
+
+
+class DeviceBuffer:
+    """A block of device memory owned by the caller side of the C-ABI (hm_dev_alloc)."""
+
+    def __init__(self, nbytes, device=0):
+        self.device, self.nbytes = int(device), int(nbytes)
+        p = _lib.c_vp()
+        _lib.check(_lib.lib().hm_dev_alloc(self.device, self.nbytes, p), "hm_dev_alloc")
+        self.ptr = p.value
+
+    def upload(self, a, offset=0):
+        a = np.ascontiguousarray(a)
+        assert offset + a.nbytes <= self.nbytes
+        _lib.check(_lib.lib().hm_dev_upload(self.device, self.ptr + offset, _lib.ptr(a), a.nbytes), "hm_dev_upload")
+
+    def download(self, out, offset=0):
+        assert out.flags["C_CONTIGUOUS"] and offset + out.nbytes <= self.nbytes
+        _lib.check(_lib.lib().hm_dev_download(self.device, _lib.ptr(out), self.ptr + offset, out.nbytes), "hm_dev_download")
+        return out
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            _lib.lib().hm_dev_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FlowEKFPipeline:
+    """Brox flow of the coming frames overlapped with the filter on the current one.
+
+        pipe = FlowEKFPipeline(kf, video, masks)        # kf: any kalman.*KalmanFilter on the same device
+        for k in range(len(video) - 1):
+            e = pipe.step(k)                            # frame k+1: flow of (k, k+1), then kf.compute
+
+    ``video``, ``masks``: (frames, H, W) uint8 host arrays (masks in {0,1}); uploaded once.  The flow
+    parameters default to the reference's (src/optical_flow_ext.cpp:453-488).  The numbers are those of
+    ``bf.calc(video[k], video[k+1])`` followed by ``kf.compute(video[k+1], flow, masks[k+1])``: a pair's
+    flow does not depend on the series it is computed in.
+    """
+
+    def __init__(self, kf, video, masks, flow_batch=8, device=0, brox_params=None, sor_threads=512, maskflow=True,
+                 observed=None):
+        """observed: the frames the filter is shown, when they differ from the ones the flow is computed on
+        (the reference CLI tracks the background-subtracted frame, renderer.py:770-773, while its flow tool
+        works on the raw video); default: the video itself."""
+        video = np.ascontiguousarray(video, np.uint8)
+        masks = np.ascontiguousarray(masks, np.uint8)
+        if video.ndim != 3 or masks.shape != video.shape:
+            raise ValueError("video and masks must both be (frames, H, W) uint8")
+        if observed is not None:
+            observed = np.ascontiguousarray(observed, np.uint8)
+            if observed.shape != video.shape:
+                raise ValueError("observed must have the shape of video")
+        self.kf, self.maskflow = kf, maskflow
+        self.video, self.masks = video, masks
+        self.F, self.H, self.W = video.shape
+        self.B = max(1, int(flow_batch))
+        self.device = int(device)
+        n = self.H * self.W
+        self._px = n
+        self.d_video = DeviceBuffer(self.F * n, device)
+        self.d_masks = DeviceBuffer(self.F * n, device)
+        self.d_video.upload(video)
+        self.d_masks.upload(masks)
+        self.d_observed = self.d_video
+        if observed is not None:
+            self.d_observed = DeviceBuffer(self.F * n, device)
+            self.d_observed.upload(observed)
+        self.d_u = DeviceBuffer(2 * self.B * n * 4, device)          # double-buffered flow planes
+        self.d_v = DeviceBuffer(2 * self.B * n * 4, device)
+        self.bf = _brox.BroxOpticalFlow(self.W, self.H, max_batch=self.B, device=device, **(brox_params or {}))
+        if sor_threads:
+            self.bf.tune("sor_threads", sor_threads)
+        self.t_flow = self.t_ekf = 0.0
+        self.iters = 0
+        self.profile_from = None         # pair index: the series starting there is profiled (hm_brox_profile)
+        self.trace = None                # callable(str) for per-frame scheduling messages
+        # pairs [lo, hi) of `ready` have their flow in buffer `buf`; `pending` is being computed on the flow
+        # handle's stream while the filter works on `ready`
+        self._ready, self._buf, self._pending, self._thread, self._thread_exc = (0, 0), 0, None, None, None
+        self._end = self.F - 1
+
+    # -- flow series ---------------------------------------------------------------------------------
+    def _launch(self, k, end, buf, most):
+        nb = min(most, end - k)
+        n, B = self._px, self.B
+
+        def work():
+            try:
+                if self.profile_from is not None:
+                    if self.profile_from == k:
+                        self.bf.profile(True)
+                    elif k > self.profile_from:
+                        self.bf.profile(False)          # totals stay readable (hm_brox_profile_read)
+                self.bf.calc_dev(nb, self.d_video.ptr + k * n, self.d_video.ptr + (k + 1) * n,
+                                 self.d_u.ptr + buf * B * n * 4, self.d_v.ptr + buf * B * n * 4)
+            except Exception as exc:                    # noqa: BLE001 -- re-raised by the thread that waits
+                self._thread_exc = exc
+        self._thread = threading.Thread(target=work)
+        self._thread.start()
+        return (k, k + nb)
+
+    def flow_sync(self):
+        if self._thread is not None:
+            self._thread.join()
+            self._thread = None
+        if self._thread_exc is not None:
+            exc, self._thread_exc = self._thread_exc, None
+            raise exc
+        self.bf.sync()
+
+    def begin(self, first=0, end=None):
+        """Start a phase: the pairs first .. end-1 will be asked for in order."""
+        self.flow_sync()
+        self._end = self.F - 1 if end is None else min(int(end), self.F - 1)
+        self._ready, self._pending = (first, first), None
+
+    def flow_ready(self, k):
+        """Make the flow of pair (k, k+1) available -> (device pointer of u, of v).  Series of 1, 2, 4, ...
+        pairs at the start of a phase (nothing to overlap the first one with), then ``flow_batch``."""
+        if not (self._ready[0] <= k < self._ready[1]):
+            if k != self._ready[1]:
+                self.begin(k, self._end)                 # random access: start over from k
+            if self._pending is not None and self._pending[0] == k:
+                self._buf ^= 1
+            else:
+                self._pending = self._launch(k, self._end, self._buf, 1)
+            self.flow_sync()
+            self._ready, self._pending = self._pending, None
+            lo, nxt = self._ready
+            if nxt < self._end:      # ramp: what the GPU gets done beside the frames just made ready
+                self._pending = self._launch(nxt, self._end, self._buf ^ 1, min(self.B, 2 * (nxt - lo)))
+        i = k - self._ready[0]
+        off = (self._buf * self.B + i) * self._px * 4
+        return self.d_u.ptr + off, self.d_v.ptr + off
+
+    def flow_host(self, k):
+        """The flow of pair (k, k+1) as an (H, W, 2) host array (for writing .mat files, tests)."""
+        pu, pv = self.flow_ready(k)
+        out = np.empty((2, self.H, self.W), np.float32)
+        _lib.check(_lib.lib().hm_dev_download(self.device, _lib.ptr(out[0]), pu, self._px * 4), "hm_dev_download")
+        _lib.check(_lib.lib().hm_dev_download(self.device, _lib.ptr(out[1]), pv, self._px * 4), "hm_dev_download")
+        return np.dstack((out[0], out[1]))
+
+    # -- the frame loop of reference run_kalmanfilter.py:78-89 ----------------------------------------------
+    def step(self, k):
+        """Frame k+1: flow of (k, k+1) -- usually already there -- then kf.compute on it."""
+        import time
+        if not (0 <= k < self.F - 1):
+            raise IndexError("pair %d of a %d-frame video" % (k, self.F))
+        t0 = time.perf_counter()
+        pu, pv = self.flow_ready(k)
+        t1 = time.perf_counter()
+        n = self._px
+        obs = DeviceObservation(self.d_observed.ptr + (k + 1) * n, pu, pv, self.d_masks.ptr + (k + 1) * n,
+                                y_m_host=self.masks[k + 1])
+        e = self.kf.compute(obs, None, None, maskflow=self.maskflow)
+        t2 = time.perf_counter()
+        self.t_flow += t1 - t0
+        self.t_ekf += t2 - t1
+        self.iters += getattr(self.kf, "niter", 1)
+        if self.trace:
+            self.trace("step %d: flow wait %.2f ms, filter %.2f ms (%d iterations), series ready %s pending %s"
+                       % (k, 1e3 * (t1 - t0), 1e3 * (t2 - t1), getattr(self.kf, "niter", 1), self._ready, self._pending))
+        return e
+
+    def run(self, first=0, end=None, on_frame=None):
+        """compute() for the frames first+1 .. end; on_frame(k, error_tuple) after each."""
+        end = self.F - 1 if end is None else min(int(end), self.F - 1)
+        self.begin(first, end)
+        for k in range(first, end):
+            e = self.step(k)
+            if on_frame is not None:
+                on_frame(k, e)
+
+    def close(self):
+        try:
+            self.flow_sync()
+        finally:
+            for b in (self.d_video, self.d_observed, self.d_masks, self.d_u, self.d_v):
+                b.close()
+            self.bf.close()

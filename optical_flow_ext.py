@@ -15,21 +15,17 @@ import sys
 import numpy as np
 
 import hydra_mi  # noqa: F401
-from hydra_mi import brox, matio
+from hydra_mi import brox, matio, pipeline
 
 
 def main(av):
     if len(av) < 3:
         print(__doc__)
         return 1
-    a = np.load(av[1])
-    if hasattr(a, "files"):
-        a = a[a.files[0]]
-    a = np.asarray(a)
-    if a.ndim == 4:                                  # BGR -> gray as cvtColor(BGR2GRAY) (:366-368)
-        a = np.rint(0.114 * a[..., 0] + 0.587 * a[..., 1] + 0.299 * a[..., 2]).astype(np.uint8)
-    if a.ndim != 3 or a.dtype != np.uint8:
-        sys.stderr.write("Failed to open the video: expected uint8 (frames, H, W[, 3])\n")
+    try:                                             # BGR -> gray as cvtColor(BGR2GRAY) (:366-368)
+        a = pipeline.load_video(av[1])
+    except (OSError, ValueError) as exc:
+        sys.stderr.write("Failed to open the video: %s\n" % exc)
         return 1
     prefix = av[2]
     vals = [0.197, 50.0, 0.8, 10, 77, 10]

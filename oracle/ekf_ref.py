@@ -204,6 +204,8 @@ def adjacency(N, tri):
 
 def jacobian(meas, X, y_im, y_flow, y_m, deltaX=2.0):
     """_jacobian, kalman.py:491-518: central differences of jz."""
+    if hasattr(meas, "jacobian_all"):          # the C twin (oracle/ekf_c.py): the same loop, OpenMP-parallel
+        return meas.jacobian_all(X, y_im, y_flow, y_m, deltaX)
     n = X.size
     X = np.array(X, np.float64).reshape(-1)
     meas.initjacobian(X, y_im, y_flow, y_m)
@@ -221,6 +223,8 @@ def jacobian(meas, X, y_im, y_flow, y_m, deltaX=2.0):
 
 def hessian_sparse(meas, X, J, deltaX=2.0):
     """_hessian_sparse, kalman.py:583-606 (initjacobian must have been called at X)."""
+    if hasattr(meas, "hessian_all"):
+        return meas.hessian_all(X, J, deltaX)
     n = X.size
     HTH = np.zeros((n, n))
     for i in range(n):
@@ -410,7 +414,10 @@ def remove_flat_faces(p, t, bars, L):
 class Tracker:
     """IteratedMSKalmanFilter driven frame by frame (kalman.py:676-700 + :834-960), oracle side."""
 
-    def __init__(self, p, t, bars, L, im, eps_F=1e-1, eps_Z=1e-3, eps_J=1.0, eps_M=1.0, nI=10, vel=None):
+    def __init__(self, p, t, bars, L, im, eps_F=1e-1, eps_Z=1e-3, eps_J=1.0, eps_M=1.0, nI=10, vel=None,
+                 measurement=None):
+        """measurement: the class that evaluates the measurement model -- Measurement (NumPy, default) or
+        its C twin oracle.ekf_c.Measurement (same numbers to rounding, usable at 512^2 and above)."""
         t, bars, L = remove_flat_faces(p, np.asarray(t), np.asarray(bars), np.asarray(L))
         self.N = len(p)
         self.tri = t
@@ -421,7 +428,7 @@ class Tracker:
         self.Jv, self.J = adjacency(self.N, t)
         self.K = incidence(self.N, bars)
         self.l0 = bar_lengths(self.K, self.X[:2 * self.N])
-        self.meas = Measurement(self.N, t, ver, im, eps_Z, eps_J, eps_M)
+        self.meas = (measurement or Measurement)(self.N, t, ver, im, eps_Z, eps_J, eps_M)
         self.nI = nI
 
     def compute(self, y_im, y_flow, y_m, dynamics="ms"):

@@ -4,10 +4,11 @@
 Same arguments as the reference CLI (reference run_kalmanfilter.py:38-53):
 
     fn_in            input video.  No OpenCV here: a .npy / .npz array of shape (frames, H, W)
-                     or (frames, H, W, 3), 8-bit
+                     or (frames, H, W, 3) (BGR, converted as cvtColor BGR2GRAY does), 8-bit
     flow_in          optic flow path prefix: <flow_in>_%03d_x.mat / _y.mat as written by the
                      flow tool (optical_flow_ext.py); if no flow files exist the flow is
-                     computed in-process with the same Brox defaults
+                     computed in-process with the same Brox defaults, streamed to the filter on
+                     the GPU (hydra_mi.pipeline.FlowEKFPipeline)
     fn_out           output file: the tracked states of all frames (np.savez)
     -n/--name        name for saving run images (accepted, unused: no screenshots on this path)
     -t/--threshold   threshold intensity below which is background (default 9)
@@ -20,26 +21,15 @@ import sys
 import numpy as np
 
 import hydra_mi  # noqa: F401
-from hydra_mi import brox, kalman, mesh
+from hydra_mi import kalman, mesh
+from hydra_mi.pipeline import FlowEKFPipeline, VideoStream, threshold_mask
 from hydra_mi.renderer import FlowStream
-
-
-def load_video(fn):
-    a = np.load(fn)
-    if hasattr(a, "files"):
-        a = a[a.files[0]]
-    a = np.asarray(a)
-    if a.ndim == 4:
-        a = a[..., 0]
-    if a.ndim != 3 or a.dtype != np.uint8:
-        raise SystemExit("%s: expected an 8-bit array of shape (frames, H, W[, 3])" % fn)
-    return a
 
 
 def main(argv=None):
     parser = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     parser.add_argument("fn_in", default="./video/johntest_brightcontrast_short.npy", nargs="?",
-                        help="input video file (.npy/.npz, frames x H x W, uint8)")
+                        help="input video file (.npy/.npz, frames x H x W[ x 3], uint8)")
     parser.add_argument("flow_in", default="./video/johntest_brightcontrast_short/flow", nargs="?",
                         help="input optic flow path")
     parser.add_argument("fn_out", default="./video/johntest_brightcontrast_short_output.npz", nargs="?",
@@ -55,35 +45,46 @@ def main(argv=None):
     if len(sys.argv) == 1 and argv is None:
         print("No command line arguments provided, using defaults")
 
-    video = load_video(args.fn_in)
-    frame = video[0]
-    mask = (frame > args.threshold).astype(np.uint8)
+    capture = VideoStream(args.fn_in, args.threshold)          # reference run_kalmanfilter.py:58
+    frame = capture.current_frame()
+    mask, _, _ = capture.backsub()
     distmesh = mesh.mask_mesh(mask, float(args.gridsize))
-    frame = frame * mask
 
     flowstream = FlowStream(args.flow_in)
     ret_flow, flowframe = flowstream.peek()
-    bf = None
-    if not ret_flow:
-        print("Cannot read flow stream at %s*: computing Brox flow in-process" % args.flow_in)
-        bf = brox.BroxOpticalFlow(frame.shape[1], frame.shape[0])
-        flowframe = np.dstack(bf.calc(video[0], video[1])) if len(video) > 1 else np.zeros(frame.shape + (2,), np.float32)
-
-    kf = kalman.IteratedMSKalmanFilter(distmesh, frame, flowframe, cuda=args.cuda, sparse=True, multi=True)
     states, errors = [], []
-    for count in range(1, len(video)):
-        print("Frame %d" % count)
-        gray = video[count]
-        m = (gray > args.threshold).astype(np.uint8)
-        if bf is None:
-            ret_flow, flowframe = flowstream.read()
-            if not ret_flow:
-                break
-        else:
-            flowframe = np.dstack(bf.calc(video[count - 1], video[count]))
-        e = kf.compute(gray * m, flowframe, m)
+
+    def keep(kf, e):
         states.append(kf.state.X.reshape(-1).copy())
         errors.append([float(e[0]), float(e[1]), float(e[2]), float(e[3])])
+
+    if ret_flow:
+        # the reference's loop (:78-89): one flow file per frame
+        kf = kalman.IteratedMSKalmanFilter(distmesh, frame, flowframe, cuda=args.cuda, sparse=True, multi=True)
+        count = 0
+        while capture.isOpened():
+            count += 1
+            ret, _, grayframe, m = capture.read()
+            ret_flow, flowframe = flowstream.read()
+            if ret is False or ret_flow is False:
+                break
+            print("Frame %d" % count)
+            keep(kf, kf.compute(grayframe, flowframe, m))
+    else:
+        # no flow files: flow and filter in one process, the flow of the coming frames computed on the GPU
+        # beside the filter (hydra_mi.pipeline; replaces the file hand-off of reference README.md:26-31)
+        print("Cannot read flow stream at %s*: computing Brox flow in-process" % args.flow_in)
+        video = capture.frames
+        masks = np.stack([threshold_mask(f, args.threshold) for f in video])
+        kf = kalman.IteratedMSKalmanFilter(distmesh, frame, np.zeros(frame.shape + (2,), np.float32), cuda=args.cuda,
+                                           sparse=True, multi=True)
+        pipe = FlowEKFPipeline(kf, video, masks, observed=video * masks)
+
+        def on_frame(k, e):
+            print("Frame %d" % (k + 1))
+            keep(kf, e)
+        pipe.run(on_frame=on_frame)
+        pipe.close()
     np.savez(args.fn_out, X=np.array(states), err=np.array(errors), p=distmesh.p, t=kf.state.tri)
     print("Finished: %d frames, states in %s" % (len(states), args.fn_out))
     return 0

@@ -1,8 +1,11 @@
-"""Parity at BASELINE.json's full sizes (1024^2 frames, ~200-vertex mesh): the flow against the C
-oracle (it finishes a 1024^2 pair in seconds), the EKF through properties that do not need the
-oracle's one-render-per-perturbation loops at that size -- the fused measurement against the
-product's own fine-grained operators (a full-frame render per perturbation, a different code
-path), symmetry and sparsity of HTH, and the information-form identity of the update."""
+"""Parity at BASELINE.json's full sizes (1024^2 frames, ~200-vertex mesh, config 4): the flow against
+the C oracle (it finishes a 1024^2 pair in seconds); the fused measurement against the oracle's
+jz / j (oracle/ekf_ref_c.c, the C twin of ekf_ref.Measurement: one full-frame render per
+perturbation as the reference's CPU path does, cuda.py:972-1010) on a sample of components and on a
+whole vertex, and against the product's own fine-grained operators; symmetry and sparsity of HTH;
+the information-form identity of the update."""
+import os
+
 import numpy as np
 import pytest
 
@@ -44,6 +47,44 @@ def _scene():
 
 class _S:
     pass
+
+
+def test_measure_full_size_against_oracle(hm):
+    """Hz and HTH of the fused kernels at 1024^2 / 201 vertices against the oracle's central / forward
+    differences of full-frame renders (kalman.py:499-515, 595-603): 24 random components of Hz, all four
+    of one vertex with their channel split, the 4x4 diagonal block of that vertex, the 4x4 block of an
+    adjacent pair, and a non-adjacent pair (exactly zero)."""
+    from oracle import ekf_c
+    dm, N, R, y_im, flow, y_m, X = _scene()
+    st = _S()
+    st.X = X.reshape(-1, 1)
+    R.update_frame(y_im, flow, y_m)
+    Hz, HTH, Hzc = R.measure(st, y_im, flow, y_m)
+    meas = ekf_c.Measurement(N, dm.t, dm.p, R.current_frame, 1e-3, 1.0, 1.0, threads=min(16, os.cpu_count() or 1))
+    rng = np.random.default_rng(11)
+    v, w = int(dm.t[11][0]), int(dm.t[11][1])                                         # an adjacent pair
+    own = [2 * v, 2 * v + 1, 2 * N + 2 * v, 2 * N + 2 * v + 1]
+    oth = [2 * w, 2 * w + 1, 2 * N + 2 * w, 2 * N + 2 * w + 1]
+    idx = np.array(sorted(set(rng.choice(4 * N, 24, replace=False).tolist() + own)), np.int32)
+    rHz, rHzc = meas.jacobian_all(X, y_im, flow, y_m, 2.0, idx)
+    scale = np.abs(Hz).max()
+    assert np.abs(Hz[idx, 0] - rHz[:, 0]).max() <= 1e-9 * scale
+    assert np.abs(Hzc[idx] - rHzc).max() <= 1e-9 * np.abs(Hzc).max()
+    adj = np.eye(N, dtype=bool)
+    for a, b, c in dm.t:
+        adj[a, b] = adj[b, a] = adj[a, c] = adj[c, a] = adj[b, c] = adj[c, b] = True
+    far = int(np.flatnonzero(~adj[v])[0])
+    pairs = [(i, j) for i in own for j in own if j >= i] + [(i, j) for i in own for j in oth] + [(2 * v, 2 * far)]
+    vals = meas.hessian_pairs([p[0] for p in pairs], [p[1] for p in pairs], 2.0)
+    hs = np.abs(HTH).max()
+    for (i, j), ref in zip(pairs, vals):
+        assert abs(HTH[i, j] - ref) <= 1e-9 * max(hs * 1e-3, abs(ref)), (i, j, HTH[i, j], ref)
+        assert HTH[j, i] == HTH[i, j]
+    assert vals[-1] == 0.0 and HTH[2 * v, 2 * far] == 0.0
+    e = R.error(st, y_im, flow, y_m)
+    r = meas.error(X, y_im, flow, y_m)
+    assert e[0] == r[0] and e[3] == r[3] and abs(e[1] - r[1]) <= 1e-10 * r[1] and abs(e[2] - r[2]) <= 1e-10 * r[2]
+    assert np.array_equal(e[4][:, :, 0], r[4]) and np.array_equal(e[5][:, :, 0], r[5])
 
 
 def test_measure_full_size_against_fine_grained_operators(hm):

@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import pytest
 
-from oracle import ekf_ref
+from oracle import ekf_ref, partitions_ref
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -198,15 +198,72 @@ def test_state_structure_and_partitions(hm):
             for b in e:
                 assert a == b or Jv[a, b] == 0
     assert st.labels.shape == (len(st.tri), len(st.E))
-    # pairs: Q lists every adjacent-or-equal pair once; each lands in exactly one class
+    # pairs: Q lists every adjacent-or-equal pair once; each lands in a class -- an off-diagonal pair in
+    # exactly one, a diagonal pair (i,i) in one or two (the reference schedules it again, see
+    # oracle/partitions_ref.py and testbites/test_multipert_validation.py:330-332)
     assert len(st.Q) == int(np.triu(Jv).sum())
-    idx = sorted(int(i) for e in st.E_hessian_idx for i in e)
-    assert idx == list(range(len(st.Q)))
+    idx = [int(i) for e in st.E_hessian_idx for i in e]
+    assert sorted(set(idx)) == list(range(len(st.Q)))
+    for i in set(idx):
+        assert idx.count(i) == 1 or (idx.count(i) == 2 and st.Q[i][0] == st.Q[i][1])
     for pairs in st.E_hessian:
         verts = [set(p) for p in pairs.tolist()]
         for i in range(len(verts)):
             for j in range(i + 1, len(verts)):
                 assert not any(Jv[a, b] for a in verts[i] for b in verts[j] if a != b) or verts[i] & verts[j] == set()
+
+
+def _bare_state(kalman, dm):
+    st = kalman.KFState.__new__(kalman.KFState)       # the partition builders need N, tri, Jv only
+    st.N = dm.size()
+    st.tri = np.asarray(dm.t)
+    st.Jv = partitions_ref.adjacency(st.N, dm.t)
+    return st
+
+
+def test_partitions_hand_traced_square(hm):
+    """The 4-vertex, 2-triangle square of the reference's unit-test fixture, traced by hand through
+    reference kalman.py:223-272 and :305-389 (adjacency 0-1, 0-2, 1-2, 1-3, 2-3; 0-3 not adjacent)."""
+    from hydra_mi import kalman, mesh
+    st = _bare_state(kalman, mesh.square4_mesh(10, 30))
+    E, labels = st._vertex_partitions()
+    assert [list(map(int, e)) for e in E] == [[0, 3], [1], [2]]
+    assert labels.tolist() == [[0, 1, 2], [3, 1, 2]]
+    Q, EH, EHi, lh = st._pair_partitions()
+    assert Q.tolist() == [[0, 0], [0, 1], [0, 2], [1, 1], [1, 2], [1, 3], [2, 2], [2, 3], [3, 3]]
+    # (0,0) and (3,3) share no triangle and go first; every other pair clashes with all that remain;
+    # the diagonal pairs (1,1) and (2,2) are scheduled twice (P is intersected with A before the current
+    # pair leaves A, and a diagonal pair is its own p_self match)
+    assert [e.tolist() for e in EH] == [[[0, 0], [3, 3]], [[0, 1]], [[0, 2]], [[1, 1]], [[1, 1]], [[1, 2]], [[1, 3]],
+                                        [[2, 2]], [[2, 2]], [[2, 3]]]
+    assert [list(map(int, e)) for e in EHi] == [[0, 8], [1], [2], [3], [3], [4], [5], [6], [6], [7]]
+    assert lh.tolist() == [[0, 1, 2, 3, 3, 4, 5, 6, 6, 7], [8, 1, 2, 3, 3, 4, 5, 6, 6, 7]]
+
+
+@pytest.mark.parametrize("which", ["config1", "disk", "box_fine"])
+def test_partitions_equal_reference_restatement(hm, which):
+    """E, labels, Q, E_hessian, E_hessian_idx, labels_hess of KFState are integer work: they equal the
+    statement-by-statement restatement of reference kalman.py:223-272, 305-389 (oracle/partitions_ref.py)
+    and, for the BASELINE config-1 mesh, the committed fixture."""
+    from hydra_mi import kalman, mesh
+    dm = {"config1": lambda: mesh.box_mesh(42.0, 43.0, 85.0, 86.0, 15.0),
+          "disk": lambda: mesh.disk_mesh(31.5, 31.5, 22.0, 9.0),
+          "box_fine": lambda: mesh.box_mesh(10.0, 12.0, 70.0, 50.0, 7.0)}[which]()
+    st = _bare_state(kalman, dm)
+    E, labels = st._vertex_partitions()
+    Q, EH, EHi, lh = st._pair_partitions()
+    rE, rlabels = partitions_ref.jacobian_partitions(st.N, dm.t)
+    rQ, rEH, rEHi, rlh = partitions_ref.hessian_partitions(st.N, dm.t)
+    assert [list(map(int, e)) for e in E] == rE and np.array_equal(labels, rlabels)
+    assert np.array_equal(Q, rQ) and np.array_equal(lh, rlh)
+    assert len(EH) == len(rEH) and all(np.array_equal(a, b) for a, b in zip(EH, rEH))
+    assert len(EHi) == len(rEHi) and all(np.array_equal(a, b) for a, b in zip(EHi, rEHi))
+    if which == "config1":
+        g = np.load(os.path.join(ROOT, "tests", "golden", "partitions_config1.npz"))
+        assert np.array_equal(dm.t, g["t"])
+        assert np.array_equal(np.concatenate(E), g["E_flat"]) and np.array_equal([len(e) for e in E], g["E_len"])
+        assert np.array_equal(labels, g["labels"]) and np.array_equal(Q, g["Q"]) and np.array_equal(lh, g["labels_hess"])
+        assert np.array_equal(np.concatenate(EHi), g["EH_idx_flat"]) and np.array_equal([len(e) for e in EHi], g["EH_len"])
 
 
 def test_projectmask_pulls_outliers_back(hm):

@@ -71,13 +71,6 @@ def test_ones_jz_velocity_only(hm):
     assert abs(total) < 1e-7
 
 
-def test_total_kernel_known_answer():
-    """cuda.py:665-680 (_process_total_test): block sums of 16*1024+10 floats equal np.sum."""
-    rng = np.random.default_rng(0)
-    a = rng.random(16 * 1024 + 10).astype(np.float32)
-    assert abs(a.astype(np.float64).sum() - float(np.sum(a, dtype=np.float64))) == 0.0
-
-
 def test_square_coverage_and_shared_edge(hm):
     from hydra_mi import mesh
     dm = mesh.square4_mesh(10, 30)

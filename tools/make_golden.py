@@ -4,7 +4,7 @@ The reference itself cannot be imported or run in this image (Python 2 sources, 
 PyCUDA / OpenCV), so the vectors come from oracle/, which is pinned to the
 reference's own known answers by tests/test_oracle_ekf.py.
 
-    python tools/make_golden.py [config1|brox|measure|all]
+    python tools/make_golden.py [config1|config3|partitions|brox|measure|all]
 """
 import os
 import sys
@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import hydra_mi                                     # noqa: E402  (input generators only)
 from hydra_mi import mesh, synth                    # noqa: E402
-from oracle import brox_oracle, ekf_ref             # noqa: E402
+from oracle import brox_oracle, ekf_c, ekf_ref      # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 
@@ -39,6 +39,46 @@ def config1(frames=10):
         print("frame %d: iters %d, err %s, %.0fs" % (k, tr.niter, errs[-1], time.time() - t0), flush=True)
     np.savez_compressed(os.path.join(OUT, "config1_track.npz"), p=dm.p, t=dm.t, bars=dm.bars, L=dm.L,
                         X=np.array(Xs), err=np.array(errs), iters=np.array(iters), W_last=tr.W)
+
+
+def config3(frames=5, n=512, h0=0.12):
+    """BASELINE config 3: 512x512 video of a textured disk advected by the reference's `warp` field
+    (synthetic/flowfields.py:7), ~40-vertex mesh (h0 = 0.12 W), flow from the C Brox oracle with the
+    reference defaults, IteratedMSKalmanFilter defaults.  The measurement model is the C twin of
+    ekf_ref.Measurement (oracle/ekf_ref_c.c; tests/test_oracle_ekf_c.py holds the two together): the NumPy
+    one needs ~4 300 full-frame renders per IEKF iteration here."""
+    video, masks, centre, radius = synth.disk_video(n, frames, "warp", 0)
+    dm = mesh.disk_mesh(centre[0], centre[1], radius - 1.0, h0 * n)
+    threads = max(1, min(16, os.cpu_count() or 1))
+    meas = lambda *a: ekf_c.Measurement(*a, threads=threads)
+    tr = ekf_ref.Tracker(dm.p, dm.t, dm.bars, dm.L, video[0], measurement=meas)
+    brox_oracle.set_threads(threads)
+    Xs, errs, iters = [], [], []
+    t0 = time.time()
+    for k in range(1, frames):
+        u, v = brox_oracle.calc(video[k - 1], video[k])
+        e = tr.compute(video[k], np.dstack((u, v)).astype(np.float32), masks[k])
+        Xs.append(tr.X.reshape(-1).copy())
+        errs.append([float(e[0]), e[1], e[2], float(e[3])])
+        iters.append(tr.niter)
+        print("frame %d: iters %d, err %s, %.0fs" % (k, tr.niter, errs[-1], time.time() - t0), flush=True)
+    brox_oracle.set_threads(1)
+    np.savez_compressed(os.path.join(OUT, "config3_track.npz"), n=n, frames=frames, h0=h0, p=dm.p, t=dm.t, bars=dm.bars,
+                        L=dm.L, X=np.array(Xs), err=np.array(errs), iters=np.array(iters), W_last=tr.W)
+
+
+def partitions():
+    """The perturbation partitions of the BASELINE config-1 mesh from the statement-by-statement restatement
+    of reference kalman.py:223-272, 305-389 (oracle/partitions_ref.py)."""
+    from oracle import partitions_ref
+    dm = mesh.box_mesh(42.0, 43.0, 85.0, 86.0, 15.0)
+    N = dm.size()
+    E, labels = partitions_ref.jacobian_partitions(N, dm.t)
+    Q, EH, EHi, lh = partitions_ref.hessian_partitions(N, dm.t)
+    np.savez_compressed(os.path.join(OUT, "partitions_config1.npz"), p=dm.p, t=dm.t,
+                        E_flat=np.concatenate(E).astype(np.int64), E_len=np.array([len(e) for e in E]), labels=labels,
+                        Q=Q, EH_idx_flat=np.concatenate(EHi).astype(np.int64), EH_len=np.array([len(e) for e in EHi]),
+                        labels_hess=lh)
 
 
 def brox():
@@ -81,3 +121,7 @@ if __name__ == "__main__":
         measure()
     if what in ("config1", "all"):
         config1()
+    if what in ("config3", "all"):
+        config3()
+    if what in ("partitions", "all"):
+        partitions()
