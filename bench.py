@@ -11,10 +11,15 @@ mesh" -- a textured disk advected by an analytic field, synthetic, one independe
 per GPU (weak scaling: the EKF is a recurrence over the frames of one video, videos are
 the shardable unit; the only collective is the final gather of the tracked states).
 
-Prints ONE JSON line (rank 0).  `roofline` is the SOR kernel: HIP-event time of every
-SOR launch inside the timed region against 52 B per pixel per red-black iteration
-(SURVEY.md 8d).  `cpu_baseline` is the oracle (NumPy/C restatement of the reference's
-CPU path) timed on this host on a bounded sample.
+Prints ONE JSON line (rank 0).  `roofline` is the SOR kernel: kernel start/stop events of every
+SOR launch of one full flow series inside the timed region.  `achieved` / `frac` follow the contract's
+figure, 52 B per pixel per red-black iteration -- but k_sor runs K iterations per pass
+over memory, so that figure is not a bound; the numbers that are:  `min_bytes_per_launch` = 52 B/px per
+LAUNCH (every field crosses HBM once per launch at best), `frac_min_traffic` = that over time over
+8 TB/s (cannot exceed 1), and `traffic` / `frac_hbm` = HBM bytes per launch from the rocprofv3 PMC passes
+(FETCH_SIZE x 2 + WRITE_SIZE, profiles/r02_sor_pmc.json, null when that file was taken for another
+kernel revision).  `cpu_baseline` is the oracle (C/OpenMP restatement of the reference's CPU path)
+timed on this host: whole Brox pairs and one whole KFState.update at the bench's size.
 """
 import argparse
 import json
@@ -31,15 +36,54 @@ SOR_BYTES_PER_PIXEL_ITERATION = 52.0      # 11 f32 fields read +
 HBM_PEAK_GBPS = 8000.0                    # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+SOR_PMC = os.path.join(ROOT, "profiles", "r02_sor_pmc.json")
+
+
+def kernel_revision():
+    """sha256 of the SOR kernel's sources: the PMC file names the revision it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for fn in ("brox_kernels.h", "brox.hip"):
+        with open(os.path.join(ROOT, "kalman-hydra_amd", "csrc", fn), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic():
-    """HBM bytes per SOR launch from the committed PMC passes (profiles/r01_sor_pmc.json: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of the same 8-pair 1024^2 flow batch, FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes and as the k_add calibration in that file confirms)."""
+    """HBM bytes per SOR launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE runs of the same 8-pair 1024^2 flow series, tools/run_pmc.sh + tools/sor_pmc_json.py;
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes and as the k_add calibration in that file
+    confirms).  None unless the file was taken for the kernel sources as they are now."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_sor_pmc.json")) as f:
-            return float(json.load(f)["traffic_bytes_per_launch"])
+        with open(SOR_PMC) as f:
+            d = json.load(f)
+        if d.get("kernel_revision") != kernel_revision():
+            return None
+        return float(d["traffic_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         return None
+
+
+def sor_roofline(sor_ms, sor_launches, sor_pxit, sor_px, traffic, profiled):
+    """The roofline block of the JSON line.  sor_pxit = sum over the timed launches of pixels x fused
+    iterations, sor_px = sum of pixels (one pass over memory each)."""
+    t = sor_ms * 1e-3
+    alg = SOR_BYTES_PER_PIXEL_ITERATION * sor_pxit
+    achieved = alg / t / 1e9 if t > 0 else 0.0
+    minb = SOR_BYTES_PER_PIXEL_ITERATION * sor_px
+    n = max(1, sor_launches)
+    out = {"bound": "hbm", "kernel": "k_sor", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+           "algorithmic_bytes_per_launch": alg / n, "bytes_per_pixel_iteration": SOR_BYTES_PER_PIXEL_ITERATION,
+           "min_bytes_per_launch": minb / n,
+           "frac_min_traffic": (minb / t / 1e9 / HBM_PEAK_GBPS) if t > 0 else 0.0,
+           "frac_hbm": (traffic * n / t / 1e9 / HBM_PEAK_GBPS) if (traffic and t > 0) else None,
+           "launches": sor_launches, "avg_launch_us": 1e3 * sor_ms / n, "profiled": profiled,
+           "note": "frac follows the contract's per-iteration byte model and exceeds 1 because k_sor fuses several "
+                   "red-black iterations per pass over memory; frac_min_traffic (52 B/px per launch) and frac_hbm "
+                   "(PMC bytes) are physical bounds; profiles/r02_sor_sq_counters.csv: the kernel is bound by vector "
+                   "instruction issue and barrier waits, not by HBM"}
+    return out
 
 
 def make_video(n, frames, seed):
@@ -48,43 +92,76 @@ def make_video(n, frames, seed):
     return video, masks, centre, radius
 
 
-def cpu_baseline(n, video, masks, dm, iters_per_frame, budget_s=25.0):
-    """Oracle on the host cores: one Brox pair + a timed sample of EKF perturbation evaluations,
-    scaled to the evaluations one frame needs (2*4N jz + nzj j per IEKF iteration, kalman.py:397,498-515,595-598)."""
-    from oracle import brox_oracle, ekf_ref
-    threads = max(1, min(16, os.cpu_count() or 1))
+def cpu_baseline(n, video, masks, dm, iters_per_frame, budget_s=30.0):
+    """The oracle on the host cores, BASELINE.md section 2 protocol where the budget allows:
+
+    * Brox: whole 1024^2 pairs with the C oracle, 3 warm + 5 timed, median, with all cores and with
+      one thread;
+    * EKF: ONE whole KFState.update of the reference's CPU path (kalman.py:491-518, 583-606: 2*4N jz
+      evaluations + one j per non-zero of the upper triangle of J, every one of them full-frame renders,
+      cuda.py:972-1010) with the C/OpenMP twin of the NumPy oracle (oracle/ekf_ref_c.c), all cores, timed
+      once -- it is tens of seconds; with one thread a 1/32 strided sample of the same evaluations is timed
+      and scaled.
+    frames/sec = 1 / (t_brox + iterations_per_frame * t_update)."""
+    from oracle import brox_oracle, ekf_c, ekf_ref
+    cores = os.cpu_count() or 1
+    threads = max(1, min(64, cores))
+
+    def timed(fn, warm, reps):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
     brox_oracle.set_threads(threads)
-    npairs = min(3, len(video) - 1)
-    t0 = time.perf_counter()
-    for k in range(npairs):
-        u, v = brox_oracle.calc(video[k], video[k + 1])
-    t_brox = (time.perf_counter() - t0) / npairs
+    t_brox = timed(lambda: brox_oracle.calc(video[0], video[1]), 3, 5)
+    brox_oracle.set_threads(1)
+    t_brox1 = timed(lambda: brox_oracle.calc(video[0], video[1]), 0, 1)
+    brox_oracle.set_threads(threads)
     u, v = brox_oracle.calc(video[0], video[1])
     brox_oracle.set_threads(1)
     N = dm.size()
-    meas = ekf_ref.Measurement(N, dm.t, dm.p, video[0], 1e-3, 1.0, 1.0)
+    meas = ekf_c.Measurement(N, dm.t, dm.p, video[0], 1e-3, 1.0, 1.0, threads=threads)
     X = np.concatenate((dm.p.reshape(-1), np.zeros(2 * N)))
     flow = np.dstack((u, v)).astype(np.float32)
-    t0 = time.perf_counter()
-    meas.initjacobian(X, video[1], flow, masks[1])
-    t_init = time.perf_counter() - t0
-    n_jz = n_j = 0
-    t_jz = t_j = 0.0
-    k = 0
-    while t_jz + t_j < budget_s and k < 4 * N:
-        Xp = X.copy()
-        Xp[k] += 2.0
-        t0 = time.perf_counter(); meas.jz(Xp); t_jz += time.perf_counter() - t0; n_jz += 1
-        t0 = time.perf_counter(); meas.j(2.0, k, k); t_j += time.perf_counter() - t0; n_j += 1
-        k += max(1, (4 * N) // 96)
     _, J = ekf_ref.adjacency(N, dm.t)
-    nzj = float(np.sum(np.triu(J)))
-    per_iter = t_init + 2 * 4 * N * (t_jz / n_jz) + nzj * (t_j / n_j)
-    t_frame = t_brox + iters_per_frame * per_iter
+    pi, pj = np.nonzero(np.triu(J == 1))
+    t0 = time.perf_counter()
+    meas.jacobian_all(X, video[1], flow, masks[1])
+    t_jac = time.perf_counter() - t0
+    # the Hessian pass within the budget: everything if it fits, else a strided sample scaled up
+    t0 = time.perf_counter()
+    meas.hessian_pairs(pi[::64], pj[::64])
+    t_probe = time.perf_counter() - t0
+    est = t_probe * 64
+    stride = 1 if est <= budget_s else int(np.ceil(est / budget_s))
+    t0 = time.perf_counter()
+    meas.hessian_pairs(pi[::stride], pj[::stride])
+    t_hess = (time.perf_counter() - t0) * (len(pi) / len(pi[::stride]))
+    t_update = t_jac + t_hess
+    # one thread: a 1/32 sample of both passes
+    meas.set_threads(1)
+    idx = np.arange(0, 4 * N, 32, dtype=np.int32)
+    t0 = time.perf_counter()
+    meas.jacobian_all(X, video[1], flow, masks[1], 2.0, idx)
+    t1 = (time.perf_counter() - t0) * (4 * N / len(idx))
+    t0 = time.perf_counter()
+    meas.hessian_pairs(pi[::128], pj[::128])
+    t1 += (time.perf_counter() - t0) * (len(pi) / len(pi[::128]))
+    t_frame = t_brox + iters_per_frame * t_update
+    t_frame1 = t_brox1 + iters_per_frame * t1
     return {"value": 1.0 / t_frame, "unit": "frames/sec", "cores": threads, "kind": "port",
-            "sample": "oracle Brox on %d pairs (%d OpenMP threads, %.2f s each) + %d jz and %d j evaluations of the NumPy "
-                      "EKF twin (1 thread) scaled to 2*4N=%d jz + %d j per IEKF iteration x %.1f iterations/frame"
-                      % (npairs, threads, t_brox, n_jz, n_j, 8 * N, int(nzj), iters_per_frame)}
+            "value_one_thread": 1.0 / t_frame1, "os_cpu_count": cores,
+            "seconds": {"brox_pair": t_brox, "brox_pair_one_thread": t_brox1, "kfstate_update": t_update,
+                        "kfstate_update_one_thread_scaled": t1},
+            "sample": "C/OpenMP restatement of the reference CPU path (oracle/): Brox on a %dx%d pair, 3 warm + 5 timed, "
+                      "median (%d threads: %.3f s; 1 thread, 1 run: %.2f s); one whole KFState.update = %d jz (central "
+                      "differences, 2 renders each) + %s of the %d j evaluations (2 renders each%s), %d threads: %.1f s; "
+                      "1 thread from a 1/32 (jz) and 1/128 (j) strided sample scaled: %.0f s; x %.1f IEKF iterations per "
+                      "frame" % (n, n, threads, t_brox, t_brox1, 4 * N, "all" if stride == 1 else "every %d-th" % stride,
+                                 len(pi), "" if stride == 1 else ", scaled", threads, t_update, t1, iters_per_frame)}
 
 
 def flowbatch(args, rank, world, dev, coll_dev):
@@ -121,7 +198,7 @@ def flowbatch(args, rank, world, dev, coll_dev):
         if k == args.steps - 1:
             bf.profile(True)
         step()
-    sor_ms, sor_launches, sor_pxit = bf.profile_read()
+    sor_ms, sor_launches, sor_pxit, sor_px = bf.profile_read()
     if world > 1:
         flows = torch.stack((U, V)).to(coll_dev)
         parts = [torch.empty_like(flows) for _ in range(world)] if rank == 0 else None
@@ -134,7 +211,6 @@ def flowbatch(args, rank, world, dev, coll_dev):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
-        achieved = SOR_BYTES_PER_PIXEL_ITERATION * sor_pxit / (sor_ms * 1e-3) / 1e9 if sor_ms > 0 else 0.0
         print(json.dumps({
             "metric": "frame pairs/sec (Brox flow) at %d^2" % n, "value": world * P * args.steps / elapsed,
             "unit": "pairs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -142,9 +218,9 @@ def flowbatch(args, rank, world, dev, coll_dev):
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%d independent %dx%d frame pairs per GPU, Brox defaults, flows gathered to rank 0"
                                    % (P, n, n), "flow_batch": B, "parallelism": "pairs x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_sor", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic() if (n == 1024 and B == 8) else None,
-                         "launches": sor_launches, "profiled": "last step of the timed region"}}), flush=True)
+            "roofline": sor_roofline(sor_ms, sor_launches, sor_pxit, sor_px,
+                                     pmc_traffic() if (n == 1024 and B == 8) else None,
+                                     "last step of the timed region")}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -178,8 +254,7 @@ def main():
     import torch
     import torch.distributed as dist
     import hydra_mi  # noqa: F401
-    from hydra_mi import brox, kalman, mesh
-    from hydra_mi.renderer import DeviceObservation
+    from hydra_mi import kalman, mesh
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path)")
@@ -200,101 +275,40 @@ def main():
     if args.workload == "flowbatch":
         return flowbatch(args, rank, world, dev, coll_dev)
     import threading
+    from hydra_mi.pipeline import FlowEKFPipeline
     B = max(1, args.flow_batch)
     V = max(1, args.videos_per_gpu)
 
     class Track:
-        """One video: its frames and flow planes in HBM, a flow handle, a filter, and the schedule that
-        computes the flow of the next frames while the filter works on the current ones."""
+        """One video: a filter and the package's streaming pipeline (hydra_mi.pipeline.FlowEKFPipeline: frames
+        and flow planes in HBM, the flow of the next frames computed on the flow handle's stream while the
+        filter works on the current ones)."""
 
         def __init__(self, seed):
             frames = K + Wm + 1
             self.video, self.masks, centre, radius = make_video(n, frames, seed=seed)
             self.dm = mesh.disk_mesh(centre[0], centre[1], radius - 1.0, args.h0 * n)
-            self.d_video = torch.from_numpy(self.video).cuda()
-            self.d_masks = torch.from_numpy(self.masks).cuda()
-            self.d_u = torch.empty((2, B, n, n), dtype=torch.float32, device="cuda")      # double-buffered flow planes
-            self.d_v = torch.empty_like(self.d_u)
-            torch.cuda.synchronize()
-            self.bf = brox.BroxOpticalFlow(n, n, max_batch=B, device=dev)
-            self.bf.tune("sor_threads", 512)
             self.kf = kalman.IteratedMSKalmanFilter(self.dm, self.video[0], np.zeros((n, n, 2), np.float32), True, device=dev)
-            self.t_flow = self.t_ekf = 0.0
-            self.iters = 0
-            # frame pairs [lo, hi) of `ready` have their flow in buffer `buf`; `pending` is being computed
-            # on the flow handle's own stream while the filter works on `ready`
-            self.sched = {"ready": (0, 0), "buf": 0, "pending": None, "profile_from": None, "thread": None}
-
-        def launch(self, k, phase_end, buf, most=None):
-            """Queue the flow of the pairs [k, k+nb) on the flow handle's stream.  The calls are made from a
-            helper thread (ctypes drops the GIL): a series is ~900 launches (the profiled one with an event
-            pair for every SOR launch on top), several milliseconds of host time that the filter's thread
-            does not have to spend."""
-            nb = min(B if most is None else most, phase_end - k)
-            bf, sched = self.bf, self.sched
-
-            def work():
-                if sched["profile_from"] == k:
-                    bf.profile(True)
-                elif sched["profile_from"] is not None and k > sched["profile_from"]:
-                    bf.profile(False)              # totals stay readable (hm_brox_profile_read)
-                bf.calc_dev(nb, self.d_video[k].data_ptr(), self.d_video[k + 1].data_ptr(), self.d_u[buf].data_ptr(),
-                            self.d_v[buf].data_ptr())
-            th = threading.Thread(target=work)
-            th.start()
-            sched["thread"] = th
-            return (k, k + nb)
-
-        def flow_sync(self):
-            if self.sched["thread"] is not None:
-                self.sched["thread"].join()
-                self.sched["thread"] = None
-            self.bf.sync()
-
-        def step(self, k, phase_end):
-            """Frame k+1: flow of (k, k+1) -- computed for up to B consecutive pairs per launch series (they do
-            not depend on the filter), the next series running on the GPU while the filter works through
-            this one (series of 1, 2, 4, ... pairs at the start of a phase: nothing to overlap the first with) --
-            then the EKF on frame k+1."""
-            sched = self.sched
-            t0 = time.perf_counter()
-            if k >= sched["ready"][1]:
-                if sched["pending"] is not None and sched["pending"][0] == k:
-                    sched["buf"] ^= 1
-                else:                      # start of a phase: one pair only, so that the filter can start
-                    sched["pending"] = self.launch(k, phase_end, sched["buf"], most=1)
-                self.flow_sync()
-                sched["ready"], sched["pending"] = sched["pending"], None
-                lo, nxt = sched["ready"]
-                if nxt < phase_end:        # ramp: what the GPU gets done beside the frames just made ready
-                    sched["pending"] = self.launch(nxt, phase_end, sched["buf"] ^ 1, most=min(B, 2 * (nxt - lo)))
-            i = k - sched["ready"][0]
-            cur = sched["buf"]
-            t1 = time.perf_counter()
-            obs = DeviceObservation(self.d_video[k + 1].data_ptr(), self.d_u[cur, i].data_ptr(), self.d_v[cur, i].data_ptr(),
-                                    self.d_masks[k + 1].data_ptr(), y_m_host=self.masks[k + 1])
-            self.kf.compute(obs, None, None)
-            t2 = time.perf_counter()
-            self.t_flow += t1 - t0
-            self.t_ekf += t2 - t1
+            self.pipe = FlowEKFPipeline(self.kf, self.video, self.masks, flow_batch=B, device=dev, sor_threads=512)
+            self.bf = self.pipe.bf
             if os.environ.get("HYDRA_MI_BENCH_TRACE"):
-                print("step %d: flow wait %.2f ms, filter %.2f ms (%d iterations), series ready %s pending %s"
-                      % (k, 1e3 * (t1 - t0), 1e3 * (t2 - t1), self.kf.niter, sched["ready"], sched["pending"]), file=sys.stderr)
-            self.iters += self.kf.niter
+                self.pipe.trace = lambda msg: print(msg, file=sys.stderr)
 
         def warmup(self):
             self.bf.profile(True)
-            for k in range(Wm):
-                self.step(k, Wm)
+            self.pipe.run(0, Wm)
+            self.pipe.flow_sync()
             self.bf.profile_read()
             self.bf.profile(False)
-            self.t_flow = self.t_ekf = 0.0
-            self.iters = 0
+            self.pipe.t_flow = self.pipe.t_ekf = 0.0
+            self.pipe.iters = 0
             self.kf.predtime = self.kf.updatetime = self.kf.projecttime = 0.0
 
         def timed(self):
-            for k in range(Wm, Wm + K):
-                self.step(k, Wm + K)
+            self.pipe.run(Wm, Wm + K)
+
+        def flow_sync(self):
+            self.pipe.flow_sync()
 
     # the videos of this rank: seeds rank * V .. rank * V + V - 1 (one video per GPU unless --videos-per-gpu)
     tracks = [Track(rank * V + i) for i in range(V)]
@@ -309,7 +323,7 @@ def main():
         starts.append((k_, size))
         k_ += size
     full = [st for st in starts if st[1] == B]
-    tracks[0].sched["profile_from"], prof_pairs = full[0] if full else starts[-1]
+    tracks[0].pipe.profile_from, prof_pairs = full[0] if full else starts[-1]
 
     if world > 1:
         dist.barrier()
@@ -341,12 +355,12 @@ def main():
     elapsed = time.perf_counter() - t0
     for tr in tracks:
         tr.flow_sync()
-    sor_ms, sor_launches, sor_pxit = tracks[0].bf.profile_read()
+    sor_ms, sor_launches, sor_pxit, sor_px = tracks[0].bf.profile_read()
     kf, video, masks, dm = tracks[0].kf, tracks[0].video, tracks[0].masks, tracks[0].dm
     N = kf.N
-    t_flow = sum(tr.t_flow for tr in tracks) / V
-    t_ekf = sum(tr.t_ekf for tr in tracks) / V
-    iters = sum(tr.iters for tr in tracks) / V
+    t_flow = sum(tr.pipe.t_flow for tr in tracks) / V
+    t_ekf = sum(tr.pipe.t_ekf for tr in tracks) / V
+    iters = sum(tr.pipe.iters for tr in tracks) / V
     predtime = sum(tr.kf.predtime for tr in tracks) / V
     updatetime = sum(tr.kf.updatetime for tr in tracks) / V
 
@@ -356,7 +370,6 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        achieved = SOR_BYTES_PER_PIXEL_ITERATION * sor_pxit / (sor_ms * 1e-3) / 1e9 if sor_ms > 0 else 0.0
         out = {
             "metric": "frames/sec (Brox flow + EKF update) at 1024^2" if n == 1024 else
                       "frames/sec (Brox flow + EKF update) at %d^2" % n,
@@ -370,12 +383,9 @@ def main():
             "breakdown_ms_per_step": {"brox_flow": 1e3 * t_flow / K, "ekf_compute": 1e3 * t_ekf / K,
                                       "ekf_predict": 1e3 * predtime / K, "ekf_update": 1e3 * updatetime / K,
                                       "iekf_iterations": iters / K},
-            "roofline": {"bound": "hbm", "kernel": "k_sor", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": pmc_traffic() if (n == 1024 and prof_pairs == 8) else None,
-                         "algorithmic_bytes_per_launch": SOR_BYTES_PER_PIXEL_ITERATION * sor_pxit / max(1, sor_launches),
-                         "launches": sor_launches, "profiled": "one flow series (%d pairs) of the timed region" % prof_pairs, "avg_launch_us": 1e3 * sor_ms / max(1, sor_launches),
-                         "bytes_per_pixel_iteration": SOR_BYTES_PER_PIXEL_ITERATION},
+            "roofline": sor_roofline(sor_ms, sor_launches, sor_pxit, sor_px,
+                                     pmc_traffic() if (n == 1024 and prof_pairs == 8) else None,
+                                     "one flow series (%d pairs) of the timed region" % prof_pairs),
         }
         out["cpu_baseline"] = None                           # a reported baseline, timed at N = 1 only
         if not args.no_cpu_baseline and world == 1:

@@ -81,30 +81,35 @@ int hm_brox_levels(hm_brox_t h, int *widths, int *heights, int cap);
 int hm_brox_set_omega(hm_brox_t h, float omega);
 /* launch tuning, never changes results: "sor_fuse" = red-black iterations fused
  * per SOR launch (0 = choose per level, else a divisor of solver_iterations),
- * "sor_threads" = 256, 512 or 1024 threads per SOR workgroup, "graph" = 1/0 replay the launch
- * series of a calc call as a captured hipGraph or launch kernel by kernel (default 0: with ROCm 7.2
- * replays were seen to produce garbage from the fifth launch of a graph on when the caller allocated
- * device memory between calls -- tools/graph_debug.py; the direct launches are not affected), "warp_window" =
+ * "sor_threads" = 256, 512 or 1024 threads per SOR workgroup, "warp_window" =
  * 1/0 the warp kernel stages its taps as an LDS window or reads them directly (default 0: measured
- * faster, see brox_kernels.h) */
+ * faster, see brox_kernels.h).  (Round 1 also had "graph": replaying a call's launch series as a captured
+ * hipGraph.  Replays went wrong when the caller allocated device memory between calls, the cause was not
+ * found, and with the series queued from a helper thread it bought nothing: removed.) */
 int hm_brox_tune(hm_brox_t h, const char *key, int value);
-/* set-up work of the first calc call for n pairs (capturing its launch series as a graph) done ahead
- * of time; optional */
-int hm_brox_prepare(hm_brox_t h, int n);
 
 /* HIP-event timing of the SOR launches of subsequent calc calls.
- * read: total milliseconds, launches, and pixel-iterations (sum over launches of
- * pixels * red-black iterations) since profiling was switched on or last read
- * (switching it off stops the recording and keeps the totals for `read`). */
+ * read: total milliseconds, launches, pixel-iterations (sum over launches of
+ * pixels * red-black iterations) and pixels (sum over launches of pixels: every launch is one pass
+ * over memory) since profiling was switched on or last read (switching it off stops the recording
+ * and keeps the totals for `read`).  Any output pointer may be NULL. */
 int hm_brox_profile(hm_brox_t h, int enable);
 int hm_brox_profile_read(hm_brox_t h, double *sor_ms, long long *sor_launches,
-                         double *sor_pixel_iterations);
+                         double *sor_pixel_iterations, double *sor_pixels);
 
 /* Single operators on host arrays, for parity tests against the oracle.
  * Each allocates scratch, runs the same kernel calc uses, and copies back. */
 int hm_op_blur(const float *src, int w, int h, float scale_factor, float *dst);
 int hm_op_resample(const float *src, int ws, int hs, float *dst, int wd, int hd, float mul);
 int hm_op_deriv(const float *src, int w, int h, float *dx, float *dy);
+/* the fused launches calc is made of (each gives the bits of the separate operators above applied in
+ * turn): one pyramid level = blur + resample; all derivative images of a level (out: Ix0, Iy0 of I0;
+ * I1x, I1y, I1xx, I1xy, I1yy of I1); u + du, v + dv prolonged to the next finer level with the flow
+ * rescaled (wd = ws and hd = hs: the level-0 form, the sums themselves) */
+int hm_op_pyr_down(const float *src, int ws, int hs, float scale_factor, float *dst, int wd, int hd);
+int hm_op_deriv_all(const float *I0, const float *I1, int w, int h, float *const out[7]);
+int hm_op_add_prolong(const float *u, const float *v, const float *du, const float *dv, int ws, int hs,
+                      float *u2, float *v2, int wd, int hd);
 /* in: I0,Ix0,Iy0,I1,I1x,I1y,I1xx,I1xy,I1yy,u,v   out: Iz,Ix,Iy,Ixz,Iyz,Ixx,Ixy,Iyy;
  * window: 1 = the LDS-window variant of the kernel (hm_brox_tune "warp_window"), 0 = direct reads */
 int hm_op_warp(const float *const in[11], int w, int h, float *const out[8], int window);

@@ -40,13 +40,16 @@ SIGNATURES = {
     "hm_brox_levels": (ctypes.c_int, [c_vp, c_i32p, c_i32p, ctypes.c_int]),
     "hm_brox_set_omega": (ctypes.c_int, [c_vp, ctypes.c_float]),
     "hm_brox_tune": (ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int]),
-    "hm_brox_prepare": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "hm_brox_profile": (ctypes.c_int, [c_vp, ctypes.c_int]),
-    "hm_brox_profile_read": (ctypes.c_int, [c_vp, c_f64p, ctypes.POINTER(ctypes.c_longlong), c_f64p]),
+    "hm_brox_profile_read": (ctypes.c_int, [c_vp, c_f64p, ctypes.POINTER(ctypes.c_longlong), c_f64p, c_f64p]),
     "hm_op_blur": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, c_vp]),
     "hm_op_resample": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_float]),
     "hm_op_deriv": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
+    "hm_op_pyr_down": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, c_vp, ctypes.c_int, ctypes.c_int]),
+    "hm_op_deriv_all": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_vp)]),
+    "hm_op_add_prolong": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_vp, ctypes.c_int,
+                                         ctypes.c_int]),
     "hm_op_warp": (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_vp), ctypes.c_int]),
     "hm_op_prepare": (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                      ctypes.c_float, ctypes.POINTER(c_vp)]),

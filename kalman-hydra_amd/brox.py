@@ -103,10 +103,6 @@ class BroxOpticalFlow:
     def set_omega(self, omega):
         _lib.check(_lib.lib().hm_brox_set_omega(self._h, omega), "hm_brox_set_omega")
 
-    def prepare(self, n):
-        """Do the set-up work of the first calc call for n pairs now (hm_brox_prepare)."""
-        _lib.check(_lib.lib().hm_brox_prepare(self._h, int(n)), "hm_brox_prepare")
-
     def tune(self, key, value):
         _lib.check(_lib.lib().hm_brox_tune(self._h, key.encode(), int(value)), "hm_brox_tune")
 
@@ -114,13 +110,14 @@ class BroxOpticalFlow:
         _lib.check(_lib.lib().hm_brox_profile(self._h, 1 if enable else 0), "hm_brox_profile")
 
     def profile_read(self):
-        """(sor_ms, sor_launches, sor_pixel_iterations) since the last read."""
+        """(sor_ms, sor_launches, sor_pixel_iterations, sor_pixels) since the last read."""
         ms = ctypes.c_double()
         n = ctypes.c_longlong()
+        pxit = ctypes.c_double()
         px = ctypes.c_double()
-        _lib.check(_lib.lib().hm_brox_profile_read(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(px)),
-                   "hm_brox_profile_read")
-        return ms.value, n.value, px.value
+        _lib.check(_lib.lib().hm_brox_profile_read(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(pxit),
+                                                   ctypes.byref(px)), "hm_brox_profile_read")
+        return ms.value, n.value, pxit.value, px.value
 
 
 # ---- single operators (the kernels calc() is made of), host arrays -----------------------
@@ -147,6 +144,31 @@ def op_deriv(img):
     dx, dy = np.empty_like(img), np.empty_like(img)
     _lib.check(_lib.lib().hm_op_deriv(_lib.ptr(img), img.shape[1], img.shape[0], _lib.ptr(dx), _lib.ptr(dy)))
     return dx, dy
+
+
+def op_pyr_down(img, wd, hd, scale_factor=0.8):
+    """one pyramid level as calc builds it: Gaussian + resampling in one launch"""
+    img = _f32(img)
+    out = np.empty((hd, wd), np.float32)
+    _lib.check(_lib.lib().hm_op_pyr_down(_lib.ptr(img), img.shape[1], img.shape[0], scale_factor, _lib.ptr(out), wd, hd))
+    return out
+
+
+def op_deriv_all(I0, I1):
+    """-> Ix0, Iy0, I1x, I1y, I1xx, I1xy, I1yy (one launch)"""
+    I0, I1 = _f32(I0), _f32(I1)
+    outs = [np.empty_like(I0) for _ in range(7)]
+    _lib.check(_lib.lib().hm_op_deriv_all(_lib.ptr(I0), _lib.ptr(I1), I0.shape[1], I0.shape[0], _lib.ptr_array(outs)))
+    return outs
+
+
+def op_add_prolong(u, v, du, dv, wd, hd):
+    """(u + du, v + dv) prolonged to wd x hd with the flow rescaled (same size: the sums themselves)"""
+    u, v, du, dv = _f32(u), _f32(v), _f32(du), _f32(dv)
+    u2, v2 = np.empty((hd, wd), np.float32), np.empty((hd, wd), np.float32)
+    _lib.check(_lib.lib().hm_op_add_prolong(_lib.ptr(u), _lib.ptr(v), _lib.ptr(du), _lib.ptr(dv), u.shape[1], u.shape[0],
+                                            _lib.ptr(u2), _lib.ptr(v2), wd, hd))
+    return u2, v2
 
 
 def op_warp(*fields, window=False):

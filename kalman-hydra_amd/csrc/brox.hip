@@ -149,9 +149,7 @@ static SorPlan sor_plan(const Geo &g, int solver, int fuse, int threads)
 
 // e0 / e1 (profiling only): events that receive the start and stop time of the kernel itself
 // (hipExtLaunchKernelGGL) -- events recorded around the launch would add the command processor's
-// dispatch latency to every launch.  Without events the plain launch is used: the Ext launch must not
-// be captured into a graph (the captured node keeps pointers to the caller's argument storage instead
-// of a copy; replays then read whatever the host stack holds by then).
+// dispatch latency to every launch.  Without events the plain launch is used.
 static void sor_launch(const SorPlan &p, SorArgs a, int n, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
 {
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y;
@@ -191,12 +189,9 @@ struct hm_brox {
     float *Iz, *Ix, *Iy, *Ixz, *Iyz, *Ixx, *Ixy, *Iyy;
     float *nu, *nv, *a12, *idu, *idv, *sx, *sy;
     float *u, *v, *u2, *v2, *du[2], *dv[2];
+    float *zero;                 // a plane of zeros, only ever read
     uint8_t *d_f0, *d_f1;        // staging of host frames
     float *d_ox, *d_oy;          // staging of the host-bound result (tight W*H per pair)
-    // one captured launch series (hipGraph) per batch size; replaying it costs the host a few tens of
-    // microseconds instead of ~1100 kernel launches.  Dropped when a tuning knob changes.
-    std::vector<hipGraphExec_t> graphs;   // index n-1
-    bool use_graph;
     bool warp_window;                     // k_warp stages its taps as an LDS window (hm_brox_tune)
     // profiling
     bool prof;
@@ -204,7 +199,8 @@ struct hm_brox {
     size_t ev_used;
     double prof_ms, prof_pxit;
     long long prof_launches;
-    std::vector<double> ev_pxit;
+    double prof_px;
+    std::vector<double> ev_pxit, ev_px;
 };
 
 static int brox_free(hm_brox *h)
@@ -212,8 +208,6 @@ static int brox_free(hm_brox *h)
     if (!h) return HM_OK;
     hipSetDevice(h->device);
     for (hipEvent_t e : h->ev) hipEventDestroy(e);
-    for (hipGraphExec_t g : h->graphs)
-        if (g) hipGraphExecDestroy(g);
     if (h->arena) hipFree(h->arena);
     if (h->d_f0) hipFree(h->d_f0);
     if (h->d_f1) hipFree(h->d_f1);
@@ -240,9 +234,7 @@ extern "C" int hm_brox_create(int device, int W, int H, int max_batch, float alp
     h->alpha = alpha; h->gamma = gamma; h->scale = scale; h->omega = 1.99f;
     h->inner = inner; h->outer = outer; h->solver = solver; h->fuse = 0; h->sor_threads = 256;
     h->arena = nullptr; h->d_f0 = h->d_f1 = nullptr; h->d_ox = h->d_oy = nullptr; h->stream = nullptr;
-    h->prof = false; h->ev_used = 0; h->prof_ms = 0; h->prof_pxit = 0; h->prof_launches = 0;
-    h->graphs.assign(max_batch, nullptr);
-    h->use_graph = false;                         // see hm_brox_tune "graph" in the header: off by default
+    h->prof = false; h->ev_used = 0; h->prof_ms = 0; h->prof_pxit = 0; h->prof_px = 0; h->prof_launches = 0;
     h->warp_window = false;
     make_levels(W, H, scale, outer, h->geo);
     h->taps = make_taps(scale);
@@ -251,7 +243,7 @@ extern "C" int hm_brox_create(int device, int W, int H, int max_batch, float alp
     const size_t plane0 = (size_t)h->geo[0].plane;
     size_t pyr_floats = 0;
     for (const Geo &g : h->geo) pyr_floats += (size_t)g.plane * B;
-    const int nfields = 2 + 7 + 8 + 7 + 4 + 4;
+    const int nfields = 2 + 7 + 8 + 7 + 4 + 4 + 1;
     h->arena_floats = 2 * pyr_floats + (size_t)nfields * plane0 * B;
     hipError_t e = hipMalloc((void **)&h->arena, h->arena_floats * sizeof(float));
     if (e != hipSuccess) {
@@ -281,8 +273,8 @@ extern "C" int hm_brox_create(int device, int W, int H, int max_batch, float alp
     float **fields[] = {&h->tmpA, &h->tmpB, &h->Ix0, &h->Iy0, &h->I1x, &h->I1y, &h->I1xx, &h->I1xy, &h->I1yy,
                         &h->Iz, &h->Ix, &h->Iy, &h->Ixz, &h->Iyz, &h->Ixx, &h->Ixy, &h->Iyy,
                         &h->nu, &h->nv, &h->a12, &h->idu, &h->idv, &h->sx, &h->sy,
-                        &h->u, &h->v, &h->u2, &h->v2, &h->du[0], &h->du[1], &h->dv[0], &h->dv[1]};
-    static_assert(sizeof(fields) / sizeof(fields[0]) == 32, "field count");
+                        &h->u, &h->v, &h->u2, &h->v2, &h->du[0], &h->du[1], &h->dv[0], &h->dv[1], &h->zero};
+    static_assert(sizeof(fields) / sizeof(fields[0]) == 33, "field count");
     for (float **f : fields) *f = take(plane0 * B);
     *out = h;
     return HM_OK;
@@ -301,21 +293,11 @@ extern "C" int hm_brox_levels(hm_brox_t h, int *ws, int *hs, int cap)
     return n;
 }
 
-// captured launch series bake kernel arguments and the launch plan in: drop them when either changes
-static void drop_graphs(hm_brox *h)
-{
-    for (hipGraphExec_t &g : h->graphs) {
-        if (g) (void)hipGraphExecDestroy(g);
-        g = nullptr;
-    }
-}
-
 extern "C" int hm_brox_set_omega(hm_brox_t h, float omega)
 {
     HM_ARG(h != nullptr, "hm_brox_set_omega: NULL handle");
     HM_ARG(omega > 0.0f && omega < 2.0f, "hm_brox_set_omega: omega must be in (0,2), got %g", omega);
     h->omega = omega;
-    drop_graphs(h);
     return HM_OK;
 }
 
@@ -332,14 +314,10 @@ extern "C" int hm_brox_tune(hm_brox_t h, const char *key, int value)
     } else if (!strcmp(key, "warp_window")) {
         HM_ARG(value == 0 || value == 1, "hm_brox_tune: warp_window must be 0 or 1");
         h->warp_window = value != 0;
-    } else if (!strcmp(key, "graph")) {
-        HM_ARG(value == 0 || value == 1, "hm_brox_tune: graph must be 0 or 1");
-        h->use_graph = value != 0;
     } else {
         hm_set_error("hm_brox_tune: unknown key '%s'", key);
         return HM_ERR_ARG;
     }
-    drop_graphs(h);
     return HM_OK;
 }
 
@@ -359,8 +337,8 @@ extern "C" int hm_brox_profile(hm_brox_t h, int enable)
     HM_HIP(hipSetDevice(h->device));
     h->prof = enable != 0;
     if (enable) {                                  // switching off keeps what was recorded for hm_brox_profile_read
-        h->ev_used = 0; h->prof_ms = 0; h->prof_pxit = 0; h->prof_launches = 0;
-        h->ev_pxit.clear();
+        h->ev_used = 0; h->prof_ms = 0; h->prof_pxit = 0; h->prof_px = 0; h->prof_launches = 0;
+        h->ev_pxit.clear(); h->ev_px.clear();
     }
     return HM_OK;
 }
@@ -373,14 +351,15 @@ static int prof_collect(hm_brox *h)
         HM_HIP(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
         h->prof_ms += ms;
         h->prof_pxit += h->ev_pxit[i / 2];
+        h->prof_px += h->ev_px[i / 2];
         h->prof_launches++;
     }
     h->ev_used = 0;
-    h->ev_pxit.clear();
+    h->ev_pxit.clear(); h->ev_px.clear();
     return HM_OK;
 }
 
-extern "C" int hm_brox_profile_read(hm_brox_t h, double *ms, long long *launches, double *pxit)
+extern "C" int hm_brox_profile_read(hm_brox_t h, double *ms, long long *launches, double *pxit, double *px)
 {
     HM_ARG(h != nullptr, "hm_brox_profile_read: NULL handle");
     HM_HIP(hipSetDevice(h->device));
@@ -390,7 +369,8 @@ extern "C" int hm_brox_profile_read(hm_brox_t h, double *ms, long long *launches
     if (ms) *ms = h->prof_ms;
     if (launches) *launches = h->prof_launches;
     if (pxit) *pxit = h->prof_pxit;
-    h->prof_ms = 0; h->prof_pxit = 0; h->prof_launches = 0;
+    if (px) *px = h->prof_px;
+    h->prof_ms = 0; h->prof_pxit = 0; h->prof_px = 0; h->prof_launches = 0;
     return HM_OK;
 }
 
@@ -400,10 +380,19 @@ static int brox_run(hm_brox *h, int n, const uint8_t *d_f0, const uint8_t *d_f1,
     hipStream_t s = h->stream;
     const int L = (int)h->geo.size();
     const Geo &g0 = h->geo[0];
-    hipLaunchKernelGGL(k_u8_to_f32, grid2d(g0, n), kBlock2d, 0, s, d_f0, h->W, h->W * h->H, h->pyr0[0], g0);
-    hipLaunchKernelGGL(k_u8_to_f32, grid2d(g0, n), kBlock2d, 0, s, d_f1, h->W, h->W * h->H, h->pyr1[0], g0);
+    hipLaunchKernelGGL(k_u8_to_f32, grid2d(g0, 2 * n), kBlock2d, 0, s, d_f0, d_f1, h->W, h->W * h->H, h->pyr0[0], h->pyr1[0], g0, n);
+    // Small levels are launch-latency bound: one fused launch per level (k_pyr_down, k_deriv_all recompute
+    // their taps instead of storing intermediate images -- ~100 / ~56 cached reads per pixel).  Large levels
+    // are bandwidth bound and keep the separate streaming kernels, which read every pixel once per pass
+    // (measured at 8 x 1024^2: fused everywhere 17.8 ms per series against 16.9).
+    const long long fuse_below = 131072;                // pixels of a launch (all pairs)
     for (int k = 1; k < L; k++) {
         const Geo &gs = h->geo[k - 1], &gd = h->geo[k];
+        if ((long long)gd.w * gd.h * n <= fuse_below) {
+            hipLaunchKernelGGL(k_pyr_down, grid2d(gd, 2 * n), kBlock2d, 0, s, h->pyr0[k - 1], h->pyr1[k - 1], gs, h->pyr0[k],
+                               h->pyr1[k], gd, h->taps, n);
+            continue;
+        }
         for (int im = 0; im < 2; im++) {
             float *src = im ? h->pyr1[k - 1] : h->pyr0[k - 1];
             float *dst = im ? h->pyr1[k] : h->pyr0[k];
@@ -412,36 +401,38 @@ static int brox_run(hm_brox *h, int n, const uint8_t *d_f0, const uint8_t *d_f1,
             hipLaunchKernelGGL(k_resample, grid2d(gd, n), kBlock2d, 0, s, h->tmpB, gs, dst, gd, 1.0f);
         }
     }
-    float *u = h->u, *v = h->v, *u2 = h->u2, *v2 = h->v2;
-    {
-        const Geo &gc = h->geo[L - 1];
-        HM_HIP(hipMemsetAsync(u, 0, (size_t)gc.plane * n * sizeof(float), s));
-        HM_HIP(hipMemsetAsync(v, 0, (size_t)gc.plane * n * sizeof(float), s));
-    }
+    // u = v = 0 at the coarsest level and du = dv = 0 at the start of every level: a plane of zeros that is
+    // only ever read (no memsets); u / v of a level are written by the level above it, never in place
+    const float *u = h->zero, *v = h->zero;
+    float *un = h->u, *vn = h->v, *uo = h->u2, *vo = h->v2;      // next level's u, v; the pair after that
     for (int k = L - 1; k >= 0; k--) {
         const Geo &g = h->geo[k];
         const dim3 gr = grid2d(g, n);
-        hipLaunchKernelGGL(k_deriv, gr, kBlock2d, 0, s, h->pyr0[k], h->Ix0, h->Iy0, g);
-        hipLaunchKernelGGL(k_deriv, gr, kBlock2d, 0, s, h->pyr1[k], h->I1x, h->I1y, g);
-        hipLaunchKernelGGL(k_deriv, gr, kBlock2d, 0, s, h->I1x, h->I1xx, h->I1xy, g);
-        hipLaunchKernelGGL(k_deriv, gr, kBlock2d, 0, s, h->I1y, (float *)nullptr, h->I1yy, g);
+        if ((long long)g.w * g.h * n <= fuse_below) {
+            DerivOut dout = {h->Ix0, h->Iy0, h->I1x, h->I1y, h->I1xx, h->I1xy, h->I1yy};
+            hipLaunchKernelGGL(k_deriv_all, gr, kBlock2d, 0, s, h->pyr0[k], h->pyr1[k], dout, g);
+        } else {
+            hipLaunchKernelGGL(k_deriv, gr, kBlock2d, 0, s, h->pyr0[k], h->Ix0, h->Iy0, g);
+            hipLaunchKernelGGL(k_deriv, gr, kBlock2d, 0, s, h->pyr1[k], h->I1x, h->I1y, g);
+            hipLaunchKernelGGL(k_deriv, gr, kBlock2d, 0, s, h->I1x, h->I1xx, h->I1xy, g);
+            hipLaunchKernelGGL(k_deriv, gr, kBlock2d, 0, s, h->I1y, (float *)nullptr, h->I1yy, g);
+        }
         WarpIn wi = {h->pyr0[k], h->Ix0, h->Iy0, h->pyr1[k], h->I1x, h->I1y, h->I1xx, h->I1xy, h->I1yy, u, v};
         WarpOut wo = {h->Iz, h->Ix, h->Iy, h->Ixz, h->Iyz, h->Ixx, h->Ixy, h->Iyy};
         if (h->warp_window) hipLaunchKernelGGL((k_warp<true>), gr, kBlock2d, 0, s, wi, wo, g);
         else hipLaunchKernelGGL((k_warp<false>), gr, kBlock2d, 0, s, wi, wo, g);
-        int cur = 0;
-        HM_HIP(hipMemsetAsync(h->du[0], 0, (size_t)g.plane * n * sizeof(float), s));
-        HM_HIP(hipMemsetAsync(h->dv[0], 0, (size_t)g.plane * n * sizeof(float), s));
+        const float *du = h->zero, *dv = h->zero;
+        int nxt = 0;
         const SorPlan plan = sor_plan(g, h->solver, h->fuse, h->sor_threads);
         Coef co = {h->nu, h->nv, h->a12, h->idu, h->idv, h->sx, h->sy};
         for (int it = 0; it < h->inner; it++) {
-            PrepIn pi = {u, v, h->du[cur], h->dv[cur], h->Iz, h->Ix, h->Iy, h->Ixz, h->Iyz, h->Ixx, h->Ixy, h->Iyy};
+            PrepIn pi = {u, v, du, dv, h->Iz, h->Ix, h->Iy, h->Ixz, h->Iyz, h->Ixx, h->Ixy, h->Iyy};
             hipLaunchKernelGGL(k_prepare, dim3(hm_cdiv(g.w, PREP_BX), hm_cdiv(g.h, PREP_BY), n), dim3(PREP_BX, PREP_BY), 0, s,
                                pi, co, g, h->alpha, h->gamma);
             for (int done = 0; done < h->solver; done += plan.K) {
                 SorArgs a;
-                a.du_in = h->du[cur]; a.dv_in = h->dv[cur];
-                a.du_out = h->du[cur ^ 1]; a.dv_out = h->dv[cur ^ 1];
+                a.du_in = du; a.dv_in = dv;
+                a.du_out = h->du[nxt]; a.dv_out = h->dv[nxt];
                 a.nu = h->nu; a.nv = h->nv; a.a12 = h->a12; a.idu = h->idu; a.idv = h->idv;
                 a.sx = h->sx; a.sy = h->sy;
                 a.g = g;
@@ -461,54 +452,26 @@ static int brox_run(hm_brox *h, int n, const uint8_t *d_f0, const uint8_t *d_f1,
                 if (rec) {
                     h->ev_used += 2;
                     h->ev_pxit.push_back((double)g.w * g.h * n * plan.K);
+                    h->ev_px.push_back((double)g.w * g.h * n);
                 }
-                cur ^= 1;
+                du = h->du[nxt]; dv = h->dv[nxt];
+                nxt ^= 1;
             }
         }
-        hipLaunchKernelGGL(k_add, gr, kBlock2d, 0, s, u, v, h->du[cur], h->dv[cur], g);
         if (k > 0) {
             const Geo &gf = h->geo[k - 1];
-            const dim3 grf = grid2d(gf, n);
-            hipLaunchKernelGGL(k_resample, grf, kBlock2d, 0, s, u, g, u2, gf, (float)gf.w / (float)g.w);
-            hipLaunchKernelGGL(k_resample, grf, kBlock2d, 0, s, v, g, v2, gf, (float)gf.h / (float)g.h);
-            float *t = u; u = u2; u2 = t;
-            t = v; v = v2; v2 = t;
+            hipLaunchKernelGGL(k_add_prolong, grid2d(gf, n), kBlock2d, 0, s, u, v, du, dv, g, un, vn, gf,
+                               (float)gf.w / (float)g.w, (float)gf.h / (float)g.h);
+            u = un; v = vn;
+            float *t = un; un = uo; uo = t;
+            t = vn; vn = vo; vo = t;
+        } else {
+            // level-0 planes are pitched; the caller's arrays are tight
+            hipLaunchKernelGGL(k_add_out, gr, kBlock2d, 0, s, u, v, du, dv, g, d_ox, d_oy);
         }
-    }
-    // level-0 planes are pitched; the caller's arrays are tight
-    for (int b = 0; b < n; b++) {
-        HM_HIP(hipMemcpy2DAsync(d_ox + (size_t)b * h->W * h->H, h->W * sizeof(float), u + (size_t)b * g0.plane,
-                                g0.pitch * sizeof(float), h->W * sizeof(float), h->H, hipMemcpyDeviceToDevice, s));
-        HM_HIP(hipMemcpy2DAsync(d_oy + (size_t)b * h->W * h->H, h->W * sizeof(float), v + (size_t)b * g0.plane,
-                                g0.pitch * sizeof(float), h->W * sizeof(float), h->H, hipMemcpyDeviceToDevice, s));
     }
     HM_HIP(hipGetLastError());
     return HM_OK;
-}
-
-// the launch series of a calc call for n pairs as an instantiated graph (captured on first use)
-static int brox_graph(hm_brox *h, int n)
-{
-    hipGraphExec_t &exec = h->graphs[n - 1];
-    if (exec) return HM_OK;
-    hipGraph_t graph = nullptr;
-    HM_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    int rc = brox_run(h, n, h->d_f0, h->d_f1, h->d_ox, h->d_oy);
-    hipError_t e = hipStreamEndCapture(h->stream, &graph);
-    if (rc != HM_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-    if (e != hipSuccess) { hm_set_error("hm_brox: stream capture failed: %s", hipGetErrorString(e)); return HM_ERR_HIP; }
-    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (e != hipSuccess) { exec = nullptr; hm_set_error("hm_brox: hipGraphInstantiate failed: %s", hipGetErrorString(e)); return HM_ERR_HIP; }
-    return HM_OK;
-}
-
-extern "C" int hm_brox_prepare(hm_brox_t h, int n)
-{
-    HM_ARG(h != nullptr, "hm_brox_prepare: NULL handle");
-    HM_ARG(n >= 1 && n <= h->B, "hm_brox_prepare: n=%d outside 1..max_batch=%d", n, h->B);
-    HM_HIP(hipSetDevice(h->device));
-    return h->use_graph ? brox_graph(h, n) : HM_OK;
 }
 
 extern "C" int hm_brox_calc_dev(hm_brox_t h, int n, const uint8_t *d_f0, const uint8_t *d_f1, float *d_ox, float *d_oy)
@@ -517,25 +480,7 @@ extern "C" int hm_brox_calc_dev(hm_brox_t h, int n, const uint8_t *d_f0, const u
     HM_ARG(n >= 1 && n <= h->B, "hm_brox_calc_dev: n=%d outside 1..max_batch=%d", n, h->B);
     HM_ARG(d_f0 && d_f1 && d_ox && d_oy, "hm_brox_calc_dev: NULL pointer");
     HM_HIP(hipSetDevice(h->device));
-    if (h->prof || !h->use_graph)                  // per-launch events need real launches
-        return brox_run(h, n, d_f0, d_f1, d_ox, d_oy);
-    // The captured series works on the handle's own staging buffers (graph nodes hold fixed
-    // addresses); the caller's frames and flow planes are copied in and out around it.
-    const size_t px = (size_t)h->W * h->H * n;
-    const bool in_place = d_f0 == h->d_f0 && d_f1 == h->d_f1 && d_ox == h->d_ox && d_oy == h->d_oy;
-    if (!in_place) {
-        HM_HIP(hipMemcpyAsync(h->d_f0, d_f0, px, hipMemcpyDeviceToDevice, h->stream));
-        HM_HIP(hipMemcpyAsync(h->d_f1, d_f1, px, hipMemcpyDeviceToDevice, h->stream));
-    }
-    int rc = brox_graph(h, n);
-    if (rc) return rc;
-    hipGraphExec_t exec = h->graphs[n - 1];
-    HM_HIP(hipGraphLaunch(exec, h->stream));
-    if (!in_place) {
-        HM_HIP(hipMemcpyAsync(d_ox, h->d_ox, px * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-        HM_HIP(hipMemcpyAsync(d_oy, h->d_oy, px * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-    }
-    return HM_OK;
+    return brox_run(h, n, d_f0, d_f1, d_ox, d_oy);
 }
 
 extern "C" int hm_brox_calc_batch(hm_brox_t h, int n, const uint8_t *f0, const uint8_t *f1, float *ox, float *oy)
@@ -623,6 +568,68 @@ extern "C" int hm_op_resample(const float *src, int ws, int hs, float *dst, int 
     hipLaunchKernelGGL(k_resample, grid2d(gd, 1), kBlock2d, 0, 0, a, gs, b, gd, mul);
     HM_HIP(hipDeviceSynchronize());
     OP_CHECK(Scratch::down(gd, b, dst));
+    return HM_OK;
+}
+
+// the fused launches calc uses: one pyramid level (blur rows, blur columns, resample) ...
+extern "C" int hm_op_pyr_down(const float *src, int ws, int hs, float scale, float *dst, int wd, int hd)
+{
+    HM_ARG(src && dst && ws >= 1 && hs >= 1 && wd >= 1 && hd >= 1 && scale > 0.0f && scale < 1.0f, "hm_op_pyr_down: bad argument");
+    Geo gs = make_geo(ws, hs), gd = make_geo(wd, hd);
+    Taps t = make_taps(scale);
+    Scratch sc;
+    float *a = sc.up(gs, src), *b = sc.plane(gd), *c = sc.plane(gd);
+    OP_CHECK(a && b && c);
+    hipLaunchKernelGGL(k_pyr_down, grid2d(gd, 2), kBlock2d, 0, 0, a, a, gs, b, c, gd, t, 1);     // both "frames" = src
+    HM_HIP(hipDeviceSynchronize());
+    OP_CHECK(Scratch::down(gd, c, dst));
+    return HM_OK;
+}
+
+// ... all derivative images of a level (out: Ix0, Iy0, I1x, I1y, I1xx, I1xy, I1yy) ...
+extern "C" int hm_op_deriv_all(const float *I0, const float *I1, int w, int h, float *const out[7])
+{
+    HM_ARG(I0 && I1 && out && w >= 1 && h >= 1, "hm_op_deriv_all: bad argument");
+    Geo g = make_geo(w, h);
+    Scratch sc;
+    float *a = sc.up(g, I0), *b = sc.up(g, I1), *o[7];
+    OP_CHECK(a && b);
+    for (int i = 0; i < 7; i++) { o[i] = sc.plane(g); OP_CHECK(o[i]); }
+    DerivOut d = {o[0], o[1], o[2], o[3], o[4], o[5], o[6]};
+    hipLaunchKernelGGL(k_deriv_all, grid2d(g, 1), kBlock2d, 0, 0, a, b, d, g);
+    HM_HIP(hipDeviceSynchronize());
+    for (int i = 0; i < 7; i++) OP_CHECK(Scratch::down(g, o[i], out[i]));
+    return HM_OK;
+}
+
+// ... and u + du, v + dv prolonged to the next finer level (wd x hd; wd = ws, hd = hs: the level-0 form,
+// the sums written to tight planes)
+extern "C" int hm_op_add_prolong(const float *u, const float *v, const float *du, const float *dv, int ws, int hs,
+                                 float *u2, float *v2, int wd, int hd)
+{
+    HM_ARG(u && v && du && dv && u2 && v2 && ws >= 1 && hs >= 1 && wd >= 1 && hd >= 1, "hm_op_add_prolong: bad argument");
+    Geo gs = make_geo(ws, hs), gd = make_geo(wd, hd);
+    Scratch sc;
+    float *a = sc.up(gs, u), *b = sc.up(gs, v), *c = sc.up(gs, du), *d = sc.up(gs, dv);
+    OP_CHECK(a && b && c && d);
+    if (wd == ws && hd == hs) {
+        float *ox = nullptr, *oy = nullptr;
+        OP_CHECK(hipMalloc((void **)&ox, (size_t)ws * hs * sizeof(float)) == hipSuccess);
+        sc.bufs.push_back(ox);
+        OP_CHECK(hipMalloc((void **)&oy, (size_t)ws * hs * sizeof(float)) == hipSuccess);
+        sc.bufs.push_back(oy);
+        hipLaunchKernelGGL(k_add_out, grid2d(gs, 1), kBlock2d, 0, 0, a, b, c, d, gs, ox, oy);
+        HM_HIP(hipDeviceSynchronize());
+        OP_CHECK(hipMemcpy(u2, ox, (size_t)ws * hs * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess);
+        OP_CHECK(hipMemcpy(v2, oy, (size_t)ws * hs * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess);
+        return HM_OK;
+    }
+    float *e = sc.plane(gd), *f = sc.plane(gd);
+    OP_CHECK(e && f);
+    hipLaunchKernelGGL(k_add_prolong, grid2d(gd, 1), kBlock2d, 0, 0, a, b, c, d, gs, e, f, gd, (float)wd / (float)ws,
+                       (float)hd / (float)hs);
+    HM_HIP(hipDeviceSynchronize());
+    OP_CHECK(Scratch::down(gd, e, u2) && Scratch::down(gd, f, v2));
     return HM_OK;
 }
 

@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #define BROX_EPS2 1e-6f
 #define BROX_MAX_TAPS 33
@@ -33,14 +34,16 @@ __device__ __forceinline__ int d_mirror(int i, int n)
 __device__ __forceinline__ int d_clampi(int i, int lo, int hi) { return i < lo ? lo : (i > hi ? hi : i); }
 
 // ---- frame conversion: x * (1/255), as the reference does before calc() -----
-__global__ void k_u8_to_f32(const uint8_t *__restrict__ src, int src_pitch, int src_plane,
-                            float *__restrict__ dst, Geo g)
+// blockIdx.z < nb: frame 0 of pair z -> dst0, else frame 1 of pair z - nb -> dst1 (one launch for both)
+__global__ void k_u8_to_f32(const uint8_t *__restrict__ src0, const uint8_t *__restrict__ src1, int src_pitch, int src_plane,
+                            float *__restrict__ dst0, float *__restrict__ dst1, Geo g, int nb)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x;
     int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= g.w || y >= g.h) return;
-    const uint8_t *s = src + (size_t)blockIdx.z * src_plane;
-    float *d = dst + (size_t)blockIdx.z * g.plane;
+    const int second = (int)blockIdx.z >= nb, b = second ? blockIdx.z - nb : blockIdx.z;
+    const uint8_t *s = (second ? src1 : src0) + (size_t)b * src_plane;
+    float *d = (second ? dst1 : dst0) + (size_t)b * g.plane;
     d[y * g.pitch + x] = (float)s[y * src_pitch + x] * (1.0f / 255.0f);
 }
 
@@ -116,6 +119,139 @@ __global__ void k_deriv(const float *__restrict__ src, float *__restrict__ dx, f
         dy[off + y * g.pitch + x] = d_d5(s[d_mirror(y - 2, g.h) * g.pitch + x], s[d_mirror(y - 1, g.h) * g.pitch + x],
                                          s[d_mirror(y + 1, g.h) * g.pitch + x], s[d_mirror(y + 2, g.h) * g.pitch + x]);
     }
+}
+
+// ---- one pyramid level in one launch: Gaussian (rows, then columns) and resampling, both frames ------
+// The value of every tap is computed the way the separate kernels compute it (k_blur<false>, k_blur<true>,
+// k_resample: the same operations in the same order, so the same bits); the blurred image is never
+// stored.  A level costs one launch instead of six; the ~100 reads per output pixel come out of L1 / L2.
+// blockIdx.z < nb: frame 0, else frame 1.
+__device__ __forceinline__ float d_blur_at(const float *__restrict__ s, const Geo &g, const Taps &t, int x, int y)
+{
+    float acc = 0.0f;                                   // k_blur<true> over rows y - R .. y + R of ...
+    for (int j = -t.R; j <= t.R; j++) {
+        const float *row = s + d_mirror(y + j, g.h) * g.pitch;
+        float h = 0.0f;                                 // ... k_blur<false> of that row at x
+        for (int i = -t.R; i <= t.R; i++) h = h + t.g[i + t.R] * row[d_mirror(x + i, g.w)];
+        acc = acc + t.g[j + t.R] * h;
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void k_pyr_down(const float *__restrict__ src0, const float *__restrict__ src1, Geo gs,
+                                                   float *__restrict__ dst0, float *__restrict__ dst1, Geo gd, Taps t, int nb)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= gd.w || y >= gd.h) return;
+    const int second = (int)blockIdx.z >= nb, b = second ? blockIdx.z - nb : blockIdx.z;
+    const float *s = (second ? src1 : src0) + (size_t)b * gs.plane;
+    float *d = (second ? dst1 : dst0) + (size_t)b * gd.plane;
+    // k_resample / d_bilin on the blurred image
+    const float rx = (float)gs.w / (float)gd.w, ry = (float)gs.h / (float)gd.h;
+    float px = ((float)x + 0.5f) * rx - 0.5f;
+    float py = ((float)y + 0.5f) * ry - 0.5f;
+    const int w = gs.w, h = gs.h;
+    if (px < 0.0f) px = 0.0f;
+    if (py < 0.0f) py = 0.0f;
+    if (px > (float)(w - 1)) px = (float)(w - 1);
+    if (py > (float)(h - 1)) py = (float)(h - 1);
+    const float fx0 = floorf(px), fy0 = floorf(py);
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const int x1 = x0 + 1 < w ? x0 + 1 : w - 1;
+    const int y1 = y0 + 1 < h ? y0 + 1 : h - 1;
+    const float ax = px - fx0, ay = py - fy0;
+    const float a = d_blur_at(s, gs, t, x0, y0), bq = d_blur_at(s, gs, t, x1, y0);
+    const float c = d_blur_at(s, gs, t, x0, y1), dq = d_blur_at(s, gs, t, x1, y1);
+    const float top = (1.0f - ax) * a + ax * bq;
+    const float bot = (1.0f - ax) * c + ax * dq;
+    d[y * gd.pitch + x] = ((1.0f - ay) * top + ay * bot) * 1.0f;
+}
+
+// ---- all derivative images of a level in one launch ----------------------------------------------------
+// Ix0, Iy0 of frame 0; I1x, I1y, I1xx, I1xy, I1yy of frame 1 -- what four k_deriv launches produce
+// (second derivatives = the first-derivative operator applied to the first-derivative image, evaluated
+// here from the image itself: the same operations on the same values).
+struct DerivOut {
+    float *Ix0, *Iy0, *I1x, *I1y, *I1xx, *I1xy, *I1yy;
+};
+__device__ __forceinline__ float d_dx_at(const float *__restrict__ s, const Geo &g, int x, int y)
+{
+    const float *r = s + y * g.pitch;
+    return d_d5(r[d_mirror(x - 2, g.w)], r[d_mirror(x - 1, g.w)], r[d_mirror(x + 1, g.w)], r[d_mirror(x + 2, g.w)]);
+}
+__device__ __forceinline__ float d_dy_at(const float *__restrict__ s, const Geo &g, int x, int y)
+{
+    return d_d5(s[d_mirror(y - 2, g.h) * g.pitch + x], s[d_mirror(y - 1, g.h) * g.pitch + x],
+                s[d_mirror(y + 1, g.h) * g.pitch + x], s[d_mirror(y + 2, g.h) * g.pitch + x]);
+}
+__global__ __launch_bounds__(256) void k_deriv_all(const float *__restrict__ I0, const float *__restrict__ I1, DerivOut o, Geo g)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    const size_t off = (size_t)blockIdx.z * g.plane;
+    const float *a = I0 + off, *b = I1 + off;
+    const size_t p = off + y * g.pitch + x;
+    o.Ix0[p] = d_dx_at(a, g, x, y);
+    o.Iy0[p] = d_dy_at(a, g, x, y);
+    o.I1x[p] = d_dx_at(b, g, x, y);
+    o.I1y[p] = d_dy_at(b, g, x, y);
+    const int xm2 = d_mirror(x - 2, g.w), xm1 = d_mirror(x - 1, g.w), xp1 = d_mirror(x + 1, g.w), xp2 = d_mirror(x + 2, g.w);
+    const int ym2 = d_mirror(y - 2, g.h), ym1 = d_mirror(y - 1, g.h), yp1 = d_mirror(y + 1, g.h), yp2 = d_mirror(y + 2, g.h);
+    o.I1xx[p] = d_d5(d_dx_at(b, g, xm2, y), d_dx_at(b, g, xm1, y), d_dx_at(b, g, xp1, y), d_dx_at(b, g, xp2, y));
+    o.I1xy[p] = d_d5(d_dx_at(b, g, x, ym2), d_dx_at(b, g, x, ym1), d_dx_at(b, g, x, yp1), d_dx_at(b, g, x, yp2));
+    o.I1yy[p] = d_d5(d_dy_at(b, g, x, ym2), d_dy_at(b, g, x, ym1), d_dy_at(b, g, x, yp1), d_dy_at(b, g, x, yp2));
+}
+
+// ---- u + du, v + dv carried to the next finer level (or, at level 0, to the caller's arrays) in one launch ----
+// What k_add followed by two k_resample launches (and, at the end, two strided copies per pair) did: the taps
+// of the bilinear prolongation are the sums u + du themselves.
+__device__ __forceinline__ float d_bilin_sum(const float *__restrict__ a, const float *__restrict__ b, int w, int h, int pitch,
+                                             float px, float py)
+{
+    if (px < 0.0f) px = 0.0f;
+    if (py < 0.0f) py = 0.0f;
+    if (px > (float)(w - 1)) px = (float)(w - 1);
+    if (py > (float)(h - 1)) py = (float)(h - 1);
+    float fx0 = floorf(px), fy0 = floorf(py);
+    int x0 = (int)fx0, y0 = (int)fy0;
+    int x1 = x0 + 1 < w ? x0 + 1 : w - 1;
+    int y1 = y0 + 1 < h ? y0 + 1 : h - 1;
+    float ax = px - fx0, ay = py - fy0;
+    float q00 = a[y0 * pitch + x0] + b[y0 * pitch + x0], q01 = a[y0 * pitch + x1] + b[y0 * pitch + x1];
+    float q10 = a[y1 * pitch + x0] + b[y1 * pitch + x0], q11 = a[y1 * pitch + x1] + b[y1 * pitch + x1];
+    float top = (1.0f - ax) * q00 + ax * q01;
+    float bot = (1.0f - ax) * q10 + ax * q11;
+    return (1.0f - ay) * top + ay * bot;
+}
+
+__global__ __launch_bounds__(256) void k_add_prolong(const float *__restrict__ u, const float *__restrict__ v,
+                                                      const float *__restrict__ du, const float *__restrict__ dv, Geo gs,
+                                                      float *__restrict__ u2, float *__restrict__ v2, Geo gd, float mulx, float muly)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= gd.w || y >= gd.h) return;
+    const float rx = (float)gs.w / (float)gd.w, ry = (float)gs.h / (float)gd.h;
+    const float sx = ((float)x + 0.5f) * rx - 0.5f;
+    const float sy = ((float)y + 0.5f) * ry - 0.5f;
+    const size_t so = (size_t)blockIdx.z * gs.plane, q = (size_t)blockIdx.z * gd.plane + y * gd.pitch + x;
+    u2[q] = d_bilin_sum(u + so, du + so, gs.w, gs.h, gs.pitch, sx, sy) * mulx;
+    v2[q] = d_bilin_sum(v + so, dv + so, gs.w, gs.h, gs.pitch, sx, sy) * muly;
+}
+
+// level 0: the sums go straight into the caller's tight W x H planes
+__global__ void k_add_out(const float *__restrict__ u, const float *__restrict__ v, const float *__restrict__ du,
+                          const float *__restrict__ dv, Geo g, float *__restrict__ ox, float *__restrict__ oy)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    const size_t p = (size_t)blockIdx.z * g.plane + y * g.pitch + x;
+    const size_t q = ((size_t)blockIdx.z * g.h + y) * g.w + x;
+    ox[q] = u[p] + du[p];
+    oy[q] = v[p] + dv[p];
 }
 
 // ---- warp: frame 1 and its derivative images sampled at (x+u, y+v) ---------------
@@ -479,44 +615,56 @@ __global__ __launch_bounds__(NT) void k_sor(SorArgs a, int K)
     }
     __syncthreads();
 
+    // A tile that does not touch the image border needs none of the border selects below (they never fire):
+    // the loop is compiled twice and the workgroup takes its variant -- a quarter fewer vector instructions
+    // for all but the outermost ring of tiles (profiles/r02_sor_sq_counters.csv: the kernel is bound by
+    // vector-instruction issue, not by memory).
+    const bool touches = gx0 <= 0 || gy0 <= 0 || gx0 + TW >= w || gy0 + TH >= h;
     const float om = a.om, om1 = a.om1;
+    auto sweep = [&](auto border_tag) {
+        constexpr bool BORDER = decltype(border_tag)::value;
 #pragma unroll 1
-    for (int it = 0; it < K; it++) {
+        for (int it = 0; it < K; it++) {
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
+            for (int c = 0; c < 2; c++) {
 #pragma unroll
-            for (int j = 0; j < RPT; j++) {
-                // colour c in row r: pixel x = 2i + q with q = (r + c) & 1 = (j + c) & 1
-                const int q = (j + c) & 1;
-                const int r = r0 + j, gy = gy0 + r, gx = gxa + q;
-                const int oc = (1 - c) * HALF;           // neighbours have the other colour
-                // slots of the left / right neighbours inside their row
-                int il = q ? i : i - 1, ir = q ? i + 1 : i;
-                il = il < 0 ? 0 : il;
-                ir = ir > HALF - 1 ? HALF - 1 : ir;
-                const int ru = r > 0 ? r - 1 : 0, rd = r < TH - 1 ? r + 1 : TH - 1;
-                const float2 pc = s_uv[r * TW + c * HALF + i];
-                const float2 pl = s_uv[r * TW + oc + il], pr = s_uv[r * TW + oc + ir];
-                const float2 pt = s_uv[ru * TW + oc + i], pb = s_uv[rd * TW + oc + i];
-                const float cu = pc.x, cv = pc.y;
-                float ul = pl.x, ur = pr.x, ut = pt.x, ub = pb.x;
-                float vl = pl.y, vr = pr.y, vt = pt.y, vb = pb.y;
-                // at the image border the oracle pairs the (zero) weight with the pixel itself
-                if (gx <= 0) { ul = cu; vl = cv; }
-                if (gx >= w - 1) { ur = cu; vr = cv; }
-                if (gy <= 0) { ut = cu; vt = cv; }
-                if (gy >= h - 1) { ub = cu; vb = cv; }
-                const float wl = q ? sr[j][0] : sl0[j];
-                const float wt = j > 0 ? sb[j > 0 ? j - 1 : 0][q] : st0[q];
-                const float su = ((wl * ul + sr[j][q] * ur) + wt * ut) + sb[j][q] * ub;
-                const float sv = ((wl * vl + sr[j][q] * vr) + wt * vt) + sb[j][q] * vb;
-                const float dun = om1 * cu + om * (((nu[j][q] - a12[j][q] * cv) + su) * idu[j][q]);
-                const float dvn = om1 * cv + om * (((nv[j][q] - a12[j][q] * dun) + sv) * idv[j][q]);
-                s_uv[r * TW + c * HALF + i] = make_float2(dun, dvn);
+                for (int j = 0; j < RPT; j++) {
+                    // colour c in row r: pixel x = 2i + q with q = (r + c) & 1 = (j + c) & 1
+                    const int q = (j + c) & 1;
+                    const int r = r0 + j, gy = gy0 + r, gx = gxa + q;
+                    const int oc = (1 - c) * HALF;           // neighbours have the other colour
+                    // slots of the left / right neighbours inside their row
+                    int il = q ? i : i - 1, ir = q ? i + 1 : i;
+                    il = il < 0 ? 0 : il;
+                    ir = ir > HALF - 1 ? HALF - 1 : ir;
+                    const int ru = r > 0 ? r - 1 : 0, rd = r < TH - 1 ? r + 1 : TH - 1;
+                    const float2 pc = s_uv[r * TW + c * HALF + i];
+                    const float2 pl = s_uv[r * TW + oc + il], pr = s_uv[r * TW + oc + ir];
+                    const float2 pt = s_uv[ru * TW + oc + i], pb = s_uv[rd * TW + oc + i];
+                    const float cu = pc.x, cv = pc.y;
+                    float ul = pl.x, ur = pr.x, ut = pt.x, ub = pb.x;
+                    float vl = pl.y, vr = pr.y, vt = pt.y, vb = pb.y;
+                    if (BORDER) {
+                        // at the image border the oracle pairs the (zero) weight with the pixel itself
+                        if (gx <= 0) { ul = cu; vl = cv; }
+                        if (gx >= w - 1) { ur = cu; vr = cv; }
+                        if (gy <= 0) { ut = cu; vt = cv; }
+                        if (gy >= h - 1) { ub = cu; vb = cv; }
+                    }
+                    const float wl = q ? sr[j][0] : sl0[j];
+                    const float wt = j > 0 ? sb[j > 0 ? j - 1 : 0][q] : st0[q];
+                    const float su = ((wl * ul + sr[j][q] * ur) + wt * ut) + sb[j][q] * ub;
+                    const float sv = ((wl * vl + sr[j][q] * vr) + wt * vt) + sb[j][q] * vb;
+                    const float dun = om1 * cu + om * (((nu[j][q] - a12[j][q] * cv) + su) * idu[j][q]);
+                    const float dvn = om1 * cv + om * (((nv[j][q] - a12[j][q] * dun) + sv) * idv[j][q]);
+                    s_uv[r * TW + c * HALF + i] = make_float2(dun, dvn);
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
-    }
+    };
+    if (touches) sweep(std::true_type{});
+    else sweep(std::false_type{});
 
     // write back the interior
     const int lx = 2 * i;

@@ -108,14 +108,24 @@ static int ctx_join(hm_ctx *h)
 
 // Wait for the stream: poll it for a while (a few microseconds of latency) before falling back on
 // hipStreamSynchronize, whose wake-up costs ~20 us -- three of those per frame on the compute() path.
+// (A short pure spin, then the core is offered to other threads between polls: with several trackers
+// per GPU plus their flow and prefactor helper threads on a CPU-quota'd host the pollers must not take
+// the cores away from the threads that queue the launches.)
 static hipError_t stream_wait(hipStream_t s)
 {
-    const auto t_give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+    const auto t0 = std::chrono::steady_clock::now();
+    const auto t_yield = t0 + std::chrono::microseconds(50), t_give_up = t0 + std::chrono::milliseconds(20);
+    bool polite = false;
     for (int spin = 0;; spin++) {
         const hipError_t e = hipStreamQuery(s);
         if (e != hipErrorNotReady) return e;
-        __builtin_ia32_pause();
-        if ((spin & 255) == 255 && std::chrono::steady_clock::now() > t_give_up) return hipStreamSynchronize(s);
+        if (polite) std::this_thread::yield();
+        else __builtin_ia32_pause();
+        if ((spin & 15) == 15) {
+            const auto now = std::chrono::steady_clock::now();
+            if (now > t_give_up) return hipStreamSynchronize(s);
+            polite = now > t_yield;
+        }
     }
 }
 
@@ -128,7 +138,7 @@ static int ctx_free(hm_ctx *h)
                     h->d_yfy, h->d_yfxm, h->d_yfym, h->d_setup, h->d_cfgs, h->d_ubox, h->d_X, h->d_out, h->d_partial, h->d_im8, h->d_m8,
                     h->d_HTH, h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_T[0], h->d_T[1], h->d_step, h->d_Wprior, h->d_gain, h->d_Awork, h->d_Lt[0], h->d_Lt[1],
                     h->d_Wtmp, h->d_X0, h->d_Xn, h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk,
-                    h->pool.hdr, h->pool.xim, h->pool.xm, h->pool.yim, h->pool.ym, h->pool.xfx, h->pool.xfy,
+                    h->pool.hdr, h->pool.xi, h->pool.yi, h->pool.xfx, h->pool.xfy,
                     h->pool.yfx, h->pool.yfy, h->pool.vxfx, h->pool.vyfy, h->pool.overflow, h->d_area,
                     h->d_outline, h->d_outline_cnt, h->d_pm_mask};
     for (void *p : ptrs)
@@ -257,17 +267,18 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         if (e == hipSuccess) e = hipHostMalloc((void **)&h->pin, h->pin_n * sizeof(double), hipHostMallocCoherent);
         if (e == hipSuccess) memset(h->pin, 0, h->pin_n * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_X0, n4 * sizeof(double));
-        // pool of parked difference images: the star regions overlap a few times; 16 frames' worth of
-        // pixels is far above what a triangulated object needs (hm_measure reports an overflow)
-        h->pool.cap = (long long)16 * W * H;
+        // pool of parked difference images (32 B per pixel): the star regions overlap about six times, so a
+        // mesh that covers the whole frame needs about six frames' worth of pixels (the bench's disk, a third
+        // of the frame: 1.5); 8 frames' worth = 268 MB at 1024^2 (hm_measure reports an overflow)
+        h->pool.cap = (long long)8 * W * H;
         const size_t pc = (size_t)h->pool.cap;
         if (e == hipSuccess) e = hipMalloc((void **)&h->pool.hdr, (size_t)4 * N * sizeof(int));
         if (e == hipSuccess) e = hipMalloc((void **)&h->pool.overflow, sizeof(int));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_area, (size_t)N * sizeof(int));
         h->pool.area = h->d_area;
-        short **sp[] = {&h->pool.xim, &h->pool.xm, &h->pool.yim, &h->pool.ym};
-        for (short **q : sp)
-            if (e == hipSuccess) e = hipMalloc((void **)q, pc * sizeof(short));
+        short2 **sp[] = {&h->pool.xi, &h->pool.yi};
+        for (short2 **q : sp)
+            if (e == hipSuccess) e = hipMalloc((void **)q, pc * sizeof(short2));
         float **fp[] = {&h->pool.xfx, &h->pool.xfy, &h->pool.yfx, &h->pool.yfy, &h->pool.vxfx, &h->pool.vyfy};
         for (float **q : fp)
             if (e == hipSuccess) e = hipMalloc((void **)q, pc * sizeof(float));
@@ -577,10 +588,13 @@ extern "C" int hm_measure(hm_ctx_t h, const double *X, double deltaX, int masked
     HM_HIP(hipMemcpyAsync(Hz, h->d_Hz, n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (Hzc) HM_HIP(hipMemcpyAsync(Hzc, h->d_Hzc, n4 * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HM_HIP(hipMemcpyAsync(HTH, h->d_HTH, n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    int ovf = 0;
-    HM_HIP(hipMemcpyAsync(&ovf, h->pool.overflow, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    // the flag lands in the handle's pinned block, not in this frame: an error return below must not leave a
+    // copy in flight towards a dead stack slot
+    int *ovf = (int *)(h->pin + n4 + 6);
+    *ovf = 0;
+    HM_HIP(hipMemcpyAsync(ovf, h->pool.overflow, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HM_HIP(hipStreamSynchronize(h->stream));
-    if (ovf) { hm_set_error("hm_measure: the star regions do not fit the difference-image pool"); return HM_ERR_STATE; }
+    if (*ovf) { hm_set_error("hm_measure: the star regions do not fit the difference-image pool"); return HM_ERR_STATE; }
     return HM_OK;
 }
 
@@ -725,20 +739,22 @@ extern "C" int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int ma
     HM_HIP(hipGetLastError());
     HM_HIP(hipMemcpyAsync(step, rhs_row, (size_t)n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (Hzc) HM_HIP(hipMemcpyAsync(Hzc, h->d_Hzc, (size_t)n4 * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    int ovf = 0;
-    HM_HIP(hipMemcpyAsync(&ovf, h->pool.overflow, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    int *ovf = (int *)(h->pin + n4 + 6);                     // pinned, lives with the handle (see hm_measure)
+    *ovf = 0;
+    HM_HIP(hipMemcpyAsync(ovf, h->pool.overflow, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (err) {
         // Renderer.error of the new iterate X0 + step, without another host round trip
         rc = render_dev(h, h->d_Xn, h->P);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_error, dim3(h->red_blocks), dim3(RED_NT), 0, h->stream, h->P, obs_of(h, masked),
-                           h->W * h->H, h->d_partial);
-        rc = collect4(h, err);                                   // synchronises the stream
-        if (rc) return rc;
+        if (rc == HM_OK) {
+            hipLaunchKernelGGL(k_error, dim3(h->red_blocks), dim3(RED_NT), 0, h->stream, h->P, obs_of(h, masked),
+                               h->W * h->H, h->d_partial);
+            rc = collect4(h, err);                               // synchronises the stream
+        }
+        if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }   // nothing of this call stays in flight
     } else {
         HM_HIP(hipStreamSynchronize(h->stream));
     }
-    if (ovf) { hm_set_error("hm_update_step: the star regions do not fit the difference-image pool"); return HM_ERR_STATE; }
+    if (*ovf) { hm_set_error("hm_update_step: the star regions do not fit the difference-image pool"); return HM_ERR_STATE; }
     h->upd_prev = h->upd_last;
     h->upd_last = slot;
     return HM_OK;
@@ -870,12 +886,18 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
         {
             const volatile double *ticket = res + n4 + 5;
             const double want = (double)h->run_ticket;
-            const auto t_give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
-            bool seen = false;
+            const auto t_start = std::chrono::steady_clock::now();
+            const auto t_yield = t_start + std::chrono::microseconds(700), t_give_up = t_start + std::chrono::milliseconds(20);
+            bool seen = false, polite = false;          // an iteration takes ~0.4 ms: spin for that long, then yield between polls
             for (int spin = 0;; spin++) {
                 if (*ticket == want) { seen = true; break; }
-                __builtin_ia32_pause();
-                if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() > t_give_up) break;
+                if (polite) std::this_thread::yield();
+                else __builtin_ia32_pause();
+                if ((spin & 255) == 255) {
+                    const auto now = std::chrono::steady_clock::now();
+                    if (now > t_give_up) break;
+                    polite = now > t_yield;
+                }
             }
             if (!seen) HM_HIP(hipStreamSynchronize(h->stream));
             std::atomic_thread_fence(std::memory_order_acquire);

@@ -471,10 +471,16 @@ __device__ inline void d_star_setups(TriSetup *dst, int ns, const int *tris, con
 // vertex v its star region (bounding box over all configurations) is a slab of the pool starting at
 // pixel offset off[v]; per pixel: D_{v,x} and D_{v,y} in the four channels (image and mask as 16-bit
 // integers in 1/255 units, flow as f32) and the flow channel of the two velocity perturbations.
+// Layout for whole sectors: a region starts at a column that is a multiple of 8 and is a multiple of 8
+// columns wide, so that the 8-pixel rows of the tiles k_measure_vertex works on are aligned 32-byte pieces
+// of every plane (the two 16-bit channels of a perturbation share one 32-bit plane) -- and of the reference
+// render and the observation, whose rows the same tiles read.  Unaligned, an 8-pixel row of a 16-bit plane
+// is a quarter of a sector and an f32 row straddles two: the kernel moved 3.5x its payload
+// (profiles/r01_ekf_traffic.csv).
 struct DPool {
-    int *hdr;                 // N x 4: c0, r0, rw, rh of the region
+    int *hdr;                 // N x 4: c0, r0, rw, rh of the region (c0 and rw multiples of 8)
     const int *area;          // N region areas (k_star_regions); a region's offset is the sum of those before it
-    short *xim, *xm, *yim, *ym;
+    short2 *xi, *yi;          // (image, mask) numerators of D_{v,x} and D_{v,y}
     float *xfx, *xfy, *yfx, *yfy, *vxfx, *vyfy;
     long long cap;            // pixels in the pool
     int *overflow;            // set to 1 if the regions do not fit
@@ -583,7 +589,8 @@ __global__ __launch_bounds__(REGION_NT) void k_star_regions(MeasureArgs a, int *
         c0 = min(c0, s_box[cfg][0]); c1 = max(c1, s_box[cfg][1]);
         r0 = min(r0, s_box[cfg][2]); r1 = max(r1, s_box[cfg][3]);
     }
-    const int rw = max(0, c1 - c0 + 1), rh = max(0, r1 - r0 + 1);
+    if (c1 >= c0) c0 &= ~7;                                        // whole sectors: see DPool
+    const int rw = c1 >= c0 ? (c1 - c0 + 8) & ~7 : 0, rh = max(0, r1 - r0 + 1);
     a.pool.hdr[4 * v] = c0; a.pool.hdr[4 * v + 1] = r0; a.pool.hdr[4 * v + 2] = rw; a.pool.hdr[4 * v + 3] = rh;
     area[v] = rw * rh;
 }
@@ -662,7 +669,7 @@ __global__ __launch_bounds__(MEAS_NT, 4) void k_measure_vertex(MeasureArgs a, co
             const int4 b = ubox[(size_t)v * UBOX_STRIDE + k];
             if (!((b.y < tc0) | (b.x > tc0 + 7) | (b.w < tr0) | (b.z > tr0 + 7))) mask |= 1u << k;
         }
-        if (r >= r0 + rh || c >= c0 + rw) continue;
+        if (r >= r0 + rh || c >= c0 + rw || c >= W) continue;      // (the padding of a region may leave the frame)
         const int i = (r - r0) * rw + (c - c0);
         const int p = r * W + c;
         const int racc = a.ref.acc[p], rcnt = a.ref.cnt[p];
@@ -684,7 +691,7 @@ __global__ __launch_bounds__(MEAS_NT, 4) void k_measure_vertex(MeasureArgs a, co
         }
         if (sref.cnt + sxp.cnt + sxm.cnt + syp.cnt + sym.cnt == 0) {
             if (park) {
-                a.pool.xim[pp] = 0; a.pool.xm[pp] = 0; a.pool.yim[pp] = 0; a.pool.ym[pp] = 0;
+                a.pool.xi[pp] = make_short2(0, 0); a.pool.yi[pp] = make_short2(0, 0);
                 a.pool.xfx[pp] = 0.0f; a.pool.xfy[pp] = 0.0f; a.pool.yfx[pp] = 0.0f; a.pool.yfy[pp] = 0.0f;
                 a.pool.vxfx[pp] = 0.0f; a.pool.vyfy[pp] = 0.0f;
             }
@@ -724,8 +731,8 @@ __global__ __launch_bounds__(MEAS_NT, 4) void k_measure_vertex(MeasureArgs a, co
             acc[A_VXVX] = fma(vf, vf, acc[A_VXVX]); acc[A_VYVY] = fma(vg, vg, acc[A_VYVY]);
         }
         if (park) {
-            a.pool.xim[pp] = (short)d_i255(dxp.im); a.pool.xm[pp] = (short)d_i255(dxp.m);
-            a.pool.yim[pp] = (short)d_i255(dyp.im); a.pool.ym[pp] = (short)d_i255(dyp.m);
+            a.pool.xi[pp] = make_short2((short)d_i255(dxp.im), (short)d_i255(dxp.m));
+            a.pool.yi[pp] = make_short2((short)d_i255(dyp.im), (short)d_i255(dyp.m));
             a.pool.xfx[pp] = dxp.fx; a.pool.xfy[pp] = dxp.fy; a.pool.yfx[pp] = dyp.fx; a.pool.yfy[pp] = dyp.fy;
             a.pool.vxfx[pp] = dvxp.fx; a.pool.vyfy[pp] = dvyp.fy;
         }
@@ -748,7 +755,7 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure_edge(MeasureArgs a)
     const int v = a.topo.edges[2 * e], w = a.topo.edges[2 * e + 1];
     const int *hv = a.pool.hdr + 4 * v, *hw = a.pool.hdr + 4 * w;
     const int c0 = max(hv[0], hw[0]), r0 = max(hv[1], hw[1]);
-    const int c1 = min(hv[0] + hv[2], hw[0] + hw[2]) - 1, r1 = min(hv[1] + hv[3], hw[1] + hw[3]) - 1;
+    const int c1 = min(min(hv[0] + hv[2], hw[0] + hw[2]), a.m.W) - 1, r1 = min(hv[1] + hv[3], hw[1] + hw[3]) - 1;
     const int rw = c1 - c0 + 1, rh = r1 - r0 + 1;
     const int npx = (rw > 0 && rh > 0) ? rw * rh : 0;
     __shared__ long long s_sum[(MEAS_NT / 64) * 3];
@@ -770,10 +777,11 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure_edge(MeasureArgs a)
         const long long pw = bw + (long long)(r - hw[1]) * hw[2] + (c - hw[0]);
         r += dr; c += dc;
         if (c > c1) { c -= rw; r++; }
-        const double axim = k255[P.xim[pv]], axm = k255[P.xm[pv]];     // parked as numerators in -255..255
-        const double ayim = k255[P.yim[pv]], aym = k255[P.ym[pv]];
-        const double bxim = k255[P.xim[pw]], bxm = k255[P.xm[pw]];
-        const double byim = k255[P.yim[pw]], bym = k255[P.ym[pw]];
+        const short2 ax_ = P.xi[pv], ay_ = P.yi[pv], bx_ = P.xi[pw], by_ = P.yi[pw];   // numerators in -255..255
+        const double axim = k255[ax_.x], axm = k255[ax_.y];
+        const double ayim = k255[ay_.x], aym = k255[ay_.y];
+        const double bxim = k255[bx_.x], bxm = k255[bx_.y];
+        const double byim = k255[by_.x], bym = k255[by_.y];
         const double axfx = P.xfx[pv], axfy = P.xfy[pv], ayfx = P.yfx[pv], ayfy = P.yfy[pv];
         const double bxfx = P.xfx[pw], bxfy = P.xfy[pw], byfx = P.yfx[pw], byfy = P.yfy[pw];
         const double avx = P.vxfx[pv], avy = P.vyfy[pv], bvx = P.vxfx[pw], bvy = P.vyfy[pw];

@@ -14,10 +14,13 @@ reference's.  What changes is where the work is done:
   result has the single-perturbation semantics of the reference
   (``multi=False``); ``multi=True`` -- the reference's way of batching several
   perturbations into one render -- is accepted and gives the same numbers.
-* the dense algebra of the update uses one LU factorisation per IEKF iteration
-  instead of an explicit inverse per iteration; the covariance is formed once,
-  for the state that is kept.  Same mathematics, rounding-level differences.
-* the mass-spring predict uses the sparsity of the incidence matrix.
+* the dense algebra of the update runs on the device (``hm_update_run`` /
+  ``hm_update_begin`` / ``_step`` / ``_cov``): one blocked Cholesky factorisation per IEKF
+  iteration on the f64 matrix cores instead of an explicit inverse per iteration; the
+  covariance is formed once, for the state that is kept, and stays on the device between
+  predict and update.  Same mathematics, rounding-level differences.
+* the mass-spring predict is native code (``hm_ms_newton``: block-eliminated Newton, the spring
+  operator applied bar by bar), the covariance prediction a device kernel (``hm_cov_predict``).
 
 There is no CPU measurement path: ``cuda=False`` raises.
 """
@@ -57,9 +60,11 @@ class Statistics:
 
 stats = Statistics()
 
-# The dense update runs on host BLAS.  A default-sized BLAS thread team on a many-core host
-# with a small CPU quota (a container, the GPU box) is slower than a handful of threads by
-# orders of magnitude, so the team is capped (HYDRA_MI_BLAS_THREADS overrides the cap).
+# Host BLAS is only used when a caller supplies its own measurement object (the `renderer=` seam of
+# the constructors, which the CPU tests of the host logic use); the product path does its dense
+# algebra on the device.  For that seam: a default-sized BLAS thread team on a many-core host with a
+# small CPU quota (a container, the GPU box) is slower than a handful of threads by orders of
+# magnitude, so the team is capped (HYDRA_MI_BLAS_THREADS overrides the cap).
 try:
     from threadpoolctl import ThreadpoolController as _ThreadpoolController
 except ImportError:                                   # pragma: no cover
@@ -393,6 +398,10 @@ class KalmanFilter:
         self.predtime = 0
         self.updatetime = 0
         self.projecttime = 0
+        # compute() returns the rendered flow planes as host arrays, as the reference does (renderer.py:485-501).
+        # A streaming caller that only wants the four error sums sets this to False: the planes stay on the
+        # device (8 MB less over PCIe per 1024^2 frame) and compute() returns None in their place.
+        self.return_flow = True
 
     def size(self):
         return self.N * 4
@@ -414,21 +423,26 @@ class KalmanFilter:
         else:
             self.state.renderer.update_frame(y_im, y_flow, y_m)
             y_flow_mask = MaskedFlow(y_flow, y_m) if maskflow is True else y_flow
-        with _blas_cap(enabled=not hasattr(self.state.renderer, "update_run")):
-            t0 = time.time()
-            self.predict()
-            t1 = time.time()
-            self.projectmask(y_m)
-            t2 = time.time()
-            self.update(y_im, y_flow_mask, y_m)
-            t3 = time.time()
-        self.predtime += t1 - t0
-        self.projecttime += t2 - t1
-        self.updatetime += t3 - t2
-        self._say("Prediction time: %g\nProjection time: %g\nUpdate time: %g" % (t1 - t0, t2 - t1, t3 - t2))
-        if imageoutput is not None:
-            self._say("imageoutput=%r ignored: screenshots are not part of this path" % (imageoutput,))
-        return self.error(y_im, y_flow, y_m)
+        r = self.state.renderer
+        r.frame_in_place = True          # the operators below work on the frame just uploaded: no second copy
+        try:
+            with _blas_cap(enabled=not hasattr(r, "update_run")):
+                t0 = time.time()
+                self.predict()
+                t1 = time.time()
+                self.projectmask(y_m)
+                t2 = time.time()
+                self.update(y_im, y_flow_mask, y_m)
+                t3 = time.time()
+            self.predtime += t1 - t0
+            self.projecttime += t2 - t1
+            self.updatetime += t3 - t2
+            self._say("Prediction time: %g\nProjection time: %g\nUpdate time: %g" % (t1 - t0, t2 - t1, t3 - t2))
+            if imageoutput is not None:
+                self._say("imageoutput=%r ignored: screenshots are not part of this path" % (imageoutput,))
+            return self.error(y_im, y_flow, y_m, want_flow=self.return_flow)
+        finally:
+            r.frame_in_place = False
 
     def predict(self):
         """Constant-velocity prediction (:703-718): X <- F X, W <- F W F^T + Weps, F = [[I, I], [0, I]]."""
@@ -500,8 +514,8 @@ class KalmanFilter:
         self.fv = Wn.dot(Hzc[:, 1] + Hzc[:, 2])
         self.mv = Wn.dot(Hzc[:, 3])
 
-    def error(self, y_im, y_flow, y_m):
-        return self.state.renderer.error(self.state, y_im, y_flow, y_m)
+    def error(self, y_im, y_flow, y_m, want_flow=True):
+        return self.state.renderer.error(self.state, y_im, y_flow, y_m, want_flow=want_flow)
 
 
 class IteratedKalmanFilter(KalmanFilter):

@@ -145,8 +145,12 @@ class FlowEKFPipeline:
     """
 
     def __init__(self, kf, video, masks, flow_batch=8, device=0, brox_params=None, sor_threads=512, maskflow=True,
-                 observed=None):
-        """observed: the frames the filter is shown, when they differ from the ones the flow is computed on
+                 observed=None, return_flow=False):
+        """return_flow: whether step() brings the rendered flow planes of every frame to the host, as
+        KalmanFilter.compute does for the reference's callers (8 MB per 1024^2 frame); a frame loop that
+        looks at the error sums and the state only (reference run_kalmanfilter.py:78-89 ignores the return
+        value altogether) leaves them on the device.
+        observed: the frames the filter is shown, when they differ from the ones the flow is computed on
         (the reference CLI tracks the background-subtracted frame, renderer.py:770-773, while its flow tool
         works on the raw video); default: the video itself."""
         video = np.ascontiguousarray(video, np.uint8)
@@ -158,6 +162,7 @@ class FlowEKFPipeline:
             if observed.shape != video.shape:
                 raise ValueError("observed must have the shape of video")
         self.kf, self.maskflow = kf, maskflow
+        kf.return_flow = bool(return_flow)
         self.video, self.masks = video, masks
         self.F, self.H, self.W = video.shape
         self.B = max(1, int(flow_batch))

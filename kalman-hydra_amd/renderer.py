@@ -56,6 +56,7 @@ class Renderer:
         self.vertices = np.array(distmesh.p, np.float64)
         self.velocities = np.array(vel, np.float64).reshape(self.vertices.shape)
         self._obs = None
+        self.frame_in_place = False             # set by KalmanFilter.compute() while the frame it uploaded is current
         self._cov_serial = 0                    # names the covariance resident on the device (DeviceCovariance)
         self.current_frame = tex
         self.current_flowx, self.current_flowy = flow[:, :, 0], flow[:, :, 1]
@@ -128,17 +129,27 @@ class Renderer:
         self._obs = obs
 
     def _masked_flag(self, y_im, y_flow, y_m):
-        """0/1 if the arrays are the uploaded observation (raw or mask-multiplied), else upload them."""
+        """Which of the two device copies of the observed flow an operator uses (0 raw, 1 mask-multiplied),
+        uploading the arrays first unless they are known to be the observation in place.
+
+        The reference's operators always work on the arrays they are given (renderer.py:485-501, 674-679).
+        Host arrays are therefore uploaded on every call -- a caller may have refilled its buffers in
+        place -- except inside KalmanFilter.compute(), which has just uploaded them itself
+        (``frame_in_place``): there the arrays are recognised by identity and the copies are skipped."""
         o = self._obs
         if isinstance(y_im, DeviceObservation):
             if o is not y_im:
                 self.set_observation_dev(y_im)
             return 1 if y_flow is y_im.masked else 0
-        if o is not None and len(o) == 3 and y_im is o[0] and y_m is o[2]:
+        if self.frame_in_place and o is not None and len(o) == 3 and y_im is o[0] and y_m is o[2]:
             if y_flow is o[1]:
                 return 0
             if getattr(y_flow, "_hm_masked_from", None) is o[1]:
                 return 1
+        raw = getattr(y_flow, "_hm_masked_from", None)
+        if raw is not None:                       # a MaskedFlow: upload the flow it was made from, use the masked copy
+            self.set_observation(y_im, raw, y_m)
+            return 1
         self.set_observation(y_im, y_flow, y_m)
         return 0
 

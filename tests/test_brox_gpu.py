@@ -40,6 +40,33 @@ def test_blur_resample_deriv(hm, oracle_brox, w, h):
     assert np.array_equal(dx, rx) and np.array_equal(dy, ry)
 
 
+@pytest.mark.parametrize("w,h", SIZES)
+def test_fused_launches_equal_the_separate_operators(hm, oracle_brox, w, h):
+    """calc builds a pyramid level, the derivative images of a level and the prolongation of u + du in one
+    launch each; every one gives the bits of the oracle's separate operators applied in turn."""
+    from hydra_mi import brox
+    img, img1 = _smooth((h, w), 1), _smooth((h, w), 2)
+    for scale in (0.8, 0.5):
+        wd, hd = int(np.ceil(w * scale)), int(np.ceil(h * scale))
+        want = oracle_brox.resample(oracle_brox.blur(img, scale), wd, hd, 1.0)
+        assert np.array_equal(brox.op_pyr_down(img, wd, hd, scale), want), scale
+    Ix0, Iy0 = oracle_brox.deriv(img)
+    I1x, I1y = oracle_brox.deriv(img1)
+    I1xx, I1xy = oracle_brox.deriv(I1x)
+    _, I1yy = oracle_brox.deriv(I1y)
+    for name, g, r in zip("Ix0 Iy0 I1x I1y I1xx I1xy I1yy".split(), brox.op_deriv_all(img, img1),
+                          (Ix0, Iy0, I1x, I1y, I1xx, I1xy, I1yy)):
+        assert np.array_equal(g, r), name
+    u, v = _rand((h, w), 3, -3, 3), _rand((h, w), 4, -3, 3)
+    du, dv = _rand((h, w), 5, -0.5, 0.5), _rand((h, w), 6, -0.5, 0.5)
+    wf, hf = int(np.ceil(w / 0.8)), int(np.ceil(h / 0.8)) + 1
+    gu, gv = brox.op_add_prolong(u, v, du, dv, wf, hf)
+    assert np.array_equal(gu, oracle_brox.resample(u + du, wf, hf, np.float32(wf) / np.float32(w)))
+    assert np.array_equal(gv, oracle_brox.resample(v + dv, wf, hf, np.float32(hf) / np.float32(h)))
+    su, sv = brox.op_add_prolong(u, v, du, dv, w, h)                  # the level-0 form
+    assert np.array_equal(su, u + du) and np.array_equal(sv, v + dv)
+
+
 def _level_fields(oracle_brox, w, h, seed):
     I0 = _smooth((h, w), seed)
     I1 = _smooth((h, w), seed + 1)
@@ -156,8 +183,8 @@ def test_calc_batch_and_tuning_do_not_change_results(hm, oracle_brox):
     for i in range(3):
         ru, rv = oracle_brox.calc(F0[i], F1[i])
         assert np.array_equal(U[i], ru) and np.array_equal(V[i], rv)
-    for key, val in [("sor_fuse", 1), ("sor_fuse", 2), ("sor_threads", 512), ("sor_fuse", 0), ("sor_threads", 1024), ("graph", 0),
-                     ("graph", 1), ("warp_window", 1), ("warp_window", 0)]:
+    for key, val in [("sor_fuse", 1), ("sor_fuse", 2), ("sor_threads", 512), ("sor_fuse", 0), ("sor_threads", 1024),
+                     ("warp_window", 1), ("warp_window", 0)]:
         bf.tune(key, val)
         U2, V2 = bf.calc_batch(F0, F1)
         assert np.array_equal(U, U2) and np.array_equal(V, V2), (key, val)
@@ -183,38 +210,37 @@ def test_errors_are_loud(hm):
         bf.tune("sor_fuse", 3)        # 3 does not divide solver_iterations = 10
 
 
-def test_prepare_and_profile_totals(hm, oracle_brox):
-    """hm_brox_prepare captures the launch series ahead of the first call (same result); switching
-    the profile off keeps the recorded totals for profile_read."""
+def test_profile_totals(hm, oracle_brox):
+    """Profiling does not change the result; switching it off keeps the recorded totals for profile_read;
+    the totals are those of the launch plan (pixels x fused iterations, pixels per pass)."""
     from hydra_mi import brox, synth
     n = 80
     f0, f1, _, _ = synth.warp_pair(n, "rotate", 1)
     ru, rv = oracle_brox.calc(f0, f1)
     bf = brox.BroxOpticalFlow(n, n, max_batch=2)
-    bf.prepare(1)
-    bf.prepare(2)
-    u, v = bf.calc(f0, f1)
-    assert np.array_equal(u, ru) and np.array_equal(v, rv)
     with pytest.raises(RuntimeError):
-        bf.prepare(3)                 # beyond max_batch
+        bf.tune("graph", 1)           # the round-1 hipGraph knob is gone
     bf.profile(True)
-    bf.calc(f0, f1)
+    u, v = bf.calc(f0, f1)
     bf.profile(False)
-    u2, v2 = bf.calc(f0, f1)          # a replayed graph: not recorded
-    ms, launches, pxit = bf.profile_read()
-    assert launches > 0 and ms > 0 and pxit > 0
-    assert np.array_equal(u2, ru) and np.array_equal(v2, rv)
+    u2, v2 = bf.calc(f0, f1)          # not recorded
+    ms, launches, pxit, px = bf.profile_read()
+    assert launches > 0 and ms > 0 and pxit > 0 and 0 < px <= pxit
+    assert np.array_equal(u, ru) and np.array_equal(v, rv) and np.array_equal(u2, ru) and np.array_equal(v2, rv)
+    # every level: inner x solver red-black iterations over its pixels
+    want = sum(w * h for w, h in bf.levels()) * 10 * 10
+    assert pxit == want
     per_call = launches
     bf.profile(True)
     bf.calc(f0, f1)
-    ms2, launches2, _ = bf.profile_read()
-    assert launches2 == per_call
+    ms2, launches2, pxit2, _ = bf.profile_read()
+    assert launches2 == per_call and pxit2 == want
 
 
 def test_repeated_series_with_caller_reallocating_buffers(hm):
     """A caller that allocates fresh device buffers for every series (a new video each time): the
-    flows must not depend on how often the handle has been used or where the buffers live.  (Replayed
-    hipGraphs failed exactly this from the fifth launch on; the default path launches directly.)"""
+    flows must not depend on how often the handle has been used or where the buffers live.  (The
+    round-1 hipGraph replay failed exactly this from the fifth launch on and was removed.)"""
     torch = pytest.importorskip("torch")
     from hydra_mi import brox, synth
     n, B = 256, 4

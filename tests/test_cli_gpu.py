@@ -42,3 +42,45 @@ def test_flow_tool_then_tracker(hm, tmp_path, oracle_brox):
     res2 = np.load(out2)
     assert res2["X"].shape == res["X"].shape and np.all(np.isfinite(res2["X"]))
     assert np.abs(res2["X"][-1][:2 * N] - res["X"][-1][:2 * N]).max() < 1.5   # flows with 10/10 vs 5/5 iterations
+
+
+def test_pipeline_equals_sequential_calls(hm):
+    """hydra_mi.pipeline.FlowEKFPipeline (flow series of 1, 2, 4 pairs on the flow handle's stream, overlapped
+    with the filter, flow handed over in device memory) gives bit for bit the states of the sequential
+    loop bf.calc(frame k, frame k+1) -> kf.compute (reference run_kalmanfilter.py:78-89 with the flow of
+    README.md:26-31 computed in process)."""
+    from hydra_mi import brox, kalman, mesh, synth
+    from hydra_mi.pipeline import FlowEKFPipeline
+    n, F = 96, 7
+    video, masks, c, r = synth.disk_video(n, F, "warp", 1)
+    zero = np.zeros((n, n, 2), np.float32)
+
+    def new_filter():
+        return kalman.IteratedMSKalmanFilter(mesh.disk_mesh(c[0], c[1], r - 1.0, 14.0), video[0], zero, True, nI=4)
+
+    kf_a = new_filter()
+    bf = brox.BroxOpticalFlow(n, n)
+    seq, seq_err, flows = [], [], []
+    for k in range(F - 1):
+        u, v = bf.calc(video[k], video[k + 1])
+        flows.append((u, v))
+        e = kf_a.compute(video[k + 1], np.dstack((u, v)), masks[k + 1])
+        seq.append(kf_a.state.X.copy())
+        seq_err.append(e[:4])
+    kf_b = new_filter()
+    pipe = FlowEKFPipeline(kf_b, video, masks, flow_batch=4)
+    got = []
+    pipe.run(on_frame=lambda k, e: got.append((k, kf_b.state.X.copy(), e[:4])))
+    assert [g[0] for g in got] == list(range(F - 1))
+    for k, X, e in got:
+        assert np.array_equal(X, seq[k]), k
+        assert e[0] == seq_err[k][0] and e[3] == seq_err[k][3] and e[1] == seq_err[k][1] and e[2] == seq_err[k][2]
+    assert np.array_equal(kf_a.state.W, kf_b.state.W)
+    # random access restarts the series; the flow of a pair does not depend on the series it is computed in
+    f3 = pipe.flow_host(3)
+    assert np.array_equal(f3[:, :, 0], flows[3][0]) and np.array_equal(f3[:, :, 1], flows[3][1])
+    f0 = pipe.flow_host(0)
+    assert np.array_equal(f0[:, :, 0], flows[0][0]) and np.array_equal(f0[:, :, 1], flows[0][1])
+    with pytest.raises(IndexError):
+        pipe.step(F - 1)
+    pipe.close()

@@ -306,6 +306,41 @@ def test_mask_distance_equals_whole_frame_transform(hm):
         assert np.array_equal(kalman._mask_distance(blank)(p), np.zeros(len(p)))
 
 
+def test_videostream_and_shared_gray_conversion(hm, tmp_path):
+    """VideoStream mirrors reference renderer.py:739-805 on an array source; a colour video is converted the way
+    cvtColor(BGR2GRAY) does (renderer.py:752, src/optical_flow_ext.cpp:366-368) by ONE function both command
+    line tools use, so the tracker sees the frames its flow files were computed on."""
+    from hydra_mi import pipeline
+    rng = np.random.default_rng(0)
+    col = rng.integers(0, 256, (4, 12, 10, 3), dtype=np.uint8)
+    fn = str(tmp_path / "colour.npy")
+    np.save(fn, col)
+    gray = pipeline.load_video(fn)
+    want = np.rint(0.114 * col[..., 0] + 0.587 * col[..., 1] + 0.299 * col[..., 2]).astype(np.uint8)
+    assert gray.dtype == np.uint8 and np.array_equal(gray, want)
+    assert np.array_equal(pipeline.to_gray(gray), gray)                   # gray stays gray
+    sys.path.insert(0, ROOT)
+    import inspect
+    import optical_flow_ext
+    import run_kalmanfilter
+    assert "pipeline.load_video" in inspect.getsource(optical_flow_ext.main)
+    assert "VideoStream(args.fn_in" in inspect.getsource(run_kalmanfilter.main)
+    vs = pipeline.VideoStream(fn, 100)
+    assert (vs.nx, vs.ny) == (12, 10) and vs.isOpened()
+    mask, ctrs, fd = vs.backsub()
+    assert np.array_equal(mask, (want[0] > 100).astype(np.uint8))
+    assert np.array_equal(vs.current_frame(), want[0] * mask) and np.array_equal(vs.current_frame(False), want[0])
+    assert np.array_equal(vs.backsub(col[0]), mask[:, :, None] * col[0])
+    for k in (1, 2, 3):
+        ret, frame, grayframe, m = vs.read()
+        assert ret and np.array_equal(m, (want[k] > 100).astype(np.uint8)) and np.array_equal(grayframe, want[k] * m)
+    ret, frame, grayframe, m = vs.read()
+    assert ret is False and frame is None and not vs.isOpened()
+    with pytest.raises(ValueError):
+        np.save(fn, col.astype(np.float32))
+        pipeline.load_video(fn)
+
+
 # ---- sharding over ranks (gloo, world_size 2) ---------------------------------------------------
 def _worker(rank, world, port, out):
     import torch

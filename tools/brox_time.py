@@ -28,7 +28,7 @@ def run(n, batch, reps, tunes):
         bf.profile(True)
         for _ in range(reps):
             bf.calc_dev(batch, F0.data_ptr(), F1.data_ptr(), U.data_ptr(), V.data_ptr())
-        ms, launches, pxit = bf.profile_read()
+        ms, launches, pxit, _ = bf.profile_read()
         bf.profile(False)
         print(json.dumps(dict(n=n, batch=batch, tune=tune, ms_per_call=dt * 1e3, pairs_per_s=batch / dt,
                               sor_ms_per_call=ms / reps, sor_launches=launches // reps,

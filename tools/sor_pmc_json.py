@@ -1,4 +1,4 @@
-"""profiles/r01_sor_pmc.json from the two PMC passes of tools/brox_pmc.py:
+"""profiles/r02_sor_pmc.json from the two PMC passes of tools/brox_pmc.py:
 
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <dir>/fetch -o b -- python tools/brox_pmc.py
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d <dir>/write -o b -- python tools/brox_pmc.py
@@ -6,7 +6,17 @@
 
 FETCH_SIZE / WRITE_SIZE are in KB (MI355X_MICROARCH.md, HBM section); FETCH_SIZE is doubled on
 gfx950 as that section prescribes -- checked here on k_add, whose traffic is known exactly."""
-import csv, json, sys, collections
+import csv, json, sys, collections, hashlib, os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_revision():
+    h = hashlib.sha256()
+    for fn in ("brox_kernels.h", "brox.hip"):
+        with open(os.path.join(ROOT, "kalman-hydra_amd", "csrc", fn), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def per_kernel(path, counter):
@@ -29,7 +39,8 @@ def main():
     n_px = 8 * 1024 * 1024
     out = {
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), tools/brox_pmc.py: 2 calls of "
-                  "hm_brox_calc_dev (replayed hipGraphs), 8 pairs of 1024x1024, sor_threads 512, sor_fuse auto",
+                  "hm_brox_calc_dev, 8 pairs of 1024x1024, sor_threads 512, sor_fuse auto",
+        "kernel_revision": kernel_revision(),
         "kernel": sor.split("(")[0],
         "launches": len(f),
         "fetch_size_kb_per_launch_raw": sum(f) / len(f),
