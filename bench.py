@@ -180,7 +180,6 @@ def flowbatch(args, rank, world, dev, coll_dev):
     V = torch.empty_like(U)
     torch.cuda.synchronize()
     bf = brox.BroxOpticalFlow(n, n, max_batch=B, device=dev)
-    bf.tune("sor_threads", 512)
 
     def step():
         for s in range(0, P, B):
@@ -289,7 +288,7 @@ def main():
             self.video, self.masks, centre, radius = make_video(n, frames, seed=seed)
             self.dm = mesh.disk_mesh(centre[0], centre[1], radius - 1.0, args.h0 * n)
             self.kf = kalman.IteratedMSKalmanFilter(self.dm, self.video[0], np.zeros((n, n, 2), np.float32), True, device=dev)
-            self.pipe = FlowEKFPipeline(self.kf, self.video, self.masks, flow_batch=B, device=dev, sor_threads=512)
+            self.pipe = FlowEKFPipeline(self.kf, self.video, self.masks, flow_batch=B, device=dev)
             self.bf = self.pipe.bf
             if os.environ.get("HYDRA_MI_BENCH_TRACE"):
                 self.pipe.trace = lambda msg: print(msg, file=sys.stderr)

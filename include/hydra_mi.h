@@ -81,7 +81,8 @@ int hm_brox_levels(hm_brox_t h, int *widths, int *heights, int cap);
 int hm_brox_set_omega(hm_brox_t h, float omega);
 /* launch tuning, never changes results: "sor_fuse" = red-black iterations fused
  * per SOR launch (0 = choose per level, else a divisor of solver_iterations),
- * "sor_threads" = 256, 512 or 1024 threads per SOR workgroup, "warp_window" =
+ * "sor_threads" = 256, 512 or 1024 threads per SOR workgroup (0, the default: 1024 for calls of one or two pairs,
+ * 512 for larger ones), "warp_window" =
  * 1/0 the warp kernel stages its taps as an LDS window or reads them directly (default 0: measured
  * faster, see brox_kernels.h).  (Round 1 also had "graph": replaying a call's launch series as a captured
  * hipGraph.  Replays went wrong when the caller allocated device memory between calls, the cause was not
@@ -165,6 +166,23 @@ int hm_jz(hm_ctx_t h, const double *Xp, int masked, double *jz, double jzc[4]);
 /* j (cuda.py:982-1010): renders X + dX e_i and X + dX e_j and reduces the products
  * of their differences to the reference render */
 int hm_j(hm_ctx_t h, const double *X, double deltaX, int i, int j, double *out);
+/* The reference's multi-perturbation operators: several non-interacting perturbations in one render, the
+ * sums separated by the label of the triangle a pixel belongs to.  labels: one per triangle (the palette
+ * update_vertex_buffer selects, renderer.py:553-556, built at :610-614; -1 = none); a pixel takes the label
+ * shown by the reference render where that covers it, else by the perturbed render(s) in turn
+ * (cuda_multi.py:132-143, 215-235).  hm_initjacobian must have been called.
+ *   jz_multi (cuda_multi.py:81-157, 721-845): Xp = the state with all its perturbations applied;
+ *       hz[n_labels], hzc[n_labels x 4] (may be NULL): the sums of hm_jz per label;
+ *   j_multi (cuda_multi.py:159-248, 979-1129): ee = n_pairs x 2 state indices; one render of X with every
+ *       ee[k][0] raised by deltaX, one with every ee[k][1]; hsum, nz (pixels counted), hcomp[n_labels x 4]
+ *       (may be NULL) per label.
+ * The fused hm_measure does not need them (it evaluates every single perturbation inside its own star);
+ * they are here so that KFState._jacobian_multi / _hessian_sparse_multi (kalman.py:452-489, 539-581) run
+ * as in the reference. */
+int hm_jz_multi(hm_ctx_t h, const double *Xp, int masked, const int32_t *labels, int n_labels,
+                double *hz, double *hzc);
+int hm_j_multi(hm_ctx_t h, const double *X, double deltaX, int n_pairs, const int32_t *ee,
+               const int32_t *labels, int n_labels, double *hsum, double *nz, double *hcomp);
 /* KalmanFilter.projectmask (kalman.py:724-742): every vertex whose signed
  * distance d to the object outline exceeds 1 px takes 10 steps
  * p -= d g/|g|^2 (g: forward differences of 0.1 px; d and the set of vertices

@@ -65,6 +65,8 @@ SIGNATURES = {
     "hm_initjacobian": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int]),
     "hm_jz": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_f64p, c_f64p]),
     "hm_j": (ctypes.c_int, [c_vp, c_vp, ctypes.c_double, ctypes.c_int, ctypes.c_int, c_f64p]),
+    "hm_jz_multi": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_vp, ctypes.c_int, c_vp, c_vp]),
+    "hm_j_multi": (ctypes.c_int, [c_vp, c_vp, ctypes.c_double, ctypes.c_int, c_vp, c_vp, ctypes.c_int, c_vp, c_vp, c_vp]),
     "hm_error": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_f64p, c_vp, c_vp]),
     "hm_measure": (ctypes.c_int, [c_vp, c_vp, ctypes.c_double, ctypes.c_int, c_vp, c_vp, c_vp]),
     "hm_update_begin": (ctypes.c_int, [c_vp, c_vp, c_vp]),

@@ -178,6 +178,7 @@ struct hm_brox {
     int device, W, H, B;
     float alpha, gamma, scale, omega;
     int inner, outer, solver, fuse, sor_threads;
+    int sor_dry;                 // development knob: SOR launches load and store but do not iterate (wrong results)
     std::vector<Geo> geo;
     Taps taps;
     hipStream_t stream;
@@ -232,7 +233,7 @@ extern "C" int hm_brox_create(int device, int W, int H, int max_batch, float alp
     hm_brox *h = new hm_brox();
     h->device = device; h->W = W; h->H = H; h->B = max_batch;
     h->alpha = alpha; h->gamma = gamma; h->scale = scale; h->omega = 1.99f;
-    h->inner = inner; h->outer = outer; h->solver = solver; h->fuse = 0; h->sor_threads = 256;
+    h->inner = inner; h->outer = outer; h->solver = solver; h->fuse = 0; h->sor_threads = 0; h->sor_dry = 0;
     h->arena = nullptr; h->d_f0 = h->d_f1 = nullptr; h->d_ox = h->d_oy = nullptr; h->stream = nullptr;
     h->prof = false; h->ev_used = 0; h->prof_ms = 0; h->prof_pxit = 0; h->prof_px = 0; h->prof_launches = 0;
     h->warp_window = false;
@@ -309,8 +310,10 @@ extern "C" int hm_brox_tune(hm_brox_t h, const char *key, int value)
                "hm_brox_tune: sor_fuse=%d must be 0 or a divisor of solver_iterations (%d) not above 7", value, h->solver);
         h->fuse = value;
     } else if (!strcmp(key, "sor_threads")) {
-        HM_ARG(value == 256 || value == 512 || value == 1024, "hm_brox_tune: sor_threads must be 256, 512 or 1024");
+        HM_ARG(value == 0 || value == 256 || value == 512 || value == 1024, "hm_brox_tune: sor_threads must be 0 (choose per call), 256, 512 or 1024");
         h->sor_threads = value;
+    } else if (!strcmp(key, "sor_dry")) {            // timing experiments only (tools/): the flow is wrong with 1
+        h->sor_dry = value != 0;
     } else if (!strcmp(key, "warp_window")) {
         HM_ARG(value == 0 || value == 1, "hm_brox_tune: warp_window must be 0 or 1");
         h->warp_window = value != 0;
@@ -423,13 +426,19 @@ static int brox_run(hm_brox *h, int n, const uint8_t *d_f0, const uint8_t *d_f1,
         else hipLaunchKernelGGL((k_warp<false>), gr, kBlock2d, 0, s, wi, wo, g);
         const float *du = h->zero, *dv = h->zero;
         int nxt = 0;
-        const SorPlan plan = sor_plan(g, h->solver, h->fuse, h->sor_threads);
+        // workgroup size: with few pairs a launch is bound by the latency of one workgroup (its ten half-sweeps in
+        // sequence) -- 1024 threads, two rows per thread, finish a tile soonest; a launch that fills the chip several
+        // times over is bound by how many tiles are resident -- 512 threads, two workgroups per CU (measured, one /
+        // eight 1024^2 pairs: 4.31 / 12.3 ms of SOR per series with 1024 threads, 4.71 / 10.4 with 512, 6.65 / 13.7 with 256)
+        const int threads = h->sor_threads ? h->sor_threads : (n <= 2 ? 1024 : 512);
+        SorPlan plan = sor_plan(g, h->solver, h->fuse, threads);
+        const int launches_per_inner = h->solver / plan.K;
         Coef co = {h->nu, h->nv, h->a12, h->idu, h->idv, h->sx, h->sy};
         for (int it = 0; it < h->inner; it++) {
             PrepIn pi = {u, v, du, dv, h->Iz, h->Ix, h->Iy, h->Ixz, h->Iyz, h->Ixx, h->Ixy, h->Iyy};
             hipLaunchKernelGGL(k_prepare, dim3(hm_cdiv(g.w, PREP_BX), hm_cdiv(g.h, PREP_BY), n), dim3(PREP_BX, PREP_BY), 0, s,
                                pi, co, g, h->alpha, h->gamma);
-            for (int done = 0; done < h->solver; done += plan.K) {
+            for (int pass = 0; pass < launches_per_inner; pass++) {
                 SorArgs a;
                 a.du_in = du; a.dv_in = dv;
                 a.du_out = h->du[nxt]; a.dv_out = h->dv[nxt];
@@ -447,8 +456,10 @@ static int brox_run(hm_brox *h, int n, const uint8_t *d_f0, const uint8_t *d_f1,
                         h->ev.push_back(e1);
                     }
                 }
-                if (rec) sor_launch(plan, a, n, s, h->ev[h->ev_used], h->ev[h->ev_used + 1]);
-                else sor_launch(plan, a, n, s);
+                SorPlan run = plan;
+                if (h->sor_dry) run.K = 0;
+                if (rec) sor_launch(run, a, n, s, h->ev[h->ev_used], h->ev[h->ev_used + 1]);
+                else sor_launch(run, a, n, s);
                 if (rec) {
                     h->ev_used += 2;
                     h->ev_pxit.push_back((double)g.w * g.h * n * plan.K);

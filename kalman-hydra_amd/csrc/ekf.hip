@@ -67,6 +67,12 @@ struct hm_ctx {
     bool worker_active;
     int worker_rc;
     char worker_err[512];
+    int *d_ids[3];                   // hm_jz_multi / hm_j_multi: id images of the reference and the two perturbed renders,
+    int *d_labels;                   // the label palette (T), per-label boxes and sums; allocated on first use
+    int4 *d_lbox;
+    double *d_lout;
+    int lcap;                        // labels the last two hold
+    std::vector<double> h_lout;
     int2 *d_outline;                 // hm_project_mask: outline pixels (W*H), counters, uploaded mask; allocated on first use
     int *d_outline_cnt;
     uint8_t *d_pm_mask;
@@ -140,7 +146,8 @@ static int ctx_free(hm_ctx *h)
                     h->d_Wtmp, h->d_X0, h->d_Xn, h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk,
                     h->pool.hdr, h->pool.xi, h->pool.yi, h->pool.xfx, h->pool.xfy,
                     h->pool.yfx, h->pool.yfy, h->pool.vxfx, h->pool.vyfy, h->pool.overflow, h->d_area,
-                    h->d_outline, h->d_outline_cnt, h->d_pm_mask};
+                    h->d_outline, h->d_outline_cnt, h->d_pm_mask, h->d_ids[0], h->d_ids[1], h->d_ids[2], h->d_labels, h->d_lbox,
+                    h->d_lout};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     free_targets(h->ref);
@@ -205,6 +212,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->d_Wprior = h->d_gain = h->d_Awork = h->d_Lt[0] = h->d_Lt[1] = nullptr; h->d_Wres = nullptr; h->pin = nullptr; h->pin_n = 0;
     h->tri.assign(tri, tri + (size_t)3 * T);
     h->d_outline = nullptr; h->d_outline_cnt = nullptr; h->d_pm_mask = nullptr;
+    h->d_ids[0] = h->d_ids[1] = h->d_ids[2] = nullptr; h->d_labels = nullptr; h->d_lbox = nullptr; h->d_lout = nullptr; h->lcap = 0;
     h->worker_active = false; h->worker_rc = HM_OK; h->worker_err[0] = 0;
     h->d_T[0] = h->d_T[1] = h->d_step = nullptr; h->d_X0 = h->d_Xn = nullptr;
     memset(&h->pool, 0, sizeof h->pool); h->d_area = nullptr;
@@ -387,8 +395,8 @@ static int render_dev(hm_ctx *h, const double *dX, Targets t)
 {
     Mesh m = {h->W, h->H, h->N, h->T, h->d_tri, h->d_uv, h->d_tex};
     hipLaunchKernelGGL(k_setup_all, dim3(hm_cdiv(h->T, 64)), dim3(64), 0, h->stream, m, dX, h->d_setup);
-    hipLaunchKernelGGL(k_render, dim3(hm_cdiv(h->W, EKF_TILE), hm_cdiv(h->H, EKF_TILE)), dim3(EKF_TILE, EKF_TILE), 0,
-                       h->stream, m, dX, h->d_setup, t);
+    hipLaunchKernelGGL((k_render<0>), dim3(hm_cdiv(h->W, EKF_TILE), hm_cdiv(h->H, EKF_TILE)), dim3(EKF_TILE, EKF_TILE), 0,
+                       h->stream, m, dX, h->d_setup, t, (const int *)nullptr, (int *)nullptr);
     HM_HIP(hipGetLastError());
     return HM_OK;
 }
@@ -498,6 +506,130 @@ extern "C" int hm_j(hm_ctx_t h, const double *X, double deltaX, int i, int j, do
     rc = collect4(h, s);
     if (rc) return rc;
     *out = ((s[0] / h->eps_Z + s[1] / h->eps_J) + s[2] / h->eps_J) + s[3] / h->eps_M;
+    return HM_OK;
+}
+
+// ---- the reference's multi-perturbation operators (cuda_multi.py:81-248, 721-845, 979-1129) ---------------------
+// label palette, id images and per-label boxes of the renders involved; states: host copies of the 2 or 3 states
+static int multi_setup(hm_ctx *h, const int32_t *labels, int n_labels, const double *const states[], int n_states)
+{
+    const size_t n = (size_t)h->W * h->H;
+    if (!h->d_ids[0]) {
+        for (int k = 0; k < 3; k++) HM_HIP(hipMalloc((void **)&h->d_ids[k], n * sizeof(int)));
+        HM_HIP(hipMalloc((void **)&h->d_labels, (size_t)h->T * sizeof(int)));
+    }
+    if (n_labels > h->lcap) {
+        if (h->d_lbox) (void)hipFree(h->d_lbox);
+        if (h->d_lout) (void)hipFree(h->d_lout);
+        h->d_lbox = nullptr; h->d_lout = nullptr; h->lcap = 0;
+        HM_HIP(hipMalloc((void **)&h->d_lbox, (size_t)n_labels * sizeof(int4)));
+        HM_HIP(hipMalloc((void **)&h->d_lout, (size_t)n_labels * 5 * sizeof(double)));
+        h->lcap = n_labels;
+    }
+    std::vector<int4> box(n_labels, make_int4(1, 0, 1, 0));
+    for (int t = 0; t < h->T; t++) {
+        const int lab = labels[t];
+        if (lab < 0) continue;
+        HM_ARG(lab < n_labels && lab < 65535, "multi-perturbation label %d of triangle %d outside 0..%d", lab, t, n_labels - 1);
+        double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+        for (int sidx = 0; sidx < n_states; sidx++)
+            for (int k = 0; k < 3; k++) {
+                const int v = h->tri[3 * t + k];
+                const double x = states[sidx][2 * v], y = states[sidx][2 * v + 1];
+                x0 = std::min(x0, x); x1 = std::max(x1, x); y0 = std::min(y0, y); y1 = std::max(y1, y);
+            }
+        if (!(x0 <= x1 && y0 <= y1)) continue;                              // non-finite state: nothing is drawn
+        // pixel (c, r) is drawn iff its centre (c + .5, r + .5) is inside: one pixel of margin each way
+        const int c0 = (int)std::max(0.0, std::floor(std::min(x0, (double)h->W)) - 1.0);
+        const int c1 = (int)std::min((double)h->W - 1.0, std::ceil(std::max(x1, -1.0)) + 1.0);
+        const int r0 = (int)std::max(0.0, std::floor(std::min(y0, (double)h->H)) - 1.0);
+        const int r1 = (int)std::min((double)h->H - 1.0, std::ceil(std::max(y1, -1.0)) + 1.0);
+        int4 &b = box[lab];
+        if (b.x > b.y) b = make_int4(c0, c1, r0, r1);
+        else b = make_int4(std::min(b.x, c0), std::max(b.y, c1), std::min(b.z, r0), std::max(b.w, r1));
+    }
+    HM_HIP(hipMemcpyAsync(h->d_labels, labels, (size_t)h->T * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HM_HIP(hipMemcpyAsync(h->d_lbox, box.data(), (size_t)n_labels * sizeof(int4), hipMemcpyHostToDevice, h->stream));
+    HM_HIP(hipStreamSynchronize(h->stream));                                   // box is a local
+    return HM_OK;
+}
+
+// render state X (host) into target t with its id image (MODE 1), or the id image only (MODE 2)
+static int render_ids(hm_ctx *h, const double *X, Targets t, int *ids, bool ids_only)
+{
+    HM_HIP(hipMemcpyAsync(h->d_X, X, (size_t)4 * h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    Mesh m = {h->W, h->H, h->N, h->T, h->d_tri, h->d_uv, h->d_tex};
+    hipLaunchKernelGGL(k_setup_all, dim3(hm_cdiv(h->T, 64)), dim3(64), 0, h->stream, m, h->d_X, h->d_setup);
+    const dim3 grid(hm_cdiv(h->W, EKF_TILE), hm_cdiv(h->H, EKF_TILE)), block(EKF_TILE, EKF_TILE);
+    if (ids_only) hipLaunchKernelGGL((k_render<2>), grid, block, 0, h->stream, m, h->d_X, h->d_setup, t, (const int *)h->d_labels, ids);
+    else hipLaunchKernelGGL((k_render<1>), grid, block, 0, h->stream, m, h->d_X, h->d_setup, t, (const int *)h->d_labels, ids);
+    HM_HIP(hipGetLastError());
+    HM_HIP(hipStreamSynchronize(h->stream));                                   // d_X is reused by the next render
+    return HM_OK;
+}
+
+extern "C" int hm_jz_multi(hm_ctx_t h, const double *Xp, int masked, const int32_t *labels, int n_labels, double *hz,
+                           double *hzc)
+{
+    HM_ARG(h && Xp && labels && hz && n_labels >= 1, "hm_jz_multi: bad argument");
+    HM_JOIN(h);
+    NEED_REF(h, "hm_jz_multi");
+    HM_HIP(hipSetDevice(h->device));
+    const double *states[2] = {h->X0.data(), Xp};
+    int rc = multi_setup(h, labels, n_labels, states, 2);
+    if (rc) return rc;
+    rc = render_ids(h, h->X0.data(), h->ref, h->d_ids[0], true);               // the reference render's ids (its targets stand)
+    if (rc == HM_OK) rc = render_ids(h, Xp, h->P, h->d_ids[1], false);
+    if (rc) return rc;
+    MultiArgs a = {h->ref, h->P, h->P, h->d_ids[0], h->d_ids[1], h->d_ids[1], obs_of(h, masked), h->W, h->d_lbox, h->d_lout};
+    hipLaunchKernelGGL(k_jz_multi, dim3(n_labels), dim3(RED_NT), 0, h->stream, a);
+    HM_HIP(hipGetLastError());
+    h->h_lout.resize((size_t)n_labels * 5);
+    HM_HIP(hipMemcpyAsync(h->h_lout.data(), h->d_lout, (size_t)n_labels * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HM_HIP(hipStreamSynchronize(h->stream));
+    for (int l = 0; l < n_labels; l++) {
+        const double *s = h->h_lout.data() + 4 * l;
+        const double c[4] = {s[0] / h->eps_Z, s[1] / h->eps_J, -s[2] / h->eps_J, s[3] / h->eps_M};
+        hz[l] = ((c[0] + c[1]) + c[2]) + c[3];
+        if (hzc) for (int k = 0; k < 4; k++) hzc[4 * l + k] = c[k];
+    }
+    return HM_OK;
+}
+
+extern "C" int hm_j_multi(hm_ctx_t h, const double *X, double deltaX, int n_pairs, const int32_t *ee, const int32_t *labels,
+                          int n_labels, double *hsum, double *nz, double *hcomp)
+{
+    HM_ARG(h && X && ee && labels && hsum && nz && n_pairs >= 1 && n_labels >= 1, "hm_j_multi: bad argument");
+    HM_JOIN(h);
+    NEED_REF(h, "hm_j_multi");
+    HM_HIP(hipSetDevice(h->device));
+    const int n4 = 4 * h->N;
+    std::vector<double> Xp(X, X + n4), Xq(X, X + n4);
+    for (int k = 0; k < n_pairs; k++) {
+        HM_ARG(ee[2 * k] >= 0 && ee[2 * k] < n4 && ee[2 * k + 1] >= 0 && ee[2 * k + 1] < n4, "hm_j_multi: state index outside 0..%d", n4 - 1);
+        Xp[ee[2 * k]] += deltaX;                                            // all first indices at once (cuda_multi.py:987-990)
+        Xq[ee[2 * k + 1]] += deltaX;                                        // all second indices at once (:1004-1007)
+    }
+    const double *states[3] = {h->X0.data(), Xp.data(), Xq.data()};
+    int rc = multi_setup(h, labels, n_labels, states, 3);
+    if (rc) return rc;
+    rc = render_ids(h, h->X0.data(), h->ref, h->d_ids[0], true);
+    if (rc == HM_OK) rc = render_ids(h, Xp.data(), h->P, h->d_ids[1], false);
+    if (rc == HM_OK) rc = render_ids(h, Xq.data(), h->Q, h->d_ids[2], false);
+    if (rc) return rc;
+    MultiArgs a = {h->ref, h->P, h->Q, h->d_ids[0], h->d_ids[1], h->d_ids[2], obs_of(h, 0), h->W, h->d_lbox, h->d_lout};
+    hipLaunchKernelGGL(k_j_multi, dim3(n_labels), dim3(RED_NT), 0, h->stream, a);
+    HM_HIP(hipGetLastError());
+    h->h_lout.resize((size_t)n_labels * 5);
+    HM_HIP(hipMemcpyAsync(h->h_lout.data(), h->d_lout, (size_t)n_labels * 5 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HM_HIP(hipStreamSynchronize(h->stream));
+    for (int l = 0; l < n_labels; l++) {
+        const double *s = h->h_lout.data() + 5 * l;
+        const double c[4] = {s[0] / h->eps_Z, s[1] / h->eps_J, s[2] / h->eps_J, s[3] / h->eps_M};
+        hsum[l] = ((c[0] + c[1]) + c[2]) + c[3];
+        nz[l] = s[4];
+        if (hcomp) for (int k = 0; k < 4; k++) hcomp[4 * l + k] = c[k];
+    }
     return HM_OK;
 }
 

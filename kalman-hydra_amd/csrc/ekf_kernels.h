@@ -177,8 +177,14 @@ __global__ void k_setup_all(Mesh m, const double *__restrict__ X, TriSetup *__re
 // ---- full-frame render: one 16x16 tile per workgroup -----------------------------------
 // The triangles whose bounding box meets the tile are marked in an LDS bit set and
 // visited in ascending index order by every pixel (the order the oracle adds in).
+// MODE 0: the four targets; 1: targets and the id image of the label palette; 2: the id image only.
+// The id image is the G and B channel of the reference's mask render (renderer.py:90-101, 610-614): a
+// primitive's colour is (255, label / 256, label % 256), (255, 255, 255) for label -1, blended additively
+// with 8-bit saturation; id = 256 G + B (cuda_multi.py:137-143), 0 where nothing is drawn.
+template <int MODE>
 __global__ __launch_bounds__(EKF_TILE *EKF_TILE) void k_render(Mesh m, const double *__restrict__ X,
-                                                                const TriSetup *__restrict__ setup, Targets out)
+                                                                const TriSetup *__restrict__ setup, Targets out,
+                                                                const int *__restrict__ labels, int *__restrict__ ids)
 {
     __shared__ unsigned s_mask[EKF_MAX_TRI / 32];
     const int tid = threadIdx.y * EKF_TILE + threadIdx.x;
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(EKF_TILE *EKF_TILE) void k_render(Mesh m, const dou
     __syncthreads();
     const int c = c0 + threadIdx.x, r = r0 + threadIdx.y;
     if (c >= m.W || r >= m.H) return;
-    int acc = 0, cnt = 0;
+    int acc = 0, cnt = 0, sg = 0, sb = 0;
     float fx = 0.0f, fy = 0.0f;
     for (int wd = 0; wd < words; wd++) {
         unsigned bits = s_mask[wd];
@@ -204,14 +210,22 @@ __global__ __launch_bounds__(EKF_TILE *EKF_TILE) void k_render(Mesh m, const dou
             const TriSetup &s = setup[wd * 32 + b];
             float l1, l2;
             if (!d_tri_eval(s, c, r, l1, l2)) continue;
-            acc += d_texel(m.tex, s, l1, l2, m.W, m.H);
-            fx = fx + d_lerp(s.ax[0], s.ax[1], s.ax[2], l1, l2);
-            fy = fy + d_lerp(s.ay[0], s.ay[1], s.ay[2], l1, l2);
-            cnt++;
+            if (MODE != 2) {
+                acc += d_texel(m.tex, s, l1, l2, m.W, m.H);
+                fx = fx + d_lerp(s.ax[0], s.ax[1], s.ax[2], l1, l2);
+                fy = fy + d_lerp(s.ay[0], s.ay[1], s.ay[2], l1, l2);
+                cnt++;
+            }
+            if (MODE != 0) {
+                const int lab = labels[wd * 32 + b];
+                sg += lab < 0 ? 255 : lab / 256;
+                sb += lab < 0 ? 255 : lab % 256;
+            }
         }
     }
     const int p = r * m.W + c;
-    out.acc[p] = acc; out.fx[p] = fx; out.fy[p] = fy; out.cnt[p] = cnt;
+    if (MODE != 2) { out.acc[p] = acc; out.fx[p] = fx; out.fy[p] = fy; out.cnt[p] = cnt; }
+    if (MODE != 0) ids[p] = 256 * min(sg, 255) + min(sb, 255);
 }
 
 // unclamped targets -> the 8-bit images a caller sees
@@ -321,6 +335,74 @@ __global__ __launch_bounds__(RED_NT) void k_error(Targets ref, Obs o, int n, dou
         a[3] += (double)((dm * dm) & 255u);
     }
     d_block_reduce<4, RED_NT>(a, s_red, partial + 4 * blockIdx.x);
+}
+
+// ---- label-segmented reductions: the reference's multi-perturbation kernels ---------------------------------
+// histogram_jz / histogram_j (cuda_multi.py:81-248) attribute every pixel to a label -- the id the mask
+// render shows there, taken from the reference render where it covers the pixel, else from the (first, then
+// second) perturbed render (:132-143, :215-235) -- and add the pixel's terms into that label's bin with float
+// atomics.  Here one workgroup owns one label: it scans the bounding box of the triangles that carry the label
+// (in any of the renders involved; the host knows the states) and adds the pixels whose id is its own, in a
+// fixed order -- the same sums, reproducible, binary64 like the other reductions.
+struct MultiArgs {
+    Targets ref, p, q;        // q unused by jz_multi
+    const int *idr, *idp, *idq;
+    Obs o;
+    int W;
+    const int4 *box;          // per label: cmin, cmax, rmin, rmax (empty if cmin > cmax)
+    double *out;              // per label: 4 sums (jz_multi) or 4 sums + pixel count (j_multi)
+};
+
+__global__ __launch_bounds__(RED_NT) void k_jz_multi(MultiArgs a)
+{
+    __shared__ double s_red[(RED_NT / 64) * 4];
+    const int lab = blockIdx.x;
+    const int4 b = a.box[lab];
+    double s[4] = {0, 0, 0, 0};
+    const int bw = b.y - b.x + 1, bh = b.w - b.z + 1;
+    const int npx = (bw > 0 && bh > 0) ? bw * bh : 0;
+    for (int k = threadIdx.x; k < npx; k += RED_NT) {
+        const int i = (b.z + k / bw) * a.W + b.x + k % bw;
+        const bool m = a.ref.cnt[i] > 0, mp = a.p.cnt[i] > 0;
+        const int face = m ? a.idr[i] : (mp ? a.idp[i] : 65535);
+        if (face != lab || face >= 65535) continue;
+        const int rim = a.ref.acc[i] > 255 ? 255 : a.ref.acc[i], pim = a.p.acc[i] > 255 ? 255 : a.p.acc[i];
+        const int rm = m ? 255 : 0, pm = mp ? 255 : 0;
+        const double z = ((double)a.o.yim[i] - (double)rim) / 255.0;
+        const double zm = (255.0 * (double)a.o.ym[i] - (double)rm) / 255.0;
+        const float zfx = a.o.yfx[i] - a.ref.fx[i];
+        const float zfy = a.o.yfy[i] + a.ref.fy[i];
+        s[0] += ((double)(pim - rim) / 255.0) * z;
+        s[1] += (double)(a.p.fx[i] - a.ref.fx[i]) * (double)zfx;
+        s[2] += (double)(a.p.fy[i] - a.ref.fy[i]) * (double)zfy;
+        s[3] += ((double)(pm - rm) / 255.0) * zm;
+    }
+    d_block_reduce<4, RED_NT>(s, s_red, a.out + 4 * lab);
+}
+
+__global__ __launch_bounds__(RED_NT) void k_j_multi(MultiArgs a)
+{
+    __shared__ double s_red[(RED_NT / 64) * 5];
+    const int lab = blockIdx.x;
+    const int4 b = a.box[lab];
+    double s[5] = {0, 0, 0, 0, 0};
+    const int bw = b.y - b.x + 1, bh = b.w - b.z + 1;
+    const int npx = (bw > 0 && bh > 0) ? bw * bh : 0;
+    for (int k = threadIdx.x; k < npx; k += RED_NT) {
+        const int i = (b.z + k / bw) * a.W + b.x + k % bw;
+        const bool m = a.ref.cnt[i] > 0, mp = a.p.cnt[i] > 0, mq = a.q.cnt[i] > 0;
+        const int face = m ? a.idr[i] : (mp ? a.idp[i] : (mq ? a.idq[i] : 65535));
+        if (face != lab || face >= 65535) continue;
+        const int rim = a.ref.acc[i] > 255 ? 255 : a.ref.acc[i];
+        const int pim = a.p.acc[i] > 255 ? 255 : a.p.acc[i], qim = a.q.acc[i] > 255 ? 255 : a.q.acc[i];
+        const int rm = m ? 255 : 0, pm = mp ? 255 : 0, qm = mq ? 255 : 0;
+        s[0] += ((double)(pim - rim) / 255.0) * ((double)(qim - rim) / 255.0);
+        s[1] += (double)(a.p.fx[i] - a.ref.fx[i]) * (double)(a.q.fx[i] - a.ref.fx[i]);
+        s[2] += (double)(a.p.fy[i] - a.ref.fy[i]) * (double)(a.q.fy[i] - a.ref.fy[i]);
+        s[3] += ((double)(pm - rm) / 255.0) * ((double)(qm - rm) / 255.0);
+        s[4] += 1.0;
+    }
+    d_block_reduce<5, RED_NT>(s, s_red, a.out + 5 * lab);
 }
 
 // ---- fused perturb-and-reduce (KFState.update in one launch) --------------------------------------

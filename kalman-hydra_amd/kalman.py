@@ -365,7 +365,38 @@ class KFState:
             Hzc[idx, :] /= 2
         return Hz, Hzc
 
-    _jacobian_multi = _jacobian
+    def _jacobian_multi(self, y_im, y_flow, y_m, deltaX=2):
+        """reference kalman.py:452-489: the vertices of one partition (mutually non-adjacent, so their stars do
+        not overlap) are perturbed in ONE render and the sums are separated by triangle label
+        (Renderer.jz_multi -> hm_jz_multi).  8 renders per partition instead of 8 per vertex.  The product's
+        update() does not use it (measure() evaluates single perturbations inside their stars); it is the
+        reference's operator sequence, kept runnable for the multi == single protocol
+        (testbites/test_multipert_validation.py:98-189)."""
+        n = self.size()
+        Hz = np.zeros((n, 1))
+        Hzc = np.zeros((n, 4))
+        for idx, e in enumerate(self.E):
+            e = np.asarray(e, np.int64)
+            self.refresh(idx)
+            self.renderer.initjacobian(y_im, y_flow, y_m)
+            for i in range(2):
+                for j in range(2):
+                    ee = i + 2 * self.N * j + 2 * e
+                    self.X[ee, 0] += deltaX
+                    self.refresh(idx)
+                    hz, hzc = self.renderer.jz_multi(self)
+                    Hz[ee, 0] = hz[e, 0] / deltaX
+                    Hzc[ee, :] = hzc[e, :] / deltaX
+                    self.X[ee, 0] -= 2 * deltaX
+                    self.refresh(idx)
+                    hz, hzc = self.renderer.jz_multi(self)
+                    Hz[ee, 0] = Hz[ee, 0] - hz[e, 0] / deltaX
+                    Hzc[ee, :] -= hzc[e, :] / deltaX
+                    self.X[ee, 0] += deltaX
+                    Hz[ee, 0] = Hz[ee, 0] / 2
+                    Hzc[ee, :] = Hzc[ee, :] / 2
+        self.refresh()
+        return Hz, Hzc
 
     def _hessian_sparse(self, y_im, y_flow, y_m, deltaX=2, pattern=None):
         n = self.size()
@@ -380,7 +411,29 @@ class KFState:
         return HTH
 
     def _hessian_sparse_multi(self, y_im, y_flow, y_m, deltaX=2):
-        return self._hessian_sparse(y_im, y_flow, y_m, deltaX, self.J)
+        """reference kalman.py:539-581: per partition of vertex pairs 16 x 2 renders, sums separated by pair label
+        (Renderer.j_multi -> hm_j_multi)."""
+        n = self.size()
+        HTH = np.zeros((n, n))
+        for idx, e in enumerate(self.E_hessian):
+            e = np.asarray(e, np.int64).reshape(-1, 2)
+            self.refresh(idx, hess=True)
+            self.renderer.initjacobian(y_im, y_flow, y_m)
+            for i1 in range(2):
+                for j1 in range(2):
+                    for i2 in range(2):
+                        for j2 in range(2):
+                            off1 = i1 + 2 * self.N * j1
+                            off2 = i2 + 2 * self.N * j2
+                            ee = np.column_stack((2 * e[:, 0] + off1, 2 * e[:, 1] + off2))
+                            h, hist, _ = self.renderer.j_multi(self, deltaX, ee, idx, self.E_hessian_idx[idx])
+                            for qi in np.flatnonzero(hist):
+                                q = self.Q[qi]
+                                q1, q2 = 2 * q[0] + off1, 2 * q[1] + off2
+                                HTH[q1, q2] = h[0, qi] / deltaX / deltaX
+                                HTH[q2, q1] = HTH[q1, q2]
+        self.refresh()
+        return HTH
 
     def _hessian(self, y_im, y_flow, y_m, deltaX=2):
         return self._hessian_sparse(y_im, y_flow, y_m, deltaX, None)

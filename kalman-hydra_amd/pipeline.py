@@ -144,7 +144,7 @@ class FlowEKFPipeline:
     flow does not depend on the series it is computed in.
     """
 
-    def __init__(self, kf, video, masks, flow_batch=8, device=0, brox_params=None, sor_threads=512, maskflow=True,
+    def __init__(self, kf, video, masks, flow_batch=8, device=0, brox_params=None, sor_threads=0, maskflow=True,
                  observed=None, return_flow=False):
         """return_flow: whether step() brings the rendered flow planes of every frame to the host, as
         KalmanFilter.compute does for the reference's callers (8 MB per 1024^2 frame); a frame loop that
@@ -180,8 +180,7 @@ class FlowEKFPipeline:
         self.d_u = DeviceBuffer(2 * self.B * n * 4, device)          # double-buffered flow planes
         self.d_v = DeviceBuffer(2 * self.B * n * 4, device)
         self.bf = _brox.BroxOpticalFlow(self.W, self.H, max_batch=self.B, device=device, **(brox_params or {}))
-        if sor_threads:
-            self.bf.tune("sor_threads", sor_threads)
+        self.bf.tune("sor_threads", sor_threads)        # 0: chosen per series (1024 for one or two pairs, else 512)
         self.t_flow = self.t_ekf = 0.0
         self.iters = 0
         self.profile_from = None         # pair index: the series starting there is profiled (hm_brox_profile)

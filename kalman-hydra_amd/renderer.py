@@ -56,6 +56,7 @@ class Renderer:
         self.vertices = np.array(distmesh.p, np.float64)
         self.velocities = np.array(vel, np.float64).reshape(self.vertices.shape)
         self._obs = None
+        self._palette = None
         self.frame_in_place = False             # set by KalmanFilter.compute() while the frame it uploaded is current
         self._cov_serial = 0                    # names the covariance resident on the device (DeviceCovariance)
         self.current_frame = tex
@@ -75,10 +76,16 @@ class Renderer:
 
     # -- state ----------------------------------------------------------------------------
     def update_vertex_buffer(self, vertices, velocities, multi_idx=-1, hess=False):
-        """reference renderer.py:503-556.  The label palettes selected by multi_idx / hess
-        only exist for the reference's multi-perturbation trick and have no effect here."""
+        """reference renderer.py:503-556: the vertex buffer and the label palette of the mask render
+        (multi_idx: the partition whose labels colour the triangles, -1: none; hess: the pair partitions).
+        The palette only matters to jz_multi / j_multi."""
         self.vertices = np.asarray(vertices, np.float64).reshape(-1, 2)
         self.velocities = np.asarray(velocities, np.float64).reshape(-1, 2)
+        table = self.labels_hess if hess else self.labels
+        if multi_idx is None or multi_idx < 0 or table is None:
+            self._palette = None                                      # every triangle (255, 255, 255): no label
+        else:
+            self._palette = np.ascontiguousarray(np.asarray(table)[:, multi_idx], np.int32)
 
     def _X(self, state=None):
         if state is not None:
@@ -167,10 +174,21 @@ class Renderer:
                                     ctypes.byref(out), comp), "hm_jz")
         return out.value, np.array(comp[:])
 
+    def _labels_now(self, who):
+        if getattr(self, "_palette", None) is None:
+            raise RuntimeError("%s: no label palette selected (update_vertex_buffer / KFState.refresh with the "
+                               "partition index first, reference kalman.py:459, 545)" % who)
+        return self._palette
+
     def jz_multi(self, state):
-        """reference renderer.py:696-709.  The label-segmented sums of the reference equal the
-        single-perturbation sums for every perturbed vertex; evaluate those directly."""
-        raise NotImplementedError("use Renderer.measure(): it returns Hz for all vertices in one launch")
+        """reference renderer.py:696-709 / cuda_multi.py:721-845 -> (hz [N,1], hzc [N,4]): the terms of jz summed
+        per vertex label of the palette in place (hm_jz_multi)."""
+        lab = self._labels_now("jz_multi")
+        hz = np.zeros(self.n)
+        hzc = np.zeros((self.n, 4))
+        _lib.check(_lib.lib().hm_jz_multi(self._h, _lib.ptr(self._X(state)), getattr(self, "_masked", 0), _lib.ptr(lab),
+                                          self.n, _lib.ptr(hz), _lib.ptr(hzc)), "hm_jz_multi")
+        return hz.reshape(-1, 1), hzc
 
     def j(self, state, deltaX, i, j):
         """reference renderer.py:711-721 / cuda.py:982-1010."""
@@ -179,16 +197,19 @@ class Renderer:
                                    ctypes.byref(out)), "hm_j")
         return out.value
 
-    def j_multi(self, state, deltaX, ee, labelidx, ee_idx):
-        """reference renderer.py:723-737 (CPU branch): one j per listed pair -> (h, h_hist)."""
+    def j_multi(self, state, deltaX, ee, labelidx, ee_idx=None):
+        """reference renderer.py:723-737 / cuda_multi.py:979-1129 -> (h [1,|Q|], nz [|Q|] bool, hcomp [|Q|,4]): the
+        terms of j for the pairs ee (|e| x 2 state indices, all perturbed at once) summed per pair label of the
+        hessian palette `labelidx` (hm_j_multi)."""
+        lab = np.ascontiguousarray(np.asarray(self.labels_hess)[:, labelidx], np.int32)
+        ee = np.ascontiguousarray(np.asarray(ee).reshape(-1, 2), np.int32)
         nq = len(self.Q)
-        h = np.zeros((nq, 1))
-        hist = np.zeros((nq, 1))
-        for idx, eidx in enumerate(ee_idx):
-            e = ee[idx]
-            h[int(eidx)] = self.j(state, deltaX, int(e[0]), int(e[1]))
-            hist[int(eidx)] = 1
-        return h, hist
+        h = np.zeros(nq)
+        nz = np.zeros(nq)
+        hc = np.zeros((nq, 4))
+        _lib.check(_lib.lib().hm_j_multi(self._h, _lib.ptr(self._X(state)), float(deltaX), int(ee.shape[0]), _lib.ptr(ee),
+                                         _lib.ptr(lab), nq, _lib.ptr(h), _lib.ptr(nz), _lib.ptr(hc)), "hm_j_multi")
+        return h.reshape(1, -1), nz > 0, hc
 
     def measure(self, state, y_im, y_flow, y_m, deltaX=2.0):
         """KFState.update (kalman.py:437-449) fused: -> (Hz [4N,1], HTH [4N,4N], Hz_components [4N,4])."""

@@ -54,11 +54,16 @@ def _topleft(dx, dy):
     return (dy > 0) | ((dy == 0) & (dx < 0))
 
 
-def render(X, N, tri, uv, tex, W, H):
+def render(X, N, tri, uv, tex, W, H, labels=None):
     """Render state X -> (im u8, fx f32, fy f32, m u8), each HxW.
 
     X: 4N doubles [x0,y0,...,vx0,vy0,...] (kalman.py:178).  fy is the render of
     -v_y (renderer.py:513).  m is 255 where any triangle covers the pixel.
+
+    labels (one per triangle, -1 = none): also return the id image of the mask render's G and B channels,
+    id = 256 G + B with the primitive's colour (255, label // 256, label % 256), label -1 -> (255, 255, 255)
+    (renderer.py:610-614, shader :90-101), blended additively with 8-bit saturation like the other targets;
+    uncovered pixels have id 0.  This is what cuda_multi.py:132-143 reads its `face` from.
     """
     X = np.asarray(X, np.float64).reshape(-1)
     P = snap(X[:2 * N].reshape(N, 2))
@@ -70,7 +75,11 @@ def render(X, N, tri, uv, tex, W, H):
     fx = np.zeros((H, W), np.float32)
     fy = np.zeros((H, W), np.float32)
     cnt = np.zeros((H, W), np.int64)
-    for t in np.asarray(tri):
+    if labels is not None:
+        labels = np.asarray(labels).astype(np.int64)
+        sum_g = np.zeros((H, W), np.int64)
+        sum_b = np.zeros((H, W), np.int64)
+    for tidx, t in enumerate(np.asarray(tri)):
         i0, i1, i2 = int(t[0]), int(t[1]), int(t[2])
         (x0, y0), (x1, y1), (x2, y2) = P[i0], P[i1], P[i2]
         area = (x1 - x0) * (y2 - y0) - (y1 - y0) * (x2 - x0)
@@ -110,8 +119,15 @@ def render(X, N, tri, uv, tex, W, H):
         fx[sl] = np.where(ins, fx[sl] + lerp(ax), fx[sl])
         fy[sl] = np.where(ins, fy[sl] + lerp(ay), fy[sl])
         cnt[sl] += ins
+        if labels is not None:
+            lab = int(labels[tidx])
+            g_, b_ = (255, 255) if lab < 0 else (lab // 256, lab % 256)
+            sum_g[sl] += np.where(ins, g_, 0)
+            sum_b[sl] += np.where(ins, b_, 0)
     im = np.minimum(acc_im, 255).astype(np.uint8)
     m = np.where(cnt > 0, 255, 0).astype(np.uint8)
+    if labels is not None:
+        return im, fx, fy, m, 256 * np.minimum(sum_g, 255) + np.minimum(sum_b, 255)
     return im, fx, fy, m
 
 
@@ -165,6 +181,49 @@ class Measurement:
                 + np.sum(a[1].astype(np.float64) * b[1].astype(np.float64)) / self.eps_J
                 + np.sum(a[2].astype(np.float64) * b[2].astype(np.float64)) / self.eps_J
                 + np.sum(a[3] * b[3]) / self.eps_M)
+
+    # -- the label-segmented ("multi-perturbation") variants, cuda_multi.py:81-248 ------------------------
+    def _face(self, labels, *states):
+        """cuda_multi.py:132-143 / :215-235: the id of the first render that covers the pixel, in the order
+        reference render, first perturbed render, second perturbed render; 65535 where none does."""
+        face = np.full((self.H, self.W), 65535, np.int64)
+        done = np.zeros((self.H, self.W), bool)
+        for X in states:
+            _, _, _, m, ids = render(X, self.N, self.tri, self.uv, self.tex, self.W, self.H, labels)
+            take = (m == 255) & ~done
+            face[take] = ids[take]
+            done |= m == 255
+        return face
+
+    def jz_multi(self, Xp, labels, n_labels):
+        """histogram_jz (cuda_multi.py:81-157): the per-pixel terms of jz summed per label -> (hz [n], hzc [n,4]).
+        Sums in binary64 like jz (the reference's kernel adds binary32 terms with atomics)."""
+        d, dfx, dfy, dm = self._diff(Xp)
+        face = self._face(labels, self.X0, Xp)
+        terms = (d * self.z / self.eps_Z, dfx.astype(np.float64) * self.zfx.astype(np.float64) / self.eps_J,
+                 -dfy.astype(np.float64) * self.zfy.astype(np.float64) / self.eps_J, dm * self.zm / self.eps_M)
+        hzc = np.zeros((n_labels, 4))
+        ok = face < min(n_labels, 65535)
+        for k, t in enumerate(terms):
+            hzc[:, k] = np.bincount(face[ok], weights=t[ok], minlength=n_labels)[:n_labels]
+        return hzc.sum(axis=1), hzc
+
+    def j_multi(self, deltaX, ee, labels, n_labels):
+        """histogram_j (cuda_multi.py:159-248) with the two renders of CUDAGL_multi.j_multi (:979-1027): X0 with
+        ee[:,0] perturbed, X0 with ee[:,1] perturbed -> (h [n], nz [n], hcomp [n,4])."""
+        ee = np.asarray(ee).reshape(-1, 2)
+        Xp = self.X0.copy(); Xp[ee[:, 0]] += deltaX
+        Xq = self.X0.copy(); Xq[ee[:, 1]] += deltaX
+        a, b = self._diff(Xp), self._diff(Xq)
+        face = self._face(labels, self.X0, Xp, Xq)
+        terms = (a[0] * b[0] / self.eps_Z, a[1].astype(np.float64) * b[1].astype(np.float64) / self.eps_J,
+                 a[2].astype(np.float64) * b[2].astype(np.float64) / self.eps_J, a[3] * b[3] / self.eps_M)
+        hc = np.zeros((n_labels, 4))
+        ok = face < min(n_labels, 65535)
+        for k, t in enumerate(terms):
+            hc[:, k] = np.bincount(face[ok], weights=t[ok], minlength=n_labels)[:n_labels]
+        nz = np.bincount(face[ok], minlength=n_labels)[:n_labels].astype(np.float64)
+        return hc.sum(axis=1), nz, hc
 
     def error(self, X, y_im, y_flow, y_m):
         """renderer.py:485-501.  y_im / y_m / the renders are uint8 there, so the
@@ -232,6 +291,59 @@ def hessian_sparse(meas, X, J, deltaX=2.0):
             if J[i, k] == 1:
                 HTH[i, k] = meas.j(deltaX, i, k) / deltaX / deltaX
                 HTH[k, i] = HTH[i, k]
+    return HTH
+
+
+def jacobian_multi(meas, X, E, labels, y_im, y_flow, y_m, deltaX=2.0):
+    """_jacobian_multi, kalman.py:452-489: every partition's vertices perturbed together, label-segmented sums."""
+    N = meas.N
+    X = np.array(X, np.float64).reshape(-1)
+    n = X.size
+    Hz = np.zeros((n, 1))
+    Hzc = np.zeros((n, 4))
+    for idx, e in enumerate(E):
+        e = np.asarray(e, np.int64)
+        meas.initjacobian(X, y_im, y_flow, y_m)
+        lab = labels[:, idx]
+        for i in range(2):
+            for j in range(2):
+                ee = i + 2 * N * j + 2 * e
+                Xp = X.copy(); Xp[ee] += deltaX
+                hz, hzc = meas.jz_multi(Xp, lab, N)
+                Hz[ee, 0] = hz[e] / deltaX
+                Hzc[ee, :] = hzc[e, :] / deltaX
+                Xm = X.copy(); Xm[ee] -= deltaX
+                hz, hzc = meas.jz_multi(Xm, lab, N)
+                Hz[ee, 0] = Hz[ee, 0] - hz[e] / deltaX
+                Hzc[ee, :] -= hzc[e, :] / deltaX
+                Hz[ee, 0] = Hz[ee, 0] / 2
+                Hzc[ee, :] = Hzc[ee, :] / 2
+    return Hz, Hzc
+
+
+def hessian_sparse_multi(meas, X, Q, E_hessian, E_hessian_idx, labels_hess, y_im, y_flow, y_m, deltaX=2.0):
+    """_hessian_sparse_multi, kalman.py:539-581."""
+    N = meas.N
+    X = np.array(X, np.float64).reshape(-1)
+    n = X.size
+    HTH = np.zeros((n, n))
+    nq = len(Q)
+    for idx, e in enumerate(E_hessian):
+        e = np.asarray(e, np.int64).reshape(-1, 2)
+        meas.initjacobian(X, y_im, y_flow, y_m)
+        lab = labels_hess[:, idx]
+        for i1 in range(2):
+            for j1 in range(2):
+                for i2 in range(2):
+                    for j2 in range(2):
+                        ee = np.column_stack((2 * e[:, 0] + i1 + 2 * N * j1, 2 * e[:, 1] + i2 + 2 * N * j2))
+                        h, nz, hc = meas.j_multi(deltaX, ee, lab, nq)
+                        for qi in np.flatnonzero(nz > 0):
+                            q = Q[qi]
+                            q1 = 2 * q[0] + i1 + 2 * N * j1
+                            q2 = 2 * q[1] + i2 + 2 * N * j2
+                            HTH[q1, q2] = h[qi] / deltaX / deltaX
+                            HTH[q2, q1] = HTH[q1, q2]
     return HTH
 
 

@@ -595,3 +595,79 @@ def test_filter_projectmask_uses_the_device_and_matches_host_walk(hm):
     want = ekf_ref.project_mask(X0, N, y_m)
     assert kf.state.X.shape == X0.shape and np.array_equal(kf.state.X, want)
     assert not np.array_equal(kf.state.X, X0)
+
+
+# ---- the reference's multi-perturbation operators (cuda_multi.py:81-248; kalman.py:452-489, 539-581) --------------
+def _multi_case(hm, n=64, h0=11.0, seed=5):
+    from oracle import partitions_ref
+    dm, N, tex, R, meas = _setup(hm, n, h0, seed)
+    rng = np.random.default_rng(seed)
+    X = _state(dm, rng)
+    y_im, flow, y_m = _observation(dm, meas, rng, n)
+    E, labels = partitions_ref.jacobian_partitions(N, dm.t)
+    Q, EH, EHi, lh = partitions_ref.hessian_partitions(N, dm.t)
+    return dm, N, R, meas, X, y_im, flow, y_m, E, labels, Q, EH, EHi, lh
+
+
+def test_jz_multi_and_j_multi_match_oracle(hm):
+    """hm_jz_multi / hm_j_multi against the oracle's restatement of histogram_jz / histogram_j: every vertex of a
+    partition perturbed in one render, sums separated by triangle label; also with a palette that leaves
+    triangles unlabelled and with perturbations large enough to fold the mesh (ids add and saturate)."""
+    dm, N, R, meas, X, y_im, flow, y_m, E, labels, Q, EH, EHi, lh = _multi_case(hm)
+    st = _Flow()
+    R.labels, R.labels_hess, R.Q = labels, lh, Q
+    R.update_vertex_buffer(X[:2 * N].reshape(-1, 2), X[2 * N:].reshape(-1, 2))
+    R.initjacobian(y_im, flow, y_m)
+    meas.initjacobian(X, y_im, flow, y_m)
+    for idx, e in enumerate(E):
+        e = np.asarray(e)
+        for comp, delta in ((0, 2.0), (1, -2.0), (2 * N, 2.0), (2 * N + 1, -2.0), (0, 9.0)):     # 9 px: folds triangles
+            Xp = X.copy()
+            Xp[comp + 2 * e] += delta
+            st.X = Xp.reshape(-1, 1)
+            R.update_vertex_buffer(Xp[:2 * N].reshape(-1, 2), Xp[2 * N:].reshape(-1, 2), idx)
+            hz, hzc = R.jz_multi(st)
+            rhz, rhzc = meas.jz_multi(Xp, labels[:, idx], N)
+            scale = max(np.abs(rhzc).max(), 1e-30)
+            assert np.abs(hzc - rhzc).max() <= 1e-10 * scale, (idx, comp)
+            assert np.abs(hz[:, 0] - rhz).max() <= 1e-10 * scale
+    st.X = X.reshape(-1, 1)
+    for idx in (0, len(EH) // 2, len(EH) - 1):
+        e = np.asarray(EH[idx]).reshape(-1, 2)
+        for (o1, o2) in ((0, 0), (1, 2 * N), (2 * N, 2 * N + 1)):
+            ee = np.column_stack((2 * e[:, 0] + o1, 2 * e[:, 1] + o2))
+            h, hist, hc = R.j_multi(st, 2.0, ee, idx)
+            rh, rnz, rhc = meas.j_multi(2.0, ee, lh[:, idx], len(Q))
+            assert np.array_equal(hist, rnz > 0)
+            assert np.abs(hc - rhc).max() <= 1e-10 * max(np.abs(rhc).max(), 1e-30)
+            assert np.abs(h[0] - rh).max() <= 1e-10 * max(np.abs(rhc).max(), 1e-30)
+    with pytest.raises(RuntimeError):
+        R.update_vertex_buffer(X[:2 * N].reshape(-1, 2), X[2 * N:].reshape(-1, 2))       # palette -1: no labels
+        R.jz_multi(st)
+
+
+def test_multi_perturbation_assembly_equals_single_and_fused(hm):
+    """The multi == single protocol of reference testbites/test_multipert_validation.py:98-189 on the device:
+    KFState._jacobian_multi / _hessian_sparse_multi (partitions E / E_hessian, label-segmented sums) against the
+    single-perturbation assembly, the fused measure() and the oracle's multi assembly.  The reference records
+    agreement to round-off except a few mask-term entries (~2 %); with exact coverage rules and partitions whose
+    stars do not interact the two agree to rounding."""
+    from hydra_mi import kalman, renderer
+    dm, N, R0, meas, X, y_im, flow, y_m, E, labels, Q, EH, EHi, lh = _multi_case(hm, 64, 12.0, 7)
+    tex = meas.tex
+    kf = kalman.IteratedMSKalmanFilter(dm, tex, np.zeros((64, 64, 2), np.float32), True)
+    st = kf.state
+    st.X = X.reshape(-1, 1).copy()
+    assert [list(map(int, e)) for e in st.E] == E and np.array_equal(st.labels, labels)          # the palettes in use
+    Hz_m, Hzc_m = st._jacobian_multi(y_im, flow, y_m)
+    H_m = st._hessian_sparse_multi(y_im, flow, y_m)
+    assert np.abs(st.X - X.reshape(-1, 1)).max() <= 1e-12                                       # state restored (x + d - 2d + d, as the reference does it)
+    Hz_f, H_f, Hzc_f = st.update(y_im, flow, y_m)                                                # fused kernels
+    sc, hs = np.abs(Hz_f).max(), np.abs(H_f).max()
+    assert np.abs(Hz_m - Hz_f).max() <= 1e-9 * sc and np.abs(Hzc_m - Hzc_f).max() <= 1e-9 * np.abs(Hzc_f).max()
+    assert np.abs(H_m - H_f).max() <= 1e-9 * hs
+    assert not np.any((H_f != 0) & (H_m == 0))                                                   # no non-zero missing
+    rHz, rHzc = ekf_ref.jacobian_multi(meas, X, E, labels, y_im, flow, y_m)
+    assert np.abs(Hz_m - rHz).max() <= 1e-9 * sc
+    rH = ekf_ref.hessian_sparse_multi(meas, X, Q, EH, EHi, lh, y_im, flow, y_m)
+    assert np.abs(H_m - rH).max() <= 1e-9 * hs

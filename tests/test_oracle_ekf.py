@@ -159,3 +159,34 @@ def test_jacobian_sign_pulls_towards_observation(hm):
     HTH = ekf_ref.hessian_sparse(meas, X, J)
     assert np.allclose(HTH, HTH.T) and np.all(np.diag(HTH) >= 0)
     assert np.all(HTH[J == 0] == 0)
+
+
+def test_multi_perturbation_oracle_equals_single(hm):
+    """The oracle's restatement of the label-segmented kernels (cuda_multi.py:81-248) assembled as
+    kalman.py:452-489 / 539-581 gives the single-perturbation Jacobian and Hessian (the protocol of
+    testbites/test_multipert_validation.py:98-189), and the id image follows the palette rules."""
+    from hydra_mi import mesh, synth
+    from oracle import partitions_ref
+    n = 48
+    dm = mesh.disk_mesh(23.5, 23.5, 15.0, 11.0)
+    N = dm.size()
+    tex = synth.noise_texture(n, 1).astype(np.uint8)
+    rng = np.random.default_rng(2)
+    X = np.concatenate((dm.p.reshape(-1) + rng.normal(0, 0.5, 2 * N), rng.normal(0, 1.0, 2 * N)))
+    meas = ekf_ref.Measurement(N, dm.t, dm.p, tex, 1e-3, 1.0, 1.0)
+    y_im, yfx, yfy, ym = meas.render(np.concatenate((dm.p.reshape(-1) + 1.0, np.full(2 * N, 0.3))))
+    y_m = (ym // 255).astype(np.uint8)
+    flow = np.dstack((yfx, -yfy)).astype(np.float32)
+    E, labels = partitions_ref.jacobian_partitions(N, dm.t)
+    Q, EH, EHi, lh = partitions_ref.hessian_partitions(N, dm.t)
+    ids = ekf_ref.render(X, N, dm.t, dm.p, tex, n, n, labels[:, 0])[4]
+    m = meas.render(X)[3]
+    assert set(np.unique(ids[m == 255])) <= set(int(v) for v in E[0]) | {65535}      # labelled or white
+    assert np.all(ids[m == 0] == 0)
+    Hz1, Hzc1 = ekf_ref.jacobian(meas, X, y_im, flow, y_m)
+    Hzm, Hzcm = ekf_ref.jacobian_multi(meas, X, E, labels, y_im, flow, y_m)
+    assert np.abs(Hz1 - Hzm).max() <= 1e-12 * np.abs(Hz1).max() and np.abs(Hzc1 - Hzcm).max() <= 1e-12 * np.abs(Hzc1).max()
+    _, J = ekf_ref.adjacency(N, dm.t)
+    H1 = ekf_ref.hessian_sparse(meas, X, J)
+    Hm = ekf_ref.hessian_sparse_multi(meas, X, Q, EH, EHi, lh, y_im, flow, y_m)
+    assert np.abs(H1 - Hm).max() <= 1e-12 * np.abs(H1).max() and not np.any((H1 != 0) & (Hm == 0))

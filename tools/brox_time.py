@@ -37,6 +37,9 @@ def run(n, batch, reps, tunes):
 if __name__ == "__main__":
     tunes = [dict(sor_fuse=0, sor_threads=256), dict(sor_fuse=0, sor_threads=512), dict(sor_fuse=0, sor_threads=1024),
              dict(sor_fuse=2, sor_threads=512), dict(sor_fuse=2, sor_threads=1024)]
+    if len(sys.argv) > 1 and sys.argv[1] == "dry":        # where a SOR launch spends its time: loads + stores only
+        run(1024, 8, 3, [dict(sor_fuse=0, sor_threads=512, sor_dry=0), dict(sor_fuse=0, sor_threads=512, sor_dry=1)])
+        sys.exit(0)
     run(512, 1, 5, tunes[:3])
     run(1024, 1, 5, tunes)
     run(1024, 8, 3, tunes)
