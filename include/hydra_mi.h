@@ -258,6 +258,13 @@ int hm_ms_newton(int n_vertices, int n_bars, const int32_t *bars, const double *
  * W_out (NULL: not copied) and kept on the device for hm_update_begin / hm_update_run(h, NULL, ...). */
 int hm_cov_predict(hm_ctx_t h, const double *W_in, int n_bars, const int32_t *bars, const double *blocks,
                    double a, double s, double eps_F, double *W_out);
+/* IteratedMSKalmanFilter.predict (kalman.py:850-863) in one call for the covariance resident on the device:
+ * the spring Jacobian at X before the step gives F (:856, 904-912); X (4N, in place) is advanced by _newton
+ * (:923-960) -- on the device, one workgroup on a second stream, for meshes whose problem fits its LDS (about 350
+ * vertices), else by hm_ms_newton; W <- F W F^T + Weps (hm_cov_predict); prefactor != 0: also what
+ * hm_update_prefactor does, queued by the calling thread while the state prediction runs. */
+int hm_ms_predict(hm_ctx_t h, int n_bars, const int32_t *bars, const double *l0, double kappa, double M, double dt,
+                  int maxiter, double tol, double eps_F, double *X, int *newton_iterations, int prefactor);
 /* tuning knobs: "measure_split" = workgroups per vertex job of the measurement (1..16, default 5),
  * "edge_split" = workgroups per mesh-edge job (1..16, default 2); the sums change in their last
  * bits with them (another summation order) */

@@ -81,6 +81,9 @@ SIGNATURES = {
                                       ctypes.c_double, c_vp]),
     "hm_ms_newton": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp, c_vp, ctypes.c_double, ctypes.c_double,
                                     ctypes.c_double, ctypes.c_int, ctypes.c_double, c_vp, ctypes.POINTER(ctypes.c_int)]),
+    "hm_ms_predict": (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                     ctypes.c_int, ctypes.c_double, ctypes.c_double, c_vp, ctypes.POINTER(ctypes.c_int),
+                                     ctypes.c_int]),
     "hm_ctx_tune": (ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int]),
     "hm_ctx_sync": (ctypes.c_int, [c_vp]),
     "hm_ctx_stream": (c_vp, [c_vp]),

@@ -5,6 +5,7 @@
 #include "ekf_kernels.h"
 #include "dense_kernels.h"
 #include "project_kernels.h"
+#include "predict_kernels.h"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -67,6 +68,10 @@ struct hm_ctx {
     bool worker_active;
     int worker_rc;
     char worker_err[512];
+    hipStream_t stream2;             // hm_ms_predict: the state prediction runs beside the covariance half of the update
+    int *d_nbars, *d_nvoff, *d_nvbar, *d_ninfo;     // its spring topology (bars, CSR of the bars of every vertex), result words
+    double *d_nl0, *d_nX;
+    size_t ncap;                     // bars the buffers hold
     int *d_ids[3];                   // hm_jz_multi / hm_j_multi: id images of the reference and the two perturbed renders,
     int *d_labels;                   // the label palette (T), per-label boxes and sums; allocated on first use
     int4 *d_lbox;
@@ -147,13 +152,14 @@ static int ctx_free(hm_ctx *h)
                     h->pool.hdr, h->pool.xi, h->pool.yi, h->pool.xfx, h->pool.xfy,
                     h->pool.yfx, h->pool.yfy, h->pool.vxfx, h->pool.vyfy, h->pool.overflow, h->d_area,
                     h->d_outline, h->d_outline_cnt, h->d_pm_mask, h->d_ids[0], h->d_ids[1], h->d_ids[2], h->d_labels, h->d_lbox,
-                    h->d_lout};
+                    h->d_lout, h->d_nbars, h->d_nvoff, h->d_nvbar, h->d_ninfo, h->d_nl0, h->d_nX};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     free_targets(h->ref);
     free_targets(h->P);
     free_targets(h->Q);
     if (h->pin) (void)hipHostFree(h->pin);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return HM_OK;
@@ -212,6 +218,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->d_Wprior = h->d_gain = h->d_Awork = h->d_Lt[0] = h->d_Lt[1] = nullptr; h->d_Wres = nullptr; h->pin = nullptr; h->pin_n = 0;
     h->tri.assign(tri, tri + (size_t)3 * T);
     h->d_outline = nullptr; h->d_outline_cnt = nullptr; h->d_pm_mask = nullptr;
+    h->stream2 = nullptr; h->d_nbars = h->d_nvoff = h->d_nvbar = h->d_ninfo = nullptr; h->d_nl0 = h->d_nX = nullptr; h->ncap = 0;
     h->d_ids[0] = h->d_ids[1] = h->d_ids[2] = nullptr; h->d_labels = nullptr; h->d_lbox = nullptr; h->d_lout = nullptr; h->lcap = 0;
     h->worker_active = false; h->worker_rc = HM_OK; h->worker_err[0] = 0;
     h->d_T[0] = h->d_T[1] = h->d_step = nullptr; h->d_X0 = h->d_Xn = nullptr;
@@ -1177,4 +1184,89 @@ extern "C" int hm_cov_predict(hm_ctx_t h, const double *W_in, int n_bars, const 
     h->d_Wres = h->d_Wtmp;
     h->prefactored = false;
     return HM_OK;
+}
+
+
+// IteratedMSKalmanFilter.predict (kalman.py:850-863) in one call: F from the spring Jacobian at the state before the
+// step (:856, _dfdx :904-912), the state advanced by _newton (:923-960), W <- F W F^T + Weps (:863) -- and, since
+// it only needs the predicted covariance, the covariance half of the update that follows (factorisation and inverse,
+// what hm_update_prefactor queues).  The Newton iterations run as one workgroup on a second stream
+// (csrc/predict_kernels.h) while this thread queues the ~30 launches of the covariance half on the handle's stream;
+// meshes too large for that kernel's LDS footprint take the host version (hm_ms_newton).
+extern "C" int hm_ms_predict(hm_ctx_t h, int n_bars, const int32_t *bars, const double *l0, double kappa, double M, double dt,
+                             int maxiter, double tol, double eps_F, double *X, int *newton_iterations, int prefactor)
+{
+    HM_ARG(h && bars && l0 && X && n_bars >= 1, "hm_ms_predict: bad argument");
+    HM_ARG(dt > 0 && M > 0 && maxiter >= 1 && tol > 0, "hm_ms_predict: bad parameter");
+    HM_JOIN(h);
+    if (!h->d_Wres) { hm_set_error("hm_ms_predict: no covariance resident on the device"); return HM_ERR_STATE; }
+    HM_HIP(hipSetDevice(h->device));
+    const int N = h->N, n4 = 4 * N;
+    for (int i = 0; i < 2 * n_bars; i++) HM_ARG(bars[i] >= 0 && bars[i] < N, "hm_ms_predict: bar refers to vertex %d", bars[i]);
+    // the spring blocks of dfdy at the state before the step (kalman.py:892-901)
+    std::vector<double> blk(3 * (size_t)n_bars);
+    for (int i = 0; i < n_bars; i++) {
+        const int a = bars[2 * i], b = bars[2 * i + 1];
+        const double dx = X[2 * a] - X[2 * b], dy = X[2 * a + 1] - X[2 * b + 1];
+        const double l = std::sqrt(dx * dx + dy * dy);
+        const double k = kappa * (1.0 - l0[i] / l), c = kappa * l0[i] / (l * l * l);
+        blk[3 * i] = k + c * dx * dx; blk[3 * i + 1] = c * dx * dy; blk[3 * i + 2] = k + c * dy * dy;
+    }
+    const size_t lds = ((size_t)34 * N + (size_t)7 * n_bars + 8) * sizeof(double) + ((size_t)N + 1 + 4 * (size_t)n_bars) * sizeof(int);
+    const bool on_device = lds <= 160 * 1024;
+    if (on_device) {
+        if (!h->stream2) HM_HIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+        if (!h->d_nX) {
+            HM_HIP(hipMalloc((void **)&h->d_nX, (size_t)n4 * sizeof(double)));
+            HM_HIP(hipMalloc((void **)&h->d_nvoff, (size_t)(N + 1) * sizeof(int)));
+            HM_HIP(hipMalloc((void **)&h->d_ninfo, 2 * sizeof(int)));
+            HM_HIP(hipFuncSetAttribute((const void *)k_ms_newton, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
+        if ((size_t)n_bars > h->ncap) {
+            if (h->d_nbars) (void)hipFree(h->d_nbars);
+            if (h->d_nvbar) (void)hipFree(h->d_nvbar);
+            if (h->d_nl0) (void)hipFree(h->d_nl0);
+            h->d_nbars = h->d_nvbar = nullptr; h->d_nl0 = nullptr; h->ncap = 0;
+            HM_HIP(hipMalloc((void **)&h->d_nbars, 2 * (size_t)n_bars * sizeof(int)));
+            HM_HIP(hipMalloc((void **)&h->d_nvbar, 2 * (size_t)n_bars * sizeof(int)));
+            HM_HIP(hipMalloc((void **)&h->d_nl0, (size_t)n_bars * sizeof(double)));
+            h->ncap = n_bars;
+        }
+        std::vector<int> off(N + 1, 0), vbar(2 * (size_t)n_bars);
+        for (int i = 0; i < n_bars; i++) { off[bars[2 * i] + 1]++; off[bars[2 * i + 1] + 1]++; }
+        for (int v = 0; v < N; v++) off[v + 1] += off[v];
+        {
+            std::vector<int> fill(off.begin(), off.end() - 1);
+            for (int i = 0; i < n_bars; i++) { vbar[fill[bars[2 * i]]++] = i; vbar[fill[bars[2 * i + 1]]++] = i; }   // ascending per vertex
+        }
+        HM_HIP(hipMemcpyAsync(h->d_nbars, bars, 2 * (size_t)n_bars * sizeof(int), hipMemcpyHostToDevice, h->stream2));
+        HM_HIP(hipMemcpyAsync(h->d_nl0, l0, (size_t)n_bars * sizeof(double), hipMemcpyHostToDevice, h->stream2));
+        HM_HIP(hipMemcpyAsync(h->d_nvoff, off.data(), (size_t)(N + 1) * sizeof(int), hipMemcpyHostToDevice, h->stream2));
+        HM_HIP(hipMemcpyAsync(h->d_nvbar, vbar.data(), vbar.size() * sizeof(int), hipMemcpyHostToDevice, h->stream2));
+        HM_HIP(hipMemcpyAsync(h->d_nX, X, (size_t)n4 * sizeof(double), hipMemcpyHostToDevice, h->stream2));
+        HM_HIP(hipStreamSynchronize(h->stream2));            // off / vbar are locals (pageable copies have returned anyway)
+        NewtonArgs a = {N, n_bars, h->d_nbars, h->d_nl0, h->d_nvoff, h->d_nvbar, kappa, M, dt, tol, maxiter,
+                        (int)std::ceil(1.0 / dt), h->d_nX, h->d_ninfo};
+        hipLaunchKernelGGL(k_ms_newton, dim3(1), dim3(NEWTON_NT), lds, h->stream2, a);
+        HM_HIP(hipGetLastError());
+    }
+    // covariance: W <- F W F^T + Weps on the handle's stream, then (prefactor) its factor and inverse
+    int rc = hm_cov_predict(h, nullptr, n_bars, bars, blk.data(), dt, dt / M, eps_F, nullptr);
+    if (rc == HM_OK && prefactor) {
+        rc = prior_inverse(h, nullptr);
+        if (rc == HM_OK) { h->prefactored = true; h->upd_open = false; }
+    }
+    int info[2] = {0, 0};
+    if (on_device) {
+        hipError_t e = hipMemcpyAsync(X, h->d_nX, (size_t)n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream2);
+        if (e == hipSuccess) e = hipMemcpyAsync(info, h->d_ninfo, sizeof info, hipMemcpyDeviceToHost, h->stream2);
+        if (e == hipSuccess) e = stream_wait(h->stream2);
+        if (e != hipSuccess) { hm_set_error("hm_ms_predict: %s", hipGetErrorString(e)); return HM_ERR_HIP; }
+        if (rc) return rc;
+        if (info[1]) { hm_set_error("hm_ms_predict: the inner solve did not converge"); return HM_ERR_STATE; }
+        if (newton_iterations) *newton_iterations = info[0];
+        return HM_OK;
+    }
+    if (rc) return rc;
+    return hm_ms_newton(N, n_bars, bars, l0, kappa, M, dt, maxiter, tol, X, newton_iterations);
 }

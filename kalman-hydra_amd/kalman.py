@@ -702,6 +702,12 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
         self.force = lambda l1, l2: -self.kappa * (l1 - l2)
         self.state.setforce(self.force)
         self._bar_pattern()
+        # True: hm_ms_predict, the whole prediction in one native call with the Newton iterations of the state as a
+        # single workgroup on the device.  Measured at 201 vertices (tools/predict_time.py): 1.21 ms against 0.68 ms
+        # for the default below -- ~500 dependent conjugate-gradient steps of a 402-unknown system are ~2 us each
+        # on one CU and ~0.8 us on a host core.  False: hm_cov_predict, hm_update_prefactor (the covariance half
+        # of the update queued from a helper thread) and hm_ms_newton on the host, side by side.
+        self.device_predict = False
 
     def _jacobian(self):
         """d f / d y of the spring force at the current vertices (:865-902), sparse.
@@ -767,7 +773,14 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
         st = self.state
         self.orig_x = st.X.copy()
         # F = [[I, dt I], [dt/M dfdy, I]] at the state before the step (:856)
-        if hasattr(st.renderer, "cov_predict"):
+        if self.device_predict and hasattr(st.renderer, "ms_predict") and isinstance(st._W, DeviceCovariance):
+            # the whole prediction in one native call (hm_ms_predict): the Newton iterations of the state as one
+            # workgroup on a second stream while the covariance prediction and, for the fused update, the
+            # factorisation / inversion it starts with are queued on the filter's stream
+            st.X, self.newton_iterations, st.W = st.renderer.ms_predict(
+                st._W, st.X, self._bars, st.l0[:, 0], self.kappa, self.M, self.deltat, self.maxiter, self.tol, st.eps_F,
+                prefactor=self.fused_update)
+        elif hasattr(st.renderer, "cov_predict"):
             # the covariance half first: it is queued on the device (prediction, then the
             # factorisation and inversion the update starts with) and runs while the host works
             # through the Newton iterations of the state

@@ -273,6 +273,20 @@ class Renderer:
                                              float(eps_F), None), "hm_cov_predict")
         return self._cov_result(fetch)
 
+    def ms_predict(self, W, X, bars, l0, kappa, M, dt, maxiter, tol, eps_F, prefactor=True):
+        """hm_ms_predict: IteratedMSKalmanFilter.predict (kalman.py:850-863) for the DeviceCovariance W in one native
+        call -> (X predicted [4N,1], Newton iterations, DeviceCovariance of the predicted covariance)."""
+        if self._cov_arg(W, "ms_predict") is not None:
+            raise TypeError("ms_predict takes the DeviceCovariance resident on the device")
+        Xp = np.ascontiguousarray(np.asarray(X, np.float64).reshape(-1)).copy()
+        b = np.ascontiguousarray(bars, np.int32)
+        l0 = np.ascontiguousarray(np.asarray(l0, np.float64).reshape(-1))
+        its = ctypes.c_int()
+        _lib.check(_lib.lib().hm_ms_predict(self._h, int(b.shape[0]), _lib.ptr(b), _lib.ptr(l0), float(kappa), float(M),
+                                            float(dt), int(maxiter), float(tol), float(eps_F), _lib.ptr(Xp),
+                                            ctypes.byref(its), 1 if prefactor else 0), "hm_ms_predict")
+        return Xp.reshape(-1, 1), its.value, self._cov_result(False)
+
     def update_prefactor(self, W):
         """hm_update_prefactor: queue the factorisation / inversion of the DeviceCovariance W now (it
         does not need the predicted state); the next update_begin / update_run with W picks it up."""

@@ -671,3 +671,61 @@ def test_multi_perturbation_assembly_equals_single_and_fused(hm):
     assert np.abs(Hz_m - rHz).max() <= 1e-9 * sc
     rH = ekf_ref.hessian_sparse_multi(meas, X, Q, EH, EHi, lh, y_im, flow, y_m)
     assert np.abs(H_m - rH).max() <= 1e-9 * hs
+
+
+def test_ms_predict_on_device_matches_oracle_and_host(hm):
+    """hm_ms_predict (state prediction as one workgroup on the device + covariance prediction + the covariance
+    half of the next update) against the oracle's IteratedMSKalmanFilter.predict (kalman.py:850-960: dense
+    inverse per Newton iteration) and against the host Newton of the same library; then a whole frame with
+    either predict gives the same state."""
+    from hydra_mi import kalman
+    n = 64
+    dm, N, tex, R, meas = _setup(hm, n, 9.0, seed=4)
+    rng = np.random.default_rng(33)
+    n4 = 4 * N
+    Mx = rng.normal(size=(n4, n4))
+    W = np.eye(n4) * 0.3 + 0.02 * (Mx @ Mx.T) / n4
+    X = np.concatenate((dm.p.reshape(-1) + rng.normal(0, 0.6, 2 * N), rng.normal(0, 1.5, 2 * N)))
+    K = ekf_ref.incidence(N, dm.bars)
+    l0 = ekf_ref.bar_lengths(K, dm.p.reshape(-1))
+    _, Weps, _ = ekf_ref.initial_covariances(N, 0.1)
+    rX, rW = ekf_ref.ms_predict(X, W, Weps, K, l0)
+    tok = R.cov_predict(W, None, None, 0.0, 0.0, 0.0, fetch=False)           # W itself, resident on the device
+    assert np.array_equal(tok.fetch(), W)
+    Xp, its, tokp = R.ms_predict(tok, X, dm.bars, l0, -1.0, 1.0, 0.05, 1000, 1e-4, 0.1)
+    assert its >= 20                                                        # 20 sub-steps, at least one iteration each
+    assert np.linalg.norm(Xp - rX) <= 1e-9 * np.linalg.norm(rX)
+    Wp = tokp.fetch()
+    assert np.linalg.norm(Wp - rW) <= 1e-11 * np.linalg.norm(rW)
+    # the host version of the same loop (hm_ms_newton): same iteration count, same numbers to rounding
+    import ctypes
+    from hydra_mi import _lib
+    Xh = X.copy()
+    b32 = np.ascontiguousarray(dm.bars, np.int32)
+    itsh = ctypes.c_int()
+    _lib.check(_lib.lib().hm_ms_newton(N, len(b32), _lib.ptr(b32), _lib.ptr(np.ascontiguousarray(l0)), -1.0, 1.0, 0.05,
+                                       1000, 1e-4, _lib.ptr(Xh), ctypes.byref(itsh)))
+    assert itsh.value == its and np.abs(Xh - Xp[:, 0]).max() <= 1e-12 * np.abs(Xh).max()
+    # the prefactored covariance is picked up by the update: same step as with an explicit begin
+    y_im, flow, y_m = _observation(dm, meas, rng, n)
+    st = _Flow()
+    st.X = Xp
+    R.update_begin(tokp, Xp)
+    step_a, _, _ = R.update_step(st, y_im, flow, y_m)
+    R.update_begin(Wp.copy(), Xp)
+    step_b, _, _ = R.update_step(st, y_im, flow, y_m)
+    assert np.array_equal(step_a, step_b)
+    # a whole frame through the filter, device predict against host predict
+    video, flowv = __import__("hydra_mi").synth.test_data(64, 64)
+    from hydra_mi import mesh
+    outs = []
+    for dev_pred in (True, False):
+        dmq = mesh.box_mesh(21.0, 22.0, 42.0, 43.0, 10.0)
+        kf = kalman.IteratedMSKalmanFilter(dmq, video[:, :, 0], flowv[:, :, :, 0], True, nI=3)
+        assert kf.device_predict is False                                   # the faster one is the default
+        kf.device_predict = dev_pred
+        for k in (1, 2):
+            fr = video[:, :, k]
+            kf.compute(fr, flowv[:, :, :, k], (fr > 0).astype(np.uint8))
+        outs.append(kf.state.X.copy())
+    assert np.linalg.norm(outs[0] - outs[1]) <= 1e-9 * np.linalg.norm(outs[1])
