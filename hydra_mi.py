@@ -12,6 +12,6 @@ _root = os.path.dirname(os.path.abspath(__file__))
 if _root not in sys.path:
     sys.path.insert(0, _root)
 _pkg = importlib.import_module("kalman-hydra_amd")
-for _sub in ("_lib", "matio", "synth", "mesh", "brox", "renderer", "kalman", "pipeline", "batch"):
+for _sub in ("_lib", "matio", "synth", "mesh", "brox", "renderer", "kalman", "pipeline", "batch", "imgproc", "distmesh_dyn"):
     sys.modules[__name__ + "." + _sub] = importlib.import_module("kalman-hydra_amd." + _sub)
 sys.modules[__name__] = _pkg

@@ -49,8 +49,7 @@ def load_video(fn):
 
 
 def threshold_mask(gray, threshold):
-    """Object mask of a frame.  The reference thresholds, then keeps the pruned contour hierarchy
-    (imgproc.findObjectThreshold, imgproc.py:175-248, outside this path); here: intensity above threshold."""
+    """The mask imgproc.findObjectThreshold returns (reference imgproc.py:195-197): intensity above threshold."""
     return (np.asarray(gray) > threshold).astype(np.uint8)
 
 
@@ -87,9 +86,10 @@ class VideoStream:
     gray_frame = current_frame
 
     def backsub(self, im=None):
+        if im is None:                                 # (mask, contours, signed distance function): DistMesh's input
+            from .imgproc import findObjectThreshold
+            return findObjectThreshold(self.frame, threshold=self.threshold)
         mask = threshold_mask(self.frame, self.threshold)
-        if im is None:
-            return mask, None, None                    # (mask, contours, distance function): the latter two are DistMesh input
         im = np.asarray(im)
         return mask * im if im.ndim == 2 else mask[:, :, None] * im
 

@@ -21,7 +21,8 @@ import sys
 import numpy as np
 
 import hydra_mi  # noqa: F401
-from hydra_mi import kalman, mesh
+from hydra_mi import kalman
+from hydra_mi.distmesh_dyn import DistMesh
 from hydra_mi.pipeline import FlowEKFPipeline, VideoStream, threshold_mask
 from hydra_mi.renderer import FlowStream
 
@@ -47,8 +48,9 @@ def main(argv=None):
 
     capture = VideoStream(args.fn_in, args.threshold)          # reference run_kalmanfilter.py:58
     frame = capture.current_frame()
-    mask, _, _ = capture.backsub()
-    distmesh = mesh.mask_mesh(mask, float(args.gridsize))
+    mask, ctrs, fd = capture.backsub()
+    distmesh = DistMesh(frame, h0=args.gridsize)               # reference run_kalmanfilter.py:62-63
+    distmesh.createMesh(ctrs, fd, frame, plot=False)
 
     flowstream = FlowStream(args.flow_in)
     ret_flow, flowframe = flowstream.peek()

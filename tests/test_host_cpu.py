@@ -306,6 +306,73 @@ def test_mask_distance_equals_whole_frame_transform(hm):
         assert np.array_equal(kalman._mask_distance(blank)(p), np.zeros(len(p)))
 
 
+def test_signed_distance_and_distmesh(hm, tmp_path):
+    """N3: imgproc.findObjectThreshold (mask, kept contours, signed distance to the outline -- reference
+    imgproc.py:175-248) and DistMesh.createMesh (distmesh_dyn.py:42-139) on shapes whose distance is known."""
+    from hydra_mi import distmesh_dyn, imgproc
+    n = 160
+    yy, xx = np.mgrid[:n, :n]
+    img = np.zeros((n, n), np.uint8)
+    img[30:121, 40:131] = 200                                       # a square object, rows 30..120, columns 40..130
+    img[70:81, 80:91] = 0                                           # with an 11 x 11 hole (kept: >= 40 px)
+    img[50:53, 60:63] = 0                                           # a 3 x 3 pinhole (dropped: < 40 px)
+    img[5:12, 5:12] = 90                                            # and a second, smaller object (dropped)
+    mask, ctrs, fd = imgproc.findObjectThreshold(img, 9)
+    assert np.array_equal(mask, (img > 9).astype(np.uint8))
+    assert ctrs.nC == 2 and [lv for _, lv in ctrs.traverse()] == [0, 1]      # outer outline + the one real hole
+    # exact outside the object: the polygon runs through the centres of the boundary pixels
+    q = np.array([[20.0, 75.0], [140.5, 75.0], [85.0, 10.0], [30.0, 20.0], [85.0, 75.0], [8.0, 8.0], [61.0, 51.0], [84.5, 60.0]])
+    want = np.array([20.0, 10.5, 20.0, np.hypot(10.0, 10.0), 6.0, np.hypot(32.0, 22.0), None, None], dtype=object)
+    got = fd(q)
+    for g, w in zip(got[:4], want[:4]):
+        assert abs(g - w) < 1e-12
+    assert abs(got[4] - 6.0) < 1e-12          # centre of the hole: outside the object, 6 px from the hole's border pixels (79 / 91)
+    assert abs(got[5] - want[5]) < 1e-12      # the small object does not count
+    assert got[6] < 0 and got[7] < 0          # the pinhole is filled; a point of the body is inside
+    # signs against the filled region on a dense sample, magnitudes against the exact distance outside
+    rng = np.random.default_rng(1)
+    p = rng.uniform(0, n - 1, (4000, 2))
+    d = fd(p)
+    sq = lambda x, y: np.maximum(np.maximum(40 - x, x - 130), np.maximum(30 - y, y - 120))
+    hole = lambda x, y: np.maximum(np.maximum(79 - x, x - 91), np.maximum(69 - y, y - 81))       # < 0 inside the hole's polygon
+    outside_sq = (sq(p[:, 0], p[:, 1]) > 0)
+    ex = np.hypot(np.maximum(0, np.maximum(40 - p[:, 0], p[:, 0] - 130)), np.maximum(0, np.maximum(30 - p[:, 1], p[:, 1] - 120)))
+    assert np.abs(d[outside_sq] - ex[outside_sq]).max() < 1e-9
+    in_hole = hole(p[:, 0], p[:, 1]) < 0
+    assert np.all(d[in_hole] > 0) and np.all(d[~outside_sq & ~in_hole & (sq(p[:, 0], p[:, 1]) < -1e-9) & (hole(p[:, 0], p[:, 1]) > 1e-9)] < 0)
+    # DistMesh on a disk: deterministic, inside the object, near-uniform bars, well-shaped triangles
+    disk = ((xx - 79.5) ** 2 + (yy - 79.5) ** 2 <= 50.0 ** 2).astype(np.uint8) * 180
+    mask, ctrs, fd = imgproc.findObjectThreshold(disk, 9)
+    dm = distmesh_dyn.DistMesh(disk, h0=16)
+    dm.createMesh(ctrs, fd, disk)
+    dm2 = distmesh_dyn.DistMesh(disk, h0=16)
+    dm2.createMesh(ctrs, fd, disk)
+    assert np.array_equal(dm.p, dm2.p) and np.array_equal(dm.t, dm2.t)
+    assert 30 <= dm.size() <= 60 and dm.iterations < dm.maxiter
+    assert fd(dm.p).max() < 1.0                                      # vertices on or inside the outline (1 px)
+    assert np.array_equal(np.unique(dm.t), np.arange(dm.size()))     # every vertex is used
+    a, b = dm.p[dm.t[:, 1]] - dm.p[dm.t[:, 0]], dm.p[dm.t[:, 2]] - dm.p[dm.t[:, 0]]
+    cr = a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]
+    assert np.abs(cr / np.linalg.norm(a, axis=1) / np.linalg.norm(b, axis=1)).min() > 0.4
+    assert np.abs(cr).sum() / 2 > 0.93 * np.pi * 50.0 ** 2           # the mesh covers the disk
+    assert dm.L.min() > 0.6 * 16 and dm.L.max() < 2.2 * 16
+    bars = np.unique(np.sort(np.vstack((dm.t[:, [0, 1]], dm.t[:, [1, 2]], dm.t[:, [2, 0]])), axis=1), axis=0)
+    # (L are the lengths before the last move of the points, as in the reference, :104 / :119: the filter measures its own)
+    assert np.array_equal(bars, dm.bars) and np.allclose(dm.L, np.linalg.norm(dm.p[bars[:, 0]] - dm.p[bars[:, 1]], axis=1), rtol=2e-2)
+    # the 19 pickled fields round-trip (distmesh_dyn.py:205-222)
+    fn = str(tmp_path / "mesh.pkl")
+    dm.save(fn)
+    dm3 = distmesh_dyn.DistMesh(disk, h0=16)
+    dm3.load(fn)
+    assert np.array_equal(dm3.p, dm.p) and np.array_equal(dm3.t, dm.t) and dm3.size() == dm.size()
+    # updateMesh: the outline moves by 3 px, the mesh follows without re-triangulating
+    disk2 = ((xx - 82.5) ** 2 + (yy - 79.5) ** 2 <= 50.0 ** 2).astype(np.uint8) * 180
+    _, ctrs2, fd2 = imgproc.findObjectThreshold(disk2, 9)
+    nt = len(dm.t)
+    dm.updateMesh(ctrs2, fd2, disk2)
+    assert fd2(dm.p).max() < 1.0 and len(dm.t) <= nt
+
+
 def test_videostream_and_shared_gray_conversion(hm, tmp_path):
     """VideoStream mirrors reference renderer.py:739-805 on an array source; a colour video is converted the way
     cvtColor(BGR2GRAY) does (renderer.py:752, src/optical_flow_ext.cpp:366-368) by ONE function both command
@@ -328,7 +395,7 @@ def test_videostream_and_shared_gray_conversion(hm, tmp_path):
     vs = pipeline.VideoStream(fn, 100)
     assert (vs.nx, vs.ny) == (12, 10) and vs.isOpened()
     mask, ctrs, fd = vs.backsub()
-    assert np.array_equal(mask, (want[0] > 100).astype(np.uint8))
+    assert np.array_equal(mask, (want[0] > 100).astype(np.uint8)) and callable(fd)
     assert np.array_equal(vs.current_frame(), want[0] * mask) and np.array_equal(vs.current_frame(False), want[0])
     assert np.array_equal(vs.backsub(col[0]), mask[:, :, None] * col[0])
     for k in (1, 2, 3):
