@@ -267,7 +267,9 @@ int hm_ms_predict(hm_ctx_t h, int n_bars, const int32_t *bars, const double *l0,
                   int maxiter, double tol, double eps_F, double *X, int *newton_iterations, int prefactor);
 /* tuning knobs: "measure_split" = workgroups per vertex job of the measurement (1..16, default 5),
  * "edge_split" = workgroups per mesh-edge job (1..16, default 2); the sums change in their last
- * bits with them (another summation order) */
+ * bits with them (another summation order); "chol_flow" = 1/0 the blocked Cholesky factorisations of the update as one
+ * persistent launch whose block tasks hand their results over through memory, or one launch per 32-column block step
+ * (same bits either way), "chol_flow_wgs" = workgroups of that launch (default 256) */
 int hm_ctx_tune(hm_ctx_t h, const char *key, int value);
 int hm_ctx_sync(hm_ctx_t h);
 void *hm_ctx_stream(hm_ctx_t h);

@@ -1,0 +1,282 @@
+// The blocked Cholesky factorisation + inverse of the factor as ONE persistent launch (gfx950).
+//
+// k_chol_step (dense_kernels.h) takes one launch per 32-column block step: 26 dependent launches for n = 804,
+// each ~8.8 us of kernel (2.0 waiting for operands written by the previous launch, 1.1 products, 3.5 factoring
+// the next diagonal block, the rest ramp) plus ~2 us between launches -- the chain of the diagonal blocks is
+// what a factorisation costs, and 4-5 us per step of it are launch boundary.  Here the same block operations
+// run as tasks of one launch and hand their results to each other through memory:
+//
+//   D(c)    diagonal block c:  A_cc - sum_{j<c} L_cj L_cj^T  ->  T_c = chol(.)^-1            (Lt[c], Tinv_cc)
+//   F(r,c)  block below it:    (A_rc - sum_{j<c} L_rj L_cj^T) T_c^T  ->  L_rc                 (r = nb: right-hand sides)
+//   I(k,j)  inverse, k > j:    T_k (0 - sum_{i=j..k-1} L_ki Tinv_ij)  ->  Tinv_kj
+//
+// -- left-looking forms of what the step kernels do right-looking: every sum runs over j (or i) in ascending order
+// with the same 32x32x32 MFMA products subtracted one by one, so every block has the bits the step kernels give
+// (tests compare the two exactly).
+//
+// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility; cdna_hip_programming.md Guideline 16, form R2 "the
+// data is the flag"): the output arrays are pre-filled with a NaN bit pattern no computation produces; a producer
+// stores every element of a block with ONE 8-byte write-through store (agent scope, sc1); a consumer loads the block
+// with sc1 loads (they bypass its CU's L1) and takes it when no element is the pattern any more.  No flags, no
+// fences, no dependence on which XCD a workgroup runs on.  While a block is not there one lane polls one of its
+// words (s_sleep between polls); every wait is bounded and a time-out ends the launch with an error word set.
+//
+// Scheduling: tasks are numbered so that every task depends only on lower numbers (step by step: D(c), F(.,c),
+// I(c,.)), and workgroups draw numbers from one counter in the order they start running.  A workgroup therefore
+// only ever waits for tasks that other RUNNING workgroups hold -- no deadlock whatever number of workgroups is
+// resident -- and the ~250 workgroups in flight work ~9 steps ahead of the diagonal chain: a block's sum is
+// complete but for its last term by the time that term's operand appears.  The chain itself: D(c+1) waits for T_c
+// (one hand-off), multiplies the block (c+1, c) -- published before its triangular solve by F(c+1, c) -- by T_c^T,
+// subtracts its square, factors.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dense_kernels.h"
+
+#define FLOW_NT 256
+#define FLOW_SENTINEL 0x7FF8DEADBEEF0001ull       // a quiet NaN with a payload the hardware never generates
+#define FLOW_POLL_LIMIT 4000000                   // polls of one wait before it gives up (~seconds)
+
+struct FlowArgs {
+    const double *A;          // n x n matrix (+ right-hand-side rows up to nrows), read only
+    double *L;                // nrows x n: blocks below the block diagonal
+    double *Lt;               // nb x 32 x 32: T_c
+    double *Tinv;             // n x n: L^-1
+    double *P;                // nb x 32 x 32: block (c, c-1) before its triangular solve
+    int n, nrows, nb, nbr;    // nbr: block rows including the right-hand-side rows
+    unsigned *ctl;            // [0] next task, [1] set when a wait timed out
+};
+
+__device__ __forceinline__ unsigned long long flow_ld_bits(const double *p)
+{
+    return __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void flow_st(double *p, double v)
+{
+    __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Pre-fill of everything the launch produces, and the task counter (the error word is cleared by the caller of
+// a sequence of factorisations, so that a time-out is still seen at the end of it).
+__global__ void k_flow_fill(FlowArgs a)
+{
+    const size_t nL = (size_t)a.nrows * a.n, nT = (size_t)a.n * a.n, nB = (size_t)a.nb * DNB * DNB;
+    const size_t total = nL + nT + 2 * nB;
+    const double s = __longlong_as_double((long long)FLOW_SENTINEL);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        if (i < nL) a.L[i] = s;
+        else if (i < nL + nT) a.Tinv[i - nL] = s;
+        else if (i < nL + nT + nB) a.Lt[i - nL - nT] = s;
+        else a.P[i - nL - nT - nB] = s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl[0] = 0;
+}
+
+// Wait for one or two blocks other tasks produce (rows < nr and columns < nc of a block are produced; the rest
+// reads as 0) and put them into LDS.  First every thread simply loads its elements of both blocks -- one round trip
+// when they are there already, the usual case for a task that runs ahead of the diagonal chain; while something is
+// missing, one lane watches one word of the missing block (a short s_sleep between polls) before the block is
+// loaded again.  false: gave up (error word set by this or another workgroup).
+struct FlowBlock {
+    const double *src;
+    int ld, nr, nc;
+    double (*dst)[DNB + 1];
+};
+
+__device__ __forceinline__ bool flow_fetch2(const FlowBlock &b0, const FlowBlock &b1, bool two, unsigned *ctl)
+{
+    const int t = threadIdx.x;
+    __shared__ int s_ok;
+    double v0[4], v1[4];
+    for (int tries = 0;; tries++) {
+        int ok0 = 1, ok1 = 1;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int e = t + FLOW_NT * q, i = e / DNB, j = e % DNB;
+            unsigned long long x0 = 0, x1 = 0;
+            if (i < b0.nr && j < b0.nc) x0 = flow_ld_bits(b0.src + (size_t)i * b0.ld + j);
+            if (two && i < b1.nr && j < b1.nc) x1 = flow_ld_bits(b1.src + (size_t)i * b1.ld + j);
+            ok0 &= x0 != FLOW_SENTINEL;
+            ok1 &= x1 != FLOW_SENTINEL;
+            v0[q] = __longlong_as_double((long long)x0);
+            v1[q] = __longlong_as_double((long long)x1);
+        }
+        const int got0 = __syncthreads_and(ok0), got1 = two ? __syncthreads_and(ok1) : 1;
+        if (got0 && got1) break;                      // every element of what was asked for has arrived
+        if (t == 0) {                                 // one lane watches one word of the block that is missing
+            int ok = 1;
+            const FlowBlock &m = got0 ? b1 : b0;
+            const double *canary = m.src + (size_t)(m.nr - 1) * m.ld + (m.nc - 1);
+            for (int polls = 0; flow_ld_bits(canary) == FLOW_SENTINEL; polls++) {
+                __builtin_amdgcn_s_sleep(2);
+                if ((polls & 255) == 255 && __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
+                if (polls > FLOW_POLL_LIMIT) { __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+            }
+            if (tries > 1000) { __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; }
+            s_ok = ok;
+        }
+        __syncthreads();
+        if (!s_ok) return false;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int e = t + FLOW_NT * q;
+        b0.dst[e / DNB][e % DNB] = v0[q];
+        if (two) b1.dst[e / DNB][e % DNB] = v1[q];
+    }
+    return true;
+}
+
+__device__ __forceinline__ bool flow_fetch(const double *src, int ld, int nr, int nc, double (*dst)[DNB + 1], unsigned *ctl)
+{
+    const FlowBlock b = {src, ld, nr, nc, dst};
+    return flow_fetch2(b, b, false, ctl);
+}
+
+// chol32_tinv_wave with write-through stores, to Lt[c] and to the diagonal block of Tinv
+__device__ __forceinline__ void flow_chol32(double (*W)[DNB + 1], double *lt, double *tinv, int ld, int nc, int lane)
+{
+    d4_t b[2][2], t[2][2];
+    const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+    for (int R = 0; R < 2; R++)
+#pragma unroll
+        for (int C = 0; C < 2; C++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int i = 16 * R + lr + 4 * e, jc = 16 * C + lc;
+                b[R][C][e] = W[i][jc];
+                t[R][C][e] = i == jc ? 1.0 : 0.0;
+            }
+    chol32_strip<0>(b, t, lane); chol32_strip<1>(b, t, lane); chol32_strip<2>(b, t, lane); chol32_strip<3>(b, t, lane);
+    chol32_strip<4>(b, t, lane); chol32_strip<5>(b, t, lane); chol32_strip<6>(b, t, lane); chol32_strip<7>(b, t, lane);
+    // T_c first: the next diagonal task is waiting for it; the copy into the inverse after it
+#pragma unroll
+    for (int R = 0; R < 2; R++)
+#pragma unroll
+        for (int C = 0; C < 2; C++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) flow_st(lt + (16 * R + lr + 4 * e) * DNB + 16 * C + lc, t[R][C][e]);
+#pragma unroll
+    for (int R = 0; R < 2; R++)
+#pragma unroll
+        for (int C = 0; C < 2; C++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int i = 16 * R + lr + 4 * e, j = 16 * C + lc;
+                if (i < nc && j < nc) flow_st(tinv + (size_t)i * ld + j, t[R][C][e]);
+            }
+}
+
+__global__ __launch_bounds__(FLOW_NT) void k_chol_flow(FlowArgs a)
+{
+    __shared__ double Ts[DNB][DNB + 1];
+    __shared__ double Br[DNB][DNB + 1];
+    __shared__ double Bc[DNB][DNB + 1];
+    __shared__ unsigned s_task;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int n = a.n, nb = a.nb;
+    const unsigned ntasks = (unsigned)nb * (unsigned)(nb + 1);
+    // coordinates of this thread's four elements of a 32x32 product tile (accumulator layout of d_mfma_*)
+    const int mj = 16 * (wv & 1) + (lane & 15);
+    int mi[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) mi[e] = 16 * (wv >> 1) + (lane >> 4) + 4 * e;
+    const d4_t z = {0.0, 0.0, 0.0, 0.0};
+    for (;;) {
+        __syncthreads();                              // everyone is done with the previous task's LDS and s_task
+        if (t == 0) s_task = atomicAdd(a.ctl, 1u);
+        __syncthreads();
+        const unsigned task = s_task;
+        if (task >= ntasks) return;
+        const int c = (int)(task / (unsigned)(nb + 1)), idx = (int)(task % (unsigned)(nb + 1));
+        const int c0 = c * DNB, nc = min(DNB, n - c0);
+        if (idx == 0) {
+            // ---- D(c) --------------------------------------------------------------------------------------
+            double acc[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[e] = (mi[e] < nc && mj < nc) ? a.A[(size_t)(c0 + mi[e]) * n + c0 + mj] : 0.0;
+            for (int j = 0; j + 1 < c; j++) {
+                if (!flow_fetch(a.L + (size_t)c0 * n + j * DNB, n, nc, DNB, Br, a.ctl)) return;
+                __syncthreads();
+                const d4_t s = d_mfma_nt(Br, Br, wv, lane);
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[e] = acc[e] - s[e];
+                __syncthreads();
+            }
+            if (c > 0) {                              // the last term: block (c, c-1) as F(c, c-1) left it, times T_{c-1}^T
+                const FlowBlock bp = {a.P + (size_t)c * DNB * DNB, DNB, nc, DNB, Bc};
+                const FlowBlock bt = {a.Lt + (size_t)(c - 1) * DNB * DNB, DNB, DNB, DNB, Ts};
+                if (!flow_fetch2(bt, bp, true, a.ctl)) return;
+                __syncthreads();
+                const d4_t xr = d_mfma_nt(Bc, Ts, wv, lane);
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 4; e++) Br[mi[e]][mj] = xr[e];
+                __syncthreads();
+                const d4_t s = d_mfma_nt(Br, Br, wv, lane);
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[e] = acc[e] - s[e];
+                __syncthreads();
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) Br[mi[e]][mj] = (mi[e] < nc && mj < nc) ? acc[e] : (mi[e] == mj ? 1.0 : 0.0);
+            __syncthreads();
+            if (wv == 0) flow_chol32(Br, a.Lt + (size_t)c * DNB * DNB, a.Tinv + (size_t)c0 * n + c0, n, nc, lane);
+        } else if (idx <= nb - c) {
+            // ---- F(r, c) -----------------------------------------------------------------------------------
+            const int r = c + idx;
+            if (r >= a.nbr) continue;                 // no right-hand-side rows in this factorisation
+            const int r0 = r * DNB, nr = min(DNB, a.nrows - r0);
+            double acc[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[e] = (mi[e] < nr && mj < nc) ? a.A[(size_t)(r0 + mi[e]) * n + c0 + mj] : 0.0;
+            for (int j = 0; j < c; j++) {
+                const FlowBlock br = {a.L + (size_t)r0 * n + j * DNB, n, nr, DNB, Br};
+                const FlowBlock bc = {a.L + (size_t)c0 * n + j * DNB, n, nc, DNB, Bc};
+                if (!flow_fetch2(br, bc, true, a.ctl)) return;
+                __syncthreads();
+                const d4_t s = d_mfma_nt(Br, Bc, wv, lane);
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[e] = acc[e] - s[e];
+                __syncthreads();
+            }
+            if (r == c + 1 && r < nb) {               // the diagonal task of column r takes it from here
+                double *Pb = a.P + (size_t)r * DNB * DNB;
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (mi[e] < nr) flow_st(Pb + mi[e] * DNB + mj, mj < nc ? acc[e] : 0.0);
+            }
+            if (!flow_fetch(a.Lt + (size_t)c * DNB * DNB, DNB, DNB, DNB, Ts, a.ctl)) return;
+#pragma unroll
+            for (int e = 0; e < 4; e++) Br[mi[e]][mj] = acc[e];
+            __syncthreads();
+            const d4_t xr = d_mfma_nt(Br, Ts, wv, lane);
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (mi[e] < nr && mj < nc) flow_st(a.L + (size_t)(r0 + mi[e]) * n + c0 + mj, xr[e]);
+        } else {
+            // ---- I(k, j): block (k, j) of the inverse, k = c ------------------------------------------------------
+            const int k = c, j = idx - (nb - c) - 1, k0 = c0, nk = nc, j0 = j * DNB;
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int i = j; i < k; i++) {
+                const FlowBlock bl = {a.L + (size_t)k0 * n + i * DNB, n, nk, DNB, Br};
+                const FlowBlock bi = {a.Tinv + (size_t)(i * DNB) * n + j0, n, DNB, DNB, Bc};
+                if (!flow_fetch2(bl, bi, true, a.ctl)) return;
+                __syncthreads();
+                const d4_t s = d_mfma_nn(Br, Bc, wv, lane, z);
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[e] = acc[e] - s[e];
+                __syncthreads();
+            }
+            if (!flow_fetch(a.Lt + (size_t)k * DNB * DNB, DNB, DNB, DNB, Ts, a.ctl)) return;
+#pragma unroll
+            for (int e = 0; e < 4; e++) Bc[mi[e]][mj] = mi[e] < nk ? acc[e] : 0.0;
+            __syncthreads();
+            const d4_t u = d_mfma_nn(Ts, Bc, wv, lane, z);
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (mi[e] < nk) flow_st(a.Tinv + (size_t)(k0 + mi[e]) * n + j0 + mj, u[e]);
+        }
+    }
+}

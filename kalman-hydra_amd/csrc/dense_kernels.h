@@ -471,12 +471,12 @@ __global__ __launch_bounds__(256) void k_assemble(const double *__restrict__ inv
 
 // ---- end of one iteration of hm_update_run ---------------------------------------------------------------
 // res (host-visible, coherent) = [step (n) | the four error sums, partials added in index order |
-// overflow flag | ticket].  One workgroup; the partials are staged in LDS so that the in-order sums do
+// overflow flag | ticket | (spare) | factorisation time-out].  One workgroup; the partials are staged in LDS so that the in-order sums do
 // not wait on memory.  The ticket is written last, after a system-scope fence: a host that sees it
 // sees the rest.
 __global__ __launch_bounds__(256) void k_iter_result(const double *__restrict__ step, int n, const double *__restrict__ partial,
-                                                     int nblocks, const int *__restrict__ overflow, double *__restrict__ res,
-                                                     double ticket)
+                                                     int nblocks, const int *__restrict__ overflow,
+                                                     const unsigned *__restrict__ flow_ctl, double *__restrict__ res, double ticket)
 {
     extern __shared__ double sp[];                // 4 * nblocks
     const int t = threadIdx.x;
@@ -489,6 +489,8 @@ __global__ __launch_bounds__(256) void k_iter_result(const double *__restrict__ 
         res[n + t] = s;
     } else if (t == 4) {
         res[n + 4] = (double)*overflow;
+    } else if (t == 5) {
+        res[n + 7] = (double)flow_ctl[1];             // a wait of the persistent factorisation launch timed out
     }
     __threadfence_system();
     __syncthreads();

@@ -4,6 +4,7 @@
 #include "hm_common.h"
 #include "ekf_kernels.h"
 #include "dense_kernels.h"
+#include "chol_flow_kernels.h"
 #include "project_kernels.h"
 #include "predict_kernels.h"
 #include <algorithm>
@@ -68,6 +69,9 @@ struct hm_ctx {
     bool worker_active;
     int worker_rc;
     char worker_err[512];
+    int chol_flow, flow_wgs;         // the factorisation as one persistent launch (chol_flow_kernels.h) / its workgroups
+    double *d_flowP;                 // nb x 32 x 32 scratch of that launch
+    unsigned *d_flowctl;             // its task counter and time-out word
     hipStream_t stream2;             // hm_ms_predict: the state prediction runs beside the covariance half of the update
     int *d_nbars, *d_nvoff, *d_nvbar, *d_ninfo;     // its spring topology (bars, CSR of the bars of every vertex), result words
     double *d_nl0, *d_nX;
@@ -152,7 +156,7 @@ static int ctx_free(hm_ctx *h)
                     h->pool.hdr, h->pool.xi, h->pool.yi, h->pool.xfx, h->pool.xfy,
                     h->pool.yfx, h->pool.yfy, h->pool.vxfx, h->pool.vyfy, h->pool.overflow, h->d_area,
                     h->d_outline, h->d_outline_cnt, h->d_pm_mask, h->d_ids[0], h->d_ids[1], h->d_ids[2], h->d_labels, h->d_lbox,
-                    h->d_lout, h->d_nbars, h->d_nvoff, h->d_nvbar, h->d_ninfo, h->d_nl0, h->d_nX};
+                    h->d_lout, h->d_flowP, h->d_flowctl, h->d_nbars, h->d_nvoff, h->d_nvbar, h->d_ninfo, h->d_nl0, h->d_nX};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     free_targets(h->ref);
@@ -218,6 +222,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->d_Wprior = h->d_gain = h->d_Awork = h->d_Lt[0] = h->d_Lt[1] = nullptr; h->d_Wres = nullptr; h->pin = nullptr; h->pin_n = 0;
     h->tri.assign(tri, tri + (size_t)3 * T);
     h->d_outline = nullptr; h->d_outline_cnt = nullptr; h->d_pm_mask = nullptr;
+    h->chol_flow = 1; h->flow_wgs = 256; h->d_flowP = nullptr; h->d_flowctl = nullptr;
     h->stream2 = nullptr; h->d_nbars = h->d_nvoff = h->d_nvbar = h->d_ninfo = nullptr; h->d_nl0 = h->d_nX = nullptr; h->ncap = 0;
     h->d_ids[0] = h->d_ids[1] = h->d_ids[2] = nullptr; h->d_labels = nullptr; h->d_lbox = nullptr; h->d_lout = nullptr; h->lcap = 0;
     h->worker_active = false; h->worker_rc = HM_OK; h->worker_err[0] = 0;
@@ -273,6 +278,9 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Lt[0], ld_bytes);  // inverses of the factored diagonal blocks
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Lt[1], ld_bytes);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Wtmp, nn);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_flowP, ld_bytes);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_flowctl, 4 * sizeof(unsigned));
+        if (e == hipSuccess) e = hipMemsetAsync(h->d_flowctl, 0, 4 * sizeof(unsigned), h->stream);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Hz, n4 * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Hzc, n4 * 4 * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Wprior, nn);
@@ -324,6 +332,12 @@ extern "C" int hm_ctx_tune(hm_ctx_t h, const char *key, int value)
     if (!strcmp(key, "measure_split")) {
         HM_ARG(value >= 1 && value <= MEAS_VSPLIT_MAX, "hm_ctx_tune: measure_split must be in 1..%d", MEAS_VSPLIT_MAX);
         h->vsplit = value;
+    } else if (!strcmp(key, "chol_flow")) {
+        HM_ARG(value == 0 || value == 1, "hm_ctx_tune: chol_flow must be 0 (one launch per block step) or 1 (one persistent launch)");
+        h->chol_flow = value;
+    } else if (!strcmp(key, "chol_flow_wgs")) {
+        HM_ARG(value >= 1 && value <= 2048, "hm_ctx_tune: chol_flow_wgs must be in 1..2048");
+        h->flow_wgs = value;
     } else if (!strcmp(key, "edge_split")) {
         HM_ARG(value >= 1 && value <= MEAS_VSPLIT_MAX, "hm_ctx_tune: edge_split must be in 1..%d", MEAS_VSPLIT_MAX);
         h->esplit = value;
@@ -752,6 +766,14 @@ static void chol_factor(hm_ctx *h, double *A, double *L, double *Lt, double *T, 
     const int nb = hm_cdiv(n, DNB);
     const int nrows = with_rhs ? aug_rows(n) : n;
     const int nbr = hm_cdiv(nrows, DNB);
+    if (h->chol_flow) {
+        // one persistent launch: the block operations below as tasks that hand their results over through memory
+        // (chol_flow_kernels.h); the same bits as the launch-per-step form
+        FlowArgs a = {A, L, Lt, T, h->d_flowP, n, nrows, nb, nbr, h->d_flowctl};
+        hipLaunchKernelGGL(k_flow_fill, dim3(512), dim3(256), 0, h->stream, a);
+        hipLaunchKernelGGL(k_chol_flow, dim3(h->flow_wgs), dim3(FLOW_NT), 0, h->stream, a);
+        return;
+    }
     if (!first_done) hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(64), 0, h->stream, A, Lt, n);
     for (int k = 0; k < nb; k++) {
         const int mr = nbr - k - 1, mc = std::max(nb - k - 1, 1);
@@ -766,6 +788,16 @@ static void chol_inverse(hm_ctx *h, int n, const double *T, double *out)
 {
     const int nb = hm_cdiv(n, DNB);
     hipLaunchKernelGGL(k_ttt, dim3(nb, nb), dim3(256), 0, h->stream, T, n, out);
+}
+
+// the time-out word of the persistent factorisation launches since the last hm_update_begin (stream must be idle)
+static int flow_status(hm_ctx *h, const char *who)
+{
+    if (!h->chol_flow) return HM_OK;
+    unsigned ctl[2] = {0, 0};
+    HM_HIP(hipMemcpy(ctl, h->d_flowctl, sizeof ctl, hipMemcpyDeviceToHost));
+    if (ctl[1]) { hm_set_error("%s: the factorisation launch gave up waiting for a block (chol_flow time-out)", who); return HM_ERR_HIP; }
+    return HM_OK;
 }
 
 // one iteration's worth of launches of the update: system assembly, factorisation, solve.
@@ -803,6 +835,7 @@ static int prior_inverse(hm_ctx *h, const double *W_prior)
         HM_HIP(hipMemcpyAsync(h->d_Wprior, h->d_Wres, nnb, hipMemcpyDeviceToDevice, h->stream));
     HM_HIP(hipMemcpyAsync(h->d_Awork, h->d_Wprior, nnb, hipMemcpyDeviceToDevice, h->stream));
     h->d_Wres = h->d_Wprior;                     // d_Wtmp is scratch from here on
+    HM_HIP(hipMemsetAsync(h->d_flowctl, 0, 4 * sizeof(unsigned), h->stream));      // a new sequence of factorisations
     chol_factor(h, h->d_Awork, h->d_Af[0], h->d_Lt[0], h->d_Wtmp, h->d_invW0, n4, false);    // T in d_Wtmp
     chol_inverse(h, n4, h->d_Wtmp, h->d_invW0);
     HM_HIP(hipGetLastError());
@@ -894,6 +927,8 @@ extern "C" int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int ma
         HM_HIP(hipStreamSynchronize(h->stream));
     }
     if (*ovf) { hm_set_error("hm_update_step: the star regions do not fit the difference-image pool"); return HM_ERR_STATE; }
+    rc = flow_status(h, "hm_update_step");
+    if (rc) return rc;
     h->upd_prev = h->upd_last;
     h->upd_last = slot;
     return HM_OK;
@@ -1013,7 +1048,7 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
         hipLaunchKernelGGL(k_error, dim3(h->red_blocks), dim3(RED_NT), 0, h->stream, h->P, obs_of(h, masked),
                            h->W * h->H, h->d_partial);
         hipLaunchKernelGGL(k_iter_result, dim3(1), dim3(256), (size_t)h->red_blocks * 4 * sizeof(double), h->stream, rhs_row, n4, h->d_partial,
-                           h->red_blocks, h->pool.overflow, res, (double)(++h->run_ticket));
+                           h->red_blocks, h->pool.overflow, (const unsigned *)h->d_flowctl, res, (double)(++h->run_ticket));
         // the star regions of the next measurement (it needs the new iterate only) run while the host looks
         // at this iteration's result; wasted when the loop ends here
         regions_ahead = it + 1 < max_iter;
@@ -1047,6 +1082,10 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
         if (res[n4 + 4] != 0.0) {
             hm_set_error("hm_update_run: the star regions do not fit the difference-image pool");
             return HM_ERR_STATE;
+        }
+        if (res[n4 + 7] != 0.0) {
+            hm_set_error("hm_update_run: the factorisation launch gave up waiting for a block (chol_flow time-out)");
+            return HM_ERR_HIP;
         }
         bool finite = true;
         for (int i = 0; i < n4; i++) finite = finite && std::isfinite(res[i]);
