@@ -56,20 +56,33 @@ __device__ __forceinline__ void flow_st(double *p, double v)
                        __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Pre-fill of everything the launch produces, and the task counter (the error word is cleared by the caller of
-// a sequence of factorisations, so that a time-out is still seen at the end of it).
-__global__ void k_flow_fill(FlowArgs a)
+// Pre-fill of everything the launch produces -- the blocks below the block diagonal of L (and its
+// right-hand-side rows), the blocks on and below it of Tinv, Lt, P -- and the task counter (the error word is
+// cleared by the caller of a sequence of factorisations, so that a time-out is still seen at the end of it).
+// One row of the arrays per call (k_assemble does it for the row it assembles anyway) ...
+__device__ __forceinline__ void flow_fill_row(const FlowArgs &a, int row, int t, int nt)
 {
-    const size_t nL = (size_t)a.nrows * a.n, nT = (size_t)a.n * a.n, nB = (size_t)a.nb * DNB * DNB;
-    const size_t total = nL + nT + 2 * nB;
     const double s = __longlong_as_double((long long)FLOW_SENTINEL);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        if (i < nL) a.L[i] = s;
-        else if (i < nL + nT) a.Tinv[i - nL] = s;
-        else if (i < nL + nT + nB) a.Lt[i - nL - nT] = s;
-        else a.P[i - nL - nT - nB] = s;
+    if (row < a.nrows) {
+        const int upto = row < a.nb * DNB ? (row / DNB) * DNB : a.n;       // columns left of the diagonal block; all of a rhs row
+        for (int j = t; j < upto; j += nt) a.L[(size_t)row * a.n + j] = s;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl[0] = 0;
+    if (row < a.n) {
+        const int upto = min(a.n, (row / DNB + 1) * DNB);
+        for (int j = t; j < upto; j += nt) a.Tinv[(size_t)row * a.n + j] = s;
+    }
+}
+__device__ __forceinline__ void flow_fill_blocks(const FlowArgs &a, int t, int nt)
+{
+    const double s = __longlong_as_double((long long)FLOW_SENTINEL);
+    for (int i = t; i < a.nb * DNB * DNB; i += nt) { a.Lt[i] = s; a.P[i] = s; }
+    if (t == 0) a.ctl[0] = 0;
+}
+// ... or a launch of its own (the inverse of the prior has no assembly pass): one workgroup per row, one more for Lt / P
+__global__ __launch_bounds__(256) void k_flow_fill(FlowArgs a)
+{
+    if ((int)blockIdx.x == a.nrows) flow_fill_blocks(a, threadIdx.x, 256);
+    else flow_fill_row(a, blockIdx.x, threadIdx.x, 256);
 }
 
 // Wait for one or two blocks other tasks produce (rows < nr and columns < nc of a block are produced; the rest
@@ -279,4 +292,34 @@ __global__ __launch_bounds__(FLOW_NT) void k_chol_flow(FlowArgs a)
                 if (mi[e] < nk) flow_st(a.Tinv + (size_t)(k0 + mi[e]) * n + j0 + mj, u[e]);
         }
     }
+}
+
+// k_assemble (dense_kernels.h) for a factorisation by k_chol_flow: the same pass over H -- A = invW0 + H, the
+// right-hand side Hz - H (X0 - X) as row rhs_row below the matrix, zeros in the padding rows -- and, row by row, the
+// pre-fill of what the factorisation launch produces; the last workgroup pre-fills Lt and P (the first diagonal
+// block is task D(0) of that launch).  Same arithmetic as k_assemble: the systems are bit-identical.
+__global__ __launch_bounds__(256) void k_assemble_flow(const double *__restrict__ invW0, const double *__restrict__ H,
+                                                       const double *__restrict__ X0, const double *__restrict__ X,
+                                                       const double *__restrict__ Hz, double *__restrict__ A, int n, int rhs_row,
+                                                       FlowArgs f)
+{
+    __shared__ double s[4];
+    const int row = blockIdx.x;
+    if (row == (int)gridDim.x - 1) { flow_fill_blocks(f, threadIdx.x, 256); return; }
+    flow_fill_row(f, row, threadIdx.x, 256);
+    if (row >= n) {
+        if (row != rhs_row)
+            for (int j = threadIdx.x; j < n; j += 256) A[(size_t)row * n + j] = 0.0;
+        return;
+    }
+    double acc = 0.0;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        const double h = H[(size_t)row * n + j];
+        A[(size_t)row * n + j] = invW0[(size_t)row * n + j] + h;
+        acc += h * (X0[j] + -1.0 * X[j]);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) A[(size_t)rhs_row * n + row] = Hz[row] - (((s[0] + s[1]) + s[2]) + s[3]);
 }

@@ -768,9 +768,10 @@ static void chol_factor(hm_ctx *h, double *A, double *L, double *Lt, double *T, 
     const int nbr = hm_cdiv(nrows, DNB);
     if (h->chol_flow) {
         // one persistent launch: the block operations below as tasks that hand their results over through memory
-        // (chol_flow_kernels.h); the same bits as the launch-per-step form
+        // (chol_flow_kernels.h); the same bits as the launch-per-step form.  first_done: the caller's assembly pass
+        // (k_assemble_flow) has pre-filled the outputs
         FlowArgs a = {A, L, Lt, T, h->d_flowP, n, nrows, nb, nbr, h->d_flowctl};
-        hipLaunchKernelGGL(k_flow_fill, dim3(512), dim3(256), 0, h->stream, a);
+        if (!first_done) hipLaunchKernelGGL(k_flow_fill, dim3(nrows + 1), dim3(256), 0, h->stream, a);
         hipLaunchKernelGGL(k_chol_flow, dim3(h->flow_wgs), dim3(FLOW_NT), 0, h->stream, a);
         return;
     }
@@ -810,8 +811,15 @@ static double *solve_step(hm_ctx *h, int slot)
     // matrix; the rows in between and the rest of that block zero
     const int rhs_index = hm_cdiv(n4, DNB) * DNB;
     double *rhs_row = A + (size_t)rhs_index * n4;
-    hipLaunchKernelGGL(k_assemble, dim3(aug_rows(n4) + 1), dim3(256), 0, h->stream, h->d_invW0, h->d_HTH, h->d_X0, h->d_X,
-                       h->d_Hz, A, n4, rhs_index, h->d_Lt[slot]);
+    if (h->chol_flow) {
+        const int nb = hm_cdiv(n4, DNB), nrows = aug_rows(n4);
+        FlowArgs f = {A, h->d_Af[slot], h->d_Lt[slot], h->d_T[slot], h->d_flowP, n4, nrows, nb, hm_cdiv(nrows, DNB), h->d_flowctl};
+        hipLaunchKernelGGL(k_assemble_flow, dim3(nrows + 1), dim3(256), 0, h->stream, h->d_invW0, h->d_HTH, h->d_X0, h->d_X,
+                           h->d_Hz, A, n4, rhs_index, f);
+    } else {
+        hipLaunchKernelGGL(k_assemble, dim3(aug_rows(n4) + 1), dim3(256), 0, h->stream, h->d_invW0, h->d_HTH, h->d_X0, h->d_X,
+                           h->d_Hz, A, n4, rhs_index, h->d_Lt[slot]);
+    }
     if (h->d_Wres == h->d_Wtmp) h->d_Wres = nullptr;          // a covariance predicted since hm_update_begin is lost
     chol_factor(h, A, h->d_Af[slot], h->d_Lt[slot], h->d_T[slot], h->d_Wtmp, n4, true, true);
     // y = L^-1 b came out of the factorisation as the extra row and T = L^-1 with it (d_Wtmp was the
@@ -833,10 +841,11 @@ static int prior_inverse(hm_ctx *h, const double *W_prior)
         HM_HIP(hipMemcpyAsync(h->d_Wprior, W_prior, nnb, hipMemcpyHostToDevice, h->stream));
     else if (h->d_Wres != h->d_Wprior)
         HM_HIP(hipMemcpyAsync(h->d_Wprior, h->d_Wres, nnb, hipMemcpyDeviceToDevice, h->stream));
-    HM_HIP(hipMemcpyAsync(h->d_Awork, h->d_Wprior, nnb, hipMemcpyDeviceToDevice, h->stream));
+    // the launch-per-step factorisation destroys its input: it gets a copy; the persistent launch only reads it
+    if (!h->chol_flow) HM_HIP(hipMemcpyAsync(h->d_Awork, h->d_Wprior, nnb, hipMemcpyDeviceToDevice, h->stream));
     h->d_Wres = h->d_Wprior;                     // d_Wtmp is scratch from here on
     HM_HIP(hipMemsetAsync(h->d_flowctl, 0, 4 * sizeof(unsigned), h->stream));      // a new sequence of factorisations
-    chol_factor(h, h->d_Awork, h->d_Af[0], h->d_Lt[0], h->d_Wtmp, h->d_invW0, n4, false);    // T in d_Wtmp
+    chol_factor(h, h->chol_flow ? h->d_Wprior : h->d_Awork, h->d_Af[0], h->d_Lt[0], h->d_Wtmp, h->d_invW0, n4, false);    // T in d_Wtmp
     chol_inverse(h, n4, h->d_Wtmp, h->d_invW0);
     HM_HIP(hipGetLastError());
     return HM_OK;

@@ -729,3 +729,41 @@ def test_ms_predict_on_device_matches_oracle_and_host(hm):
             kf.compute(fr, flowv[:, :, :, k], (fr > 0).astype(np.uint8))
         outs.append(kf.state.X.copy())
     assert np.linalg.norm(outs[0] - outs[1]) <= 1e-9 * np.linalg.norm(outs[1])
+
+
+@pytest.mark.parametrize("n,h0", [(48, 30.0), (64, 20.0), (64, 11.0), (96, 9.0), (130, 9.0)])
+def test_persistent_factorisation_equals_launch_per_step(hm, n, h0):
+    """chol_flow = 1 (one persistent launch whose block tasks hand their results over through memory,
+    csrc/chol_flow_kernels.h) gives the very bits of chol_flow = 0 (one launch per 32-column block step): steps,
+    covariances of the last and the previous iterate, the whole iterated update -- for systems of one partial
+    block up to several blocks with a partial last one, with and without right-hand-side rows (update steps /
+    the inverse of the prior), and repeatedly on one handle (the pre-filled pattern is renewed every time)."""
+    dm, N, tex, R, meas = _setup(hm, n, h0, seed=8)
+    rng = np.random.default_rng(17)
+    X = _state(dm, rng, pos_sigma=0.5)
+    X0 = X + rng.normal(0, 0.3, X.size)
+    y_im, flow, y_m = _observation(dm, meas, rng, n)
+    n4 = 4 * N
+    M = rng.normal(size=(n4, n4))
+    W = np.eye(n4) * 0.5 + 0.05 * (M @ M.T) / n4
+    st = _Flow()
+    out = {}
+    for mode in (1, 0, 1):
+        R.tune("chol_flow", mode)
+        st.X = X.reshape(-1, 1)
+        R.update_frame(y_im, flow, y_m)
+        R.update_begin(W, X0)
+        s1, _, e1 = R.update_step(st, y_im, flow, y_m)
+        st.X = (X + 0.1).reshape(-1, 1)
+        s2, _, e2 = R.update_step(st, y_im, flow, y_m)
+        c_prev, c_last = R.update_cov(1), R.update_cov(0)
+        run = R.update_run(W, X0, y_im, flow, y_m, 4, 1e-12)
+        got = (s1, s2, c_prev, c_last, run[0], run[2], run[5].fetch(), np.array(e1), np.array(e2))
+        if mode in out:
+            assert all(np.array_equal(a, b) for a, b in zip(out[mode], got))          # and it repeats
+        out[mode] = got
+    assert all(np.array_equal(a, b) for a, b in zip(out[0], out[1]))
+    A = np.linalg.inv(W)
+    assert np.isfinite(out[1][3]).all() and np.abs(out[1][3] - out[1][3].T).max() <= 1e-12 * np.abs(out[1][3]).max()
+    with pytest.raises(RuntimeError):
+        R.tune("chol_flow", 2)
