@@ -96,7 +96,10 @@ struct FlowBlock {
     double (*dst)[DNB + 1];
 };
 
-__device__ __forceinline__ bool flow_fetch2(const FlowBlock &b0, const FlowBlock &b1, bool two, unsigned *ctl)
+// hot: the caller is on the chain of the diagonal blocks and what it waits for is about to appear -- every thread
+// keeps re-loading its own elements (one workgroup's worth of traffic) instead of handing the watch to one lane,
+// which saves the round trip of loading the block again once the watched word has changed.
+__device__ __forceinline__ bool flow_fetch2(const FlowBlock &b0, const FlowBlock &b1, bool two, unsigned *ctl, bool hot = false)
 {
     const int t = threadIdx.x;
     __shared__ int s_ok;
@@ -116,6 +119,7 @@ __device__ __forceinline__ bool flow_fetch2(const FlowBlock &b0, const FlowBlock
         }
         const int got0 = __syncthreads_and(ok0), got1 = two ? __syncthreads_and(ok1) : 1;
         if (got0 && got1) break;                      // every element of what was asked for has arrived
+        if (hot && tries < 4096) continue;            // ~ a few ms of re-loading at most, then the patient way
         if (t == 0) {                                 // one lane watches one word of the block that is missing
             int ok = 1;
             const FlowBlock &m = got0 ? b1 : b0;
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(FLOW_NT) void k_chol_flow(FlowArgs a)
             if (c > 0) {                              // the last term: block (c, c-1) as F(c, c-1) left it, times T_{c-1}^T
                 const FlowBlock bp = {a.P + (size_t)c * DNB * DNB, DNB, nc, DNB, Bc};
                 const FlowBlock bt = {a.Lt + (size_t)(c - 1) * DNB * DNB, DNB, DNB, DNB, Ts};
-                if (!flow_fetch2(bt, bp, true, a.ctl)) return;
+                if (!flow_fetch2(bt, bp, true, a.ctl, true)) return;
                 __syncthreads();
                 const d4_t xr = d_mfma_nt(Bc, Ts, wv, lane);
                 __syncthreads();
