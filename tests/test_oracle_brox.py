@@ -52,11 +52,16 @@ def test_integer_translation_is_recovered(hm, oracle_brox):
 
 
 def test_rms_against_analytic_fields(hm, oracle_brox):
-    """test_flow.py protocol: RMS of (true - computed) over the object; here the whole interior."""
+    """test_flow.py protocol (reference test_flow.py:120-138): RMS of (true - computed) over the object; here the
+    whole interior, all four fields of synthetic/flowfields.py:3-7.  Parity with OpenCV's Brox is unpinned (file
+    header), so these are the anchors that show a change of the *algorithm*: bounds = measured + 10 % (measured
+    at 128^2, seed 0: 0.0622, 0.0530, 0.1218, 0.0466 px)."""
     from hydra_mi import synth
-    for name, bound in [("translate_leftup", 0.12), ("translate_leftup_stretch", 0.12), ("warp", 0.12)]:
+    for name, bound in [("translate_leftup", 0.0684), ("translate_leftup_stretch", 0.0583), ("rotate", 0.1340),
+                        ("warp", 0.0512)]:
         f0, f1, tu, tv = synth.warp_pair(128, name, 0)
         u, v = oracle_brox.calc(f0, f1)
         b = 16
         r = np.sqrt(((u - tu) ** 2 + (v - tv) ** 2)[b:-b, b:-b].mean())
         assert r < bound, (name, r)
+        assert r > 0.5 * bound, (name, r)            # and not suspiciously better either: the inputs are what they were

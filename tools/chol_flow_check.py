@@ -30,6 +30,8 @@ for n, h0 in ((256, 0.2), (256, 0.08), (512, 0.06), (1024, 0.047)):
     out = {}
     for mode in (0, 1):
         R.tune("chol_flow", mode)
+        if os.environ.get("FLOW_WGS"):
+            R.tune("chol_flow_wgs", int(os.environ["FLOW_WGS"]))
         R.update_frame(y_im, flow, y_m)
         res = R.update_run(W0, X, y_im, flow, y_m, 3, 1e-12)
         Wd = res[5].fetch()
