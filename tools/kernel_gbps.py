@@ -13,7 +13,7 @@ FLOW = {                       # kernel prefix -> (algorithmic bytes per pixel p
     "k_prepare": (76.0, "u,v,du,dv + 8 warped fields read, 7 written"),
     "void k_warp": (76.0, "11 read + 8 written"),
     "k_deriv": (12.0, "1 read + 2 written"),
-    "k_add": (24.0, "4 read + 2 written"),
+    "k_add_out": (24.0, "4 read + 2 written"),
 }
 
 

@@ -5,7 +5,7 @@
   python tools/sor_pmc_json.py <dir>/fetch/b_counter_collection.csv <dir>/write/b_counter_collection.csv
 
 FETCH_SIZE / WRITE_SIZE are in KB (MI355X_MICROARCH.md, HBM section); FETCH_SIZE is doubled on
-gfx950 as that section prescribes -- checked here on k_add, whose traffic is known exactly."""
+gfx950 as that section prescribes -- checked here on k_add_out, whose traffic is known exactly."""
 import csv, json, sys, collections, hashlib, os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -33,7 +33,7 @@ def main():
     sor = [k for k in fetch if k.startswith("void k_sor")][0]
     f = [v for v, _ in fetch[sor]]
     w = [v for v, _ in write[sor]]
-    add = [k for k in fetch if k.startswith("k_add(")][0]
+    add = [k for k in fetch if k.startswith("k_add_out(")][0]
     add_f = max(v for v, _ in fetch[add])
     add_w = max(v for v, _ in write[add])
     n_px = 8 * 1024 * 1024
@@ -46,7 +46,7 @@ def main():
         "fetch_size_kb_per_launch_raw": sum(f) / len(f),
         "write_size_kb_per_launch": sum(w) / len(w),
         "fetch_correction": 2.0,
-        "calibration": "k_add at level 0 (8 x 1024^2 px, 16 B/px read, 8 B/px written): FETCH_SIZE %.0f KB against %d KB "
+        "calibration": "k_add_out at level 0 (8 x 1024^2 px, 16 B/px read, 8 B/px written): FETCH_SIZE %.0f KB against %d KB "
                        "read, WRITE_SIZE %.0f KB against %d KB written" % (add_f, n_px * 16 // 1024, add_w, n_px * 8 // 1024),
         "traffic_bytes_per_launch": (2.0 * sum(f) / len(f) + sum(w) / len(w)) * 1024.0,
         "finest_level": {
