@@ -80,7 +80,10 @@ int hm_brox_levels(hm_brox_t h, int *widths, int *heights, int cap);
 /* SOR relaxation factor (default 1.99) */
 int hm_brox_set_omega(hm_brox_t h, float omega);
 /* launch tuning, never changes results: "sor_fuse" = red-black iterations fused
- * per SOR launch (0 = choose per level, else a divisor of solver_iterations),
+ * per SOR launch (0 = choose per level, else a divisor of solver_iterations, at most 10),
+ * "sor_deep" = 1/0 (default 1): with sor_fuse 0, a level whose tiles would not fill the device even with the halo of
+ * all solver_iterations takes them in one launch, "coarse_max" = 0, 32 (default) or 64: pyramid levels of at most
+ * that many pixels per side run in one launch per pair (k_coarse) instead of one launch per operator,
  * "sor_threads" = 256, 512 or 1024 threads per SOR workgroup (0, the default: 1024 for calls of one or two pairs,
  * 512 for larger ones), "warp_window" =
  * 1/0 the warp kernel stages its taps as an LDS window or reads them directly (default 0: measured

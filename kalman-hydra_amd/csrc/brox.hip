@@ -124,7 +124,7 @@ struct SorPlan {
 // iterations fused per launch: everything when the level fits one tile (no halo
 // needed); otherwise the largest divisor of `solver` up to 5 (halo 2K = 10 px of a
 // 64-px tile is where redundant work starts to outweigh the saved traffic)
-static SorPlan sor_plan(const Geo &g, int solver, int fuse, int threads)
+static SorPlan sor_plan(const Geo &g, int solver, int fuse, int threads, int n = 1, long long slots = 0)
 {
     SorPlan p;
     p.threads = threads;
@@ -136,6 +136,14 @@ static SorPlan sor_plan(const Geo &g, int solver, int fuse, int threads)
         K = 1;
         for (int d = 1; d <= 5 && d <= solver; d++)
             if (solver % d == 0) K = d;
+        // A level whose tiles do not fill the chip even with the halo of all `solver` iterations (a small interior:
+        // many more tiles) is bound by the latency of one launch after the other, not by work: one launch instead
+        // of solver / K (a dependent launch costs ~8 us on the device whatever it does).
+        const int step = SOR_TW - 4 * solver;
+        if (step >= 16 && solver <= 15) {
+            const long long tiles = (long long)(fitx ? 1 : hm_cdiv(g.w, step)) * (fity ? 1 : hm_cdiv(g.h, SOR_TH - 4 * solver)) * n;
+            if (tiles * threads <= slots * 1024) K = solver;
+        }
     }
     p.K = K;
     p.halo_x = fitx ? 0 : 2 * K;
@@ -179,6 +187,9 @@ struct hm_brox {
     float alpha, gamma, scale, omega;
     int inner, outer, solver, fuse, sor_threads;
     int sor_dry;                 // development knob: SOR launches load and store but do not iterate (wrong results)
+    int cus;                     // compute units of the device
+    int sor_deep;                // levels with few tiles take all solver iterations in one launch (sor_plan)
+    int coarse_max;              // levels up to this many px per side run inside k_coarse: 0 (none), 32 or 64
     std::vector<Geo> geo;
     Taps taps;
     hipStream_t stream;
@@ -234,6 +245,8 @@ extern "C" int hm_brox_create(int device, int W, int H, int max_batch, float alp
     h->device = device; h->W = W; h->H = H; h->B = max_batch;
     h->alpha = alpha; h->gamma = gamma; h->scale = scale; h->omega = 1.99f;
     h->inner = inner; h->outer = outer; h->solver = solver; h->fuse = 0; h->sor_threads = 0; h->sor_dry = 0;
+    h->coarse_max = 32; h->sor_deep = 1; h->cus = 0;
+    if (hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) h->cus = 0;
     h->arena = nullptr; h->d_f0 = h->d_f1 = nullptr; h->d_ox = h->d_oy = nullptr; h->stream = nullptr;
     h->prof = false; h->ev_used = 0; h->prof_ms = 0; h->prof_pxit = 0; h->prof_px = 0; h->prof_launches = 0;
     h->warp_window = false;
@@ -306,14 +319,20 @@ extern "C" int hm_brox_tune(hm_brox_t h, const char *key, int value)
 {
     HM_ARG(h != nullptr && key != nullptr, "hm_brox_tune: NULL argument");
     if (!strcmp(key, "sor_fuse")) {
-        HM_ARG(value == 0 || (value >= 1 && value <= 7 && h->solver % value == 0),
-               "hm_brox_tune: sor_fuse=%d must be 0 or a divisor of solver_iterations (%d) not above 7", value, h->solver);
+        HM_ARG(value == 0 || (value >= 1 && value <= 10 && h->solver % value == 0),
+               "hm_brox_tune: sor_fuse=%d must be 0 or a divisor of solver_iterations (%d) not above 10", value, h->solver);
         h->fuse = value;
     } else if (!strcmp(key, "sor_threads")) {
         HM_ARG(value == 0 || value == 256 || value == 512 || value == 1024, "hm_brox_tune: sor_threads must be 0 (choose per call), 256, 512 or 1024");
         h->sor_threads = value;
     } else if (!strcmp(key, "sor_dry")) {            // timing experiments only (tools/): the flow is wrong with 1
         h->sor_dry = value != 0;
+    } else if (!strcmp(key, "sor_deep")) {
+        HM_ARG(value >= 0 && value <= 8, "hm_brox_tune: sor_deep must be 0 .. 8");
+        h->sor_deep = value;
+    } else if (!strcmp(key, "coarse_max")) {
+        HM_ARG(value == 0 || value == 32 || value == 64, "hm_brox_tune: coarse_max must be 0, 32 or 64");
+        h->coarse_max = value;
     } else if (!strcmp(key, "warp_window")) {
         HM_ARG(value == 0 || value == 1, "hm_brox_tune: warp_window must be 0 or 1");
         h->warp_window = value != 0;
@@ -396,29 +415,63 @@ static int brox_run(hm_brox *h, int n, const uint8_t *d_f0, const uint8_t *d_f1,
                                h->pyr1[k], gd, h->taps, n);
             continue;
         }
-        for (int im = 0; im < 2; im++) {
-            float *src = im ? h->pyr1[k - 1] : h->pyr0[k - 1];
-            float *dst = im ? h->pyr1[k] : h->pyr0[k];
-            hipLaunchKernelGGL((k_blur<false>), grid2d(gs, n), kBlock2d, 0, s, src, h->tmpA, gs, h->taps);
-            hipLaunchKernelGGL((k_blur<true>), grid2d(gs, n), kBlock2d, 0, s, h->tmpA, h->tmpB, gs, h->taps);
-            hipLaunchKernelGGL(k_resample, grid2d(gd, n), kBlock2d, 0, s, h->tmpB, gs, dst, gd, 1.0f);
-        }
+        // both frames per launch; the second one's intermediates borrow two planes the pyramid does not use yet
+        hipLaunchKernelGGL((k_blur<false>), grid2d(gs, 2 * n), kBlock2d, 0, s, h->pyr0[k - 1], h->tmpA, h->pyr1[k - 1], h->Ix0, gs,
+                           h->taps, n);
+        hipLaunchKernelGGL((k_blur<true>), grid2d(gs, 2 * n), kBlock2d, 0, s, h->tmpA, h->tmpB, h->Ix0, h->Iy0, gs, h->taps, n);
+        hipLaunchKernelGGL(k_resample, grid2d(gd, 2 * n), kBlock2d, 0, s, h->tmpB, h->pyr0[k], h->Iy0, h->pyr1[k], gs, gd, 1.0f, n);
     }
     // u = v = 0 at the coarsest level and du = dv = 0 at the start of every level: a plane of zeros that is
     // only ever read (no memsets); u / v of a level are written by the level above it, never in place
     const float *u = h->zero, *v = h->zero;
     float *un = h->u, *vn = h->v, *uo = h->u2, *vo = h->v2;      // next level's u, v; the pair after that
-    for (int k = L - 1; k >= 0; k--) {
+    // The coarse end of the pyramid -- the levels of at most coarse_max x coarse_max px, each a single SOR tile --
+    // in one launch per tile size (k_coarse<32> for levels up to 32 x 32 px, then k_coarse<64>) and per COARSE_MAX
+    // levels (more only when the scale factor is close to 1).
+    int kc = L;
+    while (kc > 0 && h->geo[kc - 1].w <= h->coarse_max && h->geo[kc - 1].h <= h->coarse_max) kc--;
+    auto tile_of = [](const Geo &g) { return g.w <= 32 && g.h <= 32 ? 32 : 64; };
+    for (int hi = L - 1; hi >= kc;) {
+        const int T = tile_of(h->geo[hi]);
+        int lo = hi;
+        while (lo - 1 >= kc && hi - (lo - 1) + 1 <= COARSE_MAX && tile_of(h->geo[lo - 1]) == T) lo--;
+        CoarseArgs ca;
+        ca.nlev = hi - lo + 1;
+        for (int k = hi; k >= lo; k--) {
+            ca.g[hi - k] = h->geo[k];
+            ca.I0[hi - k] = h->pyr0[k];
+            ca.I1[hi - k] = h->pyr1[k];
+        }
+        ca.u_in = u; ca.v_in = v;
+        ca.Ix0 = h->Ix0; ca.Iy0 = h->Iy0; ca.I1x = h->I1x; ca.I1y = h->I1y; ca.I1xx = h->I1xx; ca.I1xy = h->I1xy; ca.I1yy = h->I1yy;
+        if (lo > 0) {
+            ca.gout = h->geo[lo - 1];
+            ca.u_out = un; ca.v_out = vn;
+        } else {
+            ca.gout.w = ca.gout.h = ca.gout.pitch = ca.gout.plane = 0;
+            ca.u_out = d_ox; ca.v_out = d_oy;
+        }
+        ca.inner = h->inner; ca.solver = h->solver;
+        ca.alpha = h->alpha; ca.gamma = h->gamma; ca.om = h->omega; ca.om1 = 1.0f - h->omega;
+        if (T == 32) hipLaunchKernelGGL((k_coarse<32>), dim3(n), dim3(256), 0, s, ca);
+        else hipLaunchKernelGGL((k_coarse<64>), dim3(n), dim3(1024), 0, s, ca);
+        if (lo > 0) {
+            u = un; v = vn;
+            float *t = un; un = uo; uo = t;
+            t = vn; vn = vo; vo = t;
+        }
+        hi = lo - 1;
+    }
+    for (int k = kc - 1; k >= 0; k--) {
         const Geo &g = h->geo[k];
         const dim3 gr = grid2d(g, n);
         if ((long long)g.w * g.h * n <= fuse_below) {
             DerivOut dout = {h->Ix0, h->Iy0, h->I1x, h->I1y, h->I1xx, h->I1xy, h->I1yy};
             hipLaunchKernelGGL(k_deriv_all, gr, kBlock2d, 0, s, h->pyr0[k], h->pyr1[k], dout, g);
         } else {
-            hipLaunchKernelGGL(k_deriv, gr, kBlock2d, 0, s, h->pyr0[k], h->Ix0, h->Iy0, g);
-            hipLaunchKernelGGL(k_deriv, gr, kBlock2d, 0, s, h->pyr1[k], h->I1x, h->I1y, g);
-            hipLaunchKernelGGL(k_deriv, gr, kBlock2d, 0, s, h->I1x, h->I1xx, h->I1xy, g);
-            hipLaunchKernelGGL(k_deriv, gr, kBlock2d, 0, s, h->I1y, (float *)nullptr, h->I1yy, g);
+            const dim3 gr2 = grid2d(g, 2 * n);           // two images per launch
+            hipLaunchKernelGGL(k_deriv, gr2, kBlock2d, 0, s, h->pyr0[k], h->Ix0, h->Iy0, h->pyr1[k], h->I1x, h->I1y, g, n);
+            hipLaunchKernelGGL(k_deriv, gr2, kBlock2d, 0, s, h->I1x, h->I1xx, h->I1xy, h->I1y, (float *)nullptr, h->I1yy, g, n);
         }
         WarpIn wi = {h->pyr0[k], h->Ix0, h->Iy0, h->pyr1[k], h->I1x, h->I1y, h->I1xx, h->I1xy, h->I1yy, u, v};
         WarpOut wo = {h->Iz, h->Ix, h->Iy, h->Ixz, h->Iyz, h->Ixx, h->Ixy, h->Iyy};
@@ -431,7 +484,7 @@ static int brox_run(hm_brox *h, int n, const uint8_t *d_f0, const uint8_t *d_f1,
         // times over is bound by how many tiles are resident -- 512 threads, two workgroups per CU (measured, one /
         // eight 1024^2 pairs: 4.31 / 12.3 ms of SOR per series with 1024 threads, 4.71 / 10.4 with 512, 6.65 / 13.7 with 256)
         const int threads = h->sor_threads ? h->sor_threads : (n <= 2 ? 1024 : 512);
-        SorPlan plan = sor_plan(g, h->solver, h->fuse, threads);
+        SorPlan plan = sor_plan(g, h->solver, h->fuse, threads, n, (long long)h->sor_deep * h->cus);
         const int launches_per_inner = h->solver / plan.K;
         Coef co = {h->nu, h->nv, h->a12, h->idu, h->idv, h->sx, h->sy};
         for (int it = 0; it < h->inner; it++) {
@@ -562,8 +615,8 @@ extern "C" int hm_op_blur(const float *src, int w, int h, float scale, float *ds
     Scratch sc;
     float *a = sc.up(g, src), *b = sc.plane(g), *c = sc.plane(g);
     OP_CHECK(a && b && c);
-    hipLaunchKernelGGL((k_blur<false>), grid2d(g, 1), kBlock2d, 0, 0, a, b, g, t);
-    hipLaunchKernelGGL((k_blur<true>), grid2d(g, 1), kBlock2d, 0, 0, b, c, g, t);
+    hipLaunchKernelGGL((k_blur<false>), grid2d(g, 1), kBlock2d, 0, 0, a, b, (const float *)nullptr, (float *)nullptr, g, t, 1);
+    hipLaunchKernelGGL((k_blur<true>), grid2d(g, 1), kBlock2d, 0, 0, b, c, (const float *)nullptr, (float *)nullptr, g, t, 1);
     HM_HIP(hipDeviceSynchronize());
     OP_CHECK(Scratch::down(g, c, dst));
     return HM_OK;
@@ -576,7 +629,7 @@ extern "C" int hm_op_resample(const float *src, int ws, int hs, float *dst, int 
     Scratch sc;
     float *a = sc.up(gs, src), *b = sc.plane(gd);
     OP_CHECK(a && b);
-    hipLaunchKernelGGL(k_resample, grid2d(gd, 1), kBlock2d, 0, 0, a, gs, b, gd, mul);
+    hipLaunchKernelGGL(k_resample, grid2d(gd, 1), kBlock2d, 0, 0, a, b, (const float *)nullptr, (float *)nullptr, gs, gd, mul, 1);
     HM_HIP(hipDeviceSynchronize());
     OP_CHECK(Scratch::down(gd, b, dst));
     return HM_OK;
@@ -651,7 +704,7 @@ extern "C" int hm_op_deriv(const float *src, int w, int h, float *dx, float *dy)
     Scratch sc;
     float *a = sc.up(g, src), *b = sc.plane(g), *c = sc.plane(g);
     OP_CHECK(a && b && c);
-    hipLaunchKernelGGL(k_deriv, grid2d(g, 1), kBlock2d, 0, 0, a, b, c, g);
+    hipLaunchKernelGGL(k_deriv, grid2d(g, 1), kBlock2d, 0, 0, a, b, c, (const float *)nullptr, (float *)nullptr, (float *)nullptr, g, 1);
     HM_HIP(hipDeviceSynchronize());
     OP_CHECK(Scratch::down(g, b, dx) && Scratch::down(g, c, dy));
     return HM_OK;
@@ -697,8 +750,8 @@ extern "C" int hm_op_sor(float *du, float *dv, const float *const coef[7], int w
                          float omega)
 {
     HM_ARG(du && dv && coef && w >= 1 && h >= 1 && iterations >= 1, "hm_op_sor: bad argument");
-    HM_ARG(fuse % 100 == 0 || (fuse % 100 >= 1 && fuse % 100 <= 7 && iterations % (fuse % 100) == 0),
-           "hm_op_sor: fuse=%d must be 0 or a divisor of iterations=%d not above 7", fuse % 100, iterations);
+    HM_ARG(fuse % 100 == 0 || (fuse % 100 >= 1 && fuse % 100 <= 10 && iterations % (fuse % 100) == 0),
+           "hm_op_sor: fuse=%d must be 0 or a divisor of iterations=%d not above 10", fuse % 100, iterations);
     Geo g = make_geo(w, h);
     Scratch sc;
     const float *c[7];

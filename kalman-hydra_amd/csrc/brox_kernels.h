@@ -48,19 +48,22 @@ __global__ void k_u8_to_f32(const uint8_t *__restrict__ src0, const uint8_t *__r
 }
 
 // ---- separable Gaussian, mirrored border ---------------------------------------
+// Two images per launch (the two frames of the pairs): blockIdx.z < nb works on set 0, the rest on set 1.
 template <bool VERT>
-__global__ void k_blur(const float *__restrict__ src, float *__restrict__ dst, Geo g, Taps t)
+__global__ void k_blur(const float *__restrict__ src0, float *__restrict__ dst0, const float *__restrict__ src1,
+                       float *__restrict__ dst1, Geo g, Taps t, int nb)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x;
     int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= g.w || y >= g.h) return;
-    const float *s = src + (size_t)blockIdx.z * g.plane;
+    const int second = (int)blockIdx.z >= nb, b = second ? blockIdx.z - nb : blockIdx.z;
+    const float *s = (second ? src1 : src0) + (size_t)b * g.plane;
     float acc = 0.0f;
     for (int i = -t.R; i <= t.R; i++) {
         float val = VERT ? s[d_mirror(y + i, g.h) * g.pitch + x] : s[y * g.pitch + d_mirror(x + i, g.w)];
         acc = acc + t.g[i + t.R] * val;
     }
-    dst[(size_t)blockIdx.z * g.plane + y * g.pitch + x] = acc;
+    (second ? dst1 : dst0)[(size_t)b * g.plane + y * g.pitch + x] = acc;
 }
 
 // ---- bilinear sampling, coordinates clamped to the image -----------------------
@@ -83,8 +86,9 @@ __device__ __forceinline__ float d_bilin(const float *__restrict__ img, int w, i
     return (1.0f - ay) * top + ay * bot;
 }
 
-// resample src level onto dst level, value scaled by mul (pyramid and prolongation)
-__global__ void k_resample(const float *__restrict__ src, Geo gs, float *__restrict__ dst, Geo gd, float mul)
+// resample src level onto dst level, value scaled by mul (pyramid and prolongation); two images per launch as k_blur
+__global__ void k_resample(const float *__restrict__ src0, float *__restrict__ dst0, const float *__restrict__ src1,
+                           float *__restrict__ dst1, Geo gs, Geo gd, float mul, int nb)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x;
     int y = blockIdx.y * blockDim.y + threadIdx.y;
@@ -92,8 +96,9 @@ __global__ void k_resample(const float *__restrict__ src, Geo gs, float *__restr
     float rx = (float)gs.w / (float)gd.w, ry = (float)gs.h / (float)gd.h;
     float sx = ((float)x + 0.5f) * rx - 0.5f;
     float sy = ((float)y + 0.5f) * ry - 0.5f;
-    const float *s = src + (size_t)blockIdx.z * gs.plane;
-    dst[(size_t)blockIdx.z * gd.plane + y * gd.pitch + x] = d_bilin(s, gs.w, gs.h, gs.pitch, sx, sy) * mul;
+    const int second = (int)blockIdx.z >= nb, b = second ? blockIdx.z - nb : blockIdx.z;
+    const float *s = (second ? src1 : src0) + (size_t)b * gs.plane;
+    (second ? dst1 : dst0)[(size_t)b * gd.plane + y * gd.pitch + x] = d_bilin(s, gs.w, gs.h, gs.pitch, sx, sy) * mul;
 }
 
 // ---- 5-tap derivatives ------------------------------------------------------------
@@ -102,14 +107,17 @@ __device__ __forceinline__ float d_d5(float m2, float m1, float p1, float p2)
     return (8.0f * (p1 - m1) - (p2 - m2)) * (1.0f / 12.0f);
 }
 
-// dx and/or dy of one image (either output may be null)
-__global__ void k_deriv(const float *__restrict__ src, float *__restrict__ dx, float *__restrict__ dy, Geo g)
+// dx and/or dy of an image (either output may be null); two images per launch as k_blur
+__global__ void k_deriv(const float *__restrict__ src0, float *__restrict__ dx0, float *__restrict__ dy0,
+                        const float *__restrict__ src1, float *__restrict__ dx1, float *__restrict__ dy1, Geo g, int nb)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x;
     int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= g.w || y >= g.h) return;
-    size_t off = (size_t)blockIdx.z * g.plane;
-    const float *s = src + off;
+    const int second = (int)blockIdx.z >= nb, b = second ? blockIdx.z - nb : blockIdx.z;
+    size_t off = (size_t)b * g.plane;
+    const float *s = (second ? src1 : src0) + off;
+    float *dx = second ? dx1 : dx0, *dy = second ? dy1 : dy0;
     if (dx) {
         const float *r = s + y * g.pitch;
         dx[off + y * g.pitch + x] = d_d5(r[d_mirror(x - 2, g.w)], r[d_mirror(x - 1, g.w)],
@@ -539,27 +547,78 @@ struct SorArgs {
     float om, om1;          // omega, 1 - omega
 };
 
+// What a thread holds of the system of its pixels for all sweeps.  [row][pixel of the pair]; the weight towards the
+// upper neighbour is the lower weight of the row above (own register except for the first row), the weight
+// towards the left neighbour of the odd pixel is the right weight of the even one.
+template <int RPT>
+struct SorRegs {
+    float nu[RPT][2], nv[RPT][2], a12[RPT][2], idu[RPT][2], idv[RPT][2];
+    float sr[RPT][2], sb[RPT][2], sl0[RPT], st0[2];
+};
+
+// K red-black iterations of a tile held in s_uv (checkerboard-compressed rows: the pixels of colour 0 first,
+// then colour 1; (du, dv) side by side) by NT threads, thread (grp, i) owning rows grp * RPT .. and the pixel
+// pair 2i, 2i + 1 of each.  (gx0, gy0) = image coordinates of the tile's first pixel.  BORDER = false drops
+// the image-border selects (a tile that does not touch the border never takes them).
+template <int TW, int TH, int NT, bool BORDER>
+__device__ __forceinline__ void d_sor_sweeps(const SorRegs<TH / (NT / (TW / 2))> &R, float2 *s_uv, int K, int w, int h,
+                                             int gx0, int gy0, float om, float om1)
+{
+    constexpr int HALF = TW / 2, NG = NT / HALF, RPT = TH / NG;
+    const int grp = threadIdx.x / HALF, i = threadIdx.x - grp * HALF;
+    const int r0 = grp * RPT, gxa = gx0 + 2 * i;
+#pragma unroll 1
+    for (int it = 0; it < K; it++) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+#pragma unroll
+            for (int j = 0; j < RPT; j++) {
+                // colour c in row r: pixel x = 2i + q with q = (r + c) & 1 = (j + c) & 1
+                const int q = (j + c) & 1;
+                const int r = r0 + j, gy = gy0 + r, gx = gxa + q;
+                const int oc = (1 - c) * HALF;           // neighbours have the other colour
+                // slots of the left / right neighbours inside their row
+                int il = q ? i : i - 1, ir = q ? i + 1 : i;
+                il = il < 0 ? 0 : il;
+                ir = ir > HALF - 1 ? HALF - 1 : ir;
+                const int ru = r > 0 ? r - 1 : 0, rd = r < TH - 1 ? r + 1 : TH - 1;
+                const float2 pc = s_uv[r * TW + c * HALF + i];
+                const float2 pl = s_uv[r * TW + oc + il], pr = s_uv[r * TW + oc + ir];
+                const float2 pt = s_uv[ru * TW + oc + i], pb = s_uv[rd * TW + oc + i];
+                const float cu = pc.x, cv = pc.y;
+                float ul = pl.x, ur = pr.x, ut = pt.x, ub = pb.x;
+                float vl = pl.y, vr = pr.y, vt = pt.y, vb = pb.y;
+                if (BORDER) {
+                    // at the image border the oracle pairs the (zero) weight with the pixel itself
+                    if (gx <= 0) { ul = cu; vl = cv; }
+                    if (gx >= w - 1) { ur = cu; vr = cv; }
+                    if (gy <= 0) { ut = cu; vt = cv; }
+                    if (gy >= h - 1) { ub = cu; vb = cv; }
+                }
+                const float wl = q ? R.sr[j][0] : R.sl0[j];
+                const float wt = j > 0 ? R.sb[j > 0 ? j - 1 : 0][q] : R.st0[q];
+                const float su = ((wl * ul + R.sr[j][q] * ur) + wt * ut) + R.sb[j][q] * ub;
+                const float sv = ((wl * vl + R.sr[j][q] * vr) + wt * vt) + R.sb[j][q] * vb;
+                const float dun = om1 * cu + om * (((R.nu[j][q] - R.a12[j][q] * cv) + su) * R.idu[j][q]);
+                const float dvn = om1 * cv + om * (((R.nv[j][q] - R.a12[j][q] * dun) + sv) * R.idv[j][q]);
+                s_uv[r * TW + c * HALF + i] = make_float2(dun, dvn);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// the tile `bid` of batch item `z`, relaxed K times by the calling workgroup (NT threads; s_uv: TH * TW float2 of LDS)
 template <int TW, int TH, int NT>
-__global__ __launch_bounds__(NT) void k_sor(SorArgs a, int K)
+__device__ __forceinline__ void d_sor_tile(const SorArgs &a, int K, int bid, int z, float2 *s_uv)
 {
     constexpr int HALF = TW / 2;             // pixels of one colour per row
     constexpr int NG = NT / HALF;            // lane groups, each owns whole rows
     constexpr int RPT = TH / NG;             // rows per thread
     static_assert(TH % NG == 0 && RPT % 2 == 0, "rows per thread must be even");
-    __shared__ float2 s_uv[TH * TW];          // (du, dv) of a pixel side by side: one 8-byte LDS access each
-
-    // XCD-aware tile order: consecutive workgroup ids land on different XCDs, so
-    // give each XCD a contiguous run of tiles (neighbouring tiles share halo lines
-    // in that XCD's L2).  Speed only.
-    const int nt = a.tiles_x * a.tiles_y;
-    int bid = blockIdx.x;
-    {
-        const int xcd = bid & 7, k = bid >> 3, q = nt >> 3, rem = nt & 7;
-        bid = xcd * q + (xcd < rem ? xcd : rem) + k;   // bijection on [0, nt)
-    }
     const int ty = bid / a.tiles_x, tx = bid - ty * a.tiles_x;
     const int w = a.g.w, h = a.g.h, pitch = a.g.pitch;
-    const size_t off = (size_t)blockIdx.z * a.g.plane;
+    const size_t off = (size_t)z * a.g.plane;
     const int gx0 = tx * a.step_x - a.halo_x;      // even
     const int gy0 = ty * a.step_y - a.halo_y;      // even
 
@@ -567,13 +626,8 @@ __global__ __launch_bounds__(NT) void k_sor(SorArgs a, int K)
     const int r0 = grp * RPT;                      // even
     const int gxa = gx0 + 2 * i;                   // global x of the even pixel of the pair
 
-    // registers: [row][pixel of the pair].  The weight towards the upper neighbour
-    // is the lower weight of the row above (own register except for the first
-    // row), the weight towards the left neighbour of the odd pixel is the right
-    // weight of the even one.
-    float nu[RPT][2], nv[RPT][2], a12[RPT][2], idu[RPT][2], idv[RPT][2];
-    float sr[RPT][2], sb[RPT][2], sl0[RPT], st0[2];
-    st0[0] = 0.0f; st0[1] = 0.0f;
+    SorRegs<RPT> R;
+    R.st0[0] = 0.0f; R.st0[1] = 0.0f;
 
 #pragma unroll
     for (int j = 0; j < RPT; j++) {
@@ -598,16 +652,16 @@ __global__ __launch_bounds__(NT) void k_sor(SorArgs a, int K)
             if (gxa > 0) f_sl = a.sx[p - 1];
             if (j == 0 && gy > 0) {
                 float2 t = *(const float2 *)(a.sy + p - pitch);
-                st0[0] = t.x;
-                st0[1] = ok1 ? t.y : 0.0f;
+                R.st0[0] = t.x;
+                R.st0[1] = ok1 ? t.y : 0.0f;
             }
         }
         // a pixel outside the image gets an all-zero system: it stays finite and is never used
-        nu[j][0] = f_nu.x; nv[j][0] = f_nv.x; a12[j][0] = f_a.x; idu[j][0] = f_iu.x; idv[j][0] = f_iv.x;
-        sr[j][0] = f_sx.x; sb[j][0] = f_sy.x; sl0[j] = f_sl;
-        nu[j][1] = ok1 ? f_nu.y : 0.0f; nv[j][1] = ok1 ? f_nv.y : 0.0f; a12[j][1] = ok1 ? f_a.y : 0.0f;
-        idu[j][1] = ok1 ? f_iu.y : 0.0f; idv[j][1] = ok1 ? f_iv.y : 0.0f;
-        sr[j][1] = ok1 ? f_sx.y : 0.0f; sb[j][1] = ok1 ? f_sy.y : 0.0f;
+        R.nu[j][0] = f_nu.x; R.nv[j][0] = f_nv.x; R.a12[j][0] = f_a.x; R.idu[j][0] = f_iu.x; R.idv[j][0] = f_iv.x;
+        R.sr[j][0] = f_sx.x; R.sb[j][0] = f_sy.x; R.sl0[j] = f_sl;
+        R.nu[j][1] = ok1 ? f_nu.y : 0.0f; R.nv[j][1] = ok1 ? f_nv.y : 0.0f; R.a12[j][1] = ok1 ? f_a.y : 0.0f;
+        R.idu[j][1] = ok1 ? f_iu.y : 0.0f; R.idv[j][1] = ok1 ? f_iv.y : 0.0f;
+        R.sr[j][1] = ok1 ? f_sx.y : 0.0f; R.sb[j][1] = ok1 ? f_sy.y : 0.0f;
         // checkerboard-compressed LDS row: colour of the even pixel is (r & 1) == (j & 1)
         const int c0 = j & 1;
         s_uv[r * TW + c0 * HALF + i] = make_float2(f_du.x, f_dv.x);
@@ -615,56 +669,12 @@ __global__ __launch_bounds__(NT) void k_sor(SorArgs a, int K)
     }
     __syncthreads();
 
-    // A tile that does not touch the image border needs none of the border selects below (they never fire):
+    // A tile that does not touch the image border needs none of the border selects (they never fire):
     // the loop is compiled twice and the workgroup takes its variant -- a quarter fewer vector instructions
-    // for all but the outermost ring of tiles (profiles/r02_sor_sq_counters.csv: the kernel is bound by
-    // vector-instruction issue, not by memory).
+    // for all but the outermost ring of tiles.
     const bool touches = gx0 <= 0 || gy0 <= 0 || gx0 + TW >= w || gy0 + TH >= h;
-    const float om = a.om, om1 = a.om1;
-    auto sweep = [&](auto border_tag) {
-        constexpr bool BORDER = decltype(border_tag)::value;
-#pragma unroll 1
-        for (int it = 0; it < K; it++) {
-#pragma unroll
-            for (int c = 0; c < 2; c++) {
-#pragma unroll
-                for (int j = 0; j < RPT; j++) {
-                    // colour c in row r: pixel x = 2i + q with q = (r + c) & 1 = (j + c) & 1
-                    const int q = (j + c) & 1;
-                    const int r = r0 + j, gy = gy0 + r, gx = gxa + q;
-                    const int oc = (1 - c) * HALF;           // neighbours have the other colour
-                    // slots of the left / right neighbours inside their row
-                    int il = q ? i : i - 1, ir = q ? i + 1 : i;
-                    il = il < 0 ? 0 : il;
-                    ir = ir > HALF - 1 ? HALF - 1 : ir;
-                    const int ru = r > 0 ? r - 1 : 0, rd = r < TH - 1 ? r + 1 : TH - 1;
-                    const float2 pc = s_uv[r * TW + c * HALF + i];
-                    const float2 pl = s_uv[r * TW + oc + il], pr = s_uv[r * TW + oc + ir];
-                    const float2 pt = s_uv[ru * TW + oc + i], pb = s_uv[rd * TW + oc + i];
-                    const float cu = pc.x, cv = pc.y;
-                    float ul = pl.x, ur = pr.x, ut = pt.x, ub = pb.x;
-                    float vl = pl.y, vr = pr.y, vt = pt.y, vb = pb.y;
-                    if (BORDER) {
-                        // at the image border the oracle pairs the (zero) weight with the pixel itself
-                        if (gx <= 0) { ul = cu; vl = cv; }
-                        if (gx >= w - 1) { ur = cu; vr = cv; }
-                        if (gy <= 0) { ut = cu; vt = cv; }
-                        if (gy >= h - 1) { ub = cu; vb = cv; }
-                    }
-                    const float wl = q ? sr[j][0] : sl0[j];
-                    const float wt = j > 0 ? sb[j > 0 ? j - 1 : 0][q] : st0[q];
-                    const float su = ((wl * ul + sr[j][q] * ur) + wt * ut) + sb[j][q] * ub;
-                    const float sv = ((wl * vl + sr[j][q] * vr) + wt * vt) + sb[j][q] * vb;
-                    const float dun = om1 * cu + om * (((nu[j][q] - a12[j][q] * cv) + su) * idu[j][q]);
-                    const float dvn = om1 * cv + om * (((nv[j][q] - a12[j][q] * dun) + sv) * idv[j][q]);
-                    s_uv[r * TW + c * HALF + i] = make_float2(dun, dvn);
-                }
-                __syncthreads();
-            }
-        }
-    };
-    if (touches) sweep(std::true_type{});
-    else sweep(std::false_type{});
+    if (touches) d_sor_sweeps<TW, TH, NT, true>(R, s_uv, K, w, h, gx0, gy0, a.om, a.om1);
+    else d_sor_sweeps<TW, TH, NT, false>(R, s_uv, K, w, h, gx0, gy0, a.om, a.om1);
 
     // write back the interior
     const int lx = 2 * i;
@@ -683,6 +693,293 @@ __global__ __launch_bounds__(NT) void k_sor(SorArgs a, int K)
         } else {
             a.du_out[p] = u0;
             a.dv_out[p] = v0;
+        }
+    }
+}
+
+template <int TW, int TH, int NT>
+__global__ __launch_bounds__(NT) void k_sor(SorArgs a, int K)
+{
+    __shared__ float2 s_uv[TH * TW];          // (du, dv) of a pixel side by side: one 8-byte LDS access each
+    // XCD-aware tile order: consecutive workgroup ids land on different XCDs, so
+    // give each XCD a contiguous run of tiles (neighbouring tiles share halo lines
+    // in that XCD's L2).  Speed only.
+    const int nt = a.tiles_x * a.tiles_y;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, k = bid >> 3, q = nt >> 3, rem = nt & 7;
+        bid = xcd * q + (xcd < rem ? xcd : rem) + k;   // bijection on [0, nt)
+    }
+    d_sor_tile<TW, TH, NT>(a, K, bid, blockIdx.z, s_uv);
+}
+
+// ---- the coarse end of the pyramid in one launch -----------------------------------------------------------------
+// A level of at most 64 x 64 pixels is one SOR tile: one workgroup can take a pair through the whole level --
+// derivatives, warp, `inner` x (linear system, `solver` red-black iterations), prolongation -- and through every
+// further level that still fits, without going back to the host.  Launched per level that is 2 + 2 * inner + 1
+// launches of ~3 us each for microseconds of work (7 levels of a 1024^2 pyramid: 161 of ~650 launches).
+//
+// One workgroup of T x T / 4 threads per pair (T = 32 for levels up to 32 x 32 px, else 64); a thread owns the
+// 2 x 2 pixels (2i + q, 2 grp + j) -- the SOR tile's own layout, so the system goes from the registers that assemble it straight into the sweeps.  u, v, u + du,
+// v + dv and the edge diffusivities live in LDS as T x T planes, du / dv in the sweeps' checkerboard layout;
+// the warped data terms stay in registers for the whole level.  Global memory sees, per level, the reads of the
+// two pyramid images and one write + read of the derivative images (the warp samples those of frame 1 at
+// arbitrary positions).  Every value is computed with the operations, in the order, of k_deriv_all, k_warp,
+// k_prepare, k_sor and k_add_prolong / k_add_out: the same bits.
+#define COARSE_MAX 32
+struct CoarseArgs {
+    int nlev;                                   // levels of this launch, coarsest first
+    Geo g[COARSE_MAX];
+    const float *I0[COARSE_MAX], *I1[COARSE_MAX];
+    const float *u_in, *v_in;                   // u, v of g[0] (pitched planes)
+    float *Ix0, *Iy0, *I1x, *I1y, *I1xx, *I1xy, *I1yy;      // scratch planes
+    Geo gout;                                   // the next finer level; w == 0: g[nlev - 1] is the image itself
+    float *u_out, *v_out;                       // pitched planes of gout, or the caller's tight W x H arrays
+    int inner, solver;
+    float alpha, gamma, om, om1;
+};
+
+template <int T>
+__device__ __forceinline__ int d_cb(int x, int y) { return y * T + ((x + y) & 1) * (T / 2) + (x >> 1); }   // checkerboard slot
+
+template <int T>
+__device__ __forceinline__ float d_co_edge_x(const float (*U)[T], const float (*V)[T], int x, int y, int h, float alpha)
+{
+    const int ym = y > 0 ? y - 1 : 0, yp = y + 1 < h ? y + 1 : h - 1;
+    float ux = U[y][x + 1] - U[y][x];
+    float vx = V[y][x + 1] - V[y][x];
+    float uy = 0.25f * ((U[yp][x] - U[ym][x]) + (U[yp][x + 1] - U[ym][x + 1]));
+    float vy = 0.25f * ((V[yp][x] - V[ym][x]) + (V[yp][x + 1] - V[ym][x + 1]));
+    return alpha * d_psi(((ux * ux + uy * uy) + vx * vx) + vy * vy);
+}
+template <int T>
+__device__ __forceinline__ float d_co_edge_y(const float (*U)[T], const float (*V)[T], int x, int y, int w, float alpha)
+{
+    const int xm = x > 0 ? x - 1 : 0, xp = x + 1 < w ? x + 1 : w - 1;
+    float uy = U[y + 1][x] - U[y][x];
+    float vy = V[y + 1][x] - V[y][x];
+    float ux = 0.25f * ((U[y][xp] - U[y][xm]) + (U[y + 1][xp] - U[y + 1][xm]));
+    float vx = 0.25f * ((V[y][xp] - V[y][xm]) + (V[y + 1][xp] - V[y + 1][xm]));
+    return alpha * d_psi(((ux * ux + uy * uy) + vx * vx) + vy * vy);
+}
+
+// d_bilin_sum with u in an LDS plane and du / dv in the checkerboard tile
+template <int T, int COMP>
+__device__ __forceinline__ float d_co_bilin_sum(const float (*a)[T], const float2 *s_uv, int w, int h, float px, float py)
+{
+    if (px < 0.0f) px = 0.0f;
+    if (py < 0.0f) py = 0.0f;
+    if (px > (float)(w - 1)) px = (float)(w - 1);
+    if (py > (float)(h - 1)) py = (float)(h - 1);
+    float fx0 = floorf(px), fy0 = floorf(py);
+    int x0 = (int)fx0, y0 = (int)fy0;
+    int x1 = x0 + 1 < w ? x0 + 1 : w - 1;
+    int y1 = y0 + 1 < h ? y0 + 1 : h - 1;
+    float ax = px - fx0, ay = py - fy0;
+    const float2 d00 = s_uv[d_cb<T>(x0, y0)], d01 = s_uv[d_cb<T>(x1, y0)], d10 = s_uv[d_cb<T>(x0, y1)], d11 = s_uv[d_cb<T>(x1, y1)];
+    float q00 = a[y0][x0] + (COMP ? d00.y : d00.x), q01 = a[y0][x1] + (COMP ? d01.y : d01.x);
+    float q10 = a[y1][x0] + (COMP ? d10.y : d10.x), q11 = a[y1][x1] + (COMP ? d11.y : d11.x);
+    float top = (1.0f - ax) * q00 + ax * q01;
+    float bot = (1.0f - ax) * q10 + ax * q11;
+    return (1.0f - ay) * top + ay * bot;
+}
+
+template <int T>
+__global__ __launch_bounds__(T * T / 4) void k_coarse(CoarseArgs a)
+{
+    constexpr int NT = T * T / 4, RPT = 2, HALF = T / 2;
+    __shared__ float2 s_uv[T * T];
+    __shared__ float su0[T][T], sv0[T][T];          // u, v
+    __shared__ float sU[T][T], sV[T][T];            // u + du, v + dv
+    __shared__ float sSX[T][T], sSY[T][T];          // diffusivity of the right / lower edge of a pixel
+    const int z = blockIdx.x;
+    const int grp = threadIdx.x / HALF, i = threadIdx.x - grp * HALF;
+    const int xa = 2 * i, ya = RPT * grp;
+    {
+        const Geo g = a.g[0];
+        const size_t off = (size_t)z * g.plane;
+#pragma unroll
+        for (int j = 0; j < RPT; j++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int x = xa + q, y = ya + j;
+                const bool in = x < g.w && y < g.h;
+                su0[y][x] = in ? a.u_in[off + y * g.pitch + x] : 0.0f;
+                sv0[y][x] = in ? a.v_in[off + y * g.pitch + x] : 0.0f;
+            }
+    }
+    for (int lv = 0; lv < a.nlev; lv++) {
+        const Geo g = a.g[lv];
+        const int w = g.w, h = g.h, pitch = g.pitch;
+        const size_t off = (size_t)z * g.plane;
+        const float *I0 = a.I0[lv] + off, *I1 = a.I1[lv] + off;
+        // derivative images (k_deriv_all), pixel by pixel: nothing of this phase stays in registers
+#pragma unroll 1
+        for (int pp = 0; pp < 2 * RPT; pp++) {
+            const int x = xa + (pp & 1), y = ya + (pp >> 1);
+            s_uv[d_cb<T>(x, y)] = make_float2(0.0f, 0.0f);          // du = dv = 0 at the start of a level
+            if (x >= w || y >= h) continue;
+            const size_t p = off + y * pitch + x;
+            a.Ix0[p] = d_dx_at(I0, g, x, y);
+            a.Iy0[p] = d_dy_at(I0, g, x, y);
+            a.I1x[p] = d_dx_at(I1, g, x, y);
+            a.I1y[p] = d_dy_at(I1, g, x, y);
+            const int xm2 = d_mirror(x - 2, w), xm1 = d_mirror(x - 1, w), xp1 = d_mirror(x + 1, w), xp2 = d_mirror(x + 2, w);
+            const int ym2 = d_mirror(y - 2, h), ym1 = d_mirror(y - 1, h), yp1 = d_mirror(y + 1, h), yp2 = d_mirror(y + 2, h);
+            a.I1xx[p] = d_d5(d_dx_at(I1, g, xm2, y), d_dx_at(I1, g, xm1, y), d_dx_at(I1, g, xp1, y), d_dx_at(I1, g, xp2, y));
+            a.I1xy[p] = d_d5(d_dx_at(I1, g, x, ym2), d_dx_at(I1, g, x, ym1), d_dx_at(I1, g, x, yp1), d_dx_at(I1, g, x, yp2));
+            a.I1yy[p] = d_d5(d_dy_at(I1, g, x, ym2), d_dy_at(I1, g, x, ym1), d_dy_at(I1, g, x, yp1), d_dy_at(I1, g, x, yp2));
+        }
+        __syncthreads();                 // the derivative images are this workgroup's own writes: visible after the barrier
+        // warp (k_warp): the data terms of the own pixels, kept in registers for the level
+        float Iz[RPT][2], Ix[RPT][2], Iy[RPT][2], Ixz[RPT][2], Iyz[RPT][2], Ixx[RPT][2], Ixy[RPT][2], Iyy[RPT][2];
+#pragma unroll
+        for (int j = 0; j < RPT; j++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int x = xa + q, y = ya + j;
+                Iz[j][q] = 0.0f; Ix[j][q] = 0.0f; Iy[j][q] = 0.0f; Ixz[j][q] = 0.0f; Iyz[j][q] = 0.0f;
+                Ixx[j][q] = 0.0f; Ixy[j][q] = 0.0f; Iyy[j][q] = 0.0f;
+                if (x >= w || y >= h) continue;
+                const float px = (float)x + su0[y][x], py = (float)y + sv0[y][x];
+                if (px < 0.0f || py < 0.0f || px > (float)(w - 1) || py > (float)(h - 1)) continue;
+                const float i1 = d_bilin(I1, w, h, pitch, px, py);
+                const float ix = d_bilin(a.I1x + off, w, h, pitch, px, py);
+                const float iy = d_bilin(a.I1y + off, w, h, pitch, px, py);
+                Iz[j][q] = i1 - I0[y * pitch + x];
+                Ix[j][q] = ix;
+                Iy[j][q] = iy;
+                if (x < 2 || y < 2 || x > w - 3 || y > h - 3 ||
+                    px < 2.0f || py < 2.0f || px > (float)(w - 4) || py > (float)(h - 4)) continue;
+                Ixz[j][q] = ix - a.Ix0[off + y * pitch + x];
+                Iyz[j][q] = iy - a.Iy0[off + y * pitch + x];
+                Ixx[j][q] = d_bilin(a.I1xx + off, w, h, pitch, px, py);
+                Ixy[j][q] = d_bilin(a.I1xy + off, w, h, pitch, px, py);
+                Iyy[j][q] = d_bilin(a.I1yy + off, w, h, pitch, px, py);
+            }
+        for (int it = 0; it < a.inner; it++) {
+            // u + du, v + dv (k_prepare's staging)
+#pragma unroll
+            for (int j = 0; j < RPT; j++)
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int x = xa + q, y = ya + j;
+                    if (x >= w || y >= h) continue;
+                    const float2 d = s_uv[d_cb<T>(x, y)];
+                    sU[y][x] = su0[y][x] + d.x;
+                    sV[y][x] = sv0[y][x] + d.y;
+                }
+            __syncthreads();
+            SorRegs<RPT> R;
+#pragma unroll
+            for (int j = 0; j < RPT; j++)
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int x = xa + q, y = ya + j;
+                    float rsx = 0.0f, rsy = 0.0f;
+                    if (x < w && y < h) {
+                        if (x + 1 < w) rsx = d_co_edge_x<T>(sU, sV, x, y, h, a.alpha);
+                        if (y + 1 < h) rsy = d_co_edge_y<T>(sU, sV, x, y, w, a.alpha);
+                    }
+                    sSX[y][x] = rsx;
+                    sSY[y][x] = rsy;
+                    R.sr[j][q] = rsx;
+                    R.sb[j][q] = rsy;
+                }
+            __syncthreads();
+            // the 2 x 2 system of every own pixel (k_prepare), into the registers of the sweeps (k_sor's loads)
+#pragma unroll
+            for (int j = 0; j < RPT; j++) {
+                const int y = ya + j;
+                R.sl0[j] = (xa < w && y < h && xa > 0) ? sSX[y][xa - 1] : 0.0f;
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int x = xa + q;
+                    if (j == 0) R.st0[q] = (x < w && y < h && y > 0) ? sSY[y - 1][x] : 0.0f;
+                    R.nu[j][q] = 0.0f; R.nv[j][q] = 0.0f; R.a12[j][q] = 0.0f; R.idu[j][q] = 0.0f; R.idv[j][q] = 0.0f;
+                    if (x >= w || y >= h) continue;
+                    const float2 d = s_uv[d_cb<T>(x, y)];
+                    const float ddu = d.x, ddv = d.y;
+                    const float ix = Ix[j][q], iy = Iy[j][q], iz = Iz[j][q];
+                    const float ixx = Ixx[j][q], ixy = Ixy[j][q], iyy = Iyy[j][q], ixz = Ixz[j][q], iyz = Iyz[j][q];
+                    float q0 = (iz + ix * ddu) + iy * ddv;
+                    float pd = d_psi(q0 * q0);
+                    float q1 = (ixz + ixx * ddu) + ixy * ddv;
+                    float q2 = (iyz + ixy * ddu) + iyy * ddv;
+                    float pg = a.gamma * d_psi(q1 * q1 + q2 * q2);
+                    float A11 = pd * (ix * ix) + pg * (ixx * ixx + ixy * ixy);
+                    float A12 = pd * (ix * iy) + pg * (ixx * ixy + ixy * iyy);
+                    float A22 = pd * (iy * iy) + pg * (ixy * ixy + iyy * iyy);
+                    float b1 = -(pd * (ix * iz) + pg * (ixx * ixz + ixy * iyz));
+                    float b2 = -(pd * (iy * iz) + pg * (ixy * ixz + iyy * iyz));
+                    const int xm = x > 0 ? x - 1 : 0, xp = x + 1 < w ? x + 1 : w - 1;
+                    const int ym = y > 0 ? y - 1 : 0, yp = y + 1 < h ? y + 1 : h - 1;
+                    float sl = x > 0 ? sSX[y][x - 1] : 0.0f, sr = R.sr[j][q];
+                    float st = y > 0 ? sSY[y - 1][x] : 0.0f, sb = R.sb[j][q];
+                    float uc = su0[y][x], vc = sv0[y][x];
+                    float su = ((sl * (su0[y][xm] - uc) + sr * (su0[y][xp] - uc)) + st * (su0[ym][x] - uc)) + sb * (su0[yp][x] - uc);
+                    float sv = ((sl * (sv0[y][xm] - vc) + sr * (sv0[y][xp] - vc)) + st * (sv0[ym][x] - vc)) + sb * (sv0[yp][x] - vc);
+                    float ssum = ((sl + sr) + st) + sb;
+                    R.nu[j][q] = b1 + su;
+                    R.nv[j][q] = b2 + sv;
+                    R.a12[j][q] = A12;
+                    R.idu[j][q] = 1.0f / (A11 + ssum);
+                    R.idv[j][q] = 1.0f / (A22 + ssum);
+                }
+            }
+            d_sor_sweeps<T, T, NT, true>(R, s_uv, a.solver, w, h, 0, 0, a.om, a.om1);   // ends on a barrier
+        }
+        // u + du, v + dv carried to the next finer level (k_add_prolong) or out (k_add_out)
+        if (lv + 1 < a.nlev) {
+            const Geo gd = a.g[lv + 1];
+            const float rx = (float)w / (float)gd.w, ry = (float)h / (float)gd.h;
+            const float mulx = (float)gd.w / (float)w, muly = (float)gd.h / (float)h;
+            float nu_[RPT][2], nv_[RPT][2];
+#pragma unroll
+            for (int j = 0; j < RPT; j++)
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int x = xa + q, y = ya + j;
+                    nu_[j][q] = 0.0f; nv_[j][q] = 0.0f;
+                    if (x >= gd.w || y >= gd.h) continue;
+                    const float sx = ((float)x + 0.5f) * rx - 0.5f;
+                    const float sy = ((float)y + 0.5f) * ry - 0.5f;
+                    nu_[j][q] = d_co_bilin_sum<T, 0>(su0, s_uv, w, h, sx, sy) * mulx;
+                    nv_[j][q] = d_co_bilin_sum<T, 1>(sv0, s_uv, w, h, sx, sy) * muly;
+                }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < RPT; j++)
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    su0[ya + j][xa + q] = nu_[j][q];
+                    sv0[ya + j][xa + q] = nv_[j][q];
+                }
+            __syncthreads();
+        } else if (a.gout.w > 0) {
+            const Geo gd = a.gout;
+            const float rx = (float)w / (float)gd.w, ry = (float)h / (float)gd.h;
+            const float mulx = (float)gd.w / (float)w, muly = (float)gd.h / (float)h;
+            const size_t offd = (size_t)z * gd.plane;
+            for (int idx = threadIdx.x; idx < gd.w * gd.h; idx += NT) {
+                const int y = idx / gd.w, x = idx - y * gd.w;
+                const float sx = ((float)x + 0.5f) * rx - 0.5f;
+                const float sy = ((float)y + 0.5f) * ry - 0.5f;
+                a.u_out[offd + y * gd.pitch + x] = d_co_bilin_sum<T, 0>(su0, s_uv, w, h, sx, sy) * mulx;
+                a.v_out[offd + y * gd.pitch + x] = d_co_bilin_sum<T, 1>(sv0, s_uv, w, h, sx, sy) * muly;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < RPT; j++)
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int x = xa + q, y = ya + j;
+                    if (x >= w || y >= h) continue;
+                    const float2 d = s_uv[d_cb<T>(x, y)];
+                    const size_t o = ((size_t)z * h + y) * w + x;
+                    a.u_out[o] = su0[y][x] + d.x;
+                    a.v_out[o] = sv0[y][x] + d.y;
+                }
         }
     }
 }

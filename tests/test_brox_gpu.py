@@ -121,7 +121,7 @@ def test_warp_window_and_direct_sampling_agree_with_oracle(hm, oracle_brox, kind
 
 
 @pytest.mark.parametrize("w,h", SIZES + [(300, 300)])
-@pytest.mark.parametrize("fuse", [0, 1, 2, 5, 105, 205])
+@pytest.mark.parametrize("fuse", [0, 1, 2, 5, 105, 205, 10, 210])
 def test_sor(hm, oracle_brox, w, h, fuse):
     from hydra_mi import brox
     f = _level_fields(oracle_brox, w, h, 30)
@@ -184,10 +184,35 @@ def test_calc_batch_and_tuning_do_not_change_results(hm, oracle_brox):
         ru, rv = oracle_brox.calc(F0[i], F1[i])
         assert np.array_equal(U[i], ru) and np.array_equal(V[i], rv)
     for key, val in [("sor_fuse", 1), ("sor_fuse", 2), ("sor_threads", 512), ("sor_fuse", 0), ("sor_threads", 1024),
-                     ("warp_window", 1), ("warp_window", 0)]:
+                     ("warp_window", 1), ("warp_window", 0), ("coarse_max", 0), ("coarse_max", 32), ("coarse_max", 64), ("sor_deep", 0), ("sor_fuse", 10)]:
         bf.tune(key, val)
         U2, V2 = bf.calc_batch(F0, F1)
         assert np.array_equal(U, U2) and np.array_equal(V, V2), (key, val)
+
+
+@pytest.mark.parametrize("w,h,kw,okw", [
+    (64, 64, {}, {}),                                                        # the whole pyramid inside k_coarse
+    (57, 33, dict(inner_iterations=3, solver_iterations=4), dict(inner=3, solver=4)),
+    (17, 64, {}, {}),
+    (100, 90, dict(scale_factor=0.97, outer_iterations=70), dict(scale=0.97, outer=70)),   # > 32 coarse levels: two launches
+    (150, 100, dict(scale_factor=0.5), dict(scale=0.5)),                     # the exit level is 4x the last fused one
+])
+def test_coarse_levels_in_one_launch(hm, oracle_brox, w, h, kw, okw):
+    """k_coarse (the levels of at most 64 x 64 px in one launch per pair and tile size) against the oracle and
+    against the launch-per-operator path."""
+    from hydra_mi import brox, synth
+    n = max(w, h)
+    f0, f1, _, _ = synth.warp_pair(n + (n & 1), "warp", 5)
+    F0 = np.stack([np.ascontiguousarray(f0[:h, :w]), np.ascontiguousarray(f1[:h, :w])])
+    F1 = np.stack([np.ascontiguousarray(f1[:h, :w]), np.ascontiguousarray(f0[:h, :w])])
+    bf = brox.BroxOpticalFlow(w, h, max_batch=2, **kw)
+    assert sum(1 for lw, lh in bf.levels() if lw <= 64 and lh <= 64) >= 1
+    ref = [oracle_brox.calc(F0[i], F1[i], **okw) for i in range(2)]
+    for cmax in (64, 32, 0):
+        bf.tune("coarse_max", cmax)
+        U, V = bf.calc_batch(F0, F1)
+        for i in range(2):
+            assert np.array_equal(U[i], ref[i][0]) and np.array_equal(V[i], ref[i][1]), (cmax, i)
 
 
 def test_identical_frames_give_zero_flow(hm):
@@ -220,6 +245,7 @@ def test_profile_totals(hm, oracle_brox):
     bf = brox.BroxOpticalFlow(n, n, max_batch=2)
     with pytest.raises(RuntimeError):
         bf.tune("graph", 1)           # the round-1 hipGraph knob is gone
+    bf.tune("coarse_max", 32)
     bf.profile(True)
     u, v = bf.calc(f0, f1)
     bf.profile(False)
@@ -227,8 +253,9 @@ def test_profile_totals(hm, oracle_brox):
     ms, launches, pxit, px = bf.profile_read()
     assert launches > 0 and ms > 0 and pxit > 0 and 0 < px <= pxit
     assert np.array_equal(u, ru) and np.array_equal(v, rv) and np.array_equal(u2, ru) and np.array_equal(v2, rv)
-    # every level: inner x solver red-black iterations over its pixels
-    want = sum(w * h for w, h in bf.levels()) * 10 * 10
+    # every level that is launched per operator (the small levels run inside k_coarse and have no k_sor launches):
+    # inner x solver red-black iterations over its pixels
+    want = sum(w * h for w, h in bf.levels() if w > 32 or h > 32) * 10 * 10
     assert pxit == want
     per_call = launches
     bf.profile(True)

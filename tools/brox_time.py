@@ -23,6 +23,7 @@ def run(n, batch, reps, tunes):
         t = time.perf_counter()
         for _ in range(reps):
             bf.calc_dev(batch, F0.data_ptr(), F1.data_ptr(), U.data_ptr(), V.data_ptr())
+        t_enq = (time.perf_counter() - t) / reps          # host time to enqueue a series
         bf.sync()
         dt = (time.perf_counter() - t) / reps
         bf.profile(True)
@@ -30,7 +31,7 @@ def run(n, batch, reps, tunes):
             bf.calc_dev(batch, F0.data_ptr(), F1.data_ptr(), U.data_ptr(), V.data_ptr())
         ms, launches, pxit, _ = bf.profile_read()
         bf.profile(False)
-        print(json.dumps(dict(n=n, batch=batch, tune=tune, ms_per_call=dt * 1e3, pairs_per_s=batch / dt,
+        print(json.dumps(dict(n=n, batch=batch, tune=tune, ms_per_call=dt * 1e3, enqueue_ms=t_enq * 1e3, pairs_per_s=batch / dt,
                               sor_ms_per_call=ms / reps, sor_launches=launches // reps,
                               sor_GBps_alg=52.0 * pxit / (ms * 1e-3) / 1e9 if ms else None)), flush=True)
 
@@ -39,6 +40,13 @@ if __name__ == "__main__":
              dict(sor_fuse=2, sor_threads=512), dict(sor_fuse=2, sor_threads=1024)]
     if len(sys.argv) > 1 and sys.argv[1] == "dry":        # where a SOR launch spends its time: loads + stores only
         run(1024, 8, 3, [dict(sor_fuse=0, sor_threads=512, sor_dry=0), dict(sor_fuse=0, sor_threads=512, sor_dry=1)])
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "coarse":     # the coarse end of the pyramid: one launch against launch per operator
+        ct = [dict(coarse_max=32, sor_deep=0), dict(sor_deep=1), dict(sor_deep=2), dict(sor_deep=3), dict(sor_deep=4), dict(sor_deep=8)]
+        run(64, 1, 20, ct)
+        run(512, 1, 10, ct)
+        run(1024, 1, 10, ct)
+        run(1024, 8, 5, ct)
         sys.exit(0)
     run(512, 1, 5, tunes[:3])
     run(1024, 1, 5, tunes)
