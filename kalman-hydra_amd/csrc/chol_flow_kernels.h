@@ -6,7 +6,8 @@
 // what a factorisation costs, and 4-5 us per step of it are launch boundary.  Here the same block operations
 // run as tasks of one launch and hand their results to each other through memory:
 //
-//   D(c)    diagonal block c:  A_cc - sum_{j<c} L_cj L_cj^T  ->  T_c = chol(.)^-1            (Lt[c], Tinv_cc)
+//   S(c)    diagonal block c, all terms but the last:  A_cc - sum_{j<c-1} L_cj L_cj^T  ->  Q_c
+//   D(c)    the last term and the factor:  Q_c - L_c,c-1 L_c,c-1^T  ->  T_c = chol(.)^-1       (Lt[c], Tinv_cc)
 //   F(r,c)  block below it:    (A_rc - sum_{j<c} L_rj L_cj^T) T_c^T  ->  L_rc                 (r = nb: right-hand sides)
 //   I(k,j)  inverse, k > j:    T_k (0 - sum_{i=j..k-1} L_ki Tinv_ij)  ->  Tinv_kj
 //
@@ -21,13 +22,16 @@
 // fences, no dependence on which XCD a workgroup runs on.  While a block is not there one lane polls one of its
 // words (s_sleep between polls); every wait is bounded and a time-out ends the launch with an error word set.
 //
-// Scheduling: tasks are numbered so that every task depends only on lower numbers (step by step: D(c), F(.,c),
-// I(c,.)), and workgroups draw numbers from one counter in the order they start running.  A workgroup therefore
-// only ever waits for tasks that other RUNNING workgroups hold -- no deadlock whatever number of workgroups is
-// resident -- and the ~250 workgroups in flight work ~9 steps ahead of the diagonal chain: a block's sum is
-// complete but for its last term by the time that term's operand appears.  The chain itself: D(c+1) waits for T_c
-// (one hand-off), multiplies the block (c+1, c) -- published before its triangular solve by F(c+1, c) -- by T_c^T,
-// subtracts its square, factors.
+// Scheduling: workgroups draw numbers from one counter in the order they start running.  Number 0 makes its
+// workgroup the CHAIN: it runs D(0), D(1), ... one after the other, T_c staying in its LDS for D(c+1) -- the
+// diagonal blocks are what a factorisation waits for (4.2 of the ~6 us a column takes are the 32 dependent
+// columns of one block, profiles/README.md), and a hand-off between two of them through memory costs 1.3 us.  The
+// other numbers are tasks, step by step S(c), F(., c), I(c, .), every one depending only on lower numbers and on
+// the chain.  A workgroup therefore only ever waits for what other RUNNING workgroups hold -- no deadlock whatever
+// number of workgroups is resident -- and the ~250 workgroups in flight work ~9 steps ahead of the chain: a block's
+// sum is complete but for its last term by the time that term's operand appears.  The chain per column: wait for
+// Q_c and the block (c, c-1) -- published before its triangular solve by F(c, c-1) -- multiply the latter by
+// T_{c-1}^T, subtract its square from Q_c, factor.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "dense_kernels.h"
@@ -41,7 +45,7 @@ struct FlowArgs {
     double *L;                // nrows x n: blocks below the block diagonal
     double *Lt;               // nb x 32 x 32: T_c
     double *Tinv;             // n x n: L^-1
-    double *P;                // nb x 32 x 32: block (c, c-1) before its triangular solve
+    double *P;                // 3 x nb x 32 x 32: block (c, c-1) before its triangular solve; Q_c; block (c, c-2) likewise (Y_c)
     int n, nrows, nb, nbr;    // nbr: block rows including the right-hand-side rows
     unsigned *ctl;            // [0] next task, [1] set when a wait timed out
 };
@@ -75,7 +79,8 @@ __device__ __forceinline__ void flow_fill_row(const FlowArgs &a, int row, int t,
 __device__ __forceinline__ void flow_fill_blocks(const FlowArgs &a, int t, int nt)
 {
     const double s = __longlong_as_double((long long)FLOW_SENTINEL);
-    for (int i = t; i < a.nb * DNB * DNB; i += nt) { a.Lt[i] = s; a.P[i] = s; }
+    for (int i = t; i < a.nb * DNB * DNB; i += nt) a.Lt[i] = s;
+    for (int i = t; i < 3 * a.nb * DNB * DNB; i += nt) a.P[i] = s;
     if (t == 0) a.ctl[0] = 0;
 }
 // ... or a launch of its own (the inverse of the prior has no assembly pass): one workgroup per row, one more for Lt / P
@@ -150,8 +155,44 @@ __device__ __forceinline__ bool flow_fetch(const double *src, int ld, int nr, in
     return flow_fetch2(b, b, false, ctl);
 }
 
+// Two blocks other tasks publish (DNB columns; rows < nr of the first, all of the second; what is not published
+// reads as 0; the second only if `two`) into LDS by the 192 threads of three waves (tt = 0 .. 191) that poll for
+// them on their own -- no workgroup barrier inside: every wave re-loads its elements of both until none is the
+// fill pattern.  false: gave up.
+__device__ __forceinline__ bool flow_prefetch2(const double *src0, int nr, double (*dst0)[DNB + 1], const double *src1,
+                                               double (*dst1)[DNB + 1], bool two, int tt, unsigned *ctl)
+{
+    double v0[6], v1[6];
+    for (int polls = 0;; polls++) {
+        int ok = 1;
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const int e = tt + 192 * q, i = e / DNB;
+            unsigned long long x0 = 0, x1 = 0;
+            if (e < DNB * DNB && i < nr) x0 = flow_ld_bits(src0 + e);
+            if (e < DNB * DNB && two) x1 = flow_ld_bits(src1 + e);
+            ok &= x0 != FLOW_SENTINEL && x1 != FLOW_SENTINEL;
+            v0[q] = __longlong_as_double((long long)x0);
+            v1[q] = __longlong_as_double((long long)x1);
+        }
+        if (__all(ok)) break;
+        if ((polls & 255) == 255 && __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        if (polls > FLOW_POLL_LIMIT) { __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        const int e = tt + 192 * q;
+        if (e < DNB * DNB) {
+            dst0[e / DNB][e % DNB] = v0[q];
+            if (two) dst1[e / DNB][e % DNB] = v1[q];
+        }
+    }
+    return true;
+}
+
 // chol32_tinv_wave with write-through stores, to Lt[c] and to the diagonal block of Tinv
-__device__ __forceinline__ void flow_chol32(double (*W)[DNB + 1], double *lt, double *tinv, int ld, int nc, int lane)
+__device__ __forceinline__ void flow_chol32(double (*W)[DNB + 1], double *lt, double *tinv, int ld, int nc, int lane,
+                                            double (*keep)[DNB + 1])
 {
     d4_t b[2][2], t[2][2];
     const int lr = lane >> 4, lc = lane & 15;
@@ -173,7 +214,10 @@ __device__ __forceinline__ void flow_chol32(double (*W)[DNB + 1], double *lt, do
 #pragma unroll
         for (int C = 0; C < 2; C++)
 #pragma unroll
-            for (int e = 0; e < 4; e++) flow_st(lt + (16 * R + lr + 4 * e) * DNB + 16 * C + lc, t[R][C][e]);
+            for (int e = 0; e < 4; e++) {
+                flow_st(lt + (16 * R + lr + 4 * e) * DNB + 16 * C + lc, t[R][C][e]);
+                keep[16 * R + lr + 4 * e][16 * C + lc] = t[R][C][e];          // for the chain's next block
+            }
 #pragma unroll
     for (int R = 0; R < 2; R++)
 #pragma unroll
@@ -190,7 +234,10 @@ __global__ __launch_bounds__(FLOW_NT) void k_chol_flow(FlowArgs a)
     __shared__ double Ts[DNB][DNB + 1];
     __shared__ double Br[DNB][DNB + 1];
     __shared__ double Bc[DNB][DNB + 1];
+    __shared__ double Pn[DNB][DNB + 1];               // the chain's next operands, fetched while it factors
+    __shared__ double Qn[DNB][DNB + 1];
     __shared__ unsigned s_task;
+    __shared__ int s_fail;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int n = a.n, nb = a.nb;
     const unsigned ntasks = (unsigned)nb * (unsigned)(nb + 1);
@@ -200,20 +247,68 @@ __global__ __launch_bounds__(FLOW_NT) void k_chol_flow(FlowArgs a)
 #pragma unroll
     for (int e = 0; e < 4; e++) mi[e] = 16 * (wv >> 1) + (lane >> 4) + 4 * e;
     const d4_t z = {0.0, 0.0, 0.0, 0.0};
+    bool first = true;
     for (;;) {
         __syncthreads();                              // everyone is done with the previous task's LDS and s_task
         if (t == 0) s_task = atomicAdd(a.ctl, 1u);
         __syncthreads();
-        const unsigned task = s_task;
-        if (task >= ntasks) return;
+        if (first && s_task == 0) {
+            // ---- the chain: D(0), D(1), ... ------------------------------------------------------------------
+            // While wave 0 factors block c (4.2 us, one wave), the other three waves fetch what block c + 1 starts
+            // from -- the block (c+1, c) before its triangular solve and Q_{c+1}; both appear about now -- so that
+            // the chain never waits for a load it could have issued earlier (a load of a block that is already
+            // there still takes 1.7 us).
+            __builtin_amdgcn_s_setprio(3);            // ahead of whatever shares its SIMDs
+            if (t == 0) s_fail = 0;
+            for (int c = 0; c < nb; c++) {
+                const int c0 = c * DNB, nc = min(DNB, n - c0);
+                double acc[4];
+                if (c < 2) {                          // Q_c is the block of A itself
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc[e] = (mi[e] < nc && mj < nc) ? a.A[(size_t)(c0 + mi[e]) * n + c0 + mj] : 0.0;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc[e] = Qn[mi[e]][mj];
+                }
+                if (c > 0) {
+                    const d4_t xr = d_mfma_nt(Pn, Ts, wv, lane);        // block (c, c-1) as F(c, c-1) left it, times T_{c-1}^T
+#pragma unroll
+                    for (int e = 0; e < 4; e++) Br[mi[e]][mj] = xr[e];
+                    __syncthreads();
+                    const d4_t s = d_mfma_nt(Br, Br, wv, lane);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc[e] = acc[e] - s[e];
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) Br[mi[e]][mj] = (mi[e] < nc && mj < nc) ? acc[e] : (mi[e] == mj ? 1.0 : 0.0);
+                __syncthreads();
+                if (wv == 0) {
+                    flow_chol32(Br, a.Lt + (size_t)c * DNB * DNB, a.Tinv + (size_t)c0 * n + c0, n, nc, lane, Ts);
+                } else if (c + 1 < nb) {
+                    const int nr = min(DNB, n - (c0 + DNB));
+                    const double *Pb = a.P + (size_t)(c + 1) * DNB * DNB, *Qb = a.P + (size_t)(nb + c + 1) * DNB * DNB;
+                    if (!flow_prefetch2(Pb, nr, Pn, Qb, Qn, c + 1 >= 2, t - 64, a.ctl)) s_fail = 1;
+                }
+                __syncthreads();
+                if (s_fail) return;
+            }
+            __builtin_amdgcn_s_setprio(0);
+            first = false;
+            continue;
+        }
+        first = false;
+        if (s_task > ntasks) return;
+        const unsigned task = s_task - 1;
         const int c = (int)(task / (unsigned)(nb + 1)), idx = (int)(task % (unsigned)(nb + 1));
         const int c0 = c * DNB, nc = min(DNB, n - c0);
         if (idx == 0) {
-            // ---- D(c) --------------------------------------------------------------------------------------
+            // ---- S(c) --------------------------------------------------------------------------------------
+            if (c < 2) continue;
             double acc[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) acc[e] = (mi[e] < nc && mj < nc) ? a.A[(size_t)(c0 + mi[e]) * n + c0 + mj] : 0.0;
-            for (int j = 0; j + 1 < c; j++) {
+            for (int j = 0; j + 2 < c; j++) {
                 if (!flow_fetch(a.L + (size_t)c0 * n + j * DNB, n, nc, DNB, Br, a.ctl)) return;
                 __syncthreads();
                 const d4_t s = d_mfma_nt(Br, Br, wv, lane);
@@ -221,12 +316,13 @@ __global__ __launch_bounds__(FLOW_NT) void k_chol_flow(FlowArgs a)
                 for (int e = 0; e < 4; e++) acc[e] = acc[e] - s[e];
                 __syncthreads();
             }
-            if (c > 0) {                              // the last term: block (c, c-1) as F(c, c-1) left it, times T_{c-1}^T
-                const FlowBlock bp = {a.P + (size_t)c * DNB * DNB, DNB, nc, DNB, Bc};
-                const FlowBlock bt = {a.Lt + (size_t)(c - 1) * DNB * DNB, DNB, DNB, DNB, Ts};
-                if (!flow_fetch2(bt, bp, true, a.ctl, true)) return;
+            {   // the last term, j = c-2: L_{c,c-2} = Y_c T_{c-2}^T is formed here -- the task that stores it is one
+                // hop through memory further from T_{c-2} than this one, and the chain waits for Q_c two columns on
+                const FlowBlock by = {a.P + (size_t)(2 * nb + c) * DNB * DNB, DNB, nc, DNB, Br};
+                const FlowBlock bt = {a.Lt + (size_t)(c - 2) * DNB * DNB, DNB, DNB, DNB, Ts};
+                if (!flow_fetch2(bt, by, true, a.ctl, true)) return;
                 __syncthreads();
-                const d4_t xr = d_mfma_nt(Bc, Ts, wv, lane);
+                const d4_t xr = d_mfma_nt(Br, Ts, wv, lane);
                 __syncthreads();
 #pragma unroll
                 for (int e = 0; e < 4; e++) Br[mi[e]][mj] = xr[e];
@@ -234,21 +330,23 @@ __global__ __launch_bounds__(FLOW_NT) void k_chol_flow(FlowArgs a)
                 const d4_t s = d_mfma_nt(Br, Br, wv, lane);
 #pragma unroll
                 for (int e = 0; e < 4; e++) acc[e] = acc[e] - s[e];
-                __syncthreads();
             }
+            double *Qb = a.P + (size_t)(nb + c) * DNB * DNB;
 #pragma unroll
-            for (int e = 0; e < 4; e++) Br[mi[e]][mj] = (mi[e] < nc && mj < nc) ? acc[e] : (mi[e] == mj ? 1.0 : 0.0);
-            __syncthreads();
-            if (wv == 0) flow_chol32(Br, a.Lt + (size_t)c * DNB * DNB, a.Tinv + (size_t)c0 * n + c0, n, nc, lane);
+            for (int e = 0; e < 4; e++) flow_st(Qb + mi[e] * DNB + mj, acc[e]);
         } else if (idx <= nb - c) {
             // ---- F(r, c) -----------------------------------------------------------------------------------
             const int r = c + idx;
             if (r >= a.nbr) continue;                 // no right-hand-side rows in this factorisation
             const int r0 = r * DNB, nr = min(DNB, a.nrows - r0);
+            // F(c+1, c) feeds the chain (block (c+1, c) before its triangular solve): its last term, j = c-1, is formed
+            // from the two blocks of column c-1 BEFORE their triangular solves and T_{c-1} -- one hop through
+            // memory after T_{c-1} instead of two
+            const bool feeds = r == c + 1 && r < nb && c >= 1;
             double acc[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) acc[e] = (mi[e] < nr && mj < nc) ? a.A[(size_t)(r0 + mi[e]) * n + c0 + mj] : 0.0;
-            for (int j = 0; j < c; j++) {
+            for (int j = 0; j < (feeds ? c - 1 : c); j++) {
                 const FlowBlock br = {a.L + (size_t)r0 * n + j * DNB, n, nr, DNB, Br};
                 const FlowBlock bc = {a.L + (size_t)c0 * n + j * DNB, n, nc, DNB, Bc};
                 if (!flow_fetch2(br, bc, true, a.ctl)) return;
@@ -258,13 +356,39 @@ __global__ __launch_bounds__(FLOW_NT) void k_chol_flow(FlowArgs a)
                 for (int e = 0; e < 4; e++) acc[e] = acc[e] - s[e];
                 __syncthreads();
             }
+            if (feeds) {
+                const FlowBlock by = {a.P + (size_t)(2 * nb + r) * DNB * DNB, DNB, nr, DNB, Br};       // block (r, c-1)
+                const FlowBlock bp = {a.P + (size_t)c * DNB * DNB, DNB, nc, DNB, Bc};                  // block (c, c-1)
+                const FlowBlock bt = {a.Lt + (size_t)(c - 1) * DNB * DNB, DNB, DNB, DNB, Ts};
+                if (!flow_fetch2(by, bp, true, a.ctl)) return;
+                if (!flow_fetch2(bt, bt, false, a.ctl, true)) return;
+                __syncthreads();
+                const d4_t x1 = d_mfma_nt(Br, Ts, wv, lane), x2 = d_mfma_nt(Bc, Ts, wv, lane);
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 4; e++) { Br[mi[e]][mj] = x1[e]; Bc[mi[e]][mj] = x2[e]; }
+                __syncthreads();
+                const d4_t s = d_mfma_nt(Br, Bc, wv, lane);
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[e] = acc[e] - s[e];
+                __syncthreads();
+            }
+            if (r == c + 2 && r < nb) {               // F(r, r-1) and S(r) form L_{r,r-2} from this themselves
+                double *Yb = a.P + (size_t)(2 * nb + r) * DNB * DNB;
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (mi[e] < nr) flow_st(Yb + mi[e] * DNB + mj, mj < nc ? acc[e] : 0.0);
+            }
             if (r == c + 1 && r < nb) {               // the diagonal task of column r takes it from here
                 double *Pb = a.P + (size_t)r * DNB * DNB;
 #pragma unroll
                 for (int e = 0; e < 4; e++)
                     if (mi[e] < nr) flow_st(Pb + mi[e] * DNB + mj, mj < nc ? acc[e] : 0.0);
             }
-            if (!flow_fetch(a.Lt + (size_t)c * DNB * DNB, DNB, DNB, DNB, Ts, a.ctl)) return;
+            {
+                const FlowBlock bt = {a.Lt + (size_t)c * DNB * DNB, DNB, DNB, DNB, Ts};
+                if (!flow_fetch2(bt, bt, false, a.ctl, r <= c + 2)) return;
+            }
 #pragma unroll
             for (int e = 0; e < 4; e++) Br[mi[e]][mj] = acc[e];
             __syncthreads();

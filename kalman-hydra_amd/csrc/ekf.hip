@@ -70,7 +70,7 @@ struct hm_ctx {
     int worker_rc;
     char worker_err[512];
     int chol_flow, flow_wgs;         // the factorisation as one persistent launch (chol_flow_kernels.h) / its workgroups
-    double *d_flowP;                 // nb x 32 x 32 scratch of that launch
+    double *d_flowP;                 // 3 x nb x 32 x 32 scratch of that launch
     unsigned *d_flowctl;             // its task counter and time-out word
     hipStream_t stream2;             // hm_ms_predict: the state prediction runs beside the covariance half of the update
     int *d_nbars, *d_nvoff, *d_nvbar, *d_ninfo;     // its spring topology (bars, CSR of the bars of every vertex), result words
@@ -278,7 +278,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Lt[0], ld_bytes);  // inverses of the factored diagonal blocks
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Lt[1], ld_bytes);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Wtmp, nn);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_flowP, ld_bytes);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_flowP, 3 * ld_bytes);      // P, Q and Y blocks of k_chol_flow
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_flowctl, 4 * sizeof(unsigned));
         if (e == hipSuccess) e = hipMemsetAsync(h->d_flowctl, 0, 4 * sizeof(unsigned), h->stream);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Hz, n4 * sizeof(double));
