@@ -559,6 +559,14 @@ __device__ inline void d_star_setups(TriSetup *dst, int ns, const int *tris, con
 // render and the observation, whose rows the same tiles read.  Unaligned, an 8-pixel row of a 16-bit plane
 // is a quarter of a sector and an f32 row straddles two: the kernel moved 3.5x its payload
 // (profiles/r01_ekf_traffic.csv).
+// A pixel of a region that no configuration of the star covers (about a third of a bounding box, and most of the
+// intersection of two) has all-zero differences: its first plane holds POOL_EMPTY instead of a numerator, and the
+// edge jobs -- every term of which has a factor from each vertex -- skip the other seven planes of both vertices
+// when they meet it (182 -> 132 MB read per launch, 36 -> 33 us).  The zeros are stored all the same: leaving the
+// seven planes of such pixels unwritten saves 16 MB of writes and costs 59 MB of reads (lines written in part are
+// read back and merged by the memory side), no time gained; and skipping a tile no triangle reaches before its
+// loads pushes the vertex kernel over its 128 registers (253 spilled, 85 -> 400 us).
+#define POOL_EMPTY 0x7FFF
 struct DPool {
     int *hdr;                 // N x 4: c0, r0, rw, rh of the region (c0 and rw multiples of 8)
     const int *area;          // N region areas (k_star_regions); a region's offset is the sum of those before it
@@ -567,6 +575,13 @@ struct DPool {
     long long cap;            // pixels in the pool
     int *overflow;            // set to 1 if the regions do not fit
 };
+
+__device__ __forceinline__ void d_park_empty(const DPool &P, long long pp)
+{
+    P.xi[pp] = make_short2(POOL_EMPTY, 0); P.yi[pp] = make_short2(0, 0);
+    P.xfx[pp] = 0.0f; P.xfy[pp] = 0.0f; P.yfx[pp] = 0.0f; P.yfy[pp] = 0.0f;
+    P.vxfx[pp] = 0.0f; P.vyfy[pp] = 0.0f;
+}
 
 struct MeasureArgs {
     Mesh m;
@@ -754,9 +769,9 @@ __global__ __launch_bounds__(MEAS_NT, 4) void k_measure_vertex(MeasureArgs a, co
         if (r >= r0 + rh || c >= c0 + rw || c >= W) continue;      // (the padding of a region may leave the frame)
         const int i = (r - r0) * rw + (c - c0);
         const int p = r * W + c;
+        const long long pp = base + i;
         const int racc = a.ref.acc[p], rcnt = a.ref.cnt[p];
         const float rfx = a.ref.fx[p], rfy = a.ref.fy[p];
-        const long long pp = base + i;
         StarVel vel, none;
         StarTex q0, q1, q2, q3, q4;
         StarVal sref = d_star_eval<true>(s_cfg[0], mask, c, r, m, v, (float)(X[2 * N + 2 * v] + d),
@@ -772,11 +787,7 @@ __global__ __launch_bounds__(MEAS_NT, 4) void k_measure_vertex(MeasureArgs a, co
             sref.acc += e0; sxp.acc += e1; sxm.acc += e2; syp.acc += e3; sym.acc += e4;
         }
         if (sref.cnt + sxp.cnt + sxm.cnt + syp.cnt + sym.cnt == 0) {
-            if (park) {
-                a.pool.xi[pp] = make_short2(0, 0); a.pool.yi[pp] = make_short2(0, 0);
-                a.pool.xfx[pp] = 0.0f; a.pool.xfy[pp] = 0.0f; a.pool.yfx[pp] = 0.0f; a.pool.yfy[pp] = 0.0f;
-                a.pool.vxfx[pp] = 0.0f; a.pool.vyfy[pp] = 0.0f;
-            }
+            if (park) d_park_empty(a.pool, pp);
             continue;
         }
         // velocity perturbations keep the geometry: same coverage and texels as the reference
@@ -859,7 +870,9 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure_edge(MeasureArgs a)
         const long long pw = bw + (long long)(r - hw[1]) * hw[2] + (c - hw[0]);
         r += dr; c += dc;
         if (c > c1) { c -= rw; r++; }
-        const short2 ax_ = P.xi[pv], ay_ = P.yi[pv], bx_ = P.xi[pw], by_ = P.yi[pw];   // numerators in -255..255
+        const short2 ax_ = P.xi[pv], bx_ = P.xi[pw];                      // numerators in -255..255, or the mark of a
+        if (ax_.x == POOL_EMPTY || bx_.x == POOL_EMPTY) continue;         // pixel outside the star: every product is zero
+        const short2 ay_ = P.yi[pv], by_ = P.yi[pw];
         const double axim = k255[ax_.x], axm = k255[ax_.y];
         const double ayim = k255[ay_.x], aym = k255[ay_.y];
         const double bxim = k255[bx_.x], bxm = k255[bx_.y];
