@@ -189,6 +189,7 @@ struct hm_brox {
     int sor_dry;                 // development knob: SOR launches load and store but do not iterate (wrong results)
     int cus;                     // compute units of the device
     int sor_deep;                // levels with few tiles take all solver iterations in one launch (sor_plan)
+    int coarse_stagger;          // test knob: the pairs of a k_coarse launch start one after the other
     int coarse_max;              // levels up to this many px per side run inside k_coarse: 0 (none), 32 or 64
     std::vector<Geo> geo;
     Taps taps;
@@ -245,7 +246,7 @@ extern "C" int hm_brox_create(int device, int W, int H, int max_batch, float alp
     h->device = device; h->W = W; h->H = H; h->B = max_batch;
     h->alpha = alpha; h->gamma = gamma; h->scale = scale; h->omega = 1.99f;
     h->inner = inner; h->outer = outer; h->solver = solver; h->fuse = 0; h->sor_threads = 0; h->sor_dry = 0;
-    h->coarse_max = 32; h->sor_deep = 1; h->cus = 0;
+    h->coarse_max = 32; h->sor_deep = 1; h->cus = 0; h->coarse_stagger = 0;
     if (hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) h->cus = 0;
     h->arena = nullptr; h->d_f0 = h->d_f1 = nullptr; h->d_ox = h->d_oy = nullptr; h->stream = nullptr;
     h->prof = false; h->ev_used = 0; h->prof_ms = 0; h->prof_pxit = 0; h->prof_px = 0; h->prof_launches = 0;
@@ -327,9 +328,28 @@ extern "C" int hm_brox_tune(hm_brox_t h, const char *key, int value)
         h->sor_threads = value;
     } else if (!strcmp(key, "sor_dry")) {            // timing experiments only (tools/): the flow is wrong with 1
         h->sor_dry = value != 0;
+    } else if (!strcmp(key, "cu_reserve")) {
+        // The handle's stream leaves `value` compute units alone (a CU mask on its queue): launches of other streams
+        // -- the filter's chain of short dependent kernels -- find room at once while a flow series fills the rest.
+        HM_ARG(value >= 0 && value < h->cus, "hm_brox_tune: cu_reserve must be in 0..%d", h->cus - 1);
+        HM_HIP(hipSetDevice(h->device));
+        HM_HIP(hipStreamSynchronize(h->stream));
+        hipStream_t ns = nullptr;
+        if (value == 0) {
+            HM_HIP(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+        } else {
+            const int words = (h->cus + 31) / 32;
+            std::vector<uint32_t> mask(words, 0u);
+            for (int i = 0; i < h->cus - value; i++) mask[i / 32] |= 1u << (i % 32);
+            HM_HIP(hipExtStreamCreateWithCUMask(&ns, (uint32_t)words, mask.data()));
+        }
+        HM_HIP(hipStreamDestroy(h->stream));
+        h->stream = ns;
     } else if (!strcmp(key, "sor_deep")) {
         HM_ARG(value >= 0 && value <= 8, "hm_brox_tune: sor_deep must be 0 .. 8");
         h->sor_deep = value;
+    } else if (!strcmp(key, "coarse_stagger")) {     // tests only: results must not depend on it
+        h->coarse_stagger = value != 0;
     } else if (!strcmp(key, "coarse_max")) {
         HM_ARG(value == 0 || value == 32 || value == 64, "hm_brox_tune: coarse_max must be 0, 32 or 64");
         h->coarse_max = value;
@@ -443,6 +463,8 @@ static int brox_run(hm_brox *h, int n, const uint8_t *d_f0, const uint8_t *d_f1,
             ca.I1[hi - k] = h->pyr1[k];
         }
         ca.u_in = u; ca.v_in = v;
+        ca.scratch_plane = h->geo[lo].plane;            // the finest level of the launch
+        ca.stagger = h->coarse_stagger;
         ca.Ix0 = h->Ix0; ca.Iy0 = h->Iy0; ca.I1x = h->I1x; ca.I1y = h->I1y; ca.I1xx = h->I1xx; ca.I1xy = h->I1xy; ca.I1yy = h->I1yy;
         if (lo > 0) {
             ca.gout = h->geo[lo - 1];

@@ -732,7 +732,9 @@ struct CoarseArgs {
     Geo g[COARSE_MAX];
     const float *I0[COARSE_MAX], *I1[COARSE_MAX];
     const float *u_in, *v_in;                   // u, v of g[0] (pitched planes)
-    float *Ix0, *Iy0, *I1x, *I1y, *I1xx, *I1xy, *I1yy;      // scratch planes
+    float *Ix0, *Iy0, *I1x, *I1y, *I1xx, *I1xy, *I1yy;      // scratch planes,
+    int scratch_plane;                                        // ... floats per pair in them (>= every g[].plane)
+    int stagger;                                // tests: pairs 8.. wait ~0.3 ms between writing and reading their scratch
     Geo gout;                                   // the next finer level; w == 0: g[nlev - 1] is the image itself
     float *u_out, *v_out;                       // pitched planes of gout, or the caller's tight W x H arrays
     int inner, solver;
@@ -812,6 +814,11 @@ __global__ __launch_bounds__(T * T / 4) void k_coarse(CoarseArgs a)
         const Geo g = a.g[lv];
         const int w = g.w, h = g.h, pitch = g.pitch;
         const size_t off = (size_t)z * g.plane;
+        // The derivative planes are this workgroup's own scratch: one fixed slab per pair.  (The per-level offset
+        // z * plane that the launch-per-operator path uses -- every pair at the same level at any time -- would let
+        // the slab of pair z at one level overlap that of pair z + 1 at the next while the two workgroups are at
+        // different levels.)
+        const size_t offs = (size_t)z * a.scratch_plane;
         const float *I0 = a.I0[lv] + off, *I1 = a.I1[lv] + off;
         // derivative images (k_deriv_all), pixel by pixel: nothing of this phase stays in registers
 #pragma unroll 1
@@ -819,7 +826,7 @@ __global__ __launch_bounds__(T * T / 4) void k_coarse(CoarseArgs a)
             const int x = xa + (pp & 1), y = ya + (pp >> 1);
             s_uv[d_cb<T>(x, y)] = make_float2(0.0f, 0.0f);          // du = dv = 0 at the start of a level
             if (x >= w || y >= h) continue;
-            const size_t p = off + y * pitch + x;
+            const size_t p = offs + y * pitch + x;
             a.Ix0[p] = d_dx_at(I0, g, x, y);
             a.Iy0[p] = d_dy_at(I0, g, x, y);
             a.I1x[p] = d_dx_at(I1, g, x, y);
@@ -831,6 +838,11 @@ __global__ __launch_bounds__(T * T / 4) void k_coarse(CoarseArgs a)
             a.I1yy[p] = d_d5(d_dy_at(I1, g, x, ym2), d_dy_at(I1, g, x, ym1), d_dy_at(I1, g, x, yp1), d_dy_at(I1, g, x, yp2));
         }
         __syncthreads();                 // the derivative images are this workgroup's own writes: visible after the barrier
+        if (a.stagger && z >= 8) {       // tests: pairs 8.. linger here while pairs 0..7 run levels ahead, then
+            for (int k = 0; k < 96; k++) __builtin_amdgcn_s_sleep(127);
+            asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");   // ... read what memory holds, not their L1
+            __syncthreads();
+        }
         // warp (k_warp): the data terms of the own pixels, kept in registers for the level
         float Iz[RPT][2], Ix[RPT][2], Iy[RPT][2], Ixz[RPT][2], Iyz[RPT][2], Ixx[RPT][2], Ixy[RPT][2], Iyy[RPT][2];
 #pragma unroll
@@ -844,18 +856,18 @@ __global__ __launch_bounds__(T * T / 4) void k_coarse(CoarseArgs a)
                 const float px = (float)x + su0[y][x], py = (float)y + sv0[y][x];
                 if (px < 0.0f || py < 0.0f || px > (float)(w - 1) || py > (float)(h - 1)) continue;
                 const float i1 = d_bilin(I1, w, h, pitch, px, py);
-                const float ix = d_bilin(a.I1x + off, w, h, pitch, px, py);
-                const float iy = d_bilin(a.I1y + off, w, h, pitch, px, py);
+                const float ix = d_bilin(a.I1x + offs, w, h, pitch, px, py);
+                const float iy = d_bilin(a.I1y + offs, w, h, pitch, px, py);
                 Iz[j][q] = i1 - I0[y * pitch + x];
                 Ix[j][q] = ix;
                 Iy[j][q] = iy;
                 if (x < 2 || y < 2 || x > w - 3 || y > h - 3 ||
                     px < 2.0f || py < 2.0f || px > (float)(w - 4) || py > (float)(h - 4)) continue;
-                Ixz[j][q] = ix - a.Ix0[off + y * pitch + x];
-                Iyz[j][q] = iy - a.Iy0[off + y * pitch + x];
-                Ixx[j][q] = d_bilin(a.I1xx + off, w, h, pitch, px, py);
-                Ixy[j][q] = d_bilin(a.I1xy + off, w, h, pitch, px, py);
-                Iyy[j][q] = d_bilin(a.I1yy + off, w, h, pitch, px, py);
+                Ixz[j][q] = ix - a.Ix0[offs + y * pitch + x];
+                Iyz[j][q] = iy - a.Iy0[offs + y * pitch + x];
+                Ixx[j][q] = d_bilin(a.I1xx + offs, w, h, pitch, px, py);
+                Ixy[j][q] = d_bilin(a.I1xy + offs, w, h, pitch, px, py);
+                Iyy[j][q] = d_bilin(a.I1yy + offs, w, h, pitch, px, py);
             }
         for (int it = 0; it < a.inner; it++) {
             // u + du, v + dv (k_prepare's staging)

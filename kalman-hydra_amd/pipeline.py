@@ -20,6 +20,8 @@ through files (reference README.md:26-31; ``gen_synthetic.py:41-42`` shells out 
 """
 import threading
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -181,6 +183,8 @@ class FlowEKFPipeline:
         self.d_v = DeviceBuffer(2 * self.B * n * 4, device)
         self.bf = _brox.BroxOpticalFlow(self.W, self.H, max_batch=self.B, device=device, **(brox_params or {}))
         self.bf.tune("sor_threads", sor_threads)        # 0: chosen per series (1024 for one or two pairs, else 512)
+        if os.environ.get("HYDRA_CU_RESERVE"):
+            self.bf.tune("cu_reserve", int(os.environ["HYDRA_CU_RESERVE"]))
         self.t_flow = self.t_ekf = 0.0
         self.iters = 0
         self.profile_from = None         # pair index: the series starting there is profiled (hm_brox_profile)

@@ -215,6 +215,30 @@ def test_coarse_levels_in_one_launch(hm, oracle_brox, w, h, kw, okw):
             assert np.array_equal(U[i], ref[i][0]) and np.array_equal(V[i], ref[i][1]), (cmax, i)
 
 
+def test_coarse_launch_with_pairs_levels_apart(hm, oracle_brox):
+    """The workgroups of a k_coarse launch (one per pair) go through the levels on their own: a pair must not
+    touch what another pair uses at a different level.  With the test knob pairs 8.. wait ~0.3 ms at every level
+    between writing and reading their derivative planes (and drop their L1) while pairs 0..7 run whole levels
+    ahead; workgroups z and z + 8 usually share an XCD, i.e. an L2, so what one writes the other reads.  (Found as
+    an intermittent difference between the pipelined and the sequential frame loop at 1024^2: with the per-level
+    offset z * plane of the launch-per-operator path, the planes of pair 2 at one level overlapped those of pair 10
+    three levels down.)"""
+    from hydra_mi import brox, synth
+    n, B = 64, 12
+    names = ["warp", "rotate", "translate_leftup", "translate_leftup_stretch"]
+    pairs = [synth.warp_pair(n, names[s % 4], s)[:2] for s in range(B)]
+    F0 = np.stack([p[0] for p in pairs]); F1 = np.stack([p[1] for p in pairs])
+    ref = [oracle_brox.calc(F0[i], F1[i]) for i in range(B)]
+    bf = brox.BroxOpticalFlow(n, n, max_batch=B)
+    for cmax in (32, 64):
+        bf.tune("coarse_max", cmax)
+        for stagger in (1, 0):
+            bf.tune("coarse_stagger", stagger)
+            U, V = bf.calc_batch(F0, F1)
+            for i in range(B):
+                assert np.array_equal(U[i], ref[i][0]) and np.array_equal(V[i], ref[i][1]), (cmax, stagger, i)
+
+
 def test_identical_frames_give_zero_flow(hm):
     from hydra_mi import brox, synth
     f0 = synth.warp_pair(64, "warp")[0]
