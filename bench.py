@@ -233,6 +233,8 @@ def main():
     ap.add_argument("--h0", type=float, default=0.047, help="mesh edge length as a fraction of the frame size")
     ap.add_argument("--flow-batch", type=int, default=8, help="consecutive frame pairs per Brox launch series")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cu-reserve", type=int, default=None,
+                    help="compute units the flow stream leaves to the filter (default: the pipeline's)")
     ap.add_argument("--workload", default="video", choices=["video", "flowbatch"],
                     help="video = the headline metric (flow + EKF per frame); flowbatch = BASELINE config 5: "
                          "independent frame pairs sharded over the GPUs, one gather of the flows at the end")
@@ -288,7 +290,8 @@ def main():
             self.video, self.masks, centre, radius = make_video(n, frames, seed=seed)
             self.dm = mesh.disk_mesh(centre[0], centre[1], radius - 1.0, args.h0 * n)
             self.kf = kalman.IteratedMSKalmanFilter(self.dm, self.video[0], np.zeros((n, n, 2), np.float32), True, device=dev)
-            self.pipe = FlowEKFPipeline(self.kf, self.video, self.masks, flow_batch=B, device=dev)
+            extra = {} if args.cu_reserve is None else {"cu_reserve": args.cu_reserve}
+            self.pipe = FlowEKFPipeline(self.kf, self.video, self.masks, flow_batch=B, device=dev, **extra)
             self.bf = self.pipe.bf
             if os.environ.get("HYDRA_MI_BENCH_TRACE"):
                 self.pipe.trace = lambda msg: print(msg, file=sys.stderr)
@@ -313,16 +316,9 @@ def main():
     tracks = [Track(rank * V + i) for i in range(V)]
     for tr in tracks:
         tr.warmup()
-    # series of the timed region: 1 pair, then 2, 4, ... up to B at a time (a series of n pairs takes
-    # about 7.5 + 0.65 (n - 1) ms here, a frame of the filter about 8 ms); one of them is profiled (kernel
-    # start/stop events for every SOR launch): the first full one, or the last if there is no full one
-    starts, k_ = [], Wm
-    while k_ < Wm + K:
-        size = 1 if not starts else min(B, 2 * starts[-1][1], Wm + K - k_)
-        starts.append((k_, size))
-        k_ += size
-    full = [st for st in starts if st[1] == B]
-    tracks[0].pipe.profile_from, prof_pairs = full[0] if full else starts[-1]
+    # the flow series of the timed region start small and grow to B pairs (pipeline.py: sized from what series and
+    # frames have taken so far); the first one of B pairs is profiled (kernel start/stop events for every SOR launch)
+    tracks[0].pipe.profile_full = True
 
     if world > 1:
         dist.barrier()
@@ -354,6 +350,13 @@ def main():
     elapsed = time.perf_counter() - t0
     for tr in tracks:
         tr.flow_sync()
+    prof_pairs, prof_where = tracks[0].pipe.profiled_pairs, "of the timed region"
+    if prof_pairs == 0:                 # a timed region too short for a series of B pairs: one more, after the clock
+        tr = tracks[0]
+        prof_pairs, prof_where = min(B, len(tr.video) - 1), "after the timed region"
+        tr.bf.profile(True)
+        tr.bf.calc_dev(prof_pairs, tr.pipe.d_video.ptr, tr.pipe.d_video.ptr + n * n, tr.pipe.d_u.ptr, tr.pipe.d_v.ptr)
+        tr.bf.sync()
     sor_ms, sor_launches, sor_pxit, sor_px = tracks[0].bf.profile_read()
     kf, video, masks, dm = tracks[0].kf, tracks[0].video, tracks[0].masks, tracks[0].dm
     N = kf.N
@@ -384,7 +387,7 @@ def main():
                                       "iekf_iterations": iters / K},
             "roofline": sor_roofline(sor_ms, sor_launches, sor_pxit, sor_px,
                                      pmc_traffic() if (n == 1024 and prof_pairs == 8) else None,
-                                     "one flow series (%d pairs) of the timed region" % prof_pairs),
+                                     "one flow series (%d pairs) %s" % (prof_pairs, prof_where)),
         }
         out["cpu_baseline"] = None                           # a reported baseline, timed at N = 1 only
         if not args.no_cpu_baseline and world == 1:

@@ -19,6 +19,7 @@ through files (reference README.md:26-31; ``gen_synthetic.py:41-42`` shells out 
 ``.npy`` / ``.npz`` of shape (frames, H, W) or (frames, H, W, 3), 8-bit.
 """
 import threading
+import time
 
 import os
 
@@ -147,7 +148,7 @@ class FlowEKFPipeline:
     """
 
     def __init__(self, kf, video, masks, flow_batch=8, device=0, brox_params=None, sor_threads=0, maskflow=True,
-                 observed=None, return_flow=False):
+                 observed=None, return_flow=False, cu_reserve=32):
         """return_flow: whether step() brings the rendered flow planes of every frame to the host, as
         KalmanFilter.compute does for the reference's callers (8 MB per 1024^2 frame); a frame loop that
         looks at the error sums and the state only (reference run_kalmanfilter.py:78-89 ignores the return
@@ -183,16 +184,19 @@ class FlowEKFPipeline:
         self.d_v = DeviceBuffer(2 * self.B * n * 4, device)
         self.bf = _brox.BroxOpticalFlow(self.W, self.H, max_batch=self.B, device=device, **(brox_params or {}))
         self.bf.tune("sor_threads", sor_threads)        # 0: chosen per series (1024 for one or two pairs, else 512)
-        if os.environ.get("HYDRA_CU_RESERVE"):
-            self.bf.tune("cu_reserve", int(os.environ["HYDRA_CU_RESERVE"]))
+        if cu_reserve:
+            # the flow stream leaves some compute units alone: the filter's short dependent launches find room at once
+            # while a series fills the rest (bench: 250 -> 254 frames/s with 32 of 256 reserved)
+            self.bf.tune("cu_reserve", int(cu_reserve))
         self.t_flow = self.t_ekf = 0.0
         self.iters = 0
-        self.profile_from = None         # pair index: the series starting there is profiled (hm_brox_profile)
+        self.profile_full, self.profiled_pairs = False, 0    # set profile_full: the next series of flow_batch pairs is profiled
         self.trace = None                # callable(str) for per-frame scheduling messages
         # pairs [lo, hi) of `ready` have their flow in buffer `buf`; `pending` is being computed on the flow
         # handle's stream while the filter works on `ready`
         self._ready, self._buf, self._pending, self._thread, self._thread_exc = (0, 0), 0, None, None, None
         self._end = self.F - 1
+        self._first_series = min(2, self.B)         # a phase starts with two pairs: the second one costs a quarter of the first
 
     # -- flow series ---------------------------------------------------------------------------------
     def _launch(self, k, end, buf, most):
@@ -201,11 +205,13 @@ class FlowEKFPipeline:
 
         def work():
             try:
-                if self.profile_from is not None:
-                    if self.profile_from == k:
+                if self.profile_full:                   # hm_brox_profile around the first series of flow_batch pairs
+                    if self.profiled_pairs == 0 and nb == self.B:
                         self.bf.profile(True)
-                    elif k > self.profile_from:
+                        self.profiled_pairs = nb
+                    elif self.profiled_pairs > 0:
                         self.bf.profile(False)          # totals stay readable (hm_brox_profile_read)
+                        self.profile_full = False
                 self.bf.calc_dev(nb, self.d_video.ptr + k * n, self.d_video.ptr + (k + 1) * n,
                                  self.d_u.ptr + buf * B * n * 4, self.d_v.ptr + buf * B * n * 4)
             except Exception as exc:                    # noqa: BLE001 -- re-raised by the thread that waits
@@ -213,6 +219,13 @@ class FlowEKFPipeline:
         self._thread = threading.Thread(target=work)
         self._thread.start()
         return (k, k + nb)
+
+    def _next_series(self, ready):
+        """Pairs of the series computed while the filter works through `ready` frames.  A phase starts with two pairs
+        and grows 2, 3, 5, 8: a series of n 1024^2 pairs takes about 5.3 + 1.45 (n - 1) ms, a frame of the filter
+        about 4 ms, and this ramp is the one with the least waiting for that pair of numbers (1, 2, 4, 8 waits
+        40 % longer); a ramp that is too steep only costs the wait for its larger series, once."""
+        return min(self.B, max(ready + 1, int(1.7 * ready)))
 
     def flow_sync(self):
         if self._thread is not None:
@@ -230,20 +243,20 @@ class FlowEKFPipeline:
         self._ready, self._pending = (first, first), None
 
     def flow_ready(self, k):
-        """Make the flow of pair (k, k+1) available -> (device pointer of u, of v).  Series of 1, 2, 4, ...
-        pairs at the start of a phase (nothing to overlap the first one with), then ``flow_batch``."""
+        """Make the flow of pair (k, k+1) available -> (device pointer of u, of v).  A phase starts with a series of
+        two pairs (nothing to overlap it with) and the following ones grow (_next_series) up to ``flow_batch``."""
         if not (self._ready[0] <= k < self._ready[1]):
             if k != self._ready[1]:
                 self.begin(k, self._end)                 # random access: start over from k
             if self._pending is not None and self._pending[0] == k:
                 self._buf ^= 1
             else:
-                self._pending = self._launch(k, self._end, self._buf, 1)
+                self._pending = self._launch(k, self._end, self._buf, self._first_series)
             self.flow_sync()
             self._ready, self._pending = self._pending, None
             lo, nxt = self._ready
             if nxt < self._end:      # ramp: what the GPU gets done beside the frames just made ready
-                self._pending = self._launch(nxt, self._end, self._buf ^ 1, min(self.B, 2 * (nxt - lo)))
+                self._pending = self._launch(nxt, self._end, self._buf ^ 1, self._next_series(nxt - lo))
         i = k - self._ready[0]
         off = (self._buf * self.B + i) * self._px * 4
         return self.d_u.ptr + off, self.d_v.ptr + off

@@ -159,3 +159,31 @@ def _state_of(X):
     s = _S()
     s.X = np.asarray(X).reshape(-1, 1)
     return s
+
+
+def test_pipeline_equals_sequential_at_full_size(hm):
+    """BASELINE config 4's frame loop (1024^2, 201 vertices): the streaming pipeline -- flow series of 1, 2, 4 pairs
+    computed on the flow handle's stream while the filter works -- gives the bits of one `bf.calc` + `kf.compute`
+    after the other, twice over (a race between the two would not show every time; tools/determinism_check.py is
+    the longer form of this)."""
+    from hydra_mi import kalman, mesh, synth, brox
+    from hydra_mi.pipeline import FlowEKFPipeline
+    n, frames = 1024, 7
+    video, masks, c, r = synth.disk_video(n, frames, "translate_leftup", 0)
+    dm0 = mesh.disk_mesh(c[0], c[1], r - 1.0, 0.047 * n)
+
+    def make():
+        return kalman.IteratedMSKalmanFilter(mesh.Mesh(dm0.p, dm0.t, dm0.h0), video[0], np.zeros((n, n, 2), np.float32), True)
+
+    kf, bf, ref = make(), brox.BroxOpticalFlow(n, n), []
+    for k in range(frames - 1):
+        u, v = bf.calc(video[k], video[k + 1])
+        kf.compute(video[k + 1], np.dstack((u, v)), masks[k + 1])
+        ref.append((kf.state.X.copy(), kf.niter))
+    for rep in range(2):
+        kf, got = make(), []
+        pipe = FlowEKFPipeline(kf, video, masks, flow_batch=8)
+        pipe.run(0, frames - 1, on_frame=lambda k, e: got.append((kf.state.X.copy(), kf.niter)))
+        pipe.close()
+        for k in range(frames - 1):
+            assert got[k][1] == ref[k][1] and np.array_equal(got[k][0], ref[k][0]), (rep, k)
