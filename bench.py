@@ -233,6 +233,7 @@ def main():
     ap.add_argument("--h0", type=float, default=0.047, help="mesh edge length as a fraction of the frame size")
     ap.add_argument("--flow-batch", type=int, default=8, help="consecutive frame pairs per Brox launch series")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-flow-handles", action="store_true", help="two flow series in flight (default: one at a time)")
     ap.add_argument("--cu-reserve", type=int, default=None,
                     help="compute units the flow stream leaves to the filter (default: the pipeline's)")
     ap.add_argument("--workload", default="video", choices=["video", "flowbatch"],
@@ -291,17 +292,21 @@ def main():
             self.dm = mesh.disk_mesh(centre[0], centre[1], radius - 1.0, args.h0 * n)
             self.kf = kalman.IteratedMSKalmanFilter(self.dm, self.video[0], np.zeros((n, n, 2), np.float32), True, device=dev)
             extra = {} if args.cu_reserve is None else {"cu_reserve": args.cu_reserve}
+            if args.two_flow_handles:
+                extra["concurrent_series"] = True
             self.pipe = FlowEKFPipeline(self.kf, self.video, self.masks, flow_batch=B, device=dev, **extra)
             self.bf = self.pipe.bf
             if os.environ.get("HYDRA_MI_BENCH_TRACE"):
                 self.pipe.trace = lambda msg: print(msg, file=sys.stderr)
 
         def warmup(self):
-            self.bf.profile(True)
+            for bf in self.pipe.bfs:
+                bf.profile(True)
             self.pipe.run(0, Wm)
             self.pipe.flow_sync()
-            self.bf.profile_read()
-            self.bf.profile(False)
+            for bf in self.pipe.bfs:
+                bf.profile_read()
+                bf.profile(False)
             self.pipe.t_flow = self.pipe.t_ekf = 0.0
             self.pipe.iters = 0
             self.kf.predtime = self.kf.updatetime = self.kf.projecttime = 0.0
@@ -357,7 +362,7 @@ def main():
         tr.bf.profile(True)
         tr.bf.calc_dev(prof_pairs, tr.pipe.d_video.ptr, tr.pipe.d_video.ptr + n * n, tr.pipe.d_u.ptr, tr.pipe.d_v.ptr)
         tr.bf.sync()
-    sor_ms, sor_launches, sor_pxit, sor_px = tracks[0].bf.profile_read()
+    sor_ms, sor_launches, sor_pxit, sor_px = (tracks[0].pipe.profiled_handle or tracks[0].bf).profile_read()
     kf, video, masks, dm = tracks[0].kf, tracks[0].video, tracks[0].masks, tracks[0].dm
     N = kf.N
     t_flow = sum(tr.pipe.t_flow for tr in tracks) / V

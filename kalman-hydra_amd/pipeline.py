@@ -134,6 +134,14 @@ class DeviceBuffer:
             pass
 
 
+class _Done:
+    """Marks a series in flight that has been waited for already (its thread is gone)."""
+
+    @staticmethod
+    def join():
+        return None
+
+
 class FlowEKFPipeline:
     """Brox flow of the coming frames overlapped with the filter on the current one.
 
@@ -148,7 +156,7 @@ class FlowEKFPipeline:
     """
 
     def __init__(self, kf, video, masks, flow_batch=8, device=0, brox_params=None, sor_threads=0, maskflow=True,
-                 observed=None, return_flow=False, cu_reserve=32):
+                 observed=None, return_flow=False, cu_reserve=32, concurrent_series=False):
         """return_flow: whether step() brings the rendered flow planes of every frame to the host, as
         KalmanFilter.compute does for the reference's callers (8 MB per 1024^2 frame); a frame loop that
         looks at the error sums and the state only (reference run_kalmanfilter.py:78-89 ignores the return
@@ -180,83 +188,105 @@ class FlowEKFPipeline:
         if observed is not None:
             self.d_observed = DeviceBuffer(self.F * n, device)
             self.d_observed.upload(observed)
-        self.d_u = DeviceBuffer(2 * self.B * n * 4, device)          # double-buffered flow planes
-        self.d_v = DeviceBuffer(2 * self.B * n * 4, device)
-        self.bf = _brox.BroxOpticalFlow(self.W, self.H, max_batch=self.B, device=device, **(brox_params or {}))
-        self.bf.tune("sor_threads", sor_threads)        # 0: chosen per series (1024 for one or two pairs, else 512)
-        if cu_reserve:
-            # the flow stream leaves some compute units alone: the filter's short dependent launches find room at once
-            # while a series fills the rest (bench: 250 -> 254 frames/s with 32 of 256 reserved)
-            self.bf.tune("cu_reserve", int(cu_reserve))
+        self.d_u = DeviceBuffer(3 * self.B * n * 4, device)          # flow planes: one buffer in use, two being filled
+        self.d_v = DeviceBuffer(3 * self.B * n * 4, device)
+        # concurrent_series: two flow handles (streams), two series in flight at a time.  Measured at 1024^2 / 201
+        # vertices, 20 frames: 182 frames/s against 214 with one series at a time -- the filter's frames take 5.3 to
+        # 13 ms beside two series (4.2 to 5.6 beside one) and the first pair of a phase is no sooner there (7.4 ms).
+        # Off by default; the results are the same bits either way (tools/determinism_check.py).
+        self.bfs = [_brox.BroxOpticalFlow(self.W, self.H, max_batch=self.B, device=device, **(brox_params or {}))
+                    for _ in range(2 if concurrent_series else 1)]
+        self.bf = self.bfs[0]
+        for bf in self.bfs:
+            bf.tune("sor_threads", sor_threads)         # 0: chosen per series (1024 for one or two pairs, else 512)
+            if cu_reserve:
+                # the flow streams leave some compute units alone: the filter's short dependent launches find room at
+                # once while a series fills the rest (bench: 250 -> 254 frames/s with 32 of 256 reserved)
+                bf.tune("cu_reserve", int(cu_reserve))
         self.t_flow = self.t_ekf = 0.0
         self.iters = 0
         self.profile_full, self.profiled_pairs = False, 0    # set profile_full: the next series of flow_batch pairs is profiled
         self.trace = None                # callable(str) for per-frame scheduling messages
-        # pairs [lo, hi) of `ready` have their flow in buffer `buf`; `pending` is being computed on the flow
-        # handle's stream while the filter works on `ready`
-        self._ready, self._buf, self._pending, self._thread, self._thread_exc = (0, 0), 0, None, None, None
+        # pairs [lo, hi) of `ready` have their flow in buffer `buf`; the series in `_flying` (oldest first; each a dict
+        # lo, hi, buf, handle, thread) are being computed while the filter works on `ready`
+        self._ready, self._buf, self._flying, self._thread_exc = (0, 0), 0, [], None
         self._end = self.F - 1
-        self._first_series = min(2, self.B)         # a phase starts with two pairs: the second one costs a quarter of the first
+        self.profiled_handle = None
 
     # -- flow series ---------------------------------------------------------------------------------
-    def _launch(self, k, end, buf, most):
+    def _launch(self, k, end, most):
+        """Queue the series of pairs k .. k + nb - 1 on a handle and a buffer that are free."""
         nb = min(most, end - k)
         n, B = self._px, self.B
+        busy_h = {f["handle"] for f in self._flying}
+        busy_b = {f["buf"] for f in self._flying} | {self._buf}
+        h = next(i for i in range(len(self.bfs)) if i not in busy_h)
+        buf = next(i for i in range(3) if i not in busy_b)
+        bf = self.bfs[h]
 
         def work():
             try:
-                if self.profile_full:                   # hm_brox_profile around the first series of flow_batch pairs
-                    if self.profiled_pairs == 0 and nb == self.B:
-                        self.bf.profile(True)
-                        self.profiled_pairs = nb
-                    elif self.profiled_pairs > 0:
-                        self.bf.profile(False)          # totals stay readable (hm_brox_profile_read)
-                        self.profile_full = False
-                self.bf.calc_dev(nb, self.d_video.ptr + k * n, self.d_video.ptr + (k + 1) * n,
-                                 self.d_u.ptr + buf * B * n * 4, self.d_v.ptr + buf * B * n * 4)
+                if self.profile_full and self.profiled_pairs == 0 and nb == self.B:
+                    bf.profile(True)                    # hm_brox_profile around the first series of flow_batch pairs
+                    self.profiled_pairs, self.profiled_handle, self.profile_full = nb, bf, False
+                elif bf is self.profiled_handle:
+                    bf.profile(False)                   # totals stay readable (hm_brox_profile_read)
+                bf.calc_dev(nb, self.d_video.ptr + k * n, self.d_video.ptr + (k + 1) * n,
+                            self.d_u.ptr + buf * B * n * 4, self.d_v.ptr + buf * B * n * 4)
             except Exception as exc:                    # noqa: BLE001 -- re-raised by the thread that waits
                 self._thread_exc = exc
-        self._thread = threading.Thread(target=work)
-        self._thread.start()
-        return (k, k + nb)
+        t = threading.Thread(target=work)
+        t.start()
+        self._flying.append({"lo": k, "hi": k + nb, "buf": buf, "handle": h, "thread": t})
 
-    def _next_series(self, ready):
-        """Pairs of the series computed while the filter works through `ready` frames.  A phase starts with two pairs
-        and grows 2, 3, 5, 8: a series of n 1024^2 pairs takes about 5.3 + 1.45 (n - 1) ms, a frame of the filter
-        about 4 ms, and this ramp is the one with the least waiting for that pair of numbers (1, 2, 4, 8 waits
-        40 % longer); a ramp that is too steep only costs the wait for its larger series, once."""
-        return min(self.B, max(ready + 1, int(1.7 * ready)))
+    def _next_series(self, last):
+        """Pairs of the series that follows one of `last` pairs.  A phase starts with two pairs and grows 2, 3, 5, 8: a
+        series of n 1024^2 pairs takes about 5.3 + 1.45 (n - 1) ms, a frame of the filter about 4 ms, and this ramp
+        is the one with the least waiting for that pair of numbers (1, 2, 4, 8 waits 40 % longer); a ramp that is too
+        steep only costs the wait for its larger series, once.  (With two handles: 1, 2, 3, 5, 8.)"""
+        return min(self.B, max(last + 1, int(1.7 * last)))
 
-    def flow_sync(self):
-        if self._thread is not None:
-            self._thread.join()
-            self._thread = None
+    def _wait(self, f):
+        f["thread"].join()
         if self._thread_exc is not None:
             exc, self._thread_exc = self._thread_exc, None
             raise exc
-        self.bf.sync()
+        self.bfs[f["handle"]].sync()
+
+    def flow_sync(self):
+        """Wait for every series in flight (their results stay where they are)."""
+        for f in self._flying:
+            self._wait(f)
+            f["thread"] = _Done
 
     def begin(self, first=0, end=None):
         """Start a phase: the pairs first .. end-1 will be asked for in order."""
         self.flow_sync()
+        self._flying = []
         self._end = self.F - 1 if end is None else min(int(end), self.F - 1)
-        self._ready, self._pending = (first, first), None
+        self._ready = (first, first)
+
+    def _top_up(self):
+        """Keep as many series in flight as there are handles."""
+        while len(self._flying) < len(self.bfs):
+            last = self._flying[-1] if self._flying else None
+            nxt = last["hi"] if last else self._ready[1]
+            if nxt >= self._end:
+                return
+            size = (last["hi"] - last["lo"]) if last else (self._ready[1] - self._ready[0])
+            self._launch(nxt, self._end, self._next_series(size) if size else (1 if len(self.bfs) > 1 else min(2, self.B)))
 
     def flow_ready(self, k):
-        """Make the flow of pair (k, k+1) available -> (device pointer of u, of v).  A phase starts with a series of
-        two pairs (nothing to overlap it with) and the following ones grow (_next_series) up to ``flow_batch``."""
+        """Make the flow of pair (k, k+1) available -> (device pointer of u, of v)."""
         if not (self._ready[0] <= k < self._ready[1]):
-            if k != self._ready[1]:
+            if k != self._ready[1] or (self._flying and self._flying[0]["lo"] != k):
                 self.begin(k, self._end)                 # random access: start over from k
-            if self._pending is not None and self._pending[0] == k:
-                self._buf ^= 1
-            else:
-                self._pending = self._launch(k, self._end, self._buf, self._first_series)
-            self.flow_sync()
-            self._ready, self._pending = self._pending, None
-            lo, nxt = self._ready
-            if nxt < self._end:      # ramp: what the GPU gets done beside the frames just made ready
-                self._pending = self._launch(nxt, self._end, self._buf ^ 1, self._next_series(nxt - lo))
+            self._top_up()
+            f = self._flying.pop(0)
+            if f["thread"] is not _Done:
+                self._wait(f)
+            self._ready, self._buf = (f["lo"], f["hi"]), f["buf"]
+            self._top_up()
         i = k - self._ready[0]
         off = (self._buf * self.B + i) * self._px * 4
         return self.d_u.ptr + off, self.d_v.ptr + off
@@ -287,8 +317,9 @@ class FlowEKFPipeline:
         self.t_ekf += t2 - t1
         self.iters += getattr(self.kf, "niter", 1)
         if self.trace:
-            self.trace("step %d: flow wait %.2f ms, filter %.2f ms (%d iterations), series ready %s pending %s"
-                       % (k, 1e3 * (t1 - t0), 1e3 * (t2 - t1), getattr(self.kf, "niter", 1), self._ready, self._pending))
+            self.trace("step %d: flow wait %.2f ms, filter %.2f ms (%d iterations), series ready %s in flight %s"
+                       % (k, 1e3 * (t1 - t0), 1e3 * (t2 - t1), getattr(self.kf, "niter", 1), self._ready,
+                          [(f["lo"], f["hi"]) for f in self._flying]))
         return e
 
     def run(self, first=0, end=None, on_frame=None):
@@ -306,4 +337,5 @@ class FlowEKFPipeline:
         finally:
             for b in (self.d_video, self.d_observed, self.d_masks, self.d_u, self.d_v):
                 b.close()
-            self.bf.close()
+            for bf in self.bfs:
+                bf.close()
