@@ -257,6 +257,15 @@ int hm_cov_fetch(hm_ctx_t h, double *W_out);
  * bars: I*2 vertex ids (distmesh.bars), l0: rest lengths; X: 4N doubles, advanced in place. */
 int hm_ms_newton(int n_vertices, int n_bars, const int32_t *bars, const double *l0, double kappa, double M,
                  double dt, int maxiter, double tol, double *X, int *newton_iterations);
+/* The same, started ahead of time on a host thread: the state a frame ends with is the one the next frame's
+ * prediction starts from (kalman.py:850-863 run at the top of the next compute()).  create: one persistent
+ * thread; start: copies its arguments and returns; finish: waits, X (4N) receives the advanced state.  One job at
+ * a time per worker. */
+int hm_ms_worker_create(void **worker);
+int hm_ms_worker_destroy(void *worker);
+int hm_ms_newton_start(void *worker, int n_vertices, int n_bars, const int32_t *bars, const double *l0, double kappa,
+                       double M, double dt, int maxiter, double tol, const double *X);
+int hm_ms_newton_finish(void *worker, double *X, int *newton_iterations);
 /* Covariance prediction W' = F W F^T + Weps (kalman.py:717 and :863) on the device, with
  * F = [[I, a I], [s dfdy, I]], dfdy given as one symmetric 2x2 block (Bxx, Bxy, Byy) per spring
  * (kalman.py:865-902; n_bars = 0: the constant-velocity model), Weps = eps_F [[I/4, I/2], [I/2, I]]

@@ -81,6 +81,11 @@ SIGNATURES = {
                                       ctypes.c_double, c_vp]),
     "hm_ms_newton": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp, c_vp, ctypes.c_double, ctypes.c_double,
                                     ctypes.c_double, ctypes.c_int, ctypes.c_double, c_vp, ctypes.POINTER(ctypes.c_int)]),
+    "hm_ms_worker_create": (ctypes.c_int, [ctypes.POINTER(c_vp)]),
+    "hm_ms_worker_destroy": (ctypes.c_int, [c_vp]),
+    "hm_ms_newton_start": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_vp, ctypes.c_double, ctypes.c_double,
+                                          ctypes.c_double, ctypes.c_int, ctypes.c_double, c_vp]),
+    "hm_ms_newton_finish": (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(ctypes.c_int)]),
     "hm_ms_predict": (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                      ctypes.c_int, ctypes.c_double, ctypes.c_double, c_vp, ctypes.POINTER(ctypes.c_int),
                                      ctypes.c_int]),

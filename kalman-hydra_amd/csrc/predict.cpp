@@ -12,6 +12,10 @@
 // about ten products.
 #include "hm_common.h"
 #include <cmath>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -121,5 +125,98 @@ extern "C" int hm_ms_newton(int N, int I, const int32_t *bars, const double *l0,
         }
     }
     if (newton_iterations) *newton_iterations = total;
+    return HM_OK;
+}
+
+
+// ---- the same prediction started ahead of time --------------------------------------------------------------
+// The state a frame ends with is the state the next frame's prediction starts from, and it is known on the host
+// the moment the update's last iteration has reported: hm_ms_newton for the NEXT frame can run on a host thread
+// while the device finishes the covariance of this one and the caller does its bookkeeping between frames.  One
+// persistent thread per worker object (posting a job costs a few microseconds; creating a thread per frame ~60).
+namespace {
+struct NewtonWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    bool quit = false, posted = false, busy = false;
+    // the job
+    int N = 0, I = 0, maxiter = 0, its = 0, rc = HM_OK;
+    double kappa = 0, M = 0, dt = 0, tol = 0;
+    std::vector<int32_t> bars;
+    std::vector<double> l0, X;
+    char err[512] = "";
+
+    void run()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return quit || posted; });
+            if (quit) return;
+            posted = false;
+            lk.unlock();
+            const int r = hm_ms_newton(N, I, bars.data(), l0.data(), kappa, M, dt, maxiter, tol, X.data(), &its);
+            if (r != HM_OK) snprintf(err, sizeof err, "%s", hm_last_error());
+            lk.lock();
+            rc = r;
+            busy = false;
+            cv.notify_all();
+        }
+    }
+};
+}  // namespace
+
+extern "C" int hm_ms_worker_create(void **out)
+{
+    HM_ARG(out != nullptr, "hm_ms_worker_create: out is NULL");
+    NewtonWorker *w = new NewtonWorker();
+    w->th = std::thread([w] { w->run(); });
+    *out = w;
+    return HM_OK;
+}
+
+extern "C" int hm_ms_worker_destroy(void *worker)
+{
+    NewtonWorker *w = (NewtonWorker *)worker;
+    if (!w) return HM_OK;
+    {
+        std::unique_lock<std::mutex> lk(w->m);
+        w->cv.wait(lk, [&] { return !w->busy; });
+        w->quit = true;
+        w->cv.notify_all();
+    }
+    w->th.join();
+    delete w;
+    return HM_OK;
+}
+
+extern "C" int hm_ms_newton_start(void *worker, int N, int I, const int32_t *bars, const double *l0, double kappa, double M,
+                                  double dt, int maxiter, double tol, const double *X)
+{
+    NewtonWorker *w = (NewtonWorker *)worker;
+    HM_ARG(w && N >= 1 && I >= 0 && bars && l0 && X, "hm_ms_newton_start: bad argument");
+    std::unique_lock<std::mutex> lk(w->m);
+    if (w->busy) { hm_set_error("hm_ms_newton_start: the worker has a job whose result was not fetched"); return HM_ERR_STATE; }
+    w->N = N; w->I = I; w->kappa = kappa; w->M = M; w->dt = dt; w->maxiter = maxiter; w->tol = tol;
+    w->bars.assign(bars, bars + 2 * (size_t)I);
+    w->l0.assign(l0, l0 + I);
+    w->X.assign(X, X + 4 * (size_t)N);
+    w->busy = true;
+    w->posted = true;
+    w->cv.notify_all();
+    return HM_OK;
+}
+
+// waits for the job; X (4N) receives the advanced state.  HM_ERR_STATE: nothing was started.
+extern "C" int hm_ms_newton_finish(void *worker, double *X, int *newton_iterations)
+{
+    NewtonWorker *w = (NewtonWorker *)worker;
+    HM_ARG(w && X, "hm_ms_newton_finish: bad argument");
+    std::unique_lock<std::mutex> lk(w->m);
+    if (w->X.empty()) { hm_set_error("hm_ms_newton_finish: no job was started"); return HM_ERR_STATE; }
+    w->cv.wait(lk, [&] { return !w->busy && !w->posted; });
+    if (w->rc != HM_OK) { hm_set_error("%s", w->err); return w->rc; }
+    memcpy(X, w->X.data(), w->X.size() * sizeof(double));
+    if (newton_iterations) *newton_iterations = w->its;
     return HM_OK;
 }

@@ -486,6 +486,7 @@ class KalmanFilter:
                 self.projectmask(y_m)
                 t2 = time.time()
                 self.update(y_im, y_flow_mask, y_m)
+                self._after_update()
                 t3 = time.time()
             self.predtime += t1 - t0
             self.projecttime += t2 - t1
@@ -496,6 +497,10 @@ class KalmanFilter:
             return self.error(y_im, y_flow, y_m, want_flow=self.return_flow)
         finally:
             r.frame_in_place = False
+
+    def _after_update(self):
+        """Hook for work that only needs the state the update ended with (the mass-spring filter starts the next
+        frame's state prediction here)."""
 
     def predict(self):
         """Constant-velocity prediction (:703-718): X <- F X, W <- F W F^T + Weps, F = [[I, I], [0, I]]."""
@@ -708,6 +713,10 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
         # on one CU and ~0.8 us on a host core.  False: hm_cov_predict, hm_update_prefactor (the covariance half
         # of the update queued from a helper thread) and hm_ms_newton on the host, side by side.
         self.device_predict = False
+        # True: the next frame's state prediction (hm_ms_newton, 0.42 ms of host time at 201 vertices) starts on a
+        # worker thread as soon as the update has its final state, instead of at the top of the next compute()
+        self.predict_ahead = True
+        self._worker, self._ahead = None, None
 
     def _jacobian(self):
         """d f / d y of the spring force at the current vertices (:865-902), sparse.
@@ -797,11 +806,64 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
         self.pred_x = st.X.copy()
         stats.statepredtime[0] += time.time() - t0
 
+    def _after_update(self):
+        """The state the update ended with is what the next frame's _newton starts from: start it now, on the
+        worker thread (hm_ms_newton_start), beside the end of this frame on the device and the caller's work
+        between frames.  predict() takes the result if the state is still the one it was started from."""
+        if not self.predict_ahead:
+            return
+        if self._worker is None:
+            w = ctypes.c_void_p()
+            _lib.check(_lib.lib().hm_ms_worker_create(ctypes.byref(w)), "hm_ms_worker_create")
+            self._worker = w
+        st = self.state
+        X = np.ascontiguousarray(st.X.reshape(-1), np.float64).copy()
+        bars = np.ascontiguousarray(self._bars, np.int32)
+        l0 = np.ascontiguousarray(st.l0[:, 0], np.float64)
+        _lib.check(_lib.lib().hm_ms_newton_start(self._worker, int(st.N), int(bars.shape[0]), _lib.ptr(bars), _lib.ptr(l0),
+                                                 float(self.kappa), float(self.M), float(self.deltat), int(self.maxiter),
+                                                 float(self.tol), _lib.ptr(X)), "hm_ms_newton_start")
+        self._ahead = (X, bars.copy(), l0.copy(), (float(self.kappa), float(self.M), float(self.deltat), int(self.maxiter),
+                                                   float(self.tol)))
+
+    def _take_ahead(self):
+        """The prediction started by _after_update, if its inputs are what _newton would use now; else None (its
+        result is waited for and dropped)."""
+        if self._ahead is None:
+            return None
+        X0, bars0, l00, par0 = self._ahead
+        self._ahead = None
+        st = self.state
+        out = np.empty_like(X0)
+        its = ctypes.c_int()
+        _lib.check(_lib.lib().hm_ms_newton_finish(self._worker, _lib.ptr(out), ctypes.byref(its)), "hm_ms_newton_finish")
+        same = (np.array_equal(X0, np.asarray(st.X, np.float64).reshape(-1)) and np.array_equal(bars0, self._bars)
+                and np.array_equal(l00, st.l0[:, 0])
+                and par0 == (float(self.kappa), float(self.M), float(self.deltat), int(self.maxiter), float(self.tol)))
+        return (out, its.value) if same else None
+
+    def close(self):
+        if getattr(self, "_worker", None) is not None:
+            _lib.lib().hm_ms_worker_destroy(self._worker)
+            self._worker = None
+            self._ahead = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:               # noqa: BLE001 -- interpreter shutdown
+            pass
+
     def _newton(self):
         """20 implicit-Euler sub-steps, each solved by Newton's method (:923-960) -- native host
         code in libhydra_mi.so (csrc/predict.cpp: block-eliminated 2N x 2N system, spring operator
         applied bar by bar, conjugate gradients)."""
         st = self.state
+        ahead = self._take_ahead()
+        if ahead is not None:
+            self.newton_iterations = ahead[1]
+            st.X = ahead[0].reshape(-1, 1)
+            return
         X = np.ascontiguousarray(st.X.reshape(-1), np.float64).copy()
         bars = np.ascontiguousarray(self._bars, np.int32)
         l0 = np.ascontiguousarray(st.l0[:, 0], np.float64)

@@ -233,6 +233,30 @@ def test_track_config1_matches_golden(hm):
         assert e[0] == int(g["err"][k][0]) and e[3] == int(g["err"][k][3])
 
 
+def test_prediction_started_ahead_changes_nothing(hm):
+    """IteratedMSKalmanFilter.predict_ahead (the next frame's hm_ms_newton on a worker thread from the end of the
+    update on): the same states, bit for bit, with it and without; a state touched between frames is noticed and
+    predicted again from what it is."""
+    from hydra_mi import mesh, synth, kalman
+    video, flow = synth.test_data(128, 128)
+    g = np.load(os.path.join(GOLD, "config1_track.npz"))
+    tracks = {}
+    for ahead in (True, False):
+        kf = kalman.IteratedMSKalmanFilter(mesh.Mesh(g["p"], g["t"], 15.0), video[:, :, 0], flow[:, :, :, 0], True)
+        kf.predict_ahead = ahead
+        out = []
+        for k in range(5):
+            frame = video[:, :, k]
+            if k == 3:
+                kf.state.X[0, 0] += 0.25                 # the caller moves a vertex between frames
+            kf.compute(frame, flow[:, :, :, k], (frame > 0).astype(np.uint8))
+            out.append((kf.state.X.copy(), kf.niter, kf.newton_iterations))
+        tracks[ahead] = out
+        kf.close()
+    for a, b in zip(tracks[True], tracks[False]):
+        assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
+
+
 def test_state_errors_are_loud(hm):
     from hydra_mi import mesh, renderer
     dm = mesh.square4_mesh(10, 30)

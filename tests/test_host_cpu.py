@@ -450,3 +450,34 @@ def test_sharded_batch_two_ranks_gloo(hm):
         p.join(timeout=60)
     assert res[0][1] and res[1][1]
     assert res[0][2] == [0, 1, 2, 3] and res[1][2] == [4, 5, 6]
+
+
+def test_newton_worker_equals_synchronous_call(hm):
+    """hm_ms_newton_start / _finish (the next frame's state prediction on a host thread, include/hydra_mi.h) give
+    the numbers and the iteration count of hm_ms_newton; a worker takes one job at a time and can be reused."""
+    import ctypes
+    from hydra_mi import _lib, mesh
+    dm = mesh.disk_mesh(64, 64, 50, 12.0)
+    N = dm.size()
+    bars = np.ascontiguousarray(dm.bars, np.int32)
+    l0 = np.linalg.norm(dm.p[bars[:, 0]] - dm.p[bars[:, 1]], axis=1)
+    rng = np.random.default_rng(0)
+    X0 = np.concatenate((dm.p.reshape(-1) + rng.normal(0, .3, 2 * N), rng.normal(0, .3, 2 * N)))
+    L = _lib.lib()
+    args = (N, len(bars), _lib.ptr(bars), _lib.ptr(l0), -1.0, 1.0, 0.05, 1000, 1e-4)
+    X, its = X0.copy(), ctypes.c_int()
+    _lib.check(L.hm_ms_newton(*args, _lib.ptr(X), ctypes.byref(its)), "hm_ms_newton")
+    assert its.value >= 20 and not np.array_equal(X, X0)
+    w = ctypes.c_void_p()
+    _lib.check(L.hm_ms_worker_create(ctypes.byref(w)), "create")
+    try:
+        Y, its2 = np.empty_like(X0), ctypes.c_int()
+        assert L.hm_ms_newton_finish(w, _lib.ptr(Y), ctypes.byref(its2)) != 0          # nothing started yet
+        for rep in range(3):
+            _lib.check(L.hm_ms_newton_start(w, *args, _lib.ptr(X0)), "start")
+            if rep == 0:
+                assert L.hm_ms_newton_start(w, *args, _lib.ptr(X0)) != 0              # one job at a time
+            _lib.check(L.hm_ms_newton_finish(w, _lib.ptr(Y), ctypes.byref(its2)), "finish")
+            assert np.array_equal(X, Y) and its.value == its2.value
+    finally:
+        L.hm_ms_worker_destroy(w)
