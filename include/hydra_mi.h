@@ -266,6 +266,10 @@ int hm_ms_worker_destroy(void *worker);
 int hm_ms_newton_start(void *worker, int n_vertices, int n_bars, const int32_t *bars, const double *l0, double kappa,
                        double M, double dt, int maxiter, double tol, const double *X);
 int hm_ms_newton_finish(void *worker, double *X, int *newton_iterations);
+/* one-shot: the next hm_update_run on h calls hm_ms_newton_start(worker, ..., X) with the state it ends with as soon
+ * as that state is known -- before the covariance of the kept iterate is formed and fetched */
+int hm_update_arm_newton(hm_ctx_t h, void *worker, int n_bars, const int32_t *bars, const double *l0, double kappa,
+                         double M, double dt, int maxiter, double tol);
 /* Covariance prediction W' = F W F^T + Weps (kalman.py:717 and :863) on the device, with
  * F = [[I, a I], [s dfdy, I]], dfdy given as one symmetric 2x2 block (Bxx, Bxy, Byy) per spring
  * (kalman.py:865-902; n_bars = 0: the constant-velocity model), Weps = eps_F [[I/4, I/2], [I/2, I]]

@@ -65,6 +65,13 @@ struct hm_ctx {
     int red_blocks;
     long long run_ticket;            // sequence number of hm_update_run's per-iteration result blocks
     int vsplit, esplit;              // workgroups per vertex / per edge job of the measurement (hm_ctx_tune)
+    // hm_update_arm_newton: what the next hm_update_run starts when its state is final
+    bool pn_armed = false;
+    void *pn_worker = nullptr;
+    std::vector<int32_t> pn_bars;
+    std::vector<double> pn_l0;
+    double pn_par[4] = {0, 0, 0, 0};
+    int pn_maxiter = 0;
     std::thread worker;              // hm_update_prefactor queues its launches from here while the caller predicts the state
     bool worker_active;
     int worker_rc;
@@ -1027,6 +1034,19 @@ extern "C" int hm_cov_fetch(hm_ctx_t h, double *W_out)
 // that is kept.  Per iteration the host sees one small result block (step, the four error sums)
 // that the last kernel writes into pinned memory; the iterate itself never leaves the device, and
 // the render that gave an iterate's error is the reference render of the next measurement.
+extern "C" int hm_update_arm_newton(hm_ctx_t h, void *worker, int n_bars, const int32_t *bars, const double *l0, double kappa,
+                                    double M, double dt, int maxiter, double tol)
+{
+    HM_ARG(h && worker && n_bars >= 0 && bars && l0, "hm_update_arm_newton: bad argument");
+    h->pn_worker = worker;
+    h->pn_bars.assign(bars, bars + 2 * (size_t)n_bars);
+    h->pn_l0.assign(l0, l0 + n_bars);
+    h->pn_par[0] = kappa; h->pn_par[1] = M; h->pn_par[2] = dt; h->pn_par[3] = tol;
+    h->pn_maxiter = maxiter;
+    h->pn_armed = true;
+    return HM_OK;
+}
+
 extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, double deltaX, int masked, int max_iter,
                              double reltol, int info[4], double *errs, double *Hzc, double *gains, double *W_out)
 {
@@ -1131,6 +1151,14 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
         std::swap(h->d_X, h->d_Xn);
         ref_ready = true;
         h->X0 = Xcur;
+    }
+    // the state is final: a caller that armed it gets the next frame's state prediction started now, on its worker
+    // thread, beside the covariance launches below (hm_update_arm_newton)
+    if (h->pn_armed) {
+        h->pn_armed = false;
+        rc = hm_ms_newton_start(h->pn_worker, N, (int)h->pn_l0.size(), h->pn_bars.data(), h->pn_l0.data(), h->pn_par[0],
+                                h->pn_par[1], h->pn_par[2], h->pn_maxiter, h->pn_par[3], Xcur.data());
+        if (rc) return rc;
     }
     // covariance of the state that is kept (kalman.py:806-811, 826)
     int which = -1;                                // -1: the prior

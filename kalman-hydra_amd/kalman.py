@@ -716,7 +716,7 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
         # True: the next frame's state prediction (hm_ms_newton, 0.42 ms of host time at 201 vertices) starts on a
         # worker thread as soon as the update has its final state, instead of at the top of the next compute()
         self.predict_ahead = True
-        self._worker, self._ahead = None, None
+        self._worker, self._ahead, self._armed = None, None, None
 
     def _jacobian(self):
         """d f / d y of the spring force at the current vertices (:865-902), sparse.
@@ -806,25 +806,53 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
         self.pred_x = st.X.copy()
         stats.statepredtime[0] += time.time() - t0
 
-    def _after_update(self):
-        """The state the update ended with is what the next frame's _newton starts from: start it now, on the
-        worker thread (hm_ms_newton_start), beside the end of this frame on the device and the caller's work
-        between frames.  predict() takes the result if the state is still the one it was started from."""
-        if not self.predict_ahead:
-            return
+    def _ahead_inputs(self):
+        st = self.state
+        return (np.ascontiguousarray(self._bars, np.int32).copy(), np.ascontiguousarray(st.l0[:, 0], np.float64).copy(),
+                (float(self.kappa), float(self.M), float(self.deltat), int(self.maxiter), float(self.tol)))
+
+    def _get_worker(self):
         if self._worker is None:
             w = ctypes.c_void_p()
             _lib.check(_lib.lib().hm_ms_worker_create(ctypes.byref(w)), "hm_ms_worker_create")
             self._worker = w
+        return self._worker
+
+    def _update_fused(self, y_im, y_flow, y_m):
+        """hm_update_run, armed (hm_update_arm_newton) to start the next frame's state prediction on the worker thread
+        the moment the state it ends with is known -- before the covariance of that state is formed and fetched."""
+        r = self.state.renderer
+        if self.predict_ahead and hasattr(r, "arm_newton"):
+            bars, l0, par = self._ahead_inputs()
+            r.arm_newton(self._get_worker(), bars, l0, *par)
+            self._armed = (bars, l0, par)
+        try:
+            IteratedKalmanFilter._update_fused(self, y_im, y_flow, y_m)
+        except Exception:
+            if self._armed is not None:          # whether the job was started is not known: wait for it if it was
+                self._armed = None
+                tmp = np.empty(4 * self.state.N)
+                _lib.lib().hm_ms_newton_finish(self._worker, _lib.ptr(tmp), None)
+            raise
+
+    def _after_update(self):
+        """The state the update ended with is what the next frame's _newton starts from: it runs on the worker thread
+        (started by hm_update_run itself when armed, else here by hm_ms_newton_start) beside the end of this frame
+        on the device and the caller's work between frames.  predict() takes the result if the state is still the
+        one it was started from."""
+        if not self.predict_ahead:
+            return
         st = self.state
         X = np.ascontiguousarray(st.X.reshape(-1), np.float64).copy()
-        bars = np.ascontiguousarray(self._bars, np.int32)
-        l0 = np.ascontiguousarray(st.l0[:, 0], np.float64)
-        _lib.check(_lib.lib().hm_ms_newton_start(self._worker, int(st.N), int(bars.shape[0]), _lib.ptr(bars), _lib.ptr(l0),
-                                                 float(self.kappa), float(self.M), float(self.deltat), int(self.maxiter),
-                                                 float(self.tol), _lib.ptr(X)), "hm_ms_newton_start")
-        self._ahead = (X, bars.copy(), l0.copy(), (float(self.kappa), float(self.M), float(self.deltat), int(self.maxiter),
-                                                   float(self.tol)))
+        if self._armed is not None:
+            bars, l0, par = self._armed
+            self._armed = None
+        else:
+            bars, l0, par = self._ahead_inputs()
+            _lib.check(_lib.lib().hm_ms_newton_start(self._get_worker(), int(st.N), int(bars.shape[0]), _lib.ptr(bars),
+                                                     _lib.ptr(l0), par[0], par[1], par[2], par[3], par[4], _lib.ptr(X)),
+                       "hm_ms_newton_start")
+        self._ahead = (X, bars, l0, par)
 
     def _take_ahead(self):
         """The prediction started by _after_update, if its inputs are what _newton would use now; else None (its

@@ -323,6 +323,15 @@ class Renderer:
         out = dict(niter=info[0], accepted=info[1], reverted=bool(info[2]), converged=bool(info[3]))
         return X.reshape(-1, 1), out, errs[:info[0]], Hzc, gains, self._cov_result(fetch)
 
+    def arm_newton(self, worker, bars, l0, kappa, M, dt, maxiter, tol):
+        """hm_update_arm_newton: the next update_run starts hm_ms_newton on `worker` with the state it ends with, as
+        soon as that state is known."""
+        bars = np.ascontiguousarray(bars, np.int32)
+        l0 = np.ascontiguousarray(l0, np.float64)
+        _lib.check(_lib.lib().hm_update_arm_newton(self._h, worker, int(bars.shape[0]), _lib.ptr(bars), _lib.ptr(l0),
+                                                   float(kappa), float(M), float(dt), int(maxiter), float(tol)),
+                   "hm_update_arm_newton")
+
     def update_step(self, state, y_im, y_flow, y_m, deltaX=2.0, want_error=True):
         """hm_update_step: measurement at state.X, the solve and (want_error) Renderer.error of the new
         iterate X0 + step -> (step [4N,1], Hz_components [4N,4], (e_im, e_fx, e_fy, e_m) or None)."""
