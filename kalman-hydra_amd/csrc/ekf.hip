@@ -92,6 +92,7 @@ struct hm_ctx {
     int2 *d_outline;                 // hm_project_mask: outline pixels (W*H), counters, uploaded mask; allocated on first use
     int *d_outline_cnt;
     uint8_t *d_pm_mask;
+    double *d_pm_X = nullptr;        // hm_project_mask's copy of the state (second stream)
 };
 
 static int alloc_targets(Targets &t, size_t n)
@@ -162,7 +163,7 @@ static int ctx_free(hm_ctx *h)
                     h->d_Wtmp, h->d_X0, h->d_Xn, h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk,
                     h->pool.hdr, h->pool.xi, h->pool.yi, h->pool.xfx, h->pool.xfy,
                     h->pool.yfx, h->pool.yfy, h->pool.vxfx, h->pool.vyfy, h->pool.overflow, h->d_area,
-                    h->d_outline, h->d_outline_cnt, h->d_pm_mask, h->d_ids[0], h->d_ids[1], h->d_ids[2], h->d_labels, h->d_lbox,
+                    h->d_outline, h->d_outline_cnt, h->d_pm_mask, h->d_pm_X, h->d_ids[0], h->d_ids[1], h->d_ids[2], h->d_labels, h->d_lbox,
                     h->d_lout, h->d_flowP, h->d_flowctl, h->d_nbars, h->d_nvoff, h->d_nvbar, h->d_ninfo, h->d_nl0, h->d_nX};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -984,33 +985,39 @@ extern "C" int hm_update_cov(hm_ctx_t h, int which, double *W_out)
 extern "C" int hm_project_mask(hm_ctx_t h, const uint8_t *y_m, double *X, int *moved)
 {
     HM_ARG(h && X, "hm_project_mask: NULL argument");
-    HM_JOIN(h);
     if (!y_m) { NEED_OBS(h, "hm_project_mask"); }
     HM_HIP(hipSetDevice(h->device));
+    // On the handle's second stream, with buffers of its own, and without joining the helper thread: the projection
+    // needs the mask and the predicted state only, and in a frame of the filter it comes while the covariance half of
+    // the update (hm_update_prefactor: ~0.25 ms of launches) is still being queued and run on the first stream --
+    // behind those it would have its caller wait for them.
+    if (!h->stream2) HM_HIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    hipStream_t s = h->stream2;
     const size_t n = (size_t)h->W * h->H;
+    const size_t xb = (size_t)4 * h->N * sizeof(double);
     if (!h->d_outline) {
         HM_HIP(hipMalloc((void **)&h->d_outline, n * sizeof(int2)));
         HM_HIP(hipMalloc((void **)&h->d_outline_cnt, 4 * sizeof(int)));
+        HM_HIP(hipMalloc((void **)&h->d_pm_X, xb));
     }
     const uint8_t *mask = h->o_ym;
     if (y_m) {
         if (!h->d_pm_mask) HM_HIP(hipMalloc((void **)&h->d_pm_mask, n));
-        HM_HIP(hipMemcpyAsync(h->d_pm_mask, y_m, n, hipMemcpyHostToDevice, h->stream));
+        HM_HIP(hipMemcpyAsync(h->d_pm_mask, y_m, n, hipMemcpyHostToDevice, s));
         mask = h->d_pm_mask;
     }
-    const size_t xb = (size_t)4 * h->N * sizeof(double);
-    HM_HIP(hipMemsetAsync(h->d_outline_cnt, 0, 4 * sizeof(int), h->stream));
-    HM_HIP(hipMemcpyAsync(h->d_X, X, xb, hipMemcpyHostToDevice, h->stream));
+    HM_HIP(hipMemsetAsync(h->d_outline_cnt, 0, 4 * sizeof(int), s));
+    HM_HIP(hipMemcpyAsync(h->d_pm_X, X, xb, hipMemcpyHostToDevice, s));
     Outline o = {h->d_outline, h->d_outline_cnt, (int)n};
-    hipLaunchKernelGGL(k_outline, dim3(hm_cdiv(h->W, 64), hm_cdiv(h->H, OUTLINE_NT / 64)), dim3(OUTLINE_NT), 0, h->stream,
+    hipLaunchKernelGGL(k_outline, dim3(hm_cdiv(h->W, 64), hm_cdiv(h->H, OUTLINE_NT / 64)), dim3(OUTLINE_NT), 0, s,
                        mask, h->W, h->H, o);
-    ProjArgs a = {mask, h->W, h->H, h->N, o, h->d_X};
-    hipLaunchKernelGGL(k_project_mask, dim3(h->N), dim3(PROJ_NT), 0, h->stream, a);
+    ProjArgs a = {mask, h->W, h->H, h->N, o, h->d_pm_X};
+    hipLaunchKernelGGL(k_project_mask, dim3(h->N), dim3(PROJ_NT), 0, s, a);
     HM_HIP(hipGetLastError());
     int cnt[4] = {0, 0, 0, 0};
-    HM_HIP(hipMemcpyAsync(cnt, h->d_outline_cnt, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
-    HM_HIP(hipMemcpyAsync(X, h->d_X, xb, hipMemcpyDeviceToHost, h->stream));
-    HM_HIP(stream_wait(h->stream));
+    HM_HIP(hipMemcpyAsync(cnt, h->d_outline_cnt, sizeof(cnt), hipMemcpyDeviceToHost, s));
+    HM_HIP(hipMemcpyAsync(X, h->d_pm_X, xb, hipMemcpyDeviceToHost, s));
+    HM_HIP(stream_wait(s));
     if (moved) *moved = cnt[2];
     return HM_OK;
 }

@@ -20,9 +20,11 @@ def wrap(obj, name):
             T.setdefault(name, []).append(time.perf_counter() - t0)
     setattr(obj, name, g)
 wrap(kf, "_spring_blocks"); wrap(kf, "_newton"); wrap(kf.state.renderer, "cov_predict"); wrap(kf.state.renderer, "update_prefactor")
-wrap(kf, "predict")
-for i in range(1, 11):
-    kf.compute(video[i], flow, masks[i])
+wrap(kf, "predict"); wrap(kf, "projectmask"); wrap(kf, "update"); wrap(kf, "error"); wrap(kf, "_after_update"); wrap(kf, "compute")
+wrap(kf.state.renderer, "set_observation_dev"); wrap(kf.state.renderer, "update_run"); wrap(kf.state.renderer, "project_mask")
+from hydra_mi.pipeline import FlowEKFPipeline
+pipe = FlowEKFPipeline(kf, video, masks)
+pipe.run(0, 11)
 for k, v in T.items():
     print("%-18s ms per frame (last 6): %s" % (k, " ".join("%.3f" % (1e3 * x) for x in v[-6:])))
 print("newton iterations of the last frame", kf.newton_iterations)
