@@ -531,6 +531,22 @@ __global__ __launch_bounds__(256) void k_gains(const double *__restrict__ W, con
     }
 }
 
+// what the host wants of the end of an update -- Hz components (n x 4), gains (3 x n) -- into pinned host memory,
+// then the ticket (k_iter_result's protocol)
+__global__ __launch_bounds__(1024) void k_tail_result(const double *__restrict__ Hzc, const double *__restrict__ gain, int n,
+                                                      double *__restrict__ pin_hzc, double *__restrict__ pin_gain,
+                                                      double *__restrict__ ticket_slot, double ticket)
+{
+    for (int i = threadIdx.x; i < 4 * n; i += 1024) pin_hzc[i] = Hzc[i];
+    for (int i = threadIdx.x; i < 3 * n; i += 1024) pin_gain[i] = gain[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *(volatile double *)ticket_slot = ticket;
+        __threadfence_system();
+    }
+}
+
 // ---- covariance prediction W' = F W F^T + Weps on the device -------------------------------------------
 // F = [[I, a I], [A, I]] with A = s * dfdy, dfdy assembled from one symmetric 2x2 block per spring
 // (see predict.cpp): (dfdy M)[rows of vertex v] = - sum over springs (v,u) of B (M[rows v] - M[rows u]).

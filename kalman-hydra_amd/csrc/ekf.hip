@@ -1041,6 +1041,30 @@ extern "C" int hm_cov_fetch(hm_ctx_t h, double *W_out)
 // that is kept.  Per iteration the host sees one small result block (step, the four error sums)
 // that the last kernel writes into pinned memory; the iterate itself never leaves the device, and
 // the render that gave an iterate's error is the reference render of the next measurement.
+// A result block in pinned host memory carries a ticket that the kernel writes last (system-scope fence before it).
+// Watching it costs a couple of microseconds against ~20 for waking up from a stream synchronisation; the
+// synchronisation remains as the fallback.
+static int wait_ticket(hm_ctx *h, const double *slot, double want)
+{
+    const volatile double *ticket = slot;
+    const auto t_start = std::chrono::steady_clock::now();
+    const auto t_yield = t_start + std::chrono::microseconds(700), t_give_up = t_start + std::chrono::milliseconds(20);
+    bool seen = false, polite = false;          // an iteration takes ~0.4 ms: spin for that long, then yield between polls
+    for (int spin = 0;; spin++) {
+        if (*ticket == want) { seen = true; break; }
+        if (polite) std::this_thread::yield();
+        else __builtin_ia32_pause();
+        if ((spin & 255) == 255) {
+            const auto now = std::chrono::steady_clock::now();
+            if (now > t_give_up) break;
+            polite = now > t_yield;
+        }
+    }
+    if (!seen) HM_HIP(hipStreamSynchronize(h->stream));
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return HM_OK;
+}
+
 extern "C" int hm_update_arm_newton(hm_ctx_t h, void *worker, int n_bars, const int32_t *bars, const double *l0, double kappa,
                                     double M, double dt, int maxiter, double tol)
 {
@@ -1090,28 +1114,8 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
         regions_ahead = it + 1 < max_iter;
         if (regions_ahead) measure_regions(h, h->d_Xn, deltaX);
         HM_HIP(hipGetLastError());
-        // The result block carries a ticket that the kernel writes last (system-scope fence before it).
-        // Watching it costs a couple of microseconds against ~20 for waking up from a stream
-        // synchronisation, once per iteration; the synchronisation remains as the fallback.
-        {
-            const volatile double *ticket = res + n4 + 5;
-            const double want = (double)h->run_ticket;
-            const auto t_start = std::chrono::steady_clock::now();
-            const auto t_yield = t_start + std::chrono::microseconds(700), t_give_up = t_start + std::chrono::milliseconds(20);
-            bool seen = false, polite = false;          // an iteration takes ~0.4 ms: spin for that long, then yield between polls
-            for (int spin = 0;; spin++) {
-                if (*ticket == want) { seen = true; break; }
-                if (polite) std::this_thread::yield();
-                else __builtin_ia32_pause();
-                if ((spin & 255) == 255) {
-                    const auto now = std::chrono::steady_clock::now();
-                    if (now > t_give_up) break;
-                    polite = now > t_yield;
-                }
-            }
-            if (!seen) HM_HIP(hipStreamSynchronize(h->stream));
-            std::atomic_thread_fence(std::memory_order_acquire);
-        }
+        rc = wait_ticket(h, res + n4 + 5, (double)h->run_ticket);
+        if (rc) return rc;
         h->upd_prev = h->upd_last;
         h->upd_last = slot;
         niter++;
@@ -1174,13 +1178,20 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
     rc = hm_update_cov(h, which, nullptr);
     if (rc) return rc;
     if (niter > 0) {
+        // gains and Hz components go to the pinned block by a kernel that ends with a ticket, as the iterations'
+        // results do: two blit launches and the wake-up from a stream synchronisation less per frame
         hipLaunchKernelGGL(k_gains, dim3(n4), dim3(256), 0, h->stream, h->d_Wres, h->d_Hzc, n4, h->d_gain);
-        HM_HIP(hipMemcpyAsync(pin_hzc, h->d_Hzc, (size_t)n4 * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HM_HIP(hipMemcpyAsync(pin_gain, h->d_gain, (size_t)n4 * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        hipLaunchKernelGGL(k_tail_result, dim3(1), dim3(1024), 0, h->stream, h->d_Hzc, h->d_gain, n4, pin_hzc, pin_gain, res + n4 + 5,
+                           (double)(++h->run_ticket));
     }
     if (W_out) HM_HIP(hipMemcpyAsync(W_out, h->d_Wres, (size_t)n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HM_HIP(hipGetLastError());
-    HM_HIP(stream_wait(h->stream));
+    if (niter > 0 && !W_out) {
+        rc = wait_ticket(h, res + n4 + 5, (double)h->run_ticket);
+        if (rc) return rc;
+    } else {
+        HM_HIP(stream_wait(h->stream));
+    }
     if (niter > 0) {
         if (Hzc) memcpy(Hzc, pin_hzc, (size_t)n4 * 4 * sizeof(double));
         if (gains) memcpy(gains, pin_gain, (size_t)n4 * 3 * sizeof(double));
