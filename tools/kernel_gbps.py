@@ -12,7 +12,7 @@ FLOW = {                       # kernel prefix -> (algorithmic bytes per pixel p
     "void k_sor": (52.0 * 5, "52 B/px/iteration x 5 fused iterations"),
     "k_prepare": (76.0, "u,v,du,dv + 8 warped fields read, 7 written"),
     "void k_warp": (76.0, "11 read + 8 written"),
-    "k_deriv": (12.0, "1 read + 2 written"),
+    "k_deriv": (24.0, "two images per launch, each 1 read + 2 written"),
     "k_add_out": (24.0, "4 read + 2 written"),
 }
 
@@ -22,10 +22,8 @@ def main():
     acc = collections.defaultdict(list)
     for r in rows:
         name = r["Kernel_Name"]
-        if int(r["Grid_Size_Z"]) != 8:
-            continue
         for pre in FLOW:
-            if name.startswith(pre):
+            if name.startswith(pre) and int(r["Grid_Size_Z"]) == (16 if pre == "k_deriv" else 8):   # k_deriv: blockIdx.z = 2 x pairs
                 size = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"])
                 acc[pre].append((size, int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     for pre in list(acc):                                  # finest level = the largest grid
