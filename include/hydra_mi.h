@@ -259,8 +259,8 @@ int hm_ms_newton(int n_vertices, int n_bars, const int32_t *bars, const double *
                  double dt, int maxiter, double tol, double *X, int *newton_iterations);
 /* The same, started ahead of time on a host thread: the state a frame ends with is the one the next frame's
  * prediction starts from (kalman.py:850-863 run at the top of the next compute()).  create: one persistent
- * thread; start: copies its arguments and returns; finish: waits, X (4N) receives the advanced state.  One job at
- * a time per worker. */
+ * thread; start: copies its arguments and returns (a job still running is waited for, its result dropped); finish:
+ * waits, X (4N) receives the advanced state of the job started last.  One job at a time per worker. */
 int hm_ms_worker_create(void **worker);
 int hm_ms_worker_destroy(void *worker);
 int hm_ms_newton_start(void *worker, int n_vertices, int n_bars, const int32_t *bars, const double *l0, double kappa,

@@ -196,7 +196,7 @@ extern "C" int hm_ms_newton_start(void *worker, int N, int I, const int32_t *bar
     NewtonWorker *w = (NewtonWorker *)worker;
     HM_ARG(w && N >= 1 && I >= 0 && bars && l0 && X, "hm_ms_newton_start: bad argument");
     std::unique_lock<std::mutex> lk(w->m);
-    if (w->busy) { hm_set_error("hm_ms_newton_start: the worker has a job whose result was not fetched"); return HM_ERR_STATE; }
+    w->cv.wait(lk, [&] { return !w->busy; });       // a job whose result nobody fetched is superseded
     w->N = N; w->I = I; w->kappa = kappa; w->M = M; w->dt = dt; w->maxiter = maxiter; w->tol = tol;
     w->bars.assign(bars, bars + 2 * (size_t)I);
     w->l0.assign(l0, l0 + I);

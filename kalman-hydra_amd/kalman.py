@@ -783,6 +783,7 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
         self.orig_x = st.X.copy()
         # F = [[I, dt I], [dt/M dfdy, I]] at the state before the step (:856)
         if self.device_predict and hasattr(st.renderer, "ms_predict") and isinstance(st._W, DeviceCovariance):
+            self._take_ahead()               # a prediction started ahead on the host is not what this path uses
             # the whole prediction in one native call (hm_ms_predict): the Newton iterations of the state as one
             # workgroup on a second stream while the covariance prediction and, for the fused update, the
             # factorisation / inversion it starts with are queued on the filter's stream
@@ -822,7 +823,7 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
         """hm_update_run, armed (hm_update_arm_newton) to start the next frame's state prediction on the worker thread
         the moment the state it ends with is known -- before the covariance of that state is formed and fetched."""
         r = self.state.renderer
-        if self.predict_ahead and hasattr(r, "arm_newton"):
+        if self.predict_ahead and not self.device_predict and hasattr(r, "arm_newton"):
             bars, l0, par = self._ahead_inputs()
             r.arm_newton(self._get_worker(), bars, l0, *par)
             self._armed = (bars, l0, par)
@@ -840,7 +841,7 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
         (started by hm_update_run itself when armed, else here by hm_ms_newton_start) beside the end of this frame
         on the device and the caller's work between frames.  predict() takes the result if the state is still the
         one it was started from."""
-        if not self.predict_ahead:
+        if not self.predict_ahead or (self.device_predict and self._armed is None):
             return
         st = self.state
         X = np.ascontiguousarray(st.X.reshape(-1), np.float64).copy()

@@ -475,8 +475,12 @@ def test_newton_worker_equals_synchronous_call(hm):
         assert L.hm_ms_newton_finish(w, _lib.ptr(Y), ctypes.byref(its2)) != 0          # nothing started yet
         for rep in range(3):
             _lib.check(L.hm_ms_newton_start(w, *args, _lib.ptr(X0)), "start")
-            if rep == 0:
-                assert L.hm_ms_newton_start(w, *args, _lib.ptr(X0)) != 0              # one job at a time
+            if rep == 0:                                                              # a second start supersedes the first
+                Z0 = X0 + 1e-3
+                _lib.check(L.hm_ms_newton_start(w, *args, _lib.ptr(Z0)), "start")
+                _lib.check(L.hm_ms_newton_finish(w, _lib.ptr(Y), ctypes.byref(its2)), "finish")
+                assert not np.array_equal(X, Y)
+                _lib.check(L.hm_ms_newton_start(w, *args, _lib.ptr(X0)), "start")
             _lib.check(L.hm_ms_newton_finish(w, _lib.ptr(Y), ctypes.byref(its2)), "finish")
             assert np.array_equal(X, Y) and its.value == its2.value
     finally:
