@@ -3,23 +3,30 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-One step = one video frame: Brox optical flow of the frame pair (k, k+1), both frames
-already resident in HBM, followed by IteratedMSKalmanFilter.compute on frame k+1 with
+One step = one video frame: upload of frame k+1 and its mask (copy stream, frame ring), Brox
+optical flow of the frame pair (k, k+1), then IteratedMSKalmanFilter.compute on frame k+1 with
 that flow (predict, mask projection, iterated measurement update), flow handed over in
 device memory.  Workload at every N: BASELINE.json config "1024x1024 video, ~200-vertex
 mesh" -- a textured disk advected by an analytic field, synthetic, one independent video
 per GPU (weak scaling: the EKF is a recurrence over the frames of one video, videos are
 the shardable unit; the only collective is the final gather of the tracked states).
 
-Prints ONE JSON line (rank 0).  `roofline` is the SOR kernel: kernel start/stop events of every
-SOR launch of one full flow series inside the timed region.  `achieved` / `frac` follow the contract's
-figure, 52 B per pixel per red-black iteration -- but k_sor runs K iterations per pass
-over memory, so that figure is not a bound; the numbers that are:  `min_bytes_per_launch` = 52 B/px per
-LAUNCH (every field crosses HBM once per launch at best), `frac_min_traffic` = that over time over
-8 TB/s (cannot exceed 1), and `traffic` / `frac_hbm` = HBM bytes per launch from the rocprofv3 PMC passes
-(FETCH_SIZE x 2 + WRITE_SIZE, profiles/r02_sor_pmc.json, null when that file was taken for another
-kernel revision).  `cpu_baseline` is the oracle (C/OpenMP restatement of the reference's CPU path)
-timed on this host: whole Brox pairs and one whole KFState.update at the bench's size.
+Prints ONE JSON line (rank 0).  The frames and masks of the timed region are read from host memory and
+uploaded inside it (the pipeline's frame ring: one frame + one mask per step over a copy stream), as
+SURVEY.md 8d asks.  `roofline` is the SOR kernel: kernel start/stop events of every SOR launch of one
+full flow series inside the timed region.
+  frac / achieved    PHYSICAL: HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE x 2 +
+                     WRITE_SIZE, profiles/r03_sor_pmc.json, valid for the kernel sources it names) over the
+                     launch time measured here, against 8 TB/s.  When the PMC file was taken for other
+                     kernel sources the lower bound 52 B/px per LAUNCH stands in (traffic: null).
+  *_contract         the contract's figure, 52 B per pixel per red-black ITERATION.  k_sor
+                     runs K iterations per pass over memory, so this is not a bound and exceeds 1.
+  limited_by         what the SQ counters show (profiles/r03_sor_sq_counters.csv).
+  finest_level       the same figures for the launches of pyramid level 0 alone (the 40 % target).
+`steady_state` is the rate over the last 60 % of the timed frames (the first flow series of the region
+has nothing to hide behind; `value` includes it).  `cpu_baseline` is the oracle (C/OpenMP restatement of
+the reference's CPU path) timed on this host: whole Brox pairs and one whole KFState.update at the
+bench's size.
 """
 import argparse
 import json
@@ -36,7 +43,9 @@ SOR_BYTES_PER_PIXEL_ITERATION = 52.0      # 11 f32 fields read +
 HBM_PEAK_GBPS = 8000.0                    # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-SOR_PMC = os.path.join(ROOT, "profiles", "r02_sor_pmc.json")
+SOR_PMC = os.path.join(ROOT, "profiles", "r03_sor_pmc.json")
+SOR_LIMITED_BY = ("tile load phase (seven coefficient planes per tile through the L2 -> CU path) not overlapped with the "
+                  "sweeps of the same workgroup, then vector issue and barrier waits: profiles/r03_sor_sq_counters.csv")
 
 
 def kernel_revision():
@@ -52,37 +61,53 @@ def kernel_revision():
 def pmc_traffic():
     """HBM bytes per SOR launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE runs of the same 8-pair 1024^2 flow series, tools/run_pmc.sh + tools/sor_pmc_json.py;
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes and as the k_add calibration in that file
-    confirms).  None unless the file was taken for the kernel sources as they are now."""
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes and as the k_add_out calibration in that file
+    confirms) -> dict with traffic_bytes_per_launch (series average), finest_level.traffic_bytes_per_launch.
+    None unless the file was taken for the kernel sources as they are now."""
     try:
         with open(SOR_PMC) as f:
             d = json.load(f)
         if d.get("kernel_revision") != kernel_revision():
             return None
-        return float(d["traffic_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
+        float(d["traffic_bytes_per_launch"])
+        return d
+    except (OSError, KeyError, ValueError, TypeError):
         return None
 
 
-def sor_roofline(sor_ms, sor_launches, sor_pxit, sor_px, traffic, profiled):
+def _sor_figures(ms, launches, pxit, px, traffic_per_launch):
+    """One set of roofline figures for `launches` SOR launches that took `ms` in total."""
+    t = ms * 1e-3
+    n = max(1, launches)
+    alg = SOR_BYTES_PER_PIXEL_ITERATION * pxit
+    minb = SOR_BYTES_PER_PIXEL_ITERATION * px
+    phys = traffic_per_launch * n if traffic_per_launch else minb
+    gbps = (lambda b: b / t / 1e9) if t > 0 else (lambda b: 0.0)
+    return {"achieved": gbps(phys), "frac": gbps(phys) / HBM_PEAK_GBPS,
+            "traffic": traffic_per_launch, "traffic_source": "pmc" if traffic_per_launch else "model: 52 B/px per launch",
+            "achieved_contract": gbps(alg), "frac_contract": gbps(alg) / HBM_PEAK_GBPS,
+            "algorithmic_bytes_per_launch": alg / n, "min_bytes_per_launch": minb / n,
+            "frac_min_traffic": gbps(minb) / HBM_PEAK_GBPS,
+            "launches": launches, "avg_launch_us": 1e3 * ms / n}
+
+
+def sor_roofline(sor_ms, sor_launches, sor_pxit, sor_px, pmc, profiled, levels=None):
     """The roofline block of the JSON line.  sor_pxit = sum over the timed launches of pixels x fused
-    iterations, sor_px = sum of pixels (one pass over memory each)."""
-    t = sor_ms * 1e-3
-    alg = SOR_BYTES_PER_PIXEL_ITERATION * sor_pxit
-    achieved = alg / t / 1e9 if t > 0 else 0.0
-    minb = SOR_BYTES_PER_PIXEL_ITERATION * sor_px
-    n = max(1, sor_launches)
-    out = {"bound": "hbm", "kernel": "k_sor", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-           "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-           "algorithmic_bytes_per_launch": alg / n, "bytes_per_pixel_iteration": SOR_BYTES_PER_PIXEL_ITERATION,
-           "min_bytes_per_launch": minb / n,
-           "frac_min_traffic": (minb / t / 1e9 / HBM_PEAK_GBPS) if t > 0 else 0.0,
-           "frac_hbm": (traffic * n / t / 1e9 / HBM_PEAK_GBPS) if (traffic and t > 0) else None,
-           "launches": sor_launches, "avg_launch_us": 1e3 * sor_ms / n, "profiled": profiled,
-           "note": "frac follows the contract's per-iteration byte model and exceeds 1 because k_sor fuses several "
-                   "red-black iterations per pass over memory; frac_min_traffic (52 B/px per launch) and frac_hbm "
-                   "(PMC bytes) are physical bounds; profiles/r02_sor_sq_counters.csv: the kernel is bound by vector "
-                   "instruction issue and barrier waits, not by HBM"}
+    iterations, sor_px = sum of pixels (one pass over memory each); levels = hm_brox_profile_levels."""
+    out = {"bound": "hbm", "kernel": "k_sor", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "bytes_per_pixel_iteration": SOR_BYTES_PER_PIXEL_ITERATION, "limited_by": SOR_LIMITED_BY,
+           "profiled": profiled}
+    out.update(_sor_figures(sor_ms, sor_launches, sor_pxit, sor_px, float(pmc["traffic_bytes_per_launch"]) if pmc else None))
+    if levels and levels[0]["launches"] > 0:
+        l0 = levels[0]
+        tl = None
+        if pmc and pmc.get("finest_level", {}).get("pixels_per_launch") == l0["pixels"] / l0["launches"]:
+            tl = float(pmc["finest_level"]["traffic_bytes_per_launch"])
+        f = _sor_figures(l0["ms"], l0["launches"], l0["pixel_iterations"], l0["pixels"], tl)
+        f["level"] = "%dx%d" % (l0["w"], l0["h"])
+        out["finest_level"] = f
+    out["note"] = ("frac = HBM bytes actually moved (PMC) / launch time / 8 TB/s; frac_contract follows the contract's "
+                   "per-iteration byte model and exceeds 1 because k_sor fuses K red-black iterations per pass over memory")
     return out
 
 
@@ -164,62 +189,126 @@ def cpu_baseline(n, video, masks, dm, iters_per_frame, budget_s=30.0):
                                  len(pi), "" if stride == 1 else ", scaled", threads, t_update, t1, iters_per_frame)}
 
 
-def flowbatch(args, rank, world, dev, coll_dev):
-    """BASELINE config 5: `pairs-per-gpu` independent 1024^2 pairs per rank (seeds differ per pair),
-    one step = the flow of all of them in launch series of --flow-batch pairs; no communication while
-    computing, one gather of all flow planes to rank 0 at the end of the timed region."""
-    import torch
-    import torch.distributed as dist
-    from hydra_mi import brox, synth, batch
-    n, P, B = args.size, args.pairs_per_gpu, max(1, args.flow_batch)
-    mine = batch.shard(P * world, rank, world)
-    base = [synth.warp_pair(n, "translate_leftup_stretch", seed)[:2] for seed in range(4)]   # 4 distinct pairs, cycled
-    F0 = torch.from_numpy(np.stack([base[i % 4][0] for i in mine])).cuda()
-    F1 = torch.from_numpy(np.stack([base[i % 4][1] for i in mine])).cuda()
-    U = torch.empty((P, n, n), dtype=torch.float32, device="cuda")
-    V = torch.empty_like(U)
-    torch.cuda.synchronize()
-    bf = brox.BroxOpticalFlow(n, n, max_batch=B, device=dev)
+class StubFlow:
+    """Stands in for brox.BroxOpticalFlow when the sharding / gather / reporting code is rehearsed without a
+    GPU (tests/test_host_cpu.py drives `bench.py --workload flowbatch --backend gloo --stub-flow` with two
+    ranks): u = f1 - f0, v = f0 + f1 as floats, on the CPU.  Never used on a measured run."""
 
-    def step():
+    def __init__(self, n):
+        self.n = n
+
+    def run(self, F0, F1, U, V, B):
+        import torch
+        U.copy_(F1.to(torch.float32) - F0.to(torch.float32))
+        V.copy_(F0.to(torch.float32) + F1.to(torch.float32))
+
+    def profile(self, on):
+        pass
+
+    def profile_read(self):
+        return 0.0, 0, 0.0, 0.0
+
+    def profile_levels(self):
+        return []
+
+
+class DeviceFlow:
+    """The product path: hm_brox_calc_dev in launch series of B pairs on frames resident in HBM."""
+
+    def __init__(self, n, B, dev):
+        from hydra_mi import brox
+        self.bf = brox.BroxOpticalFlow(n, n, max_batch=B, device=dev)
+
+    def run(self, F0, F1, U, V, B):
+        P = F0.shape[0]
         for s in range(0, P, B):
             nb = min(B, P - s)
-            bf.calc_dev(nb, F0[s].data_ptr(), F1[s].data_ptr(), U[s].data_ptr(), V[s].data_ptr())
-        bf.sync()
+            self.bf.calc_dev(nb, F0[s].data_ptr(), F1[s].data_ptr(), U[s].data_ptr(), V[s].data_ptr())
+        self.bf.sync()
+
+    def profile(self, on):
+        self.bf.profile(on)
+
+    def profile_read(self):
+        return self.bf.profile_read()
+
+    def profile_levels(self):
+        return self.bf.profile_levels()
+
+
+def dist_info(args, world, dev):
+    """What a SCALE record needs to show that the collective backend saw N ranks: world size, backend as
+    torch.distributed reports it, and the device of every rank (all_gather_object)."""
+    import torch.distributed as dist
+    mine = {"rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+            "device": ("cpu (stub)" if args.stub_flow else "cuda:%d" % dev), "pid": os.getpid()}
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+        return {"world": dist.get_world_size(), "backend": dist.get_backend(), "ranks": ranks}
+    return {"world": 1, "backend": None, "ranks": [mine]}
+
+
+def flowbatch(args, rank, world, dev, coll_dev):
+    """BASELINE config 5: world x `pairs-per-gpu` independent 1024^2 pairs (pair i = seed i of the
+    `translate_leftup_stretch` warp, SURVEY.md 8d: 256 pairs on 8 GPUs), cut into contiguous blocks by
+    hydra_mi.batch.shard, one block per rank; one step = the flow of the whole block in launch series of
+    --flow-batch pairs; nothing is exchanged while computing, and the timed region ends with the batch path's
+    only collective, hydra_mi.batch.gather_to_root of all flow planes (RCCL over xGMI with --backend nccl)."""
+    import torch
+    import torch.distributed as dist
+    from hydra_mi import synth, batch
+    n, P, B = args.size, args.pairs_per_gpu, max(1, args.flow_batch)
+    total = P * world
+    mine = batch.shard(total, rank, world)
+    pairs = [synth.warp_pair(n, "translate_leftup_stretch", batch.pair_seed(i))[:2] for i in mine]
+    place = (lambda t: t) if args.stub_flow else (lambda t: t.cuda())
+    F0 = place(torch.from_numpy(np.stack([p[0] for p in pairs])))
+    F1 = place(torch.from_numpy(np.stack([p[1] for p in pairs])))
+    U = torch.empty((len(mine), n, n), dtype=torch.float32, device=F0.device)
+    V = torch.empty_like(U)
+    sync = (lambda: None) if args.stub_flow else torch.cuda.synchronize
+    sync()
+    eng = StubFlow(n) if args.stub_flow else DeviceFlow(n, B, dev)
+    info = dist_info(args, world, dev)
 
     for _ in range(args.warmup):
-        step()
+        eng.run(F0, F1, U, V, B)
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
         if k == args.steps - 1:
-            bf.profile(True)
-        step()
-    sor_ms, sor_launches, sor_pxit, sor_px = bf.profile_read()
+            eng.profile(True)
+        eng.run(F0, F1, U, V, B)
+    levels = eng.profile_levels()
+    sor_ms, sor_launches, sor_pxit, sor_px = eng.profile_read()
+    flows = torch.stack((U, V), dim=1).to(coll_dev)                  # (pairs of this rank, 2, n, n)
+    gathered = batch.gather_to_root(flows, total, dst=0)
     if world > 1:
-        flows = torch.stack((U, V)).to(coll_dev)
-        parts = [torch.empty_like(flows) for _ in range(world)] if rank == 0 else None
-        dist.gather(flows, parts, dst=0)
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
+        assert gathered.shape[0] == total
         print(json.dumps({
-            "metric": "frame pairs/sec (Brox flow) at %d^2" % n, "value": world * P * args.steps / elapsed,
+            "metric": "frame pairs/sec (Brox flow) at %d^2" % n, "value": total * args.steps / elapsed,
             "unit": "pairs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%d independent %dx%d frame pairs per GPU, Brox defaults, flows gathered to rank 0"
-                                   % (P, n, n), "flow_batch": B, "parallelism": "pairs x%d" % world},
-            "roofline": sor_roofline(sor_ms, sor_launches, sor_pxit, sor_px,
-                                     pmc_traffic() if (n == 1024 and B == 8) else None,
-                                     "last step of the timed region")}), flush=True)
+            "config": {"workload": "%d independent %dx%d frame pairs (seeds 0..%d) in blocks of %d per GPU, Brox defaults, "
+                                   "flows gathered to rank 0" % (total, n, n, total - 1, P),
+                       "flow_batch": B, "parallelism": "pairs x%d" % world},
+            "distributed": dict(info, gathered_bytes=int(gathered.numel() * 4), collective="gather (hydra_mi.batch.gather_to_root)"),
+            "stub_flow": bool(args.stub_flow),
+            "roofline": None if args.stub_flow else sor_roofline(
+                sor_ms, sor_launches, sor_pxit, sor_px, pmc_traffic() if (n == 1024 and B == 8) else None,
+                "last step of the timed region", levels)}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -245,6 +334,12 @@ def main():
                          "(default 1: the configuration the metric is quoted on)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real run); gloo only to rehearse several ranks on one GPU")
+    ap.add_argument("--resident", action="store_true",
+                    help="video workload: upload the whole video before the clock starts (round 2's protocol) instead "
+                         "of streaming every frame and mask through the frame ring inside the timed region")
+    ap.add_argument("--stub-flow", action="store_true",
+                    help="flowbatch only: a CPU stand-in for the flow, to rehearse sharding + gather without a GPU "
+                         "(with --backend gloo); the line it prints is marked stub_flow and is not a measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -256,7 +351,14 @@ def main():
     import torch
     import torch.distributed as dist
     import hydra_mi  # noqa: F401
-    from hydra_mi import kalman, mesh
+
+    if args.stub_flow:
+        if args.workload != "flowbatch" or args.backend != "gloo":
+            raise SystemExit("--stub-flow is for --workload flowbatch --backend gloo")
+        if world > 1:
+            dist.init_process_group("gloo")
+        return flowbatch(args, rank, world, -1, "cpu")
+    from hydra_mi import kalman, mesh, batch
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path)")
@@ -280,11 +382,14 @@ def main():
     from hydra_mi.pipeline import FlowEKFPipeline
     B = max(1, args.flow_batch)
     V = max(1, args.videos_per_gpu)
+    info = dist_info(args, world, dev)
+    # the videos of the job are the shardable unit: video i has seed i, contiguous blocks per rank (batch.shard)
+    my_videos = batch.shard(world * V, rank, world)
 
     class Track:
-        """One video: a filter and the package's streaming pipeline (hydra_mi.pipeline.FlowEKFPipeline: frames
-        and flow planes in HBM, the flow of the next frames computed on the flow handle's stream while the
-        filter works on the current ones)."""
+        """One video: a filter and the package's streaming pipeline (hydra_mi.pipeline.FlowEKFPipeline: every frame
+        and mask read from host memory and uploaded over a copy stream into a ring of frame slots, the flow of the
+        next frames computed on the flow handle's stream while the filter works on the current ones)."""
 
         def __init__(self, seed):
             frames = K + Wm + 1
@@ -294,7 +399,7 @@ def main():
             extra = {} if args.cu_reserve is None else {"cu_reserve": args.cu_reserve}
             if args.two_flow_handles:
                 extra["concurrent_series"] = True
-            self.pipe = FlowEKFPipeline(self.kf, self.video, self.masks, flow_batch=B, device=dev, **extra)
+            self.pipe = FlowEKFPipeline(self.kf, self.video, self.masks, flow_batch=B, device=dev, resident=args.resident, **extra)
             self.bf = self.pipe.bf
             if os.environ.get("HYDRA_MI_BENCH_TRACE"):
                 self.pipe.trace = lambda msg: print(msg, file=sys.stderr)
@@ -309,6 +414,8 @@ def main():
                 bf.profile(False)
             self.pipe.t_flow = self.pipe.t_ekf = 0.0
             self.pipe.iters = 0
+            self.pipe.frame_done = []
+            self.pipe.ring.bytes_uploaded = 0
             self.kf.predtime = self.kf.updatetime = self.kf.projecttime = 0.0
 
         def timed(self):
@@ -317,8 +424,7 @@ def main():
         def flow_sync(self):
             self.pipe.flow_sync()
 
-    # the videos of this rank: seeds rank * V .. rank * V + V - 1 (one video per GPU unless --videos-per-gpu)
-    tracks = [Track(rank * V + i) for i in range(V)]
+    tracks = [Track(seed) for seed in my_videos]
     for tr in tracks:
         tr.warmup()
     # the flow series of the timed region start small and grow to B pairs (pipeline.py: sized from what series and
@@ -346,23 +452,29 @@ def main():
             th.join()
         if failures:
             raise SystemExit("a tracker failed: %s" % failures[0])
-    state = torch.from_numpy(np.concatenate([tr.kf.state.X.reshape(-1) for tr in tracks])).to(coll_dev)
-    if world > 1:                       # the batch path's only exchange: gather the tracked states
-        gathered = [torch.empty_like(state) for _ in range(world)]
-        dist.all_gather(gathered, state)
+    # the batch path's only exchange: the tracked states of all videos to rank 0 (hydra_mi.batch.gather_to_root)
+    state = torch.from_numpy(np.stack([tr.kf.state.X.reshape(-1) for tr in tracks])).to(coll_dev)
+    gathered = batch.gather_to_root(state, world * V, dst=0)
+    if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    t_end = time.perf_counter()
+    elapsed = t_end - t0
     for tr in tracks:
         tr.flow_sync()
     prof_pairs, prof_where = tracks[0].pipe.profiled_pairs, "of the timed region"
     if prof_pairs == 0:                 # a timed region too short for a series of B pairs: one more, after the clock
         tr = tracks[0]
         prof_pairs, prof_where = min(B, len(tr.video) - 1), "after the timed region"
+        tr.pipe.begin(0, prof_pairs)
+        tr.pipe.ring.ensure(prof_pairs + 1, 0)
+        tr.pipe.ring.sync()
         tr.bf.profile(True)
-        tr.bf.calc_dev(prof_pairs, tr.pipe.d_video.ptr, tr.pipe.d_video.ptr + n * n, tr.pipe.d_u.ptr, tr.pipe.d_v.ptr)
+        tr.bf.calc_dev(prof_pairs, tr.pipe.ring.run_ptr(0), tr.pipe.ring.run_ptr(0) + n * n, tr.pipe.d_u.ptr, tr.pipe.d_v.ptr)
         tr.bf.sync()
-    sor_ms, sor_launches, sor_pxit, sor_px = (tracks[0].pipe.profiled_handle or tracks[0].bf).profile_read()
+    prof_bf = tracks[0].pipe.profiled_handle or tracks[0].bf
+    levels = prof_bf.profile_levels()
+    sor_ms, sor_launches, sor_pxit, sor_px = prof_bf.profile_read()
     kf, video, masks, dm = tracks[0].kf, tracks[0].video, tracks[0].masks, tracks[0].dm
     N = kf.N
     t_flow = sum(tr.pipe.t_flow for tr in tracks) / V
@@ -370,6 +482,15 @@ def main():
     iters = sum(tr.pipe.iters for tr in tracks) / V
     predtime = sum(tr.kf.predtime for tr in tracks) / V
     updatetime = sum(tr.kf.updatetime for tr in tracks) / V
+    # steady state: the last 60 % of the frames of this rank's first video (the first flow series of the timed
+    # region has nothing to hide behind; `value` includes it, this figure leaves it out)
+    done = tracks[0].pipe.frame_done
+    steady = None
+    if len(done) >= 5:
+        skip = len(done) - max(2, int(round(0.6 * len(done))))
+        steady = {"frames": len(done) - skip, "skipped": skip,
+                  "value": world * V * (len(done) - skip) / (done[-1] - done[skip - 1]), "unit": "frames/sec",
+                  "note": "frames %d..%d of the timed region of rank 0's first video, scaled by the number of videos" % (skip, len(done) - 1)}
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
@@ -377,6 +498,8 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
+        assert gathered.shape[0] == world * V
+        h2d = sum(tr.pipe.ring.bytes_uploaded for tr in tracks)
         out = {
             "metric": "frames/sec (Brox flow + EKF update) at 1024^2" if n == 1024 else
                       "frames/sec (Brox flow + EKF update) at %d^2" % n,
@@ -386,13 +509,18 @@ def main():
             "config": {"workload": "%dx%d video, %d-vertex mesh (%d triangles), %s per GPU; Brox defaults "
                                    "alpha .197 gamma 50 scale .8 inner 10 outer 77 solver 10; IteratedMSKalmanFilter "
                                    "defaults" % (n, n, N, kf.state.NT, "one video" if V == 1 else "%d concurrent videos" % V),
-                       "frames_per_gpu": K * V, "videos_per_gpu": V, "flow_batch": B, "parallelism": "videos x%d" % (world * V)},
+                       "frames_per_gpu": K * V, "videos_per_gpu": V, "flow_batch": B, "parallelism": "videos x%d" % (world * V),
+                       "h2d": ("whole video resident before the clock" if args.resident else
+                               "streamed inside the timed region: %d bytes (frame + mask per step, copy stream, "
+                               "ring of %d slots)" % (h2d, tracks[0].pipe.ring.R))},
+            "steady_state": steady,
+            "distributed": dict(info, collective="gather of the tracked states (hydra_mi.batch.gather_to_root)"),
             "breakdown_ms_per_step": {"brox_flow": 1e3 * t_flow / K, "ekf_compute": 1e3 * t_ekf / K,
                                       "ekf_predict": 1e3 * predtime / K, "ekf_update": 1e3 * updatetime / K,
                                       "iekf_iterations": iters / K},
             "roofline": sor_roofline(sor_ms, sor_launches, sor_pxit, sor_px,
                                      pmc_traffic() if (n == 1024 and prof_pairs == 8) else None,
-                                     "one flow series (%d pairs) %s" % (prof_pairs, prof_where)),
+                                     "one flow series (%d pairs) %s" % (prof_pairs, prof_where), levels),
         }
         out["cpu_baseline"] = None                           # a reported baseline, timed at N = 1 only
         if not args.no_cpu_baseline and world == 1:

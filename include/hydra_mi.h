@@ -44,6 +44,15 @@ int hm_dev_alloc(int device, uint64_t bytes, void **out);
 int hm_dev_free(int device, void *ptr);
 int hm_dev_upload(int device, void *dst, const void *src, uint64_t bytes);
 int hm_dev_download(int device, void *dst, const void *src, uint64_t bytes);
+/* Streaming uploads (the frame loop of run_kalmanfilter.py:78-89 reads one frame per iteration): a copy
+ * stream of the caller, page-locked host staging memory, and an asynchronous host -> device copy on that
+ * stream; hm_copy_stream_sync waits for the copies queued so far. */
+int hm_copy_stream_create(int device, void **stream_out);
+int hm_copy_stream_destroy(int device, void *stream);
+int hm_copy_stream_sync(int device, void *stream);
+int hm_host_alloc(uint64_t bytes, void **out);
+int hm_host_free(void *ptr);
+int hm_dev_upload_async(int device, void *dst, const void *src, uint64_t bytes, void *stream);
 
 /* ------------------------------------------------------------------------
  * Brox optical flow.  Replaces cv::cuda::BroxOpticalFlow as used by
@@ -103,6 +112,10 @@ int hm_brox_tune(hm_brox_t h, const char *key, int value);
 int hm_brox_profile(hm_brox_t h, int enable);
 int hm_brox_profile_read(hm_brox_t h, double *sor_ms, long long *sor_launches,
                          double *sor_pixel_iterations, double *sor_pixels);
+/* the same four totals per pyramid level (index 0 = the full frame) since profiling was switched on (not reset
+ * by hm_brox_profile_read); fills at most cap entries of each array (any may be NULL), returns the number of levels */
+int hm_brox_profile_levels(hm_brox_t h, int cap, double *sor_ms, long long *sor_launches,
+                           double *sor_pixel_iterations, double *sor_pixels);
 
 /* Single operators on host arrays, for parity tests against the oracle.
  * Each allocates scratch, runs the same kernel calc uses, and copies back. */
@@ -288,7 +301,9 @@ int hm_ms_predict(hm_ctx_t h, int n_bars, const int32_t *bars, const double *l0,
  * "edge_split" = workgroups per mesh-edge job (1..16, default 2); the sums change in their last
  * bits with them (another summation order); "chol_flow" = 1/0 the blocked Cholesky factorisations of the update as one
  * persistent launch whose block tasks hand their results over through memory, or one launch per 32-column block step
- * (same bits either way), "chol_flow_wgs" = workgroups of that launch (default 256) */
+ * (same bits either way), "chol_flow_wgs" = workgroups of that launch (2..2048, default 256: the first becomes the chain of
+ * the diagonal blocks, the others run the tasks it waits for), "chol_flow_stall" = n (test knob, default 0): that chain sleeps
+ * ~4 us x n before every diagonal block, so that every wait for it takes the patient path */
 int hm_ctx_tune(hm_ctx_t h, const char *key, int value);
 int hm_ctx_sync(hm_ctx_t h);
 void *hm_ctx_stream(hm_ctx_t h);

@@ -28,6 +28,12 @@ SIGNATURES = {
     "hm_dev_free": (ctypes.c_int, [ctypes.c_int, c_vp]),
     "hm_dev_upload": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, ctypes.c_uint64]),
     "hm_dev_download": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, ctypes.c_uint64]),
+    "hm_copy_stream_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(c_vp)]),
+    "hm_copy_stream_destroy": (ctypes.c_int, [ctypes.c_int, c_vp]),
+    "hm_copy_stream_sync": (ctypes.c_int, [ctypes.c_int, c_vp]),
+    "hm_host_alloc": (ctypes.c_int, [ctypes.c_uint64, ctypes.POINTER(c_vp)]),
+    "hm_host_free": (ctypes.c_int, [c_vp]),
+    "hm_dev_upload_async": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, ctypes.c_uint64, c_vp]),
     "hm_brox_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                       ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       ctypes.POINTER(c_vp)]),
@@ -42,6 +48,7 @@ SIGNATURES = {
     "hm_brox_tune": (ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int]),
     "hm_brox_profile": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "hm_brox_profile_read": (ctypes.c_int, [c_vp, c_f64p, ctypes.POINTER(ctypes.c_longlong), c_f64p, c_f64p]),
+    "hm_brox_profile_levels": (ctypes.c_int, [c_vp, ctypes.c_int, c_f64p, ctypes.POINTER(ctypes.c_longlong), c_f64p, c_f64p]),
     "hm_op_blur": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, c_vp]),
     "hm_op_resample": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_float]),

@@ -34,6 +34,35 @@ def gather_blocks(local, n_items, group=None):
     return torch.cat([parts[r][: len(shard(n_items, r, world))] for r in range(world)], dim=0)
 
 
+def gather_to_root(local, n_items, dst=0, group=None):
+    """The batch path's one exchange: gather of per-rank blocks of unequal length along dim 0 to rank `dst`
+    (dist.gather: RCCL over xGMI when the backend is "nccl", a fan-in over the direct links rather than a
+    ring).  Returns the tensor of n_items rows on rank dst, None elsewhere; without a process group the
+    block itself."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    longest = len(shard(n_items, 0, world))
+    if local.shape[0] == longest:
+        pad = local.contiguous()
+    else:
+        pad = torch.zeros((longest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, parts, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([parts[r][: len(shard(n_items, r, world))] for r in range(world)], dim=0)
+
+
+def pair_seed(index):
+    """BASELINE config 5: pair i of the batch is the `translate_leftup_stretch` warp of the
+    noise texture of seed i, i = 0 .. 255."""
+    return int(index)
+
+
 def flow_batch_sharded(frames0, frames1, flow_fn, group=None, gather=True):
     """frames0/frames1: (n, H, W) u8 arrays present on every rank (or generated per rank by the
     caller); flow_fn(f0_block, f1_block) -> (u_block, v_block) as torch tensors.  Returns the

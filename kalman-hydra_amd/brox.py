@@ -119,6 +119,21 @@ class BroxOpticalFlow:
                                                    ctypes.byref(px)), "hm_brox_profile_read")
         return ms.value, n.value, pxit.value, px.value
 
+    def profile_levels(self):
+        """Per pyramid level (0 = the full frame) since profile(True): list of dicts ms, launches,
+        pixel_iterations, pixels, w, h."""
+        cap = 128
+        ms, pxit, px = np.zeros(cap), np.zeros(cap), np.zeros(cap)
+        ln = np.zeros(cap, np.int64)
+        L = _lib.lib().hm_brox_profile_levels(self._h, cap, ms.ctypes.data_as(_lib.c_f64p),
+                                              ln.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)),
+                                              pxit.ctypes.data_as(_lib.c_f64p), px.ctypes.data_as(_lib.c_f64p))
+        if L < 0:
+            _lib.check(L, "hm_brox_profile_levels")
+        geo = self.levels()
+        return [{"level": k, "w": geo[k][0], "h": geo[k][1], "ms": float(ms[k]), "launches": int(ln[k]),
+                 "pixel_iterations": float(pxit[k]), "pixels": float(px[k])} for k in range(min(L, cap))]
+
 
 # ---- single operators (the kernels calc() is made of), host arrays -----------------------
 def _f32(a):

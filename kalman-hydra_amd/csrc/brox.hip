@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 // ---- error plumbing (shared by the whole library) --------------------------------
@@ -47,18 +48,85 @@ extern "C" int hm_dev_free(int device, void *ptr)
     HM_HIP(hipFree(ptr));
     return HM_OK;
 }
+// The synchronous copies go over a non-blocking stream of their own, one per device: a copy on the null stream would
+// wait for every blocking stream of the device -- a flow handle's CU-masked stream (hipExtStreamCreateWithCUMask has no
+// non-blocking form) with a whole launch series queued on it.
+static hipStream_t xfer_stream(int device)
+{
+    static std::mutex mu;
+    static std::vector<hipStream_t> streams;
+    std::lock_guard<std::mutex> lock(mu);
+    if (device < 0 || device >= 64) return nullptr;
+    if ((int)streams.size() <= device) streams.resize(device + 1, nullptr);
+    if (!streams[device] && hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking) != hipSuccess) streams[device] = nullptr;
+    return streams[device];
+}
 extern "C" int hm_dev_upload(int device, void *dst, const void *src, uint64_t bytes)
 {
     HM_ARG(dst && src, "hm_dev_upload: NULL pointer");
     HM_HIP(hipSetDevice(device));
-    HM_HIP(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice));
+    hipStream_t s = xfer_stream(device);
+    HM_ARG(s != nullptr, "hm_dev_upload: no copy stream on device %d", device);
+    HM_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, s));
+    HM_HIP(hipStreamSynchronize(s));
     return HM_OK;
 }
 extern "C" int hm_dev_download(int device, void *dst, const void *src, uint64_t bytes)
 {
     HM_ARG(dst && src, "hm_dev_download: NULL pointer");
     HM_HIP(hipSetDevice(device));
-    HM_HIP(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
+    hipStream_t s = xfer_stream(device);
+    HM_ARG(s != nullptr, "hm_dev_download: no copy stream on device %d", device);
+    HM_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, s));
+    HM_HIP(hipStreamSynchronize(s));
+    return HM_OK;
+}
+
+// ---- streaming uploads: a copy stream and pinned staging memory of the caller --------------------------
+// (frame k+B and its mask go to the device while the flow series k .. k+B-1 runs; pipeline.py)
+extern "C" int hm_copy_stream_create(int device, void **out)
+{
+    HM_ARG(out != nullptr, "hm_copy_stream_create: out is NULL");
+    *out = nullptr;
+    HM_HIP(hipSetDevice(device));
+    hipStream_t s = nullptr;
+    HM_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = (void *)s;
+    return HM_OK;
+}
+extern "C" int hm_copy_stream_destroy(int device, void *stream)
+{
+    if (!stream) return HM_OK;
+    HM_HIP(hipSetDevice(device));
+    HM_HIP(hipStreamSynchronize((hipStream_t)stream));
+    HM_HIP(hipStreamDestroy((hipStream_t)stream));
+    return HM_OK;
+}
+extern "C" int hm_copy_stream_sync(int device, void *stream)
+{
+    HM_ARG(stream != nullptr, "hm_copy_stream_sync: NULL stream");
+    HM_HIP(hipSetDevice(device));
+    HM_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return HM_OK;
+}
+extern "C" int hm_host_alloc(uint64_t bytes, void **out)
+{
+    HM_ARG(out != nullptr && bytes > 0, "hm_host_alloc: bad argument");
+    *out = nullptr;
+    HM_HIP(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+    return HM_OK;
+}
+extern "C" int hm_host_free(void *ptr)
+{
+    if (!ptr) return HM_OK;
+    HM_HIP(hipHostFree(ptr));
+    return HM_OK;
+}
+extern "C" int hm_dev_upload_async(int device, void *dst, const void *src, uint64_t bytes, void *stream)
+{
+    HM_ARG(dst && src && stream, "hm_dev_upload_async: NULL pointer");
+    HM_HIP(hipSetDevice(device));
+    HM_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
     return HM_OK;
 }
 
@@ -214,6 +282,9 @@ struct hm_brox {
     long long prof_launches;
     double prof_px;
     std::vector<double> ev_pxit, ev_px;
+    std::vector<int> ev_level;   // pyramid level of every recorded launch
+    std::vector<double> lev_ms, lev_pxit, lev_px;       // per-level totals (hm_brox_profile_levels)
+    std::vector<long long> lev_launches;
 };
 
 static int brox_free(hm_brox *h)
@@ -380,7 +451,9 @@ extern "C" int hm_brox_profile(hm_brox_t h, int enable)
     h->prof = enable != 0;
     if (enable) {                                  // switching off keeps what was recorded for hm_brox_profile_read
         h->ev_used = 0; h->prof_ms = 0; h->prof_pxit = 0; h->prof_px = 0; h->prof_launches = 0;
-        h->ev_pxit.clear(); h->ev_px.clear();
+        h->ev_pxit.clear(); h->ev_px.clear(); h->ev_level.clear();
+        const size_t L = h->geo.size();
+        h->lev_ms.assign(L, 0.0); h->lev_pxit.assign(L, 0.0); h->lev_px.assign(L, 0.0); h->lev_launches.assign(L, 0);
     }
     return HM_OK;
 }
@@ -395,10 +468,32 @@ static int prof_collect(hm_brox *h)
         h->prof_pxit += h->ev_pxit[i / 2];
         h->prof_px += h->ev_px[i / 2];
         h->prof_launches++;
+        const size_t lv = (size_t)h->ev_level[i / 2];
+        if (lv < h->lev_ms.size()) {
+            h->lev_ms[lv] += ms; h->lev_pxit[lv] += h->ev_pxit[i / 2]; h->lev_px[lv] += h->ev_px[i / 2]; h->lev_launches[lv]++;
+        }
     }
     h->ev_used = 0;
-    h->ev_pxit.clear(); h->ev_px.clear();
+    h->ev_pxit.clear(); h->ev_px.clear(); h->ev_level.clear();
     return HM_OK;
+}
+
+// the same totals per pyramid level (0 = the full frame) since profiling was switched on; returns the number of levels
+extern "C" int hm_brox_profile_levels(hm_brox_t h, int cap, double *ms, long long *launches, double *pxit, double *px)
+{
+    HM_ARG(h != nullptr, "hm_brox_profile_levels: NULL handle");
+    HM_HIP(hipSetDevice(h->device));
+    HM_HIP(hipStreamSynchronize(h->stream));
+    int rc = prof_collect(h);
+    if (rc) return rc;
+    const int L = (int)h->lev_ms.size();
+    for (int k = 0; k < L && k < cap; k++) {
+        if (ms) ms[k] = h->lev_ms[k];
+        if (launches) launches[k] = h->lev_launches[k];
+        if (pxit) pxit[k] = h->lev_pxit[k];
+        if (px) px[k] = h->lev_px[k];
+    }
+    return L;
 }
 
 extern "C" int hm_brox_profile_read(hm_brox_t h, double *ms, long long *launches, double *pxit, double *px)
@@ -539,6 +634,7 @@ static int brox_run(hm_brox *h, int n, const uint8_t *d_f0, const uint8_t *d_f1,
                     h->ev_used += 2;
                     h->ev_pxit.push_back((double)g.w * g.h * n * plan.K);
                     h->ev_px.push_back((double)g.w * g.h * n);
+                    h->ev_level.push_back(k);
                 }
                 du = h->du[nxt]; dv = h->dv[nxt];
                 nxt ^= 1;

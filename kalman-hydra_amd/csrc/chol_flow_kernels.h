@@ -48,6 +48,7 @@ struct FlowArgs {
     double *P;                // 3 x nb x 32 x 32: block (c, c-1) before its triangular solve; Q_c; block (c, c-2) likewise (Y_c)
     int n, nrows, nb, nbr;    // nbr: block rows including the right-hand-side rows
     unsigned *ctl;            // [0] next task, [1] set when a wait timed out
+    int stall;                // test knob (hm_ctx_tune "chol_flow_stall"): the chain sleeps ~4 us x stall before every diagonal block
 };
 
 __device__ __forceinline__ unsigned long long flow_ld_bits(const double *p)
@@ -109,6 +110,7 @@ __device__ __forceinline__ bool flow_fetch2(const FlowBlock &b0, const FlowBlock
     const int t = threadIdx.x;
     __shared__ int s_ok;
     double v0[4], v1[4];
+    int patient = 0;                                  // rounds of the patient way (the hot re-loads are not counted)
     for (int tries = 0;; tries++) {
         int ok0 = 1, ok1 = 1;
 #pragma unroll
@@ -134,7 +136,7 @@ __device__ __forceinline__ bool flow_fetch2(const FlowBlock &b0, const FlowBlock
                 if ((polls & 255) == 255 && __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
                 if (polls > FLOW_POLL_LIMIT) { __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
             }
-            if (tries > 1000) { __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; }
+            if (++patient > 1000) { __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; }
             s_ok = ok;
         }
         __syncthreads();
@@ -262,6 +264,7 @@ __global__ __launch_bounds__(FLOW_NT) void k_chol_flow(FlowArgs a)
             if (t == 0) s_fail = 0;
             for (int c = 0; c < nb; c++) {
                 const int c0 = c * DNB, nc = min(DNB, n - c0);
+                for (int q = 0; q < a.stall; q++) __builtin_amdgcn_s_sleep(127);      // tests: everyone who waits for the chain waits long
                 double acc[4];
                 if (c < 2) {                          // Q_c is the block of A itself
 #pragma unroll

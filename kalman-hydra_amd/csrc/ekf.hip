@@ -77,6 +77,7 @@ struct hm_ctx {
     int worker_rc;
     char worker_err[512];
     int chol_flow, flow_wgs;         // the factorisation as one persistent launch (chol_flow_kernels.h) / its workgroups
+    int flow_stall = 0;              // test knob: FlowArgs.stall
     double *d_flowP;                 // 3 x nb x 32 x 32 scratch of that launch
     unsigned *d_flowctl;             // its task counter and time-out word
     hipStream_t stream2;             // hm_ms_predict: the state prediction runs beside the covariance half of the update
@@ -344,8 +345,13 @@ extern "C" int hm_ctx_tune(hm_ctx_t h, const char *key, int value)
         HM_ARG(value == 0 || value == 1, "hm_ctx_tune: chol_flow must be 0 (one launch per block step) or 1 (one persistent launch)");
         h->chol_flow = value;
     } else if (!strcmp(key, "chol_flow_wgs")) {
-        HM_ARG(value >= 1 && value <= 2048, "hm_ctx_tune: chol_flow_wgs must be in 1..2048");
+        // at least two: the first workgroup becomes the chain of the diagonal blocks and waits for blocks that only
+        // the task workgroups produce
+        HM_ARG(value >= 2 && value <= 2048, "hm_ctx_tune: chol_flow_wgs must be in 2..2048 (the chain workgroup and at least one task workgroup)");
         h->flow_wgs = value;
+    } else if (!strcmp(key, "chol_flow_stall")) {      // tests only: results must not depend on it
+        HM_ARG(value >= 0 && value <= 100000, "hm_ctx_tune: chol_flow_stall must be in 0..100000");
+        h->flow_stall = value;
     } else if (!strcmp(key, "edge_split")) {
         HM_ARG(value >= 1 && value <= MEAS_VSPLIT_MAX, "hm_ctx_tune: edge_split must be in 1..%d", MEAS_VSPLIT_MAX);
         h->esplit = value;
@@ -778,7 +784,7 @@ static void chol_factor(hm_ctx *h, double *A, double *L, double *Lt, double *T, 
         // one persistent launch: the block operations below as tasks that hand their results over through memory
         // (chol_flow_kernels.h); the same bits as the launch-per-step form.  first_done: the caller's assembly pass
         // (k_assemble_flow) has pre-filled the outputs
-        FlowArgs a = {A, L, Lt, T, h->d_flowP, n, nrows, nb, nbr, h->d_flowctl};
+        FlowArgs a = {A, L, Lt, T, h->d_flowP, n, nrows, nb, nbr, h->d_flowctl, h->flow_stall};
         if (!first_done) hipLaunchKernelGGL(k_flow_fill, dim3(nrows + 1), dim3(256), 0, h->stream, a);
         hipLaunchKernelGGL(k_chol_flow, dim3(h->flow_wgs), dim3(FLOW_NT), 0, h->stream, a);
         return;
@@ -804,7 +810,8 @@ static int flow_status(hm_ctx *h, const char *who)
 {
     if (!h->chol_flow) return HM_OK;
     unsigned ctl[2] = {0, 0};
-    HM_HIP(hipMemcpy(ctl, h->d_flowctl, sizeof ctl, hipMemcpyDeviceToHost));
+    HM_HIP(hipMemcpyAsync(ctl, h->d_flowctl, sizeof ctl, hipMemcpyDeviceToHost, h->stream));      // (not the null stream: it
+    HM_HIP(hipStreamSynchronize(h->stream));                                                         // waits for blocking streams)
     if (ctl[1]) { hm_set_error("%s: the factorisation launch gave up waiting for a block (chol_flow time-out)", who); return HM_ERR_HIP; }
     return HM_OK;
 }
@@ -821,7 +828,7 @@ static double *solve_step(hm_ctx *h, int slot)
     double *rhs_row = A + (size_t)rhs_index * n4;
     if (h->chol_flow) {
         const int nb = hm_cdiv(n4, DNB), nrows = aug_rows(n4);
-        FlowArgs f = {A, h->d_Af[slot], h->d_Lt[slot], h->d_T[slot], h->d_flowP, n4, nrows, nb, hm_cdiv(nrows, DNB), h->d_flowctl};
+        FlowArgs f = {A, h->d_Af[slot], h->d_Lt[slot], h->d_T[slot], h->d_flowP, n4, nrows, nb, hm_cdiv(nrows, DNB), h->d_flowctl, 0};
         hipLaunchKernelGGL(k_assemble_flow, dim3(nrows + 1), dim3(256), 0, h->stream, h->d_invW0, h->d_HTH, h->d_X0, h->d_X,
                            h->d_Hz, A, n4, rhs_index, f);
     } else {
@@ -1084,6 +1091,12 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
     HM_ARG(h && X && info, "hm_update_run: NULL argument");
     HM_JOIN(h);
     HM_ARG(deltaX > 0 && max_iter >= 0, "hm_update_run: deltaX must be positive, max_iter >= 0");
+    // what hm_update_arm_newton armed is for THIS call only: taken out of the handle before anything can fail, so that an
+    // error return never leaves a worker pointer behind for a later call to start a job on
+    const bool pn_go = h->pn_armed;
+    void *const pn_worker = h->pn_worker;
+    h->pn_armed = false;
+    h->pn_worker = nullptr;
     NEED_TEX(h, "hm_update_run");
     NEED_OBS(h, "hm_update_run");
     int rc = hm_update_begin(h, W_prior, X);
@@ -1165,9 +1178,8 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
     }
     // the state is final: a caller that armed it gets the next frame's state prediction started now, on its worker
     // thread, beside the covariance launches below (hm_update_arm_newton)
-    if (h->pn_armed) {
-        h->pn_armed = false;
-        rc = hm_ms_newton_start(h->pn_worker, N, (int)h->pn_l0.size(), h->pn_bars.data(), h->pn_l0.data(), h->pn_par[0],
+    if (pn_go) {
+        rc = hm_ms_newton_start(pn_worker, N, (int)h->pn_l0.size(), h->pn_bars.data(), h->pn_l0.data(), h->pn_par[0],
                                 h->pn_par[1], h->pn_par[2], h->pn_maxiter, h->pn_par[3], Xcur.data());
         if (rc) return rc;
     }

@@ -5,7 +5,10 @@ through files (reference README.md:26-31; ``gen_synthetic.py:41-42`` shells out 
 ``./bin/optical_flow_ext``); the tracker's frame loop then reads one flow file per frame
 (reference run_kalmanfilter.py:78-89).  Here both halves run in one process on one GPU:
 
-* the frames (and masks) of the video are uploaded to HBM once;
+* the frames (and masks) are read from a frame source one at a time, as the reference's loop does
+  (run_kalmanfilter.py:78-89), and uploaded on a copy stream into a ring of frame slots in HBM: the
+  frames of the next flow series go up while the current series runs (``resident=True`` uploads the
+  whole video once instead -- same results, only useful for comparisons);
 * the Brox flow of consecutive frame pairs does not depend on the filter, so it is computed ahead
   of it, in launch series of 1, 2, 4, ... up to ``flow_batch`` pairs on the flow handle's own HIP
   stream (a single pair is launch-latency bound; a series amortises the ~900 launches over its
@@ -18,6 +21,7 @@ through files (reference README.md:26-31; ``gen_synthetic.py:41-42`` shells out 
 ``VideoStream`` mirrors reference renderer.py:739-805 on an array source (no OpenCV on this path):
 ``.npy`` / ``.npz`` of shape (frames, H, W) or (frames, H, W, 3), 8-bit.
 """
+import ctypes
 import threading
 import time
 
@@ -99,6 +103,19 @@ class VideoStream:
     def isOpened(self):
         return self.pos < self.frames.shape[0]
 
+    # frame source protocol of FlowEKFPipeline: random access to (raw frame, mask, frame shown to the filter)
+    def __len__(self):
+        return self.frames.shape[0]
+
+    @property
+    def shape(self):
+        return self.frames.shape[1:3]
+
+    def frame_at(self, f):
+        fr = self.frames[f]
+        mask = threshold_mask(fr, self.threshold)
+        return fr, mask, mask * fr
+
     def release(self):
         self.pos = self.frames.shape[0]
 
@@ -134,6 +151,128 @@ class DeviceBuffer:
             pass
 
 
+class ArraySource:
+    """Frame source over host arrays: video, masks (frames, H, W) uint8, optionally the frames the filter is
+    shown when they differ from the ones the flow is computed on."""
+
+    def __init__(self, video, masks, observed=None):
+        video = np.ascontiguousarray(video, np.uint8)
+        masks = np.ascontiguousarray(masks, np.uint8)
+        if video.ndim != 3 or masks.shape != video.shape:
+            raise ValueError("video and masks must both be (frames, H, W) uint8")
+        if observed is not None:
+            observed = np.ascontiguousarray(observed, np.uint8)
+            if observed.shape != video.shape:
+                raise ValueError("observed must have the shape of video")
+        self.video, self.masks, self.observed = video, masks, observed
+
+    def __len__(self):
+        return self.video.shape[0]
+
+    @property
+    def shape(self):
+        return self.video.shape[1:3]
+
+    def frame_at(self, f):
+        return self.video[f], self.masks[f], None if self.observed is None else self.observed[f]
+
+
+class FrameRing:
+    """Ring of frame slots in HBM fed from a frame source over a copy stream.
+
+    Frame f lives in slot f % R of each plane (raw frame, mask, and -- when the source has one -- the frame
+    shown to the filter).  A flow series reads nb + 1 consecutive frames through one base pointer, so the first
+    `extra` slots are mirrored behind the ring (frames that land in slots 0 .. extra-1 are copied twice): any run of up to extra + 1
+    frames is contiguous.  Host frames are staged in page-locked memory and copied with hipMemcpyAsync on a
+    stream of their own; `sync()` makes what has been queued visible to the other streams (the caller waits
+    before it launches work that reads them).  With slots >= len(source) nothing is ever overwritten (the
+    resident mode)."""
+
+    def __init__(self, source, slots, extra, device, with_observed):
+        self.src, self.device = source, int(device)
+        self.F = len(source)
+        self.H, self.W = source.shape
+        self.n = self.H * self.W
+        self.R = int(min(slots, self.F))
+        self.extra = int(extra) if self.R < self.F else 0
+        total = self.R + self.extra
+        self.d_video = DeviceBuffer(total * self.n, device)
+        self.d_masks = DeviceBuffer(total * self.n, device)
+        self.d_observed = DeviceBuffer(total * self.n, device) if with_observed else self.d_video
+        self.planes = 3 if with_observed else 2
+        self._lock = threading.RLock()
+        self._stream = _lib.c_vp()
+        _lib.check(_lib.lib().hm_copy_stream_create(self.device, ctypes.byref(self._stream)), "hm_copy_stream_create")
+        self._nstage = max(2, self.extra + 2) if self.R < self.F else min(self.F, 16)                    # frames staged between two waits for the copy stream
+        self._stage = _lib.c_vp()
+        _lib.check(_lib.lib().hm_host_alloc(self._nstage * self.planes * self.n, ctypes.byref(self._stage)), "hm_host_alloc")
+        self._stage_np = np.ctypeslib.as_array(ctypes.cast(self._stage, ctypes.POINTER(ctypes.c_uint8)),
+                                               shape=(self._nstage, self.planes, self.n))
+        self._staged = 0
+        self.lo = self.hi = 0                                    # frames [lo, hi) are in the ring (queued or there)
+        self.bytes_uploaded = 0
+
+    def reset(self, first):
+        with self._lock:
+            self.sync()
+            self.lo = self.hi = int(first)
+
+    def ptr(self, plane, f):
+        """Device address of frame f in plane 0 (raw), 1 (mask) or 2 (shown to the filter)."""
+        buf = (self.d_video, self.d_masks, self.d_observed)[plane]
+        return buf.ptr + (f % self.R) * self.n
+
+    def run_ptr(self, f):
+        """Base address of the raw frames f, f + 1, ... (contiguous for extra + 1 frames)."""
+        return self.d_video.ptr + (f % self.R) * self.n
+
+    def ensure(self, hi, keep_from):
+        """Queue the uploads of the frames up to hi - 1; frames before keep_from may be overwritten."""
+        L = _lib.lib()
+        with self._lock:
+            hi = min(int(hi), self.F)
+            if hi - keep_from > self.R:
+                raise RuntimeError("frame ring too small: frames %d..%d asked for, %d slots" % (keep_from, hi - 1, self.R))
+            while self.hi < hi:
+                f = self.hi
+                if self._staged == self._nstage:                  # the staging block is full: wait for its copies
+                    _lib.check(L.hm_copy_stream_sync(self.device, self._stream), "hm_copy_stream_sync")
+                    self._staged = 0
+                st = self._stage_np[self._staged]
+                fr, mk, ob = self.src.frame_at(f)
+                parts = [(self.d_video, fr), (self.d_masks, mk)]
+                if self.planes == 3:
+                    parts.append((self.d_observed, fr if ob is None else ob))
+                s = f % self.R
+                for i, (buf, a) in enumerate(parts):
+                    st[i][:] = np.asarray(a, np.uint8).reshape(-1)
+                    src = self._stage.value + (self._staged * self.planes + i) * self.n
+                    _lib.check(L.hm_dev_upload_async(self.device, buf.ptr + s * self.n, src, self.n, self._stream), "hm_dev_upload_async")
+                    if s < self.extra:                            # the mirror behind the ring
+                        _lib.check(L.hm_dev_upload_async(self.device, buf.ptr + (self.R + s) * self.n, src, self.n, self._stream),
+                                   "hm_dev_upload_async")
+                    self.bytes_uploaded += self.n
+                self._staged += 1
+                self.hi = f + 1
+            self.lo = max(self.lo, self.hi - self.R)
+
+    def sync(self):
+        with self._lock:
+            _lib.check(_lib.lib().hm_copy_stream_sync(self.device, self._stream), "hm_copy_stream_sync")
+            self._staged = 0
+
+    def close(self):
+        if getattr(self, "_stream", None) is not None and self._stream:
+            _lib.lib().hm_copy_stream_destroy(self.device, self._stream)
+            self._stream = None
+        if getattr(self, "_stage", None) is not None and self._stage:
+            self._stage_np = None
+            _lib.lib().hm_host_free(self._stage)
+            self._stage = None
+        for b in {id(b): b for b in (self.d_video, self.d_masks, self.d_observed)}.values():
+            b.close()
+
+
 class _Done:
     """Marks a series in flight that has been waited for already (its thread is gone)."""
 
@@ -149,14 +288,18 @@ class FlowEKFPipeline:
         for k in range(len(video) - 1):
             e = pipe.step(k)                            # frame k+1: flow of (k, k+1), then kf.compute
 
-    ``video``, ``masks``: (frames, H, W) uint8 host arrays (masks in {0,1}); uploaded once.  The flow
-    parameters default to the reference's (src/optical_flow_ext.cpp:453-488).  The numbers are those of
-    ``bf.calc(video[k], video[k+1])`` followed by ``kf.compute(video[k+1], flow, masks[k+1])``: a pair's
-    flow does not depend on the series it is computed in.
+    ``video``: a frame source (``VideoStream``, ``ArraySource``: ``len()``, ``.shape``, ``.frame_at(f)`` ->
+    raw frame, mask, frame shown to the filter or None) or, with ``masks``, (frames, H, W) uint8 host arrays
+    (masks in {0,1}).  Frames are read from it one by one and uploaded on a copy stream into a ring of
+    ``3 flow_batch + 3`` frame slots (``FrameRing``): the upload of the frames of the next flow series is
+    queued right after the launches of the current one.  ``resident=True`` uploads the whole video at
+    construction instead.  The flow parameters default to the reference's (src/optical_flow_ext.cpp:453-488).
+    The numbers are those of ``bf.calc(video[k], video[k+1])`` followed by
+    ``kf.compute(video[k+1], flow, masks[k+1])``: a pair's flow does not depend on the series it is computed in.
     """
 
-    def __init__(self, kf, video, masks, flow_batch=8, device=0, brox_params=None, sor_threads=0, maskflow=True,
-                 observed=None, return_flow=False, cu_reserve=32, concurrent_series=False):
+    def __init__(self, kf, video, masks=None, flow_batch=8, device=0, brox_params=None, sor_threads=0, maskflow=True,
+                 observed=None, return_flow=False, cu_reserve=32, concurrent_series=False, resident=False):
         """return_flow: whether step() brings the rendered flow planes of every frame to the host, as
         KalmanFilter.compute does for the reference's callers (8 MB per 1024^2 frame); a frame loop that
         looks at the error sums and the state only (reference run_kalmanfilter.py:78-89 ignores the return
@@ -164,30 +307,30 @@ class FlowEKFPipeline:
         observed: the frames the filter is shown, when they differ from the ones the flow is computed on
         (the reference CLI tracks the background-subtracted frame, renderer.py:770-773, while its flow tool
         works on the raw video); default: the video itself."""
-        video = np.ascontiguousarray(video, np.uint8)
-        masks = np.ascontiguousarray(masks, np.uint8)
-        if video.ndim != 3 or masks.shape != video.shape:
-            raise ValueError("video and masks must both be (frames, H, W) uint8")
-        if observed is not None:
-            observed = np.ascontiguousarray(observed, np.uint8)
-            if observed.shape != video.shape:
-                raise ValueError("observed must have the shape of video")
+        if hasattr(video, "frame_at"):
+            if masks is not None or observed is not None:
+                raise ValueError("a frame source brings its own masks / observed frames")
+            source = video
+            with_observed = source.frame_at(0)[2] is not None
+        else:
+            source = ArraySource(video, masks, observed)
+            with_observed = observed is not None
+        self.source = source
         self.kf, self.maskflow = kf, maskflow
         kf.return_flow = bool(return_flow)
-        self.video, self.masks = video, masks
-        self.F, self.H, self.W = video.shape
+        self.F = len(source)
+        self.H, self.W = source.shape
         self.B = max(1, int(flow_batch))
         self.device = int(device)
         n = self.H * self.W
         self._px = n
-        self.d_video = DeviceBuffer(self.F * n, device)
-        self.d_masks = DeviceBuffer(self.F * n, device)
-        self.d_video.upload(video)
-        self.d_masks.upload(masks)
-        self.d_observed = self.d_video
-        if observed is not None:
-            self.d_observed = DeviceBuffer(self.F * n, device)
-            self.d_observed.upload(observed)
+        # the filter works on frame k + 1 while up to two series (of at most B pairs each, B + 1 frames) are in
+        # flight or ready ahead of it and the next one's frames are being uploaded
+        self.ring = FrameRing(source, self.F if resident else 3 * self.B + 3, self.B, device, with_observed)
+        if resident:
+            self.ring.ensure(self.F, 0)
+            self.ring.sync()
+        self.resident = bool(resident)
         self.d_u = DeviceBuffer(3 * self.B * n * 4, device)          # flow planes: one buffer in use, two being filled
         self.d_v = DeviceBuffer(3 * self.B * n * 4, device)
         # concurrent_series: two flow handles (streams), two series in flight at a time.  Measured at 1024^2 / 201
@@ -205,12 +348,14 @@ class FlowEKFPipeline:
                 bf.tune("cu_reserve", int(cu_reserve))
         self.t_flow = self.t_ekf = 0.0
         self.iters = 0
+        self.frame_done = []             # perf_counter() at the end of every step (steady-state rates)
         self.profile_full, self.profiled_pairs = False, 0    # set profile_full: the next series of flow_batch pairs is profiled
         self.trace = None                # callable(str) for per-frame scheduling messages
         # pairs [lo, hi) of `ready` have their flow in buffer `buf`; the series in `_flying` (oldest first; each a dict
         # lo, hi, buf, handle, thread) are being computed while the filter works on `ready`
         self._ready, self._buf, self._flying, self._thread_exc = (0, 0), 0, [], None
         self._end = self.F - 1
+        self._cursor = 0                 # the oldest frame still needed (the pair the filter is at)
         self.profiled_handle = None
 
     # -- flow series ---------------------------------------------------------------------------------
@@ -231,8 +376,16 @@ class FlowEKFPipeline:
                     self.profiled_pairs, self.profiled_handle, self.profile_full = nb, bf, False
                 elif bf is self.profiled_handle:
                     bf.profile(False)                   # totals stay readable (hm_brox_profile_read)
-                bf.calc_dev(nb, self.d_video.ptr + k * n, self.d_video.ptr + (k + 1) * n,
+                # frames k .. k + nb: normally queued for upload when the previous series was launched; the copy
+                # stream is waited for here, on the helper thread, before the flow stream is given work that reads them
+                self.ring.ensure(k + nb + 1, self._cursor)
+                self.ring.sync()
+                bf.calc_dev(nb, self.ring.run_ptr(k), self.ring.run_ptr(k) + n,
                             self.d_u.ptr + buf * B * n * 4, self.d_v.ptr + buf * B * n * 4)
+                # ... and while this series runs, the frames of the next one go up (reference run_kalmanfilter.py:78-89
+                # reads one frame per iteration; here the read-ahead is one series)
+                nxt = min(self._end, k + nb + self._next_series(nb))
+                self.ring.ensure(min(nxt + 1, self._cursor + self.ring.R), self._cursor)
             except Exception as exc:                    # noqa: BLE001 -- re-raised by the thread that waits
                 self._thread_exc = exc
         t = threading.Thread(target=work)
@@ -265,6 +418,9 @@ class FlowEKFPipeline:
         self._flying = []
         self._end = self.F - 1 if end is None else min(int(end), self.F - 1)
         self._ready = (first, first)
+        self._cursor = first
+        if not self.resident:
+            self.ring.reset(first)               # nothing of an earlier phase is assumed to be in the ring
 
     def _top_up(self):
         """Keep as many series in flight as there are handles."""
@@ -278,15 +434,21 @@ class FlowEKFPipeline:
 
     def flow_ready(self, k):
         """Make the flow of pair (k, k+1) available -> (device pointer of u, of v)."""
+        if not (0 <= k < self.F - 1):
+            raise IndexError("pair %d of a %d-frame video" % (k, self.F))
         if not (self._ready[0] <= k < self._ready[1]):
             if k != self._ready[1] or (self._flying and self._flying[0]["lo"] != k):
-                self.begin(k, self._end)                 # random access: start over from k
+                self.begin(k, max(self._end, k + 1))     # random access: start over from k
+            elif k >= self._end:
+                self._end = min(self.F - 1, k + 1)       # past the end of the phase run() announced: go on pair by pair
+            self._cursor = k
             self._top_up()
             f = self._flying.pop(0)
             if f["thread"] is not _Done:
                 self._wait(f)
             self._ready, self._buf = (f["lo"], f["hi"]), f["buf"]
             self._top_up()
+        self._cursor = k
         i = k - self._ready[0]
         off = (self._buf * self.B + i) * self._px * 4
         return self.d_u.ptr + off, self.d_v.ptr + off
@@ -309,13 +471,14 @@ class FlowEKFPipeline:
         pu, pv = self.flow_ready(k)
         t1 = time.perf_counter()
         n = self._px
-        obs = DeviceObservation(self.d_observed.ptr + (k + 1) * n, pu, pv, self.d_masks.ptr + (k + 1) * n,
-                                y_m_host=self.masks[k + 1])
+        obs = DeviceObservation(self.ring.ptr(2, k + 1), pu, pv, self.ring.ptr(1, k + 1),
+                                y_m_host=self.source.frame_at(k + 1)[1])
         e = self.kf.compute(obs, None, None, maskflow=self.maskflow)
         t2 = time.perf_counter()
         self.t_flow += t1 - t0
         self.t_ekf += t2 - t1
         self.iters += getattr(self.kf, "niter", 1)
+        self.frame_done.append(t2)
         if self.trace:
             self.trace("step %d: flow wait %.2f ms, filter %.2f ms (%d iterations), series ready %s in flight %s"
                        % (k, 1e3 * (t1 - t0), 1e3 * (t2 - t1), getattr(self.kf, "niter", 1), self._ready,
@@ -335,7 +498,8 @@ class FlowEKFPipeline:
         try:
             self.flow_sync()
         finally:
-            for b in (self.d_video, self.d_observed, self.d_masks, self.d_u, self.d_v):
+            self.ring.close()
+            for b in (self.d_u, self.d_v):
                 b.close()
             for bf in self.bfs:
                 bf.close()

@@ -23,7 +23,7 @@ import numpy as np
 import hydra_mi  # noqa: F401
 from hydra_mi import kalman
 from hydra_mi.distmesh_dyn import DistMesh
-from hydra_mi.pipeline import FlowEKFPipeline, VideoStream, threshold_mask
+from hydra_mi.pipeline import FlowEKFPipeline, VideoStream
 from hydra_mi.renderer import FlowStream
 
 
@@ -76,11 +76,9 @@ def main(argv=None):
         # no flow files: flow and filter in one process, the flow of the coming frames computed on the GPU
         # beside the filter (hydra_mi.pipeline; replaces the file hand-off of reference README.md:26-31)
         print("Cannot read flow stream at %s*: computing Brox flow in-process" % args.flow_in)
-        video = capture.frames
-        masks = np.stack([threshold_mask(f, args.threshold) for f in video])
         kf = kalman.IteratedMSKalmanFilter(distmesh, frame, np.zeros(frame.shape + (2,), np.float32), cuda=args.cuda,
                                            sparse=True, multi=True)
-        pipe = FlowEKFPipeline(kf, video, masks, observed=video * masks)
+        pipe = FlowEKFPipeline(kf, capture)          # frames, masks and background-subtracted frames read from the stream
 
         def on_frame(k, e):
             print("Frame %d" % (k + 1))

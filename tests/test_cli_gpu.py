@@ -84,3 +84,54 @@ def test_pipeline_equals_sequential_calls(hm):
     with pytest.raises(IndexError):
         pipe.step(F - 1)
     pipe.close()
+
+
+def test_streaming_frame_ring_equals_resident_video(hm):
+    """the frame loop reads one frame per iteration (reference run_kalmanfilter.py:78-89).  The
+    pipeline's default -- frames and masks read from the source one by one and uploaded over a copy stream into a ring
+    of 3 B + 3 frame slots, the frames of the next flow series going up while the current one runs -- gives the bits
+    of the whole video uploaded at once (resident=True), through several laps of the ring (16 frames, 9 slots), and a
+    VideoStream source (mask and background-subtracted frame derived per frame) the bits of the arrays it stands for."""
+    from hydra_mi import kalman, mesh, synth
+    from hydra_mi.pipeline import FlowEKFPipeline, VideoStream, threshold_mask
+    n, F = 96, 16
+    video, _, c, r = synth.disk_video(n, F, "warp", 2)
+    masks = np.stack([threshold_mask(f, 9) for f in video])
+    zero = np.zeros((n, n, 2), np.float32)
+
+    def new_filter():
+        return kalman.IteratedMSKalmanFilter(mesh.disk_mesh(c[0], c[1], r - 1.0, 14.0), video[0] * masks[0], zero, True, nI=3)
+
+    def track(make):
+        kf = new_filter()
+        pipe = make(kf)
+        got = []
+        pipe.run(on_frame=lambda k, e: got.append((kf.state.X.copy(), e[:4], kf.niter)))
+        return pipe, kf, got
+
+    pr, kfr, ref = track(lambda kf: FlowEKFPipeline(kf, video, masks, observed=video * masks, flow_batch=2, resident=True))
+    assert pr.ring.R == F and pr.ring.bytes_uploaded == 3 * F * n * n
+    ps, kfs, got = track(lambda kf: FlowEKFPipeline(kf, video, masks, observed=video * masks, flow_batch=2))
+    assert ps.ring.R == 9 and ps.ring.extra == 2 and not ps.resident
+    assert ps.ring.bytes_uploaded == 3 * F * n * n            # every frame, mask and observed frame exactly once
+    pv, kfv, gotv = track(lambda kf: FlowEKFPipeline(kf, VideoStream(video, 9), flow_batch=2))
+    assert len(ref) == len(got) == len(gotv) == F - 1
+    for k in range(F - 1):
+        for g in (got[k], gotv[k]):
+            assert np.array_equal(g[0], ref[k][0]) and g[1] == ref[k][1] and g[2] == ref[k][2], k
+    assert np.array_equal(kfs.state.W, kfr.state.W)
+    # a new phase uploads its frames again (nothing of an earlier phase is assumed to be in the ring), random access
+    # and steps past the end of the phase run() announced work
+    f5 = ps.flow_host(5)
+    r5 = pr.flow_host(5)
+    assert np.array_equal(f5, r5)
+    kf2 = new_filter()
+    p2 = FlowEKFPipeline(kf2, video, masks, observed=video * masks, flow_batch=2)
+    p2.run(0, 3)
+    for k in (3, 4, 5):
+        p2.step(k)                                            # past the end of the phase: goes on pair by pair
+    assert np.array_equal(kf2.state.X, ref[5][0])
+    with pytest.raises(IndexError):
+        p2.flow_ready(F - 1)
+    for p in (pr, ps, pv, p2):
+        p.close()

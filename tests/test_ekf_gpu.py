@@ -791,3 +791,39 @@ def test_persistent_factorisation_equals_launch_per_step(hm, n, h0):
     assert np.isfinite(out[1][3]).all() and np.abs(out[1][3] - out[1][3].T).max() <= 1e-12 * np.abs(out[1][3]).max()
     with pytest.raises(RuntimeError):
         R.tune("chol_flow", 2)
+
+
+def test_persistent_factorisation_survives_a_slow_chain(hm):
+    """The tasks of the persistent factorisation launch that wait for the chain of diagonal blocks re-load hot for a
+    few thousand rounds and then hand the watch to one lane that sleeps between polls (chol_flow_kernels.h,
+    flow_fetch2).  With the chain stalled ~10 ms per block (test knob "chol_flow_stall") every such wait goes through
+    the patient path: same bits, no time-out -- a slow chain (contention, a profiler) must not fail the frame.  And the
+    launch needs a task workgroup besides the chain: chol_flow_wgs = 1 is refused."""
+    dm, N, tex, R, meas = _setup(hm, 96, 9.0, seed=8)
+    rng = np.random.default_rng(3)
+    X = _state(dm, rng, pos_sigma=0.5)
+    X0 = X + rng.normal(0, 0.3, X.size)
+    y_im, flow, y_m = _observation(dm, meas, rng, 96)
+    n4 = 4 * N
+    assert n4 > 64                                                         # several block columns
+    M = rng.normal(size=(n4, n4))
+    W = np.eye(n4) * 0.5 + 0.05 * (M @ M.T) / n4
+    st = _Flow()
+    out = []
+    for stall in (0, 2500, 0):
+        R.tune("chol_flow_stall", stall)
+        st.X = X.reshape(-1, 1)
+        R.update_frame(y_im, flow, y_m)
+        R.update_begin(W, X0)
+        s1, _, e1 = R.update_step(st, y_im, flow, y_m)
+        out.append((s1, R.update_cov(0), np.array(e1)))
+    assert all(np.array_equal(a, b) for a, b in zip(out[0], out[1]))
+    assert all(np.array_equal(a, b) for a, b in zip(out[0], out[2]))
+    with pytest.raises(RuntimeError):
+        R.tune("chol_flow_wgs", 1)
+    R.tune("chol_flow_wgs", 2)                                             # the smallest launch that can make progress
+    st.X = X.reshape(-1, 1)
+    R.update_begin(W, X0)
+    s2, _, _ = R.update_step(st, y_im, flow, y_m)
+    assert np.array_equal(s2, out[0][0])
+    R.tune("chol_flow_wgs", 256)

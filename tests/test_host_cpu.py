@@ -428,6 +428,10 @@ def _worker(rank, world, port, out):
     u, v = batch.flow_batch_sharded(f0, f1, fake_flow)
     ok = bool(torch.equal(u, torch.from_numpy(f0.astype(np.float32) * 2))
               and torch.equal(v, torch.from_numpy(f1.astype(np.float32) - 3)))
+    # the gather the bench ends with: unequal blocks to rank 0 only
+    ub, _, mine_r = batch.flow_batch_sharded(f0, f1, fake_flow, gather=False)
+    g = batch.gather_to_root(ub, n, dst=0)
+    ok = ok and ((g is None) if rank != 0 else bool(torch.equal(g, u)))
     mine = batch.shard(n, rank, world)
     out.put((rank, ok, list(mine)))
     dist.barrier()
@@ -450,6 +454,29 @@ def test_sharded_batch_two_ranks_gloo(hm):
         p.join(timeout=60)
     assert res[0][1] and res[1][1]
     assert res[0][2] == [0, 1, 2, 3] and res[1][2] == [4, 5, 6]
+
+
+def test_bench_flowbatch_two_ranks_gloo_stub_flow(hm):
+    """bench.py's BASELINE config 5 path -- batch.shard of the pair indices (pair i = seed i), one block per rank, no
+    exchange while computing, batch.gather_to_root of all flow planes, one JSON line from rank 0 -- launched the way the
+    driver launches it (torch.distributed.run, 2 ranks), on gloo with a CPU stand-in for the flow kernel."""
+    import json
+    import subprocess
+    port = 29700 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", "flowbatch", "--backend", "gloo", "--stub-flow", "--size", "48", "--pairs-per-gpu", "3"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["unit"] == "pairs/sec" and out["stub_flow"] is True and out["roofline"] is None
+    d = out["distributed"]
+    assert d["world"] == 2 and d["backend"] == "gloo" and [r["rank"] for r in d["ranks"]] == [0, 1]
+    assert d["gathered_bytes"] == 6 * 2 * 48 * 48 * 4                       # every pair's two planes reached rank 0
+    assert "seeds 0..5" in out["config"]["workload"] and out["value"] > 0
 
 
 def test_newton_worker_equals_synchronous_call(hm):

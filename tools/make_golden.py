@@ -4,7 +4,7 @@ The reference itself cannot be imported or run in this image (Python 2 sources, 
 PyCUDA / OpenCV), so the vectors come from oracle/, which is pinned to the
 reference's own known answers by tests/test_oracle_ekf.py.
 
-    python tools/make_golden.py [config1|config3|partitions|brox|measure|all]
+    python tools/make_golden.py [config1|config3|config4|partitions|brox|measure|all]
 """
 import os
 import sys
@@ -67,6 +67,34 @@ def config3(frames=5, n=512, h0=0.12):
                         L=dm.L, X=np.array(Xs), err=np.array(errs), iters=np.array(iters), W_last=tr.W)
 
 
+def config4(frames=4, n=1024, h0=0.047):
+    """BASELINE config 4: 1024x1024 video of the textured disk advected by `translate_leftup`
+    (synthetic/flowfields.py:3), the bench's 201-vertex mesh (h0 = 0.047 W), flow from the C Brox oracle with
+    the reference defaults, IteratedMSKalmanFilter defaults (reference kalman.py:774-831, 835-960), the
+    measurement model the C/OpenMP twin of ekf_ref.Measurement: every jz / j evaluation a full-frame render
+    (cuda.py:972-1010).  ~3 min per frame on 8 cores."""
+    video, masks, centre, radius = synth.disk_video(n, frames, "translate_leftup", 0)
+    dm = mesh.disk_mesh(centre[0], centre[1], radius - 1.0, h0 * n)
+    threads = max(1, min(16, os.cpu_count() or 1))
+    meas = lambda *a: ekf_c.Measurement(*a, threads=threads)
+    tr = ekf_ref.Tracker(dm.p, dm.t, dm.bars, dm.L, video[0], measurement=meas)
+    brox_oracle.set_threads(threads)
+    Xs, errs, iters, Wd = [], [], [], []
+    t0 = time.time()
+    for k in range(1, frames):
+        u, v = brox_oracle.calc(video[k - 1], video[k])
+        e = tr.compute(video[k], np.dstack((u, v)).astype(np.float32), masks[k])
+        Xs.append(tr.X.reshape(-1).copy())
+        Wd.append(np.diag(tr.W).copy())
+        errs.append([float(e[0]), e[1], e[2], float(e[3])])
+        iters.append(tr.niter)
+        print("frame %d: iters %d, err %s, %.0fs" % (k, tr.niter, errs[-1], time.time() - t0), flush=True)
+    brox_oracle.set_threads(1)
+    np.savez_compressed(os.path.join(OUT, "config4_track.npz"), n=n, frames=frames, h0=h0, p=dm.p, t=dm.t, bars=dm.bars,
+                        L=dm.L, X=np.array(Xs), err=np.array(errs), iters=np.array(iters), W_diag=np.array(Wd),
+                        W_last_rows=tr.W[::67].copy())
+
+
 def partitions():
     """The perturbation partitions of the BASELINE config-1 mesh from the statement-by-statement restatement
     of reference kalman.py:223-272, 305-389 (oracle/partitions_ref.py)."""
@@ -123,5 +151,7 @@ if __name__ == "__main__":
         config1()
     if what in ("config3", "all"):
         config3()
+    if what == "config4":                                # not in "all": half an hour of CPU
+        config4()
     if what in ("partitions", "all"):
         partitions()
