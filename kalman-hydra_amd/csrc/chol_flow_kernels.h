@@ -454,3 +454,103 @@ __global__ __launch_bounds__(256) void k_assemble_flow(const double *__restrict_
     __syncthreads();
     if (threadIdx.x == 0) A[(size_t)rhs_row * n + row] = Hz[row] - (((s[0] + s[1]) + s[2]) + s[3]);
 }
+
+// ---- the update system straight from the measurement's job sums -------------------------------------------------
+// k_hth_scatter + k_assemble_flow in one pass (hm_update_step / hm_update_run): H = HTH is block sparse -- row (v, a)
+// has entries in the columns of v and of its mesh neighbours only (kalman.py:202-205) -- so a row's workgroup copies
+// its row of inv(W0) into A, forms the row's few entries of H from the sums of the vertex job v and of the edge jobs
+// around v (the arithmetic of k_hth_scatter: parts added in order, / eps, / d / d), adds them in, and gets the row's
+// right-hand side Hz - H (X0 - X) from the same entries; Hz and the Hz components of the row are stored for the
+// gains.  The dense H is not written at all (hm_measure still does, with k_hth_scatter).  Row by row the pre-fill of
+// what the factorisation launch produces, as k_assemble_flow does.
+struct PrepArgs {
+    const double *out;        // job sums (njobs x MEAS_VSPLIT_MAX x MEAS_OUT)
+    int N, vsplit, esplit;
+    double eZ, eJ, eM, d;
+    const int *nb_off, *nb_u, *nb_e;          // per vertex: its neighbours (ascending) and the edge job of each
+    const double *invW0, *X0, *X;
+    double *A, *Hz, *Hzc;
+    int n, rhs_row;
+    FlowArgs f;
+};
+
+__device__ __forceinline__ double d_job_sum(const double *__restrict__ out, int job, int parts, int idx)
+{
+    const double *src = out + (size_t)job * MEAS_VSPLIT_MAX * MEAS_OUT;
+    double v = src[idx];
+    for (int q = 1; q < parts; q++) v += src[q * MEAS_OUT + idx];
+    return v;
+}
+
+#define PREP_MAX_ENTRIES (4 * (EKF_MAX_STAR + 2))
+__global__ __launch_bounds__(256) void k_solve_prep(PrepArgs p)
+{
+    __shared__ double s_term[PREP_MAX_ENTRIES];
+    __shared__ double s_hz;
+    const int row = blockIdx.x, t = threadIdx.x, n = p.n;
+    if (row == (int)gridDim.x - 1) { flow_fill_blocks(p.f, t, 256); return; }
+    flow_fill_row(p.f, row, t, 256);
+    if (row >= n) {
+        if (row != p.rhs_row)
+            for (int j = t; j < n; j += 256) p.A[(size_t)row * n + j] = 0.0;
+        return;
+    }
+    double *Arow = p.A + (size_t)row * n;
+    const double *Wrow = p.invW0 + (size_t)row * n;
+    for (int j = t; j < n; j += 256) Arow[j] = Wrow[j];
+    const int N = p.N, n2 = 2 * N;
+    const int v = (row % n2) >> 1, ca = (row & 1) + (row >= n2 ? 2 : 0);      // component of the row: x, y, vx, vy
+    const int deg = p.nb_off[v + 1] - p.nb_off[v];
+    const int entries = min(PREP_MAX_ENTRIES, 4 * (deg + 1));
+    double val = 0.0;
+    int col = 0;
+    if (t < entries) {
+        const int q = t >> 2, cb = t & 3;
+        int idx = -1, job, parts, u;
+        bool weighted;                              // geometry x geometry sums come weighted by 1 / eps already
+        if (q == 0) {                               // the 4x4 block of the vertex itself (symmetric)
+            u = v; job = v; parts = p.vsplit;
+            const int lo = min(ca, cb), hi = max(ca, cb);
+            const int tab[4][4] = {{A_XX, A_XY, A_XVX, A_XVY}, {-1, A_YY, A_YVX, A_YVY}, {-1, -1, A_VXVX, -1}, {-1, -1, -1, A_VYVY}};
+            idx = tab[lo][hi];
+            weighted = hi < 2;
+        } else {
+            u = p.nb_u[p.nb_off[v] + q - 1];
+            job = N + p.nb_e[p.nb_off[v] + q - 1]; parts = p.esplit;
+            const int c1 = v < u ? ca : cb, c2 = v < u ? cb : ca;           // component of the lower / the higher vertex
+            const int tab[4][4] = {{B_XX, B_XY, B_XVX, B_XVY}, {B_YX, B_YY, B_YVX, B_YVY}, {B_VXX, B_VXY, B_VXVX, -1},
+                                   {B_VYX, B_VYY, -1, B_VYVY}};
+            idx = tab[c1][c2];
+            weighted = c1 < 2 && c2 < 2;
+        }
+        col = 2 * u + (cb & 1) + (cb >= 2 ? n2 : 0);
+        if (idx >= 0) {
+            const double raw = d_job_sum(p.out, job, parts, idx);
+            val = (weighted ? raw : raw / p.eJ) / p.d / p.d;               // d_put of k_hth_scatter
+        }
+        s_term[t] = val * (p.X0[col] + -1.0 * p.X[col]);
+    } else if (t == 255) {
+        // central differences of jz (kalman.py:499-515), as k_hth_scatter forms them
+        double c[4] = {0.0, 0.0, 0.0, 0.0};
+        if (ca < 2) {
+            const int b0 = ca == 0 ? A_X : A_Y;
+            c[0] = d_job_sum(p.out, v, p.vsplit, b0) / p.eZ; c[1] = d_job_sum(p.out, v, p.vsplit, b0 + 1) / p.eJ;
+            c[2] = -d_job_sum(p.out, v, p.vsplit, b0 + 2) / p.eJ; c[3] = d_job_sum(p.out, v, p.vsplit, b0 + 3) / p.eM;
+        } else if (ca == 2) {
+            c[1] = d_job_sum(p.out, v, p.vsplit, A_VX) / p.eJ;
+        } else {
+            c[2] = -d_job_sum(p.out, v, p.vsplit, A_VY) / p.eJ;
+        }
+        const double hz = (((c[0] + c[1]) + c[2]) + c[3]) / p.d / 2;
+        p.Hz[row] = hz;
+        for (int ch = 0; ch < 4; ch++) p.Hzc[(size_t)row * 4 + ch] = c[ch] / p.d / 2;
+        s_hz = hz;
+    }
+    __syncthreads();                                  // the copy of the row is complete, the terms are in LDS
+    if (t < entries) Arow[col] = Wrow[col] + val;
+    if (t == 0) {
+        double acc = 0.0;
+        for (int i = 0; i < entries; i++) acc += s_term[i];
+        p.A[(size_t)p.rhs_row * n + row] = s_hz - acc;
+    }
+}

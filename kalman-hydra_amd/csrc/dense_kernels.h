@@ -14,6 +14,7 @@
 // do not depend on workgroup scheduling.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "ekf_kernels.h"      // d_tile_partial_sums (k_iter_result)
 
 #define DNB 32          // block size
 #define TTT_PF 3        // block products whose operands are in flight (k_ttt)
@@ -332,30 +333,36 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ A, doubl
 
 // ---- x = T^T y: the second half of a solve with A = L L^T once T = L^-1 is at hand ---------------
 // y = L^-1 b is the right-hand-side row that went through the factorisation; x = A^-1 b = T^T y.
-// One 1024-thread workgroup per 32-column block J: thread (g, c) adds T[i][32 J + c] y[i] over the rows
-// i = 32 J + g, + 32, ... (rows of T: coalesced; at most n / 32 loads per thread, all in flight
-// together), the 32 partial sums per column are added in order.  x goes to xout (not onto y: other
-// workgroups still read it); if xn is given, xn = x0 + x is written as well (the update's new iterate).
-__global__ __launch_bounds__(1024) void k_tvec(const double *__restrict__ T, int n, const double *__restrict__ y,
-                                               double *__restrict__ xout, const double *__restrict__ x0,
-                                               double *__restrict__ xn)
+// One 1024-thread workgroup per TV_COLS columns: thread (g, c) adds T[i][col] y[i] over the rows i = i0 + g,
+// + TV_ROWS, ... from the first row i0 of the column's diagonal block on (what lies above the diagonal inside that
+// block is stored as zeros; above the block nothing is stored) -- at most ceil(n / TV_ROWS) loads per thread, all in
+// flight together: T was written by another launch a moment ago and comes from memory, one round trip instead of the
+// four of the 32-column form (26 workgroups, 26 loads per thread); 64-byte pieces of a row per workgroup.  The TV_ROWS
+// partial sums per column are added in ascending order.  x goes to xout (not onto y: other workgroups still read it);
+// if xn is given, xn = x0 + x is written as well (the update's new iterate).
+#define TV_COLS 8
+#define TV_ROWS 128
+__global__ __launch_bounds__(TV_COLS * TV_ROWS) void k_tvec(const double *__restrict__ T, int n, const double *__restrict__ y,
+                                                           double *__restrict__ xout, const double *__restrict__ x0,
+                                                           double *__restrict__ xn)
 {
-    __shared__ double S[DNB][DNB + 1];
-    const int J = blockIdx.x, t = threadIdx.x, g = t / DNB, c = t % DNB;
-    const int col = J * DNB + c;
+    __shared__ double S[TV_ROWS][TV_COLS + 1];
+    const int t = threadIdx.x, g = t / TV_COLS, c = t % TV_COLS;
+    const int col0 = blockIdx.x * TV_COLS, col = col0 + c;
+    const int i0 = (col0 / DNB) * DNB;            // TV_COLS divides DNB: the columns of a workgroup share their diagonal block
     double acc = 0.0;
     if (col < n) {
 #pragma unroll 8
-        for (int i = J * DNB + g; i < n; i += DNB) acc = acc + T[(size_t)i * n + col] * y[i];
+        for (int i = i0 + g; i < n; i += TV_ROWS) acc = acc + T[(size_t)i * n + col] * y[i];
     }
     S[g][c] = acc;
     __syncthreads();
-    if (t < DNB && J * DNB + t < n) {
+    if (t < TV_COLS && col0 + t < n) {
         double v = 0.0;
 #pragma unroll 8
-        for (int q = 0; q < DNB; q++) v = v + S[q][t];
-        xout[J * DNB + t] = v;
-        if (xn) xn[J * DNB + t] = x0[J * DNB + t] + 1.0 * v;
+        for (int q = 0; q < TV_ROWS; q++) v = v + S[q][t];
+        xout[col0 + t] = v;
+        if (xn) xn[col0 + t] = x0[col0 + t] + 1.0 * v;
     }
 }
 
@@ -469,24 +476,18 @@ __global__ __launch_bounds__(256) void k_assemble(const double *__restrict__ inv
 }
 
 // ---- end of one iteration of hm_update_run ---------------------------------------------------------------
-// res (host-visible, coherent) = [step (n) | the four error sums, partials added in index order |
-// overflow flag | ticket | (spare) | factorisation time-out].  One workgroup; the partials are staged in LDS so that the in-order sums do
-// not wait on memory.  The ticket is written last, after a system-scope fence: a host that sees it
-// sees the rest.
+// res (host-visible, coherent) = [step (n) | the four error sums of the render's per-tile partials (fixed order:
+// d_tile_partial_sums) | overflow flag | ticket | (spare) | factorisation time-out].  One workgroup.  The ticket is
+// written last, after a system-scope fence: a host that sees it sees the rest.
 __global__ __launch_bounds__(256) void k_iter_result(const double *__restrict__ step, int n, const double *__restrict__ partial,
-                                                     int nblocks, const int *__restrict__ overflow,
+                                                     int ntiles, const int *__restrict__ overflow,
                                                      const unsigned *__restrict__ flow_ctl, double *__restrict__ res, double ticket)
 {
-    extern __shared__ double sp[];                // 4 * nblocks
+    __shared__ double sp[RI_GROUPS * 4];
     const int t = threadIdx.x;
-    for (int i = t; i < 4 * nblocks; i += 256) sp[i] = partial[i];
     for (int i = t; i < n; i += 256) res[i] = step[i];
-    __syncthreads();
-    if (t < 4) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; b++) s += sp[4 * b + t];
-        res[n + t] = s;
-    } else if (t == 4) {
+    d_tile_partial_sums(partial, ntiles, sp, res + n);
+    if (t == 4) {
         res[n + 4] = (double)*overflow;
     } else if (t == 5) {
         res[n + 7] = (double)flow_ctl[1];             // a wait of the persistent factorisation launch timed out

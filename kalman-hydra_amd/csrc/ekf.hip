@@ -23,6 +23,7 @@ struct hm_ctx {
     hipStream_t stream;
     // mesh
     int *d_tri, *d_star_off, *d_star_tri, *d_edges;
+    int *d_nb_off = nullptr, *d_nb_u = nullptr, *d_nb_e = nullptr;   // per vertex: neighbours (ascending) and their edge jobs (k_solve_prep)
     float *d_uv;
     uint8_t *d_tex;
     std::vector<int> edges;          // host copy, E*2
@@ -63,6 +64,9 @@ struct hm_ctx {
     bool prefactored;                // d_invW0 is the inverse of the resident covariance d_Wprior (hm_update_prefactor)
     std::vector<double> h_partial;
     int red_blocks;
+    double *d_tpart = nullptr;       // per-tile partial sums of Renderer.error from k_render_iter (tiles x 4)
+    std::vector<double> h_tpart;
+    int ntiles = 0;
     long long run_ticket;            // sequence number of hm_update_run's per-iteration result blocks
     int vsplit, esplit;              // workgroups per vertex / per edge job of the measurement (hm_ctx_tune)
     // hm_update_arm_newton: what the next hm_update_run starts when its state is final
@@ -162,10 +166,10 @@ static int ctx_free(hm_ctx *h)
                     h->d_yfy, h->d_yfxm, h->d_yfym, h->d_setup, h->d_cfgs, h->d_ubox, h->d_X, h->d_out, h->d_partial, h->d_im8, h->d_m8,
                     h->d_HTH, h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_T[0], h->d_T[1], h->d_step, h->d_Wprior, h->d_gain, h->d_Awork, h->d_Lt[0], h->d_Lt[1],
                     h->d_Wtmp, h->d_X0, h->d_Xn, h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk,
-                    h->pool.hdr, h->pool.xi, h->pool.yi, h->pool.xfx, h->pool.xfy,
+                    h->pool.hdr, h->pool.live, h->pool.xi, h->pool.yi, h->pool.xfx, h->pool.xfy,
                     h->pool.yfx, h->pool.yfy, h->pool.vxfx, h->pool.vyfy, h->pool.overflow, h->d_area,
                     h->d_outline, h->d_outline_cnt, h->d_pm_mask, h->d_pm_X, h->d_ids[0], h->d_ids[1], h->d_ids[2], h->d_labels, h->d_lbox,
-                    h->d_lout, h->d_flowP, h->d_flowctl, h->d_nbars, h->d_nvoff, h->d_nvbar, h->d_ninfo, h->d_nl0, h->d_nX};
+                    h->d_lout, h->d_tpart, h->d_nb_off, h->d_nb_u, h->d_nb_e, h->d_flowP, h->d_flowctl, h->d_nbars, h->d_nvoff, h->d_nvbar, h->d_ninfo, h->d_nl0, h->d_nX};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     free_targets(h->ref);
@@ -254,6 +258,27 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     step(upload(&h->d_star_off, off.data(), off.size()));
     step(upload(&h->d_star_tri, flat.data(), flat.size()));
     step(upload(&h->d_edges, h->edges.data(), h->edges.size()));
+    {   // neighbours of every vertex with the edge job that holds their block of HTH
+        std::vector<std::vector<std::pair<int, int>>> nb(N);
+        for (int e = 0; e < h->E; e++) {
+            const int a = h->edges[2 * e], b = h->edges[2 * e + 1];
+            nb[a].push_back(std::make_pair(b, e));
+            nb[b].push_back(std::make_pair(a, e));
+        }
+        std::vector<int> noff(N + 1, 0), nu, ne;
+        for (int v = 0; v < N; v++) {
+            std::sort(nb[v].begin(), nb[v].end());
+            noff[v + 1] = noff[v] + (int)nb[v].size();
+            for (const auto &q : nb[v]) { nu.push_back(q.first); ne.push_back(q.second); }
+            if (rc == HM_OK && 4 * ((int)nb[v].size() + 1) > PREP_MAX_ENTRIES) {
+                hm_set_error("hm_ctx_create: vertex %d has %d neighbours, limit %d", v, (int)nb[v].size(), PREP_MAX_ENTRIES / 4 - 1);
+                rc = HM_ERR_ARG;
+            }
+        }
+        step(upload(&h->d_nb_off, noff.data(), noff.size()));
+        step(upload(&h->d_nb_u, nu.data(), nu.size()));
+        step(upload(&h->d_nb_e, ne.data(), ne.size()));
+    }
     if (rc == HM_OK) {
         hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_tex, n);
@@ -269,6 +294,8 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_X, (size_t)4 * N * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_out, (size_t)h->njobs * MEAS_VSPLIT_MAX * MEAS_OUT * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_partial, (size_t)h->red_blocks * 4 * sizeof(double));
+        h->ntiles = hm_cdiv(W, RI_W) * hm_cdiv(H, RI_H);        // strips of k_render_iter
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_tpart, (size_t)h->ntiles * 4 * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_im8, n);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_m8, n);
         const size_t n4 = (size_t)4 * N, nn = n4 * n4 * sizeof(double);
@@ -306,6 +333,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         const size_t pc = (size_t)h->pool.cap;
         if (e == hipSuccess) e = hipMalloc((void **)&h->pool.hdr, (size_t)4 * N * sizeof(int));
         if (e == hipSuccess) e = hipMalloc((void **)&h->pool.overflow, sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->pool.live, (pc / 64 + 1) * sizeof(int));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_area, (size_t)N * sizeof(int));
         h->pool.area = h->d_area;
         short2 **sp[] = {&h->pool.xi, &h->pool.yi};
@@ -328,6 +356,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         return rc;
     }
     h->h_partial.resize((size_t)h->red_blocks * 4);
+    h->h_tpart.resize((size_t)h->ntiles * 4);
     *out = h;
     return HM_OK;
 }
@@ -440,6 +469,45 @@ static int render_into(hm_ctx *h, const double *X, Targets t)
 {
     HM_HIP(hipMemcpyAsync(h->d_X, X, (size_t)4 * h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
     return render_dev(h, h->d_X, t);
+}
+
+static void measure_args(hm_ctx *h, const double *dX, double deltaX, int masked, MeasureArgs &a);
+
+// The render of the device-resident state dX into target t as ONE launch (k_render_iter): triangle setups made per
+// tile, optionally the per-tile partial sums of Renderer.error against the observation (d_tpart) and, riding along
+// as extra workgroups, the star regions of the measurement at dX (they read nothing but the state).
+static int render_iter(hm_ctx *h, const double *dX, Targets t, bool with_err, int masked, bool regions, double deltaX)
+{
+    IterRenderArgs r;
+    r.m = Mesh{h->W, h->H, h->N, h->T, h->d_tri, h->d_uv, h->d_tex};
+    r.X = dX;
+    r.out = t;
+    r.o = Obs{h->o_yim, masked ? h->d_yfxm : h->o_yfx, masked ? h->d_yfym : h->o_yfy, h->o_ym};
+    r.partial = h->d_tpart;
+    r.tiles_x = hm_cdiv(h->W, RI_W); r.tiles_y = hm_cdiv(h->H, RI_H);
+    r.with_err = with_err ? 1 : 0;
+    r.n_regions = regions ? h->N : 0;
+    MeasureArgs a;
+    measure_args(h, dX, deltaX, masked, a);
+    hipLaunchKernelGGL(k_render_iter, dim3(r.n_regions + h->ntiles), dim3(256), 0, h->stream, r, a, h->d_area);
+    HM_HIP(hipGetLastError());
+    return HM_OK;
+}
+
+// the four sums of Renderer.error from the per-tile partials, added in the order of d_tile_partial_sums
+static void hm_tile_partial_sums(const double *p, int ntiles, double s[4])
+{
+    double g[RI_GROUPS][4];
+    for (int t = 0; t < RI_GROUPS; t++) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (int i = t; i < ntiles; i += RI_GROUPS) { s0 += p[4 * (size_t)i]; s1 += p[4 * (size_t)i + 1]; s2 += p[4 * (size_t)i + 2]; s3 += p[4 * (size_t)i + 3]; }
+        g[t][0] = s0; g[t][1] = s1; g[t][2] = s2; g[t][3] = s3;
+    }
+    for (int k = 0; k < 4; k++) {
+        double v = 0.0;
+        for (int t = 0; t < RI_GROUPS; t++) v += g[t][k];
+        s[k] = v;
+    }
 }
 
 #define NEED_TEX(h, who) \
@@ -687,22 +755,15 @@ extern "C" int hm_error(hm_ctx_t h, const double *X, int masked, double err[4], 
 
 // render X as the reference, run the fused perturb-and-reduce kernel, unpack into d_H / d_Hz / d_Hzc
 // the measurement at the device-resident state dX, whose render is (ref_ready) or is to be put in h->ref
-static void measure_args(hm_ctx *h, const double *dX, double deltaX, int masked, MeasureArgs &a);
-
-// the star regions and triangle setups of the measurement at dX (the first launch of measure_dev, which a
-// caller that knows the next state early may issue ahead: it reads nothing but the state)
-static void measure_regions(hm_ctx *h, const double *dX, double deltaX)
+// scatter: the job sums go to the dense HTH / Hz / Hzc (hm_measure); the update loop forms its system from the job
+// sums directly (k_solve_prep) and leaves that launch out
+static int measure_dev(hm_ctx *h, const double *dX, bool ref_ready, double deltaX, int masked, bool regions_ready = false,
+                       bool scatter = true)
 {
-    MeasureArgs a;
-    measure_args(h, dX, deltaX, 0, a);
-    hipLaunchKernelGGL(k_star_regions, dim3(h->N), dim3(REGION_NT), 0, h->stream, a, h->d_area);
-}
-
-static int measure_dev(hm_ctx *h, const double *dX, bool ref_ready, double deltaX, int masked, bool regions_ready = false)
-{
-    if (!ref_ready) {
-        int rc = render_dev(h, dX, h->ref);
+    if (!ref_ready) {                             // the reference render, and the star regions with it when they are wanted too
+        int rc = render_iter(h, dX, h->ref, false, masked, !regions_ready, deltaX);
         if (rc) return rc;
+        regions_ready = true;
     }
     MeasureArgs a;
     measure_args(h, dX, deltaX, masked, a);
@@ -710,8 +771,10 @@ static int measure_dev(hm_ctx *h, const double *dX, bool ref_ready, double delta
     hipLaunchKernelGGL(k_measure_vertex, dim3(h->N, h->vsplit), dim3(MEAS_NT), 0, h->stream, a,
                        (const TriSetup *)h->d_cfgs, (const int4 *)h->d_ubox);
     if (h->E > 0) hipLaunchKernelGGL(k_measure_edge, dim3(h->E, h->esplit), dim3(MEAS_NT), 0, h->stream, a);
-    ScatterArgs s = {h->d_out, h->d_edges, h->N, h->E, h->vsplit, h->esplit, h->eps_Z, h->eps_J, h->eps_M, deltaX, h->d_HTH, h->d_Hz, h->d_Hzc};
-    hipLaunchKernelGGL(k_hth_scatter, dim3(hm_cdiv(h->njobs, 4)), dim3(256), 0, h->stream, s);
+    if (scatter) {
+        ScatterArgs s = {h->d_out, h->d_edges, h->N, h->E, h->vsplit, h->esplit, h->eps_Z, h->eps_J, h->eps_M, deltaX, h->d_HTH, h->d_Hz, h->d_Hzc};
+        hipLaunchKernelGGL(k_hth_scatter, dim3(hm_cdiv(h->njobs, 4)), dim3(256), 0, h->stream, s);
+    }
     HM_HIP(hipGetLastError());
     return HM_OK;
 }
@@ -733,12 +796,12 @@ static void measure_args(hm_ctx *h, const double *dX, double deltaX, int masked,
     a.ubox = h->d_ubox;
 }
 
-static int measure_on_device(hm_ctx *h, const double *X, double deltaX, int masked)
+static int measure_on_device(hm_ctx *h, const double *X, double deltaX, int masked, bool scatter = true)
 {
     HM_HIP(hipMemcpyAsync(h->d_X, X, (size_t)4 * h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
     h->X0.assign(X, X + 4 * h->N);
     h->have_ref = true;
-    return measure_dev(h, h->d_X, false, deltaX, masked);
+    return measure_dev(h, h->d_X, false, deltaX, masked, false, scatter);
 }
 
 extern "C" int hm_measure(hm_ctx_t h, const double *X, double deltaX, int masked, double *Hz, double *Hzc, double *HTH)
@@ -818,7 +881,7 @@ static int flow_status(hm_ctx *h, const char *who)
 
 // one iteration's worth of launches of the update: system assembly, factorisation, solve.
 // d_X holds the iterate the measurement was taken at; returns the step (d_step).
-static double *solve_step(hm_ctx *h, int slot)
+static double *solve_step(hm_ctx *h, int slot, double deltaX)
 {
     const int n4 = 4 * h->N;
     double *A = h->d_Awork;
@@ -826,22 +889,25 @@ static double *solve_step(hm_ctx *h, int slot)
     // matrix; the rows in between and the rest of that block zero
     const int rhs_index = hm_cdiv(n4, DNB) * DNB;
     double *rhs_row = A + (size_t)rhs_index * n4;
-    if (h->chol_flow) {
+    {   // one pass from the job sums of the measurement: A, the right-hand side, Hz / Hzc, and the pre-fill of what
+        // the persistent factorisation launch produces (harmless for the launch-per-step form, which overwrites it)
         const int nb = hm_cdiv(n4, DNB), nrows = aug_rows(n4);
-        FlowArgs f = {A, h->d_Af[slot], h->d_Lt[slot], h->d_T[slot], h->d_flowP, n4, nrows, nb, hm_cdiv(nrows, DNB), h->d_flowctl, 0};
-        hipLaunchKernelGGL(k_assemble_flow, dim3(nrows + 1), dim3(256), 0, h->stream, h->d_invW0, h->d_HTH, h->d_X0, h->d_X,
-                           h->d_Hz, A, n4, rhs_index, f);
-    } else {
-        hipLaunchKernelGGL(k_assemble, dim3(aug_rows(n4) + 1), dim3(256), 0, h->stream, h->d_invW0, h->d_HTH, h->d_X0, h->d_X,
-                           h->d_Hz, A, n4, rhs_index, h->d_Lt[slot]);
+        PrepArgs p;
+        p.out = h->d_out; p.N = h->N; p.vsplit = h->vsplit; p.esplit = h->esplit;
+        p.eZ = h->eps_Z; p.eJ = h->eps_J; p.eM = h->eps_M; p.d = deltaX;
+        p.nb_off = h->d_nb_off; p.nb_u = h->d_nb_u; p.nb_e = h->d_nb_e;
+        p.invW0 = h->d_invW0; p.X0 = h->d_X0; p.X = h->d_X;
+        p.A = A; p.Hz = h->d_Hz; p.Hzc = h->d_Hzc; p.n = n4; p.rhs_row = rhs_index;
+        p.f = FlowArgs{A, h->d_Af[slot], h->d_Lt[slot], h->d_T[slot], h->d_flowP, n4, nrows, nb, hm_cdiv(nrows, DNB), h->d_flowctl, 0};
+        hipLaunchKernelGGL(k_solve_prep, dim3(nrows + 1), dim3(256), 0, h->stream, p);
     }
     if (h->d_Wres == h->d_Wtmp) h->d_Wres = nullptr;          // a covariance predicted since hm_update_begin is lost
-    chol_factor(h, A, h->d_Af[slot], h->d_Lt[slot], h->d_T[slot], h->d_Wtmp, n4, true, true);
+    chol_factor(h, A, h->d_Af[slot], h->d_Lt[slot], h->d_T[slot], h->d_Wtmp, n4, true, h->chol_flow != 0);
     // y = L^-1 b came out of the factorisation as the extra row and T = L^-1 with it (d_Wtmp was the
     // scratch: it is free between hm_update_begin and the next hm_cov_predict); x = T^T y.  T stays in the
     // slot for hm_update_cov (inv = T^T T).
     const double *yrow = h->d_Af[slot] + (rhs_row - A);
-    hipLaunchKernelGGL(k_tvec, dim3(hm_cdiv(n4, DNB)), dim3(1024), 0, h->stream, h->d_T[slot], n4, yrow, h->d_step, h->d_X0,
+    hipLaunchKernelGGL(k_tvec, dim3(hm_cdiv(n4, TV_COLS)), dim3(TV_COLS * TV_ROWS), 0, h->stream, h->d_T[slot], n4, yrow, h->d_step, h->d_X0,
                        h->d_Xn);                              // also d_Xn = X0 + step
     return h->d_step;
 }
@@ -928,10 +994,10 @@ extern "C" int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int ma
     NEED_OBS(h, "hm_update_step");
     HM_HIP(hipSetDevice(h->device));
     const int n4 = 4 * h->N;
-    int rc = measure_on_device(h, X, deltaX, masked);          // leaves X in d_X
+    int rc = measure_on_device(h, X, deltaX, masked, false);   // leaves X in d_X; the job sums go straight into the system
     if (rc) return rc;
     const int slot = h->upd_last == 0 ? 1 : 0;
-    double *rhs_row = solve_step(h, slot);
+    double *rhs_row = solve_step(h, slot, deltaX);
     HM_HIP(hipGetLastError());
     HM_HIP(hipMemcpyAsync(step, rhs_row, (size_t)n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (Hzc) HM_HIP(hipMemcpyAsync(Hzc, h->d_Hzc, (size_t)n4 * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -939,12 +1005,14 @@ extern "C" int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int ma
     *ovf = 0;
     HM_HIP(hipMemcpyAsync(ovf, h->pool.overflow, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (err) {
-        // Renderer.error of the new iterate X0 + step, without another host round trip
-        rc = render_dev(h, h->d_Xn, h->P);
+        // Renderer.error of the new iterate X0 + step, without another host round trip: the launch and the order of
+        // additions hm_update_run uses
+        rc = render_iter(h, h->d_Xn, h->P, true, masked, false, deltaX);
         if (rc == HM_OK) {
-            hipLaunchKernelGGL(k_error, dim3(h->red_blocks), dim3(RED_NT), 0, h->stream, h->P, obs_of(h, masked),
-                               h->W * h->H, h->d_partial);
-            rc = collect4(h, err);                               // synchronises the stream
+            hipError_t e = hipMemcpyAsync(h->h_tpart.data(), h->d_tpart, (size_t)h->ntiles * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess) e = stream_wait(h->stream);
+            if (e != hipSuccess) { hm_set_error("hm_update_step: %s", hipGetErrorString(e)); rc = HM_ERR_HIP; }
+            else hm_tile_partial_sums(h->h_tpart.data(), h->ntiles, err);
         }
         if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }   // nothing of this call stays in flight
     } else {
@@ -1109,23 +1177,20 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
     bool reverted = false, conv = false, ref_ready = false, regions_ahead = false;
     double eold = 0.0;
     for (int it = 0; it < max_iter; it++) {
-        rc = measure_dev(h, h->d_X, ref_ready, deltaX, masked, regions_ahead);
+        rc = measure_dev(h, h->d_X, ref_ready, deltaX, masked, regions_ahead, false);
         if (rc) return rc;
         h->X0 = Xcur;                              // the state of the reference render (hm_jz / hm_j)
         h->have_ref = true;
         const int slot = h->upd_last == 0 ? 1 : 0;
-        double *rhs_row = solve_step(h, slot);
-        // the new iterate, its render and Renderer.error (kalman.py:813)
-        rc = render_dev(h, h->d_Xn, h->P);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_error, dim3(h->red_blocks), dim3(RED_NT), 0, h->stream, h->P, obs_of(h, masked),
-                           h->W * h->H, h->d_partial);
-        hipLaunchKernelGGL(k_iter_result, dim3(1), dim3(256), (size_t)h->red_blocks * 4 * sizeof(double), h->stream, rhs_row, n4, h->d_partial,
-                           h->red_blocks, h->pool.overflow, (const unsigned *)h->d_flowctl, res, (double)(++h->run_ticket));
-        // the star regions of the next measurement (it needs the new iterate only) run while the host looks
-        // at this iteration's result; wasted when the loop ends here
+        double *rhs_row = solve_step(h, slot, deltaX);
+        // the new iterate: its render, the partial sums of Renderer.error (kalman.py:813) and, as extra workgroups of
+        // the same launch, the star regions of the next measurement (they need the new iterate only; wasted when the
+        // loop ends here)
         regions_ahead = it + 1 < max_iter;
-        if (regions_ahead) measure_regions(h, h->d_Xn, deltaX);
+        rc = render_iter(h, h->d_Xn, h->P, true, masked, regions_ahead, deltaX);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_iter_result, dim3(1), dim3(256), 0, h->stream, rhs_row, n4, h->d_tpart,
+                           h->ntiles, h->pool.overflow, (const unsigned *)h->d_flowctl, res, (double)(++h->run_ticket));
         HM_HIP(hipGetLastError());
         rc = wait_ticket(h, res + n4 + 5, (double)h->run_ticket);
         if (rc) return rc;

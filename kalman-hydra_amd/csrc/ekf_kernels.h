@@ -47,19 +47,47 @@ __device__ __forceinline__ void d_tri_attr(TriSetup &s, const float *__restrict_
 
 __device__ __forceinline__ long long d_snap(double x) { return (long long)rint(x * (double)EKF_SUB); }
 
+// Pixel bounding box (inclusive) of the triangle with snapped integer positions, as d_tri_setup keeps it: empty
+// (cmin > cmax) for a degenerate or out-of-range triangle.  One function for every caller: a tile that asks "can
+// this triangle reach me" gets the answer the setup itself would give.
+__device__ __forceinline__ bool d_tri_sane(long long x0, long long y0, long long x1, long long y1, long long x2, long long y2)
+{
+    const long long lim = (long long)1 << 32;     // 2^24 px in 1/256 px units: the exact range of the edge functions
+    return x0 > -lim && x0 < lim && y0 > -lim && y0 < lim && x1 > -lim && x1 < lim && y1 > -lim && y1 < lim &&
+           x2 > -lim && x2 < lim && y2 > -lim && y2 < lim;
+}
+__device__ __forceinline__ void d_tri_bbox(long long x0, long long y0, long long x1, long long y1, long long x2, long long y2,
+                                           int W, int H, int &cmin, int &cmax, int &rmin, int &rmax)
+{
+    cmin = 1; cmax = 0; rmin = 1; rmax = 0;
+    const long long area = d_tri_sane(x0, y0, x1, y1, x2, y2) ? (x1 - x0) * (y2 - y0) - (y1 - y0) * (x2 - x0) : 0;
+    if (area == 0) return;
+    long long xmin = x0 < x1 ? (x0 < x2 ? x0 : x2) : (x1 < x2 ? x1 : x2);
+    long long xmax = x0 > x1 ? (x0 > x2 ? x0 : x2) : (x1 > x2 ? x1 : x2);
+    long long ymin = y0 < y1 ? (y0 < y2 ? y0 : y2) : (y1 < y2 ? y1 : y2);
+    long long ymax = y0 > y1 ? (y0 > y2 ? y0 : y2) : (y1 > y2 ? y1 : y2);
+    // floor division by 256 (arithmetic shift), as in the oracle
+    long long cl = (xmin - 128) >> 8, ch = ((xmax - 128) >> 8) + 1;
+    long long rl = (ymin - 128) >> 8, rh = ((ymax - 128) >> 8) + 1;
+    if (cl < 0) cl = 0;
+    if (rl < 0) rl = 0;
+    if (ch > W - 1) ch = W - 1;
+    if (rh > H - 1) rh = H - 1;
+    cmin = (int)cl; cmax = (int)ch; rmin = (int)rl; rmax = (int)rh;
+}
+
 // Build the setup of triangle (v0,v1,v2) with snapped integer positions p[3][2].
 __device__ inline void d_tri_setup(TriSetup &s, int v0, int v1, int v2, long long x0, long long y0,
                                    long long x1, long long y1, long long x2, long long y2, int W, int H)
 {
     s.cmin = 1; s.cmax = 0; s.rmin = 1; s.rmax = 0;
-    const long long lim = (long long)1 << 32;     // 2^24 px in 1/256 px units: the exact range of the edge functions
-    const bool sane = x0 > -lim && x0 < lim && y0 > -lim && y0 < lim && x1 > -lim && x1 < lim && y1 > -lim && y1 < lim &&
-                      x2 > -lim && x2 < lim && y2 > -lim && y2 < lim;
+    const bool sane = d_tri_sane(x0, y0, x1, y1, x2, y2);
     long long area = sane ? (x1 - x0) * (y2 - y0) - (y1 - y0) * (x2 - x0) : 0;
     s.i0 = v0; s.i1 = v1; s.i2 = v2;
     s.inv = 0.0f;
     for (int k = 0; k < 3; k++) { s.ea[k] = 0.0; s.eb[k] = 0.0; s.ec[k] = -1.0; s.ecb[k] = -1.0; s.tl[k] = 0; }
     if (area == 0) return;
+    d_tri_bbox(x0, y0, x1, y1, x2, y2, W, H, s.cmin, s.cmax, s.rmin, s.rmax);      // (the box does not depend on the orientation)
     if (area < 0) {
         long long t;
         t = x1; x1 = x2; x2 = t;
@@ -81,18 +109,6 @@ __device__ inline void d_tri_setup(TriSetup &s, int v0, int v1, int v2, long lon
         s.ecb[k] = s.ec[k] + (double)s.tl[k];
     }
     s.inv = 1.0f / (float)area;
-    long long xmin = x0 < x1 ? (x0 < x2 ? x0 : x2) : (x1 < x2 ? x1 : x2);
-    long long xmax = x0 > x1 ? (x0 > x2 ? x0 : x2) : (x1 > x2 ? x1 : x2);
-    long long ymin = y0 < y1 ? (y0 < y2 ? y0 : y2) : (y1 < y2 ? y1 : y2);
-    long long ymax = y0 > y1 ? (y0 > y2 ? y0 : y2) : (y1 > y2 ? y1 : y2);
-    // floor division by 256 (arithmetic shift), as in the oracle
-    long long cl = (xmin - 128) >> 8, ch = ((xmax - 128) >> 8) + 1;
-    long long rl = (ymin - 128) >> 8, rh = ((ymax - 128) >> 8) + 1;
-    if (cl < 0) cl = 0;
-    if (rl < 0) rl = 0;
-    if (ch > W - 1) ch = W - 1;
-    if (rh > H - 1) rh = H - 1;
-    s.cmin = (int)cl; s.cmax = (int)ch; s.rmin = (int)rl; s.rmax = (int)rh;
 }
 
 // coverage of the pixel centre (dc, dr) without the bounding-box shortcut and without branches (for
@@ -528,25 +544,27 @@ __device__ __forceinline__ Diff d_diff(const double *k255, int racc, int rcnt, f
 }
 
 // star setups of vertex v: cfg[0] = reference positions, cfg[1..] = v moved by dx / dy
+__device__ inline void d_star_setup_one(TriSetup &out, int t, const Mesh &m, const double *X, int v, double dx, double dy)
+{
+    int v0 = m.tri[3 * t], v1 = m.tri[3 * t + 1], v2 = m.tri[3 * t + 2];
+    double px[3] = {X[2 * v0], X[2 * v1], X[2 * v2]}, py[3] = {X[2 * v0 + 1], X[2 * v1 + 1], X[2 * v2 + 1]};
+    int vs[3] = {v0, v1, v2};
+    for (int q = 0; q < 3; q++)
+        if (vs[q] == v) { px[q] += dx; py[q] += dy; }
+    d_tri_setup(out, v0, v1, v2, d_snap(px[0]), d_snap(py[0]), d_snap(px[1]), d_snap(py[1]), d_snap(px[2]),
+                d_snap(py[2]), m.W, m.H);
+    d_tri_attr(out, m.uv, X, m.N);
+}
+__device__ inline void d_star_setup_pad(TriSetup &e)     // a triangle that covers nothing (pads a star to an even count)
+{
+    e.cmin = 1; e.cmax = 0; e.rmin = 1; e.rmax = 0;
+    for (int k = 0; k < 3; k++) { e.ea[k] = 0.0; e.eb[k] = 0.0; e.ec[k] = -1.0; e.ecb[k] = -1.0; e.tl[k] = 0; }
+}
 __device__ inline void d_star_setups(TriSetup *dst, int ns, const int *tris, const Mesh &m, const double *X, int v,
                                      double dx, double dy, int lane, int stride)
 {
-    for (int k = lane; k < ns; k += stride) {
-        int t = tris[k];
-        int v0 = m.tri[3 * t], v1 = m.tri[3 * t + 1], v2 = m.tri[3 * t + 2];
-        double px[3] = {X[2 * v0], X[2 * v1], X[2 * v2]}, py[3] = {X[2 * v0 + 1], X[2 * v1 + 1], X[2 * v2 + 1]};
-        int vs[3] = {v0, v1, v2};
-        for (int q = 0; q < 3; q++)
-            if (vs[q] == v) { px[q] += dx; py[q] += dy; }
-        d_tri_setup(dst[k], v0, v1, v2, d_snap(px[0]), d_snap(py[0]), d_snap(px[1]), d_snap(py[1]), d_snap(px[2]),
-                    d_snap(py[2]), m.W, m.H);
-        d_tri_attr(dst[k], m.uv, X, m.N);
-    }
-    if ((ns & 1) && lane == 0) {                   // pad to an even count with a triangle that covers nothing
-        TriSetup &e = dst[ns];
-        e.cmin = 1; e.cmax = 0; e.rmin = 1; e.rmax = 0;
-        for (int k = 0; k < 3; k++) { e.ea[k] = 0.0; e.eb[k] = 0.0; e.ec[k] = -1.0; e.ecb[k] = -1.0; e.tl[k] = 0; }
-    }
+    for (int k = lane; k < ns; k += stride) d_star_setup_one(dst[k], tris[k], m, X, v, dx, dy);
+    if ((ns & 1) && lane == 0) d_star_setup_pad(dst[ns]);
 }
 
 // Difference images of the forward position perturbations, kept for the edge jobs.  For every
@@ -566,9 +584,17 @@ __device__ inline void d_star_setups(TriSetup *dst, int ns, const int *tris, con
 // seven planes of such pixels unwritten saves 16 MB of writes and costs 59 MB of reads (lines written in part are
 // read back and merged by the memory side), no time gained; and skipping a tile no triangle reaches before its
 // loads pushes the vertex kernel over its 128 registers (253 spilled, 85 -> 400 us).
+// TILE-MAJOR: a region is a grid of 8x8-pixel tiles (c0, r0, rw, rh all multiples of 8, so the tiles of all regions lie
+// on one grid of the frame) and a tile's 64 pixels are contiguous in every plane: a wave parks a tile with one
+// 256-byte store per plane and an edge job reads it back the same way.  Row-major regions had every 8-pixel tile row
+// a separate 32-byte piece: 150 MB counted at the memory side for 50 MB of payload (profiles/r02_ekf_traffic.csv).
+// live[] has one word per tile: 0 when no pixel of the tile is covered in any configuration -- an edge job looks at
+// the two words before it touches the tile's planes.  Pixels of a padded tile that lie outside the frame are parked
+// as empty ones.
 #define POOL_EMPTY 0x7FFF
 struct DPool {
-    int *hdr;                 // N x 4: c0, r0, rw, rh of the region (c0 and rw multiples of 8)
+    int *hdr;                 // N x 4: c0, r0, rw, rh of the region (all multiples of 8)
+    int *live;                // one word per tile of the pool (cap / 64)
     const int *area;          // N region areas (k_star_regions); a region's offset is the sum of those before it
     short2 *xi, *yi;          // (image, mask) numerators of D_{v,x} and D_{v,y}
     float *xfx, *xfy, *yfx, *yfy, *vxfx, *vyfy;
@@ -636,60 +662,83 @@ __device__ inline void d_vertex_cfgs(TriSetup (*cfg)[EKF_MAX_STAR + 1], int nsv,
 }
 
 // ---- pass 0: star regions and their places in the pool -------------------------------------------------
-// One wave per configuration (MEAS_NCFG waves per vertex): setups in parallel, then the bounding box
+// One wave per configuration where there are enough (MEAS_NCFG waves per vertex in a launch of its own, four when
+// the regions ride along with the render of the iterate, k_render_iter): setups in parallel, then the bounding box
 // of the star over all configurations by a lane-parallel min/max.
 #define REGION_NT (64 * MEAS_NCFG)
-__global__ __launch_bounds__(REGION_NT) void k_star_regions(MeasureArgs a, int *__restrict__ area)
+struct RegionShared {
+    int4 tbox[MEAS_NCFG][EKF_MAX_STAR + 1];      // pixel box of every star triangle in every configuration (cmin, cmax, rmin, rmax)
+    int box[MEAS_NCFG][4];
+};
+template <int NT>
+__device__ inline void d_star_regions(const MeasureArgs &a, int *__restrict__ area, int v, RegionShared &sh)
 {
-    __shared__ TriSetup s_cfg[MEAS_NCFG][EKF_MAX_STAR + 1];
-    __shared__ int s_box[MEAS_NCFG][4];
     const Mesh &m = a.m;
-    const int v = blockIdx.x;
     const int nsv = a.topo.star_off[v + 1] - a.topo.star_off[v];
-    d_vertex_cfgs(s_cfg, nsv, a.topo.star_tri + a.topo.star_off[v], m, a.X, v, a.delta, REGION_NT);
-    __syncthreads();
+    const int *trv = a.topo.star_tri + a.topo.star_off[v];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    {   // keep the setups (with the padding entry) for the measurement kernel
-        constexpr int TW = sizeof(TriSetup) / 4;
-        const int used = (nsv + (nsv & 1)) * TW;
-        const int *src = (const int *)s_cfg[wv];
-        int *dst = (int *)(a.cfgs + ((size_t)v * MEAS_NCFG + wv) * (EKF_MAX_STAR + 1));
-        for (int i = lane; i < used; i += 64) dst[i] = src[i];
+    constexpr int NW = NT / 64;
+    const double d = a.delta;
+    const double dxs[MEAS_NCFG] = {0, d, -d, 0, 0}, dys[MEAS_NCFG] = {0, 0, 0, d, -d};
+    for (int cf = wv; cf < MEAS_NCFG; cf += NW) {
+        // lane k sets up triangle k of the star in configuration cf and stores it where k_measure_vertex reads it
+        // (the padding entry behind an odd count covers nothing); the box stays in LDS for the region
+        TriSetup *dst = a.cfgs + ((size_t)v * MEAS_NCFG + cf) * (EKF_MAX_STAR + 1);
+        if (lane < nsv) {
+            TriSetup su;
+            d_star_setup_one(su, trv[lane], m, a.X, v, dxs[cf], dys[cf]);
+            dst[lane] = su;
+            sh.tbox[cf][lane] = make_int4(su.cmin, su.cmax, su.rmin, su.rmax);
+        }
+        if ((nsv & 1) && lane == 0) {
+            TriSetup pad;
+            d_star_setup_pad(pad);
+            pad.inv = 0.0f; pad.i0 = pad.i1 = pad.i2 = 0;
+            for (int k = 0; k < 3; k++) { pad.ux[k] = pad.uy[k] = pad.ax[k] = pad.ay[k] = 0.0f; }
+            dst[nsv] = pad;
+        }
     }
+    __syncthreads();
     if (wv == 0 && lane < UBOX_STRIDE) {   // box of triangle `lane` over all configurations (cmin, cmax, rmin, rmax)
         int4 u = make_int4(1, 0, 1, 0);
         if (lane < nsv)
             for (int cfg = 0; cfg < MEAS_NCFG; cfg++) {
-                const TriSetup &s = s_cfg[cfg][lane];
-                if (s.cmin > s.cmax) continue;
-                if (u.x > u.y) u = make_int4(s.cmin, s.cmax, s.rmin, s.rmax);
-                else u = make_int4(min(u.x, s.cmin), max(u.y, s.cmax), min(u.z, s.rmin), max(u.w, s.rmax));
+                const int4 s = sh.tbox[cfg][lane];
+                if (s.x > s.y) continue;
+                if (u.x > u.y) u = s;
+                else u = make_int4(min(u.x, s.x), max(u.y, s.y), min(u.z, s.z), max(u.w, s.w));
             }
         a.ubox[(size_t)v * UBOX_STRIDE + lane] = u;
     }
-    {   // bounding box of this wave's configuration
+    for (int cf = wv; cf < MEAS_NCFG; cf += NW) {   // bounding box of configuration cf
         int c0 = m.W, c1 = -1, r0 = m.H, r1 = -1;
         if (lane < nsv) {
-            const TriSetup &s = s_cfg[wv][lane];
-            if (s.cmin <= s.cmax) { c0 = s.cmin; c1 = s.cmax; r0 = s.rmin; r1 = s.rmax; }
+            const int4 s = sh.tbox[cf][lane];
+            if (s.x <= s.y) { c0 = s.x; c1 = s.y; r0 = s.z; r1 = s.w; }
         }
         for (int o = 16; o > 0; o >>= 1) {          // EKF_MAX_STAR <= 32 lanes carry values
             c0 = min(c0, __shfl_down(c0, o, 64)); c1 = max(c1, __shfl_down(c1, o, 64));
             r0 = min(r0, __shfl_down(r0, o, 64)); r1 = max(r1, __shfl_down(r1, o, 64));
         }
-        if (lane == 0) { s_box[wv][0] = c0; s_box[wv][1] = c1; s_box[wv][2] = r0; s_box[wv][3] = r1; }
+        if (lane == 0) { sh.box[cf][0] = c0; sh.box[cf][1] = c1; sh.box[cf][2] = r0; sh.box[cf][3] = r1; }
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
     int c0 = m.W, c1 = -1, r0 = m.H, r1 = -1;
     for (int cfg = 0; cfg < MEAS_NCFG; cfg++) {
-        c0 = min(c0, s_box[cfg][0]); c1 = max(c1, s_box[cfg][1]);
-        r0 = min(r0, s_box[cfg][2]); r1 = max(r1, s_box[cfg][3]);
+        c0 = min(c0, sh.box[cfg][0]); c1 = max(c1, sh.box[cfg][1]);
+        r0 = min(r0, sh.box[cfg][2]); r1 = max(r1, sh.box[cfg][3]);
     }
-    if (c1 >= c0) c0 &= ~7;                                        // whole sectors: see DPool
-    const int rw = c1 >= c0 ? (c1 - c0 + 8) & ~7 : 0, rh = max(0, r1 - r0 + 1);
+    if (c1 >= c0) { c0 &= ~7; r0 &= ~7; }                         // whole tiles on the frame's 8x8 grid: see DPool
+    const int rw = c1 >= c0 ? (c1 - c0 + 8) & ~7 : 0, rh = (c1 >= c0 && r1 >= r0) ? (r1 - r0 + 8) & ~7 : 0;
     a.pool.hdr[4 * v] = c0; a.pool.hdr[4 * v + 1] = r0; a.pool.hdr[4 * v + 2] = rw; a.pool.hdr[4 * v + 3] = rh;
     area[v] = rw * rh;
+}
+
+__global__ __launch_bounds__(REGION_NT) void k_star_regions(MeasureArgs a, int *__restrict__ area)
+{
+    __shared__ RegionShared sh;
+    d_star_regions<REGION_NT>(a, area, blockIdx.x, sh);
 }
 
 // Places in the pool: the region of vertex v starts at pixel offset sum_{u < v} area[u].  Every
@@ -766,10 +815,12 @@ __global__ __launch_bounds__(MEAS_NT, 4) void k_measure_vertex(MeasureArgs a, co
             const int4 b = ubox[(size_t)v * UBOX_STRIDE + k];
             if (!((b.y < tc0) | (b.x > tc0 + 7) | (b.w < tr0) | (b.z > tr0 + 7))) mask |= 1u << k;
         }
-        if (r >= r0 + rh || c >= c0 + rw || c >= W) continue;      // (the padding of a region may leave the frame)
-        const int i = (r - r0) * rw + (c - c0);
+        const long long pp = base + (long long)tile * 64 + (threadIdx.x & 63);      // tile-major (DPool)
+        if (c >= W || r >= m.H) {                  // the padding of a region may leave the frame
+            if (park) d_park_empty(a.pool, pp);
+            continue;
+        }
         const int p = r * W + c;
-        const long long pp = base + i;
         const int racc = a.ref.acc[p], rcnt = a.ref.cnt[p];
         const float rfx = a.ref.fx[p], rfy = a.ref.fy[p];
         StarVel vel, none;
@@ -786,7 +837,11 @@ __global__ __launch_bounds__(MEAS_NT, 4) void k_measure_vertex(MeasureArgs a, co
             const int e3 = d_star_texels(m.tex, q3), e4 = d_star_texels(m.tex, q4);
             sref.acc += e0; sxp.acc += e1; sxm.acc += e2; syp.acc += e3; sym.acc += e4;
         }
-        if (sref.cnt + sxp.cnt + sxm.cnt + syp.cnt + sym.cnt == 0) {
+        const bool covered = sref.cnt + sxp.cnt + sxm.cnt + syp.cnt + sym.cnt != 0;
+        const bool tile_live = __any(covered);     // (over the lanes inside the frame: at least one, the regions are clipped)
+        if (park && (threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_read_exec()))      // one lane of those still here
+            a.pool.live[base / 64 + tile] = tile_live ? 1 : 0;
+        if (!covered) {
             if (park) d_park_empty(a.pool, pp);
             continue;
         }
@@ -835,7 +890,24 @@ __global__ __launch_bounds__(MEAS_NT, 4) void k_measure_vertex(MeasureArgs a, co
 
 // ---- pass 2: edge jobs ----------------------------------------------------------------------------------------
 // HTH[(v,.),(w,.)] for adjacent vertices: sums of products of the parked difference images over the
-// intersection of the two star regions (outside its own star a difference image is zero).
+// intersection of the two star regions (outside its own star a difference image is zero).  The regions lie on one
+// grid of 8x8 tiles (DPool): a wave takes whole tiles of the intersection.  First every lane looks up the live words of
+// one candidate tile for both vertices (one round trip for up to 64 tiles); the tiles live for both -- those the two
+// shared triangles and their fringes reach -- are then read plane by plane, 256 contiguous bytes per plane and
+// vertex, the loads of the next tile issued before the sums of the current one.
+struct EdgeTile {
+    short2 ax, ay, bx, by;
+    float axfx, axfy, ayfx, ayfy, avx, avy, bxfx, bxfy, byfx, byfy, bvx, bvy;
+};
+__device__ __forceinline__ EdgeTile d_edge_load(const DPool &P, long long pv, long long pw)
+{
+    EdgeTile t;
+    t.ax = P.xi[pv]; t.bx = P.xi[pw]; t.ay = P.yi[pv]; t.by = P.yi[pw];
+    t.axfx = P.xfx[pv]; t.axfy = P.xfy[pv]; t.ayfx = P.yfx[pv]; t.ayfy = P.yfy[pv]; t.avx = P.vxfx[pv]; t.avy = P.vyfy[pv];
+    t.bxfx = P.xfx[pw]; t.bxfy = P.xfy[pw]; t.byfx = P.yfx[pw]; t.byfy = P.yfy[pw]; t.bvx = P.vxfx[pw]; t.bvy = P.vyfy[pw];
+    return t;
+}
+
 __global__ __launch_bounds__(MEAS_NT) void k_measure_edge(MeasureArgs a)
 {
     __shared__ double s_red[(MEAS_NT / 64) * MEAS_OUT];
@@ -847,10 +919,13 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure_edge(MeasureArgs a)
     const int e = blockIdx.x;
     const int v = a.topo.edges[2 * e], w = a.topo.edges[2 * e + 1];
     const int *hv = a.pool.hdr + 4 * v, *hw = a.pool.hdr + 4 * w;
-    const int c0 = max(hv[0], hw[0]), r0 = max(hv[1], hw[1]);
-    const int c1 = min(min(hv[0] + hv[2], hw[0] + hw[2]), a.m.W) - 1, r1 = min(hv[1] + hv[3], hw[1] + hw[3]) - 1;
-    const int rw = c1 - c0 + 1, rh = r1 - r0 + 1;
-    const int npx = (rw > 0 && rh > 0) ? rw * rh : 0;
+    // the intersection of the two regions in tiles of the frame's grid
+    const int tx0 = max(hv[0], hw[0]) >> 3, ty0 = max(hv[1], hw[1]) >> 3;
+    const int tx1 = min(hv[0] + hv[2], hw[0] + hw[2]) >> 3, ty1 = min(hv[1] + hv[3], hw[1] + hw[3]) >> 3;
+    const int ntx = tx1 - tx0, nty = ty1 - ty0;
+    const int nt = (ntx > 0 && nty > 0) ? ntx * nty : 0;
+    const int vx0 = hv[0] >> 3, vy0 = hv[1] >> 3, vnx = hv[2] >> 3;
+    const int wx0 = hw[0] >> 3, wy0 = hw[1] >> 3, wnx = hw[2] >> 3;
     __shared__ long long s_sum[(MEAS_NT / 64) * 3];
     long long bv, bw, total;
     d_region_sums<MEAS_NT>(a.pool.area, N, v, w, bv, bw, total, s_sum);
@@ -858,42 +933,214 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure_edge(MeasureArgs a)
 #pragma unroll
     for (int k = 0; k < B_NV; k++) acc[k] = 0.0;
     const DPool &P = a.pool;
-    // the job's pixels are dealt to the threads of its gridDim.y workgroups round robin; row and column
-    // advance with the stride (no division per pixel)
-    const int nthr = MEAS_NT * gridDim.y, first = blockIdx.y * MEAS_NT + threadIdx.x;
-    const int rwd = rw > 0 ? rw : 1;
-    const int dr = nthr / rwd, dc = nthr % rwd;
-    int r = r0 + first / rwd, c = c0 + first % rwd;
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.y * (MEAS_NT / 64) + (threadIdx.x >> 6), nwaves = (MEAS_NT / 64) * gridDim.y;
     const double iZ = a.iZ, iJ = a.iJ, iM = a.iM;
-    for (int i = first; i < npx; i += nthr) {
-        const long long pv = bv + (long long)(r - hv[1]) * hv[2] + (c - hv[0]);
-        const long long pw = bw + (long long)(r - hw[1]) * hw[2] + (c - hw[0]);
-        r += dr; c += dc;
-        if (c > c1) { c -= rw; r++; }
-        const short2 ax_ = P.xi[pv], bx_ = P.xi[pw];                      // numerators in -255..255, or the mark of a
-        if (ax_.x == POOL_EMPTY || bx_.x == POOL_EMPTY) continue;         // pixel outside the star: every product is zero
-        const short2 ay_ = P.yi[pv], by_ = P.yi[pw];
-        const double axim = k255[ax_.x], axm = k255[ax_.y];
-        const double ayim = k255[ay_.x], aym = k255[ay_.y];
-        const double bxim = k255[bx_.x], bxm = k255[bx_.y];
-        const double byim = k255[by_.x], bym = k255[by_.y];
-        const double axfx = P.xfx[pv], axfy = P.xfy[pv], ayfx = P.yfx[pv], ayfy = P.yfy[pv];
-        const double bxfx = P.xfx[pw], bxfy = P.xfy[pw], byfx = P.yfx[pw], byfy = P.yfy[pw];
-        const double avx = P.vxfx[pv], avy = P.vyfy[pv], bvx = P.vxfx[pw], bvy = P.vyfy[pw];
-        const double wxi = axim * iZ, wxf = axfx * iJ, wxg = axfy * iJ, wxm = axm * iM;    // D_v,x / eps
-        const double wyi = ayim * iZ, wyf = ayfx * iJ, wyg = ayfy * iJ, wym = aym * iM;    // D_v,y / eps
-        acc[B_XX] = fma(wxm, bxm, fma(wxg, bxfy, fma(wxf, bxfx, fma(wxi, bxim, acc[B_XX]))));
-        acc[B_XY] = fma(wxm, bym, fma(wxg, byfy, fma(wxf, byfx, fma(wxi, byim, acc[B_XY]))));
-        acc[B_YX] = fma(wym, bxm, fma(wyg, bxfy, fma(wyf, bxfx, fma(wyi, bxim, acc[B_YX]))));
-        acc[B_YY] = fma(wym, bym, fma(wyg, byfy, fma(wyf, byfx, fma(wyi, byim, acc[B_YY]))));
-        acc[B_XVX] = fma(axfx, bvx, acc[B_XVX]); acc[B_YVX] = fma(ayfx, bvx, acc[B_YVX]);
-        acc[B_VXX] = fma(avx, bxfx, acc[B_VXX]); acc[B_VXY] = fma(avx, byfx, acc[B_VXY]);
-        acc[B_VXVX] = fma(avx, bvx, acc[B_VXVX]);
-        acc[B_XVY] = fma(axfy, bvy, acc[B_XVY]); acc[B_YVY] = fma(ayfy, bvy, acc[B_YVY]);
-        acc[B_VYX] = fma(avy, bxfy, acc[B_VYX]); acc[B_VYY] = fma(avy, byfy, acc[B_VYY]);
-        acc[B_VYVY] = fma(avy, bvy, acc[B_VYVY]);
+    const int ntxd = ntx > 0 ? ntx : 1;
+    for (int first = 0; first < nt; first += 64 * nwaves) {
+        // lane i: candidate tile first + i * nwaves + gw of this wave
+        const int cand = first + lane * nwaves + gw;
+        int tv = 0, tw = 0;
+        bool go = false;
+        if (cand < nt) {
+            const int tx = tx0 + cand % ntxd, ty = ty0 + cand / ntxd;
+            tv = (ty - vy0) * vnx + (tx - vx0);
+            tw = (ty - wy0) * wnx + (tx - wx0);
+            go = (P.live[bv / 64 + tv] != 0) & (P.live[bw / 64 + tw] != 0);
+        }
+        unsigned long long todo = __ballot(go);
+        if (todo == 0) continue;
+        int l = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        EdgeTile nx = d_edge_load(P, bv + (long long)__shfl(tv, l, 64) * 64 + lane, bw + (long long)__shfl(tw, l, 64) * 64 + lane);
+        for (;;) {
+            const EdgeTile t = nx;
+            const bool more = todo != 0;
+            if (more) {
+                l = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                nx = d_edge_load(P, bv + (long long)__shfl(tv, l, 64) * 64 + lane, bw + (long long)__shfl(tw, l, 64) * 64 + lane);
+            }
+            // numerators in -255..255, or the mark of a pixel outside the star (all its other planes are zero: every
+            // product below has a factor from each vertex)
+            if (t.ax.x != POOL_EMPTY && t.bx.x != POOL_EMPTY) {
+                const double axim = k255[t.ax.x], axm = k255[t.ax.y];
+                const double ayim = k255[t.ay.x], aym = k255[t.ay.y];
+                const double bxim = k255[t.bx.x], bxm = k255[t.bx.y];
+                const double byim = k255[t.by.x], bym = k255[t.by.y];
+                const double axfx = t.axfx, axfy = t.axfy, ayfx = t.ayfx, ayfy = t.ayfy;
+                const double bxfx = t.bxfx, bxfy = t.bxfy, byfx = t.byfx, byfy = t.byfy;
+                const double avx = t.avx, avy = t.avy, bvx = t.bvx, bvy = t.bvy;
+                const double wxi = axim * iZ, wxf = axfx * iJ, wxg = axfy * iJ, wxm = axm * iM;    // D_v,x / eps
+                const double wyi = ayim * iZ, wyf = ayfx * iJ, wyg = ayfy * iJ, wym = aym * iM;    // D_v,y / eps
+                acc[B_XX] = fma(wxm, bxm, fma(wxg, bxfy, fma(wxf, bxfx, fma(wxi, bxim, acc[B_XX]))));
+                acc[B_XY] = fma(wxm, bym, fma(wxg, byfy, fma(wxf, byfx, fma(wxi, byim, acc[B_XY]))));
+                acc[B_YX] = fma(wym, bxm, fma(wyg, bxfy, fma(wyf, bxfx, fma(wyi, bxim, acc[B_YX]))));
+                acc[B_YY] = fma(wym, bym, fma(wyg, byfy, fma(wyf, byfx, fma(wyi, byim, acc[B_YY]))));
+                acc[B_XVX] = fma(axfx, bvx, acc[B_XVX]); acc[B_YVX] = fma(ayfx, bvx, acc[B_YVX]);
+                acc[B_VXX] = fma(avx, bxfx, acc[B_VXX]); acc[B_VXY] = fma(avx, byfx, acc[B_VXY]);
+                acc[B_VXVX] = fma(avx, bvx, acc[B_VXVX]);
+                acc[B_XVY] = fma(axfy, bvy, acc[B_XVY]); acc[B_YVY] = fma(ayfy, bvy, acc[B_YVY]);
+                acc[B_VYX] = fma(avy, bxfy, acc[B_VYX]); acc[B_VYY] = fma(avy, byfy, acc[B_VYY]);
+                acc[B_VYVY] = fma(avy, bvy, acc[B_VYVY]);
+            }
+            if (!more) break;
+        }
     }
     d_block_reduce<B_NV, MEAS_NT>(acc, s_red, a.out + ((size_t)(N + e) * MEAS_VSPLIT_MAX + blockIdx.y) * MEAS_OUT);
+}
+
+// ---- the render of an iterate, with everything else that needs nothing but the iterate -----------------------
+// One launch per IEKF iteration in place of four (k_setup_all, k_render<0>, k_error, k_star_regions):
+//   blocks [0, n_regions)   the star regions of the measurement at this state (d_star_regions: they read the state only);
+//   the other blocks        one RI_W x RI_H strip of the render each, four pixels per thread (a wave covers a 64-pixel
+//       row: whole 256-byte lines of every target).  The triangle setups are not read from memory (69 KB per 16x16
+//       tile for a 360-triangle mesh in k_render) but made on the spot: every thread tests its share of the triangles
+//       against the strip -- first with the plain extent of the three vertices widened by two pixels (a superset of
+//       the box d_tri_setup keeps, a few instructions), then with that box itself (d_tri_bbox) -- the few that meet it
+//       are set up by one thread each into LDS, RI_CHUNK at a time, and visited by every pixel in ascending index
+//       order: the values of k_setup_all + k_render<0>, bit for bit.  With `with_err` the pixels' four terms of
+//       Renderer.error (k_error's arithmetic) are added up over the strip and stored as partial[strip]; the final sums
+//       are formed in a fixed two-level order (d_tile_partial_sums; hm_tile_partial_sums on the host).
+#define RI_CHUNK 16
+#define RI_GROUPS 256
+#define RI_W 64
+#define RI_H 16
+#define RI_PX (RI_W * RI_H / 256)      // pixels per thread: rows r0 + (tid >> 6) + 4 q
+struct IterRenderArgs {
+    Mesh m;
+    const double *X;
+    Targets out;
+    Obs o;
+    double *partial;          // strips x 4
+    int tiles_x, tiles_y, with_err, n_regions;
+};
+struct RenderShared {
+    unsigned mask[EKF_MAX_TRI / 32];
+    TriSetup cand[RI_CHUNK];
+    double red[(256 / 64) * 4];
+};
+
+__global__ __launch_bounds__(256) void k_render_iter(IterRenderArgs r, MeasureArgs a, int *__restrict__ area)
+{
+    __shared__ union {
+        RegionShared reg;
+        RenderShared t;
+    } sh;
+    if ((int)blockIdx.x < r.n_regions) {
+        d_star_regions<256>(a, area, blockIdx.x, sh.reg);
+        return;
+    }
+    const Mesh &m = r.m;
+    const int tile = blockIdx.x - r.n_regions;
+    const int tid = threadIdx.x;
+    const int words = (m.T + 31) / 32;
+    for (int i = tid; i < words; i += 256) sh.t.mask[i] = 0;
+    __syncthreads();
+    const int c0 = (tile % r.tiles_x) * RI_W, r0 = (tile / r.tiles_x) * RI_H;
+    const double *__restrict__ X = r.X;
+    for (int t = tid; t < m.T; t += 256) {
+        const int v0 = m.tri[3 * t], v1 = m.tri[3 * t + 1], v2 = m.tri[3 * t + 2];
+        const double x0 = X[2 * v0], y0 = X[2 * v0 + 1], x1 = X[2 * v1], y1 = X[2 * v1 + 1], x2 = X[2 * v2], y2 = X[2 * v2 + 1];
+        // pixel (c, r) can only be covered if its centre lies within the extent of the vertices (snapped to 1/256 px:
+        // half a pixel of slack would do); anything non-finite takes the exact test
+        const double lo_x = fmin(x0, fmin(x1, x2)) - 2.0, hi_x = fmax(x0, fmax(x1, x2)) + 2.0;
+        const double lo_y = fmin(y0, fmin(y1, y2)) - 2.0, hi_y = fmax(y0, fmax(y1, y2)) + 2.0;
+        if (hi_x < (double)c0 || lo_x > (double)(c0 + RI_W) || hi_y < (double)r0 || lo_y > (double)(r0 + RI_H)) continue;
+        int cmin, cmax, rmin, rmax;
+        d_tri_bbox(d_snap(x0), d_snap(y0), d_snap(x1), d_snap(y1), d_snap(x2), d_snap(y2), m.W, m.H, cmin, cmax, rmin, rmax);
+        if (cmin <= cmax && cmax >= c0 && cmin < c0 + RI_W && rmax >= r0 && rmin < r0 + RI_H)
+            atomicOr(&sh.t.mask[t >> 5], 1u << (t & 31));
+    }
+    __syncthreads();
+    int total = 0;
+    for (int w = 0; w < words; w++) total += __popc(sh.t.mask[w]);
+    const int c = c0 + (tid & 63), rb = r0 + (tid >> 6);
+    int acc[RI_PX], cnt[RI_PX];
+    float fx[RI_PX], fy[RI_PX];
+#pragma unroll
+    for (int q = 0; q < RI_PX; q++) { acc[q] = 0; cnt[q] = 0; fx[q] = 0.0f; fy[q] = 0.0f; }
+    for (int base = 0; base < total; base += RI_CHUNK) {
+        const int nch = min(RI_CHUNK, total - base);
+        if (tid < nch) {                           // the (base + tid)-th set bit, in ascending order
+            int k = base + tid, w = 0;
+            for (;; w++) {
+                const int pc = __popc(sh.t.mask[w]);
+                if (k < pc) break;
+                k -= pc;
+            }
+            unsigned bits = sh.t.mask[w];
+            for (; k > 0; k--) bits &= bits - 1;
+            const int t = w * 32 + __ffs(bits) - 1;
+            const int v0 = m.tri[3 * t], v1 = m.tri[3 * t + 1], v2 = m.tri[3 * t + 2];
+            TriSetup su;
+            d_tri_setup(su, v0, v1, v2, d_snap(X[2 * v0]), d_snap(X[2 * v0 + 1]), d_snap(X[2 * v1]), d_snap(X[2 * v1 + 1]),
+                        d_snap(X[2 * v2]), d_snap(X[2 * v2 + 1]), m.W, m.H);
+            d_tri_attr(su, m.uv, X, m.N);
+            sh.t.cand[tid] = su;
+        }
+        __syncthreads();
+        if (c < m.W)
+            for (int q = 0; q < nch; q++) {
+                const TriSetup &su = sh.t.cand[q];
+#pragma unroll
+                for (int j = 0; j < RI_PX; j++) {
+                    float l1, l2;
+                    if (!d_tri_eval(su, c, rb + 4 * j, l1, l2)) continue;    // (rows past the frame are outside the box)
+                    acc[j] += d_texel(m.tex, su, l1, l2, m.W, m.H);
+                    fx[j] = fx[j] + d_lerp(su.ax[0], su.ax[1], su.ax[2], l1, l2);
+                    fy[j] = fy[j] + d_lerp(su.ay[0], su.ay[1], su.ay[2], l1, l2);
+                    cnt[j]++;
+                }
+            }
+        __syncthreads();
+    }
+    double e[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < RI_PX; j++) {
+        const int rr = rb + 4 * j;
+        if (c >= m.W || rr >= m.H) continue;
+        const int p = rr * m.W + c;
+        r.out.acc[p] = acc[j]; r.out.fx[p] = fx[j]; r.out.fy[p] = fy[j]; r.out.cnt[p] = cnt[j];
+        if (r.with_err) {                          // Renderer.error (renderer.py:485-501), the arithmetic of k_error
+            const unsigned rim = acc[j] > 255 ? 255 : acc[j];
+            const unsigned rm = cnt[j] > 0 ? 255 : 0;
+            const unsigned d = ((unsigned)r.o.yim[p] - rim) & 255u;
+            const unsigned dm = ((255u * (unsigned)r.o.ym[p]) - rm) & 255u;
+            const float dfx = r.o.yfx[p] - fx[j];
+            const float dfy = r.o.yfy[p] + fy[j];
+            e[0] += (double)((d * d) & 255u);
+            e[1] += (double)dfx * (double)dfx;
+            e[2] += (double)dfy * (double)dfy;
+            e[3] += (double)((dm * dm) & 255u);
+        }
+    }
+    if (!r.with_err) return;
+    d_block_reduce<4, 256>(e, sh.t.red, r.partial + 4 * (size_t)tile);
+}
+
+// The four error sums from the per-tile partials, in a fixed order: thread g of RI_GROUPS adds the partials g,
+// g + RI_GROUPS, ... in ascending order, then the group sums are added in ascending order (hm_tile_partial_sums on
+// the host does the same additions).  sp: RI_GROUPS x 4 doubles of LDS; out[0..3] written by threads 0..3 after a
+// barrier inside.
+__device__ __forceinline__ void d_tile_partial_sums(const double *__restrict__ partial, int ntiles, double *sp, double *out)
+{
+    const int t = threadIdx.x;
+    if (t < RI_GROUPS) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 4
+        for (int i = t; i < ntiles; i += RI_GROUPS) {
+            const double4 q = *(const double4 *)(partial + 4 * (size_t)i);
+            s0 += q.x; s1 += q.y; s2 += q.z; s3 += q.w;
+        }
+        sp[4 * t] = s0; sp[4 * t + 1] = s1; sp[4 * t + 2] = s2; sp[4 * t + 3] = s3;
+    }
+    __syncthreads();
+    if (t < 4) {
+        double s = 0.0;
+        for (int g = 0; g < RI_GROUPS; g++) s += sp[4 * g + t];
+        out[t] = s;
+    }
 }
 
 // ---- job sums -> Hz, Hz components, dense HTH (device twin of the unpacking in KFState.update) -------

@@ -23,7 +23,9 @@ def test_brox_full_size_pair_matches_oracle(hm, oracle_brox):
     assert np.sqrt((u - ru) ** 2 + (v - rv) ** 2).max() <= 1e-4                        # the contract
     assert np.array_equal(u, ru) and np.array_equal(v, rv)                            # what is achieved
     b = N_FULL // 8
-    assert np.sqrt((u - tu) ** 2 + (v - tv) ** 2)[b:-b, b:-b].mean() < 0.25            # and it is the flow
+    # and it is the flow: mean end-point error against the analytic field over the interior, C oracle measured
+    # 0.04721 px for this pair -- bound = measured + 10 % (a change of the algorithm would show here)
+    assert np.sqrt((u - tu) ** 2 + (v - tv) ** 2)[b:-b, b:-b].mean() <= 0.0519
     # a series of pairs gives each pair the numbers it gets alone
     g0, g1, _, _ = synth.warp_pair(N_FULL, "rotate", 4)
     ub, vb = bf.calc_batch(np.stack((f0, g0)), np.stack((f1, g1)))
@@ -187,3 +189,117 @@ def test_pipeline_equals_sequential_at_full_size(hm):
         pipe.close()
         for k in range(frames - 1):
             assert got[k][1] == ref[k][1] and np.array_equal(got[k][0], ref[k][0]), (rep, k)
+
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _config4_inputs():
+    from hydra_mi import mesh, synth
+    g = np.load(os.path.join(GOLD, "config4_track.npz"))
+    n, frames = int(g["n"]), int(g["frames"])
+    video, masks, centre, radius = synth.disk_video(n, frames, "translate_leftup", 0)
+    dm = mesh.disk_mesh(centre[0], centre[1], radius - 1.0, float(g["h0"]) * n)
+    assert np.array_equal(dm.p, g["p"]) and np.array_equal(dm.t, g["t"])          # the golden's mesh: the bench's 201 vertices
+    assert dm.size() == 201 and n == N_FULL
+    return g, n, frames, video, masks, dm
+
+
+def _check_config4_frame(g, k, kf, e):
+    X, Xg = kf.state.X.reshape(-1), g["X"][k - 1]
+    rel = np.linalg.norm(X - Xg) / np.linalg.norm(Xg)
+    assert rel <= 1e-5, (k, rel)                                                    # the contract (north_star)
+    assert kf.niter == int(g["iters"][k - 1]), (k, kf.niter)
+    ge = g["err"][k - 1]
+    assert e[0] == int(ge[0]) and e[3] == int(ge[3]), k                             # integer error terms exact
+    assert abs(e[1] - ge[1]) <= 1e-6 * ge[1] and abs(e[2] - ge[2]) <= 1e-6 * ge[2], k
+    Wd = np.diag(kf.state.W)
+    assert np.linalg.norm(Wd - g["W_diag"][k - 1]) <= 1e-5 * np.linalg.norm(g["W_diag"][k - 1]), k
+    return rel
+
+
+def test_track_config4_matches_golden(hm):
+    """BASELINE config 4 at state level (EKF state <= 1e-5 rel): 1024^2 video, the bench's
+    201-vertex mesh, flow from the product's Brox, IteratedMSKalmanFilter.compute frame by frame, against the golden
+    track of tools/make_golden.py config4 -- the C Brox oracle + the oracle's tracker with the reference's iterated
+    update (kalman.py:774-831) over full-frame renders per perturbation (cuda.py:972-1010), 10 + 10 + 10 iterations of
+    1 608 jz + 10 906 j evaluations each.  Same iteration counts, integer error terms exact, covariance diagonal and
+    sampled covariance rows <= 1e-5."""
+    from hydra_mi import brox, kalman
+    g, n, frames, video, masks, dm = _config4_inputs()
+    bf = brox.BroxOpticalFlow(n, n)
+    kf = kalman.IteratedMSKalmanFilter(dm, video[0], np.zeros((n, n, 2), np.float32), True)
+    worst = 0.0
+    for k in range(1, frames):
+        u, v = bf.calc(video[k - 1], video[k])
+        e = kf.compute(video[k], np.dstack((u, v)), masks[k])
+        worst = max(worst, _check_config4_frame(g, k, kf, e))
+    W = kf.state.W
+    rows = g["W_last_rows"]
+    assert np.linalg.norm(W[::67] - rows) <= 1e-5 * np.linalg.norm(rows)
+    print("config 4 golden track: worst state difference %.2e rel" % worst)
+
+
+def test_track_config4_through_the_pipeline_matches_golden(hm):
+    """The same golden track through the streaming component the bench times (FlowEKFPipeline: frames uploaded one by
+    one into the frame ring, flow series beside the filter, flow handed over in device memory)."""
+    from hydra_mi import kalman
+    from hydra_mi.pipeline import FlowEKFPipeline
+    g, n, frames, video, masks, dm = _config4_inputs()
+    kf = kalman.IteratedMSKalmanFilter(dm, video[0], np.zeros((n, n, 2), np.float32), True)
+    pipe = FlowEKFPipeline(kf, video, masks, flow_batch=8)
+    pipe.run(on_frame=lambda k, e: _check_config4_frame(g, k + 1, kf, e))
+    assert len(pipe.frame_done) == frames - 1
+    pipe.close()
+
+
+# mean end-point error (px) of the C oracle against the analytic field, interior of the 1024^2 frame, for the pairs
+# of BASELINE config 5 with seeds 0..31 (tools: oracle/brox_oracle.calc on synth.warp_pair(1024,
+# "translate_leftup_stretch", seed)); the test allows measured + 10 %
+CONFIG5_EPE = [0.0433, 0.0424, 0.0484, 0.0472, 0.0466, 0.0454, 0.0409, 0.0463, 0.0482, 0.0461, 0.0483, 0.0452, 0.0478,
+               0.0464, 0.0440, 0.0417, 0.0482, 0.0475, 0.0476, 0.0475, 0.0439, 0.0385, 0.0471, 0.0473, 0.0416, 0.0447,
+               0.0456, 0.0469, 0.0467, 0.0431, 0.0467, 0.0411]
+
+
+def test_config5_rank_share_matches_oracle(hm, oracle_brox):
+    """BASELINE config 5, one rank's share of the 256-pair batch (hydra_mi.batch.shard(256, rank 0 of 8) = pairs
+    0..31, pair i = seed i of the `translate_leftup_stretch` warp) computed the way `bench.py --workload
+    flowbatch` computes it -- frames resident in HBM, hm_brox_calc_dev in launch series of 8 pairs: five pairs with
+    distinct seeds are bit-equal to the C oracle, and every one of the 32 is the flow of its analytic field (mean
+    end-point error within 10 % of what the oracle measures for that seed)."""
+    from hydra_mi import batch, brox, synth
+    from hydra_mi.pipeline import DeviceBuffer
+    n, B = N_FULL, 8
+    mine = batch.shard(256, 0, 8)
+    assert list(mine) == list(range(32))
+    P = len(mine)
+    f0 = np.empty((P, n, n), np.uint8)
+    f1 = np.empty((P, n, n), np.uint8)
+    truth = []
+    for j, i in enumerate(mine):
+        f0[j], f1[j], tu, tv = synth.warp_pair(n, "translate_leftup_stretch", batch.pair_seed(i))
+        truth.append((tu, tv))
+    d0, d1 = DeviceBuffer(f0.nbytes), DeviceBuffer(f1.nbytes)
+    du, dv = DeviceBuffer(P * n * n * 4), DeviceBuffer(P * n * n * 4)
+    d0.upload(f0)
+    d1.upload(f1)
+    bf = brox.BroxOpticalFlow(n, n, max_batch=B)
+    for s in range(0, P, B):
+        bf.calc_dev(B, d0.ptr + s * n * n, d1.ptr + s * n * n, du.ptr + s * n * n * 4, dv.ptr + s * n * n * 4)
+    bf.sync()
+    U = du.download(np.empty((P, n, n), np.float32))
+    V = dv.download(np.empty((P, n, n), np.float32))
+    b = n // 8
+    for j in range(P):
+        tu, tv = truth[j]
+        epe = np.sqrt((U[j] - tu) ** 2 + (V[j] - tv) ** 2)[b:-b, b:-b].mean()
+        assert epe <= 1.1 * CONFIG5_EPE[j], (j, epe)
+    oracle_brox.set_threads(min(16, os.cpu_count() or 1))
+    try:
+        for j in (0, 9, 14, 22, 31):
+            ru, rv = oracle_brox.calc(f0[j], f1[j])
+            assert np.array_equal(U[j], ru) and np.array_equal(V[j], rv), j
+    finally:
+        oracle_brox.set_threads(1)
+    for d in (d0, d1, du, dv):
+        d.close()
