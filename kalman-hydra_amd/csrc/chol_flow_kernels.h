@@ -497,7 +497,15 @@ __global__ __launch_bounds__(256) void k_solve_prep(PrepArgs p)
     }
     double *Arow = p.A + (size_t)row * n;
     const double *Wrow = p.invW0 + (size_t)row * n;
-    for (int j = t; j < n; j += 256) Arow[j] = Wrow[j];
+    {   // the copy of the row, its loads in flight together (a plain loop waits for every load before its store)
+        double w[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) w[q] = (t + 256 * q < n) ? Wrow[t + 256 * q] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (t + 256 * q < n) Arow[t + 256 * q] = w[q];
+        for (int j = t + 1024; j < n; j += 256) Arow[j] = Wrow[j];
+    }
     const int N = p.N, n2 = 2 * N;
     const int v = (row % n2) >> 1, ca = (row & 1) + (row >= n2 ? 2 : 0);      // component of the row: x, y, vx, vy
     const int deg = p.nb_off[v + 1] - p.nb_off[v];

@@ -67,6 +67,7 @@ struct hm_ctx {
     double *d_tpart = nullptr;       // per-tile partial sums of Renderer.error from k_render_iter (tiles x 4)
     std::vector<double> h_tpart;
     int ntiles = 0;
+    int render_rows = RI_H;          // strip height of k_render_iter (16 or 8)
     long long run_ticket;            // sequence number of hm_update_run's per-iteration result blocks
     int vsplit, esplit;              // workgroups per vertex / per edge job of the measurement (hm_ctx_tune)
     // hm_update_arm_newton: what the next hm_update_run starts when its state is final
@@ -97,6 +98,7 @@ struct hm_ctx {
     int2 *d_outline;                 // hm_project_mask: outline pixels (W*H), counters, uploaded mask; allocated on first use
     int *d_outline_cnt;
     uint8_t *d_pm_mask;
+    uint8_t *d_pm_flag = nullptr;    // border-pixel flags of that mask (W*H)
     double *d_pm_X = nullptr;        // hm_project_mask's copy of the state (second stream)
 };
 
@@ -157,6 +159,48 @@ static hipError_t stream_wait(hipStream_t s)
     }
 }
 
+// ---- the pool of parked difference images (DPool, ekf_kernels.h) -------------------------------------------------
+static void pool_release(hm_ctx *h)
+{
+    void *ptrs[] = {h->pool.live, h->pool.xi, h->pool.yi, h->pool.xfx, h->pool.xfy, h->pool.yfx, h->pool.yfy, h->pool.vxfx, h->pool.vyfy};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    h->pool.live = nullptr; h->pool.xi = h->pool.yi = nullptr;
+    h->pool.xfx = h->pool.xfy = h->pool.yfx = h->pool.yfy = h->pool.vxfx = h->pool.vyfy = nullptr;
+    h->pool.cap = 0;
+}
+static int pool_alloc(hm_ctx *h, long long cap)
+{
+    pool_release(h);
+    const size_t pc = (size_t)cap;
+    HM_HIP(hipMalloc((void **)&h->pool.live, (pc / 64 + 1) * sizeof(int)));
+    short2 **sp[] = {&h->pool.xi, &h->pool.yi};
+    for (short2 **q : sp) HM_HIP(hipMalloc((void **)q, pc * sizeof(short2)));
+    float **fp[] = {&h->pool.xfx, &h->pool.xfy, &h->pool.yfx, &h->pool.yfy, &h->pool.vxfx, &h->pool.vyfy};
+    for (float **q : fp) HM_HIP(hipMalloc((void **)q, pc * sizeof(float)));
+    h->pool.cap = cap;
+    return HM_OK;
+}
+// A measurement reported that its star regions do not fit (the reference has no such limit: its renders are whole
+// frames): make room for them -- the region areas are on the device -- plus a quarter.  The stream must be idle.
+static int pool_grow(hm_ctx *h, const char *who)
+{
+    std::vector<int> area(h->N);
+    HM_HIP(hipMemcpyAsync(area.data(), h->d_area, (size_t)h->N * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HM_HIP(hipStreamSynchronize(h->stream));
+    long long total = 0;
+    for (int a : area) total += a;
+    if (total <= h->pool.cap) { hm_set_error("%s: the difference-image pool reported an overflow it does not have", who); return HM_ERR_STATE; }
+    const long long want = total + total / 4;
+    if (want > ((long long)1 << 32)) {              // 128 GB of planes: not a mesh this path is meant for
+        hm_set_error("%s: the star regions need %lld pixels of difference images, more than the pool may hold", who, total);
+        return HM_ERR_STATE;
+    }
+    int rc = pool_alloc(h, want);
+    if (rc) { hm_set_error("%s: cannot grow the difference-image pool to %lld pixels: %s", who, want, hm_last_error()); return rc; }
+    return HM_OK;
+}
+
 static int ctx_free(hm_ctx *h)
 {
     if (!h) return HM_OK;
@@ -166,12 +210,12 @@ static int ctx_free(hm_ctx *h)
                     h->d_yfy, h->d_yfxm, h->d_yfym, h->d_setup, h->d_cfgs, h->d_ubox, h->d_X, h->d_out, h->d_partial, h->d_im8, h->d_m8,
                     h->d_HTH, h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_T[0], h->d_T[1], h->d_step, h->d_Wprior, h->d_gain, h->d_Awork, h->d_Lt[0], h->d_Lt[1],
                     h->d_Wtmp, h->d_X0, h->d_Xn, h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk,
-                    h->pool.hdr, h->pool.live, h->pool.xi, h->pool.yi, h->pool.xfx, h->pool.xfy,
-                    h->pool.yfx, h->pool.yfy, h->pool.vxfx, h->pool.vyfy, h->pool.overflow, h->d_area,
-                    h->d_outline, h->d_outline_cnt, h->d_pm_mask, h->d_pm_X, h->d_ids[0], h->d_ids[1], h->d_ids[2], h->d_labels, h->d_lbox,
+                    h->pool.hdr, h->pool.overflow, h->d_area,
+                    h->d_outline, h->d_outline_cnt, h->d_pm_mask, h->d_pm_flag, h->d_pm_X, h->d_ids[0], h->d_ids[1], h->d_ids[2], h->d_labels, h->d_lbox,
                     h->d_lout, h->d_tpart, h->d_nb_off, h->d_nb_u, h->d_nb_e, h->d_flowP, h->d_flowctl, h->d_nbars, h->d_nvoff, h->d_nvbar, h->d_ninfo, h->d_nl0, h->d_nX};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    pool_release(h);
     free_targets(h->ref);
     free_targets(h->P);
     free_targets(h->Q);
@@ -294,7 +338,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_X, (size_t)4 * N * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_out, (size_t)h->njobs * MEAS_VSPLIT_MAX * MEAS_OUT * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_partial, (size_t)h->red_blocks * 4 * sizeof(double));
-        h->ntiles = hm_cdiv(W, RI_W) * hm_cdiv(H, RI_H);        // strips of k_render_iter
+        h->ntiles = hm_cdiv(W, RI_W) * hm_cdiv(H, 8);           // most strips of k_render_iter (render_rows 8)
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_tpart, (size_t)h->ntiles * 4 * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_im8, n);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_m8, n);
@@ -326,22 +370,15 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         if (e == hipSuccess) e = hipHostMalloc((void **)&h->pin, h->pin_n * sizeof(double), hipHostMallocCoherent);
         if (e == hipSuccess) memset(h->pin, 0, h->pin_n * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_X0, n4 * sizeof(double));
-        // pool of parked difference images (32 B per pixel): the star regions overlap about six times, so a
-        // mesh that covers the whole frame needs about six frames' worth of pixels (the bench's disk, a third
-        // of the frame: 1.5); 8 frames' worth = 268 MB at 1024^2 (hm_measure reports an overflow)
-        h->pool.cap = (long long)8 * W * H;
-        const size_t pc = (size_t)h->pool.cap;
         if (e == hipSuccess) e = hipMalloc((void **)&h->pool.hdr, (size_t)4 * N * sizeof(int));
         if (e == hipSuccess) e = hipMalloc((void **)&h->pool.overflow, sizeof(int));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->pool.live, (pc / 64 + 1) * sizeof(int));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_area, (size_t)N * sizeof(int));
         h->pool.area = h->d_area;
-        short2 **sp[] = {&h->pool.xi, &h->pool.yi};
-        for (short2 **q : sp)
-            if (e == hipSuccess) e = hipMalloc((void **)q, pc * sizeof(short2));
-        float **fp[] = {&h->pool.xfx, &h->pool.xfy, &h->pool.yfx, &h->pool.yfy, &h->pool.vxfx, &h->pool.vyfy};
-        for (float **q : fp)
-            if (e == hipSuccess) e = hipMalloc((void **)q, pc * sizeof(float));
+        // pool of parked difference images (32 B per pixel): the star regions overlap about six times, so a mesh that
+        // covers the whole frame needs about six frames' worth of pixels plus the padding of every region to whole 8x8
+        // tiles (the bench's disk, a third of the frame: 1.6); it starts at 8 frames' worth = 268 MB at 1024^2 and grows
+        // when a measurement reports that its regions do not fit (pool_grow)
+        if (e == hipSuccess && pool_alloc(h, (long long)8 * W * H) != HM_OK) e = hipErrorOutOfMemory;
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Xn, n4 * sizeof(double));
         if (e != hipSuccess) {
             hm_set_error("hm_ctx_create: device allocation failed: %s", hipGetErrorString(e));
@@ -363,6 +400,16 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
 
 extern "C" int hm_ctx_destroy(hm_ctx_t h) { return ctx_free(h); }
 
+#ifdef HM_STAMP
+// development builds only: where k_render_iter writes its per-workgroup time stamps (device pointer, 8 words per workgroup)
+extern "C" int hm_debug_stamps(void *dev_ptr)
+{
+    long long *p = (long long *)dev_ptr;
+    HM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), &p, sizeof p));
+    return HM_OK;
+}
+#endif
+
 extern "C" int hm_ctx_tune(hm_ctx_t h, const char *key, int value)
 {
     HM_ARG(h != nullptr && key != nullptr, "hm_ctx_tune: NULL argument");
@@ -378,6 +425,9 @@ extern "C" int hm_ctx_tune(hm_ctx_t h, const char *key, int value)
         // the task workgroups produce
         HM_ARG(value >= 2 && value <= 2048, "hm_ctx_tune: chol_flow_wgs must be in 2..2048 (the chain workgroup and at least one task workgroup)");
         h->flow_wgs = value;
+    } else if (!strcmp(key, "render_rows")) {
+        HM_ARG(value == 8 || value == 16, "hm_ctx_tune: render_rows must be 8 or 16");
+        h->render_rows = value;
     } else if (!strcmp(key, "chol_flow_stall")) {      // tests only: results must not depend on it
         HM_ARG(value >= 0 && value <= 100000, "hm_ctx_tune: chol_flow_stall must be in 0..100000");
         h->flow_stall = value;
@@ -472,6 +522,7 @@ static int render_into(hm_ctx *h, const double *X, Targets t)
 }
 
 static void measure_args(hm_ctx *h, const double *dX, double deltaX, int masked, MeasureArgs &a);
+static int render_strips(const hm_ctx *h) { return hm_cdiv(h->W, RI_W) * hm_cdiv(h->H, h->render_rows); }
 
 // The render of the device-resident state dX into target t as ONE launch (k_render_iter): triangle setups made per
 // tile, optionally the per-tile partial sums of Renderer.error against the observation (d_tpart) and, riding along
@@ -484,12 +535,14 @@ static int render_iter(hm_ctx *h, const double *dX, Targets t, bool with_err, in
     r.out = t;
     r.o = Obs{h->o_yim, masked ? h->d_yfxm : h->o_yfx, masked ? h->d_yfym : h->o_yfy, h->o_ym};
     r.partial = h->d_tpart;
-    r.tiles_x = hm_cdiv(h->W, RI_W); r.tiles_y = hm_cdiv(h->H, RI_H);
+    r.tiles_x = hm_cdiv(h->W, RI_W); r.tiles_y = hm_cdiv(h->H, h->render_rows);
+    const int nstrips = r.tiles_x * r.tiles_y;
     r.with_err = with_err ? 1 : 0;
     r.n_regions = regions ? h->N : 0;
     MeasureArgs a;
     measure_args(h, dX, deltaX, masked, a);
-    hipLaunchKernelGGL(k_render_iter, dim3(r.n_regions + h->ntiles), dim3(256), 0, h->stream, r, a, h->d_area);
+    if (h->render_rows == 8) hipLaunchKernelGGL((k_render_iter<8>), dim3(r.n_regions + nstrips), dim3(256), 0, h->stream, r, a, h->d_area);
+    else hipLaunchKernelGGL((k_render_iter<16>), dim3(r.n_regions + nstrips), dim3(256), 0, h->stream, r, a, h->d_area);
     HM_HIP(hipGetLastError());
     return HM_OK;
 }
@@ -812,19 +865,25 @@ extern "C" int hm_measure(hm_ctx_t h, const double *X, double deltaX, int masked
     NEED_TEX(h, "hm_measure");
     NEED_OBS(h, "hm_measure");
     HM_HIP(hipSetDevice(h->device));
-    int rc = measure_on_device(h, X, deltaX, masked);
-    if (rc) return rc;
     const size_t n4 = (size_t)4 * h->N;
+    int *ovf = (int *)(h->pin + n4 + 6);
+    for (int attempt = 0;; attempt++) {              // (once more after the pool has been grown)
+        int rc = measure_on_device(h, X, deltaX, masked);
+        if (rc) return rc;
+        // the flag lands in the handle's pinned block, not in this frame: an error return below must not leave a
+        // copy in flight towards a dead stack slot
+        *ovf = 0;
+        HM_HIP(hipMemcpyAsync(ovf, h->pool.overflow, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HM_HIP(hipStreamSynchronize(h->stream));
+        if (!*ovf) break;
+        if (attempt) { hm_set_error("hm_measure: the star regions do not fit the difference-image pool"); return HM_ERR_STATE; }
+        rc = pool_grow(h, "hm_measure");
+        if (rc) return rc;
+    }
     HM_HIP(hipMemcpyAsync(Hz, h->d_Hz, n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (Hzc) HM_HIP(hipMemcpyAsync(Hzc, h->d_Hzc, n4 * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HM_HIP(hipMemcpyAsync(HTH, h->d_HTH, n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    // the flag lands in the handle's pinned block, not in this frame: an error return below must not leave a
-    // copy in flight towards a dead stack slot
-    int *ovf = (int *)(h->pin + n4 + 6);
-    *ovf = 0;
-    HM_HIP(hipMemcpyAsync(ovf, h->pool.overflow, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HM_HIP(hipStreamSynchronize(h->stream));
-    if (*ovf) { hm_set_error("hm_measure: the star regions do not fit the difference-image pool"); return HM_ERR_STATE; }
     return HM_OK;
 }
 
@@ -994,9 +1053,11 @@ extern "C" int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int ma
     NEED_OBS(h, "hm_update_step");
     HM_HIP(hipSetDevice(h->device));
     const int n4 = 4 * h->N;
-    int rc = measure_on_device(h, X, deltaX, masked, false);   // leaves X in d_X; the job sums go straight into the system
-    if (rc) return rc;
+    int rc = HM_OK;
     const int slot = h->upd_last == 0 ? 1 : 0;
+    for (int attempt = 0;; attempt++) {              // (once more after the pool of difference images has been grown)
+    rc = measure_on_device(h, X, deltaX, masked, false);   // leaves X in d_X; the job sums go straight into the system
+    if (rc) return rc;
     double *rhs_row = solve_step(h, slot, deltaX);
     HM_HIP(hipGetLastError());
     HM_HIP(hipMemcpyAsync(step, rhs_row, (size_t)n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1009,16 +1070,20 @@ extern "C" int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int ma
         // additions hm_update_run uses
         rc = render_iter(h, h->d_Xn, h->P, true, masked, false, deltaX);
         if (rc == HM_OK) {
-            hipError_t e = hipMemcpyAsync(h->h_tpart.data(), h->d_tpart, (size_t)h->ntiles * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+            hipError_t e = hipMemcpyAsync(h->h_tpart.data(), h->d_tpart, (size_t)render_strips(h) * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
             if (e == hipSuccess) e = stream_wait(h->stream);
             if (e != hipSuccess) { hm_set_error("hm_update_step: %s", hipGetErrorString(e)); rc = HM_ERR_HIP; }
-            else hm_tile_partial_sums(h->h_tpart.data(), h->ntiles, err);
+            else hm_tile_partial_sums(h->h_tpart.data(), render_strips(h), err);
         }
         if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }   // nothing of this call stays in flight
     } else {
         HM_HIP(hipStreamSynchronize(h->stream));
     }
-    if (*ovf) { hm_set_error("hm_update_step: the star regions do not fit the difference-image pool"); return HM_ERR_STATE; }
+    if (!*ovf) break;
+    if (attempt) { hm_set_error("hm_update_step: the star regions do not fit the difference-image pool"); return HM_ERR_STATE; }
+    rc = pool_grow(h, "hm_update_step");
+    if (rc) return rc;
+    }
     rc = flow_status(h, "hm_update_step");
     if (rc) return rc;
     h->upd_prev = h->upd_last;
@@ -1073,6 +1138,7 @@ extern "C" int hm_project_mask(hm_ctx_t h, const uint8_t *y_m, double *X, int *m
     if (!h->d_outline) {
         HM_HIP(hipMalloc((void **)&h->d_outline, n * sizeof(int2)));
         HM_HIP(hipMalloc((void **)&h->d_outline_cnt, 4 * sizeof(int)));
+        HM_HIP(hipMalloc((void **)&h->d_pm_flag, n));
         HM_HIP(hipMalloc((void **)&h->d_pm_X, xb));
     }
     const uint8_t *mask = h->o_ym;
@@ -1083,7 +1149,7 @@ extern "C" int hm_project_mask(hm_ctx_t h, const uint8_t *y_m, double *X, int *m
     }
     HM_HIP(hipMemsetAsync(h->d_outline_cnt, 0, 4 * sizeof(int), s));
     HM_HIP(hipMemcpyAsync(h->d_pm_X, X, xb, hipMemcpyHostToDevice, s));
-    Outline o = {h->d_outline, h->d_outline_cnt, (int)n};
+    Outline o = {h->d_outline, h->d_outline_cnt, (int)n, h->d_pm_flag};
     hipLaunchKernelGGL(k_outline, dim3(hm_cdiv(h->W, 64), hm_cdiv(h->H, OUTLINE_NT / 64)), dim3(OUTLINE_NT), 0, s,
                        mask, h->W, h->H, o);
     ProjArgs a = {mask, h->W, h->H, h->N, o, h->d_pm_X};
@@ -1174,7 +1240,7 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
     HM_HIP(hipMemcpyAsync(h->d_X, h->d_X0, (size_t)n4 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     double *res = h->pin, *pin_hzc = h->pin + n4 + 8, *pin_gain = pin_hzc + (size_t)n4 * 4;
     int niter = 0, accepted = 0;
-    bool reverted = false, conv = false, ref_ready = false, regions_ahead = false;
+    bool reverted = false, conv = false, ref_ready = false, regions_ahead = false, grown = false;
     double eold = 0.0;
     for (int it = 0; it < max_iter; it++) {
         rc = measure_dev(h, h->d_X, ref_ready, deltaX, masked, regions_ahead, false);
@@ -1190,17 +1256,28 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
         rc = render_iter(h, h->d_Xn, h->P, true, masked, regions_ahead, deltaX);
         if (rc) return rc;
         hipLaunchKernelGGL(k_iter_result, dim3(1), dim3(256), 0, h->stream, rhs_row, n4, h->d_tpart,
-                           h->ntiles, h->pool.overflow, (const unsigned *)h->d_flowctl, res, (double)(++h->run_ticket));
+                           render_strips(h), h->pool.overflow, (const unsigned *)h->d_flowctl, res, (double)(++h->run_ticket));
         HM_HIP(hipGetLastError());
         rc = wait_ticket(h, res + n4 + 5, (double)h->run_ticket);
         if (rc) return rc;
+        if (res[n4 + 4] != 0.0) {
+            // the star regions of this measurement did not fit the pool of difference images: grow it and take the
+            // iteration again (nothing of it has been kept; the regions the failed pass computed for its -- meaningless
+            // -- next iterate are computed anew)
+            if (grown) { hm_set_error("hm_update_run: the star regions do not fit the difference-image pool"); return HM_ERR_STATE; }
+            HM_HIP(hipStreamSynchronize(h->stream));
+            rc = pool_grow(h, "hm_update_run");
+            if (rc) return rc;
+            grown = true;
+            regions_ahead = false;
+            HM_HIP(hipMemsetAsync(h->d_flowctl, 0, 4 * sizeof(unsigned), h->stream));      // (a NaN system may have timed out)
+            it--;
+            continue;
+        }
+        grown = false;
         h->upd_prev = h->upd_last;
         h->upd_last = slot;
         niter++;
-        if (res[n4 + 4] != 0.0) {
-            hm_set_error("hm_update_run: the star regions do not fit the difference-image pool");
-            return HM_ERR_STATE;
-        }
         if (res[n4 + 7] != 0.0) {
             hm_set_error("hm_update_run: the factorisation launch gave up waiting for a block (chol_flow time-out)");
             return HM_ERR_HIP;

@@ -1002,11 +1002,10 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure_edge(MeasureArgs a)
 //       order: the values of k_setup_all + k_render<0>, bit for bit.  With `with_err` the pixels' four terms of
 //       Renderer.error (k_error's arithmetic) are added up over the strip and stored as partial[strip]; the final sums
 //       are formed in a fixed two-level order (d_tile_partial_sums; hm_tile_partial_sums on the host).
-#define RI_CHUNK 16
+#define RI_CHUNK 32
 #define RI_GROUPS 256
 #define RI_W 64
-#define RI_H 16
-#define RI_PX (RI_W * RI_H / 256)      // pixels per thread: rows r0 + (tid >> 6) + 4 q
+#define RI_H 16                        // strip height of the default launch (hm_ctx_tune "render_rows": 16 or 8)
 struct IterRenderArgs {
     Mesh m;
     const double *X;
@@ -1021,14 +1020,24 @@ struct RenderShared {
     double red[(256 / 64) * 4];
 };
 
+#ifdef HM_STAMP
+__device__ long long *g_stamp;          // development builds only (tools/stamp_render.py): per-workgroup wall-clock stamps
+#define HM_STAMP_AT(k) do { if (g_stamp && threadIdx.x == 0) g_stamp[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define HM_STAMP_AT(k) do { } while (0)
+#endif
+template <int RIH>
 __global__ __launch_bounds__(256) void k_render_iter(IterRenderArgs r, MeasureArgs a, int *__restrict__ area)
 {
+    HM_STAMP_AT(0);
+    constexpr int RI_PX = RI_W * RIH / 256;      // pixels per thread: rows r0 + (tid >> 6) + 4 q
     __shared__ union {
         RegionShared reg;
         RenderShared t;
     } sh;
     if ((int)blockIdx.x < r.n_regions) {
         d_star_regions<256>(a, area, blockIdx.x, sh.reg);
+        HM_STAMP_AT(4);
         return;
     }
     const Mesh &m = r.m;
@@ -1037,47 +1046,72 @@ __global__ __launch_bounds__(256) void k_render_iter(IterRenderArgs r, MeasureAr
     const int words = (m.T + 31) / 32;
     for (int i = tid; i < words; i += 256) sh.t.mask[i] = 0;
     __syncthreads();
-    const int c0 = (tile % r.tiles_x) * RI_W, r0 = (tile / r.tiles_x) * RI_H;
+    const int c0 = (tile % r.tiles_x) * RI_W, r0 = (tile / r.tiles_x) * RIH;
     const double *__restrict__ X = r.X;
-    for (int t = tid; t < m.T; t += 256) {
-        const int v0 = m.tri[3 * t], v1 = m.tri[3 * t + 1], v2 = m.tri[3 * t + 2];
-        const double x0 = X[2 * v0], y0 = X[2 * v0 + 1], x1 = X[2 * v1], y1 = X[2 * v1 + 1], x2 = X[2 * v2], y2 = X[2 * v2 + 1];
-        // pixel (c, r) can only be covered if its centre lies within the extent of the vertices (snapped to 1/256 px:
-        // half a pixel of slack would do); anything non-finite takes the exact test
-        const double lo_x = fmin(x0, fmin(x1, x2)) - 2.0, hi_x = fmax(x0, fmax(x1, x2)) + 2.0;
-        const double lo_y = fmin(y0, fmin(y1, y2)) - 2.0, hi_y = fmax(y0, fmax(y1, y2)) + 2.0;
-        if (hi_x < (double)c0 || lo_x > (double)(c0 + RI_W) || hi_y < (double)r0 || lo_y > (double)(r0 + RI_H)) continue;
-        int cmin, cmax, rmin, rmax;
-        d_tri_bbox(d_snap(x0), d_snap(y0), d_snap(x1), d_snap(y1), d_snap(x2), d_snap(y2), m.W, m.H, cmin, cmax, rmin, rmax);
-        if (cmin <= cmax && cmax >= c0 && cmin < c0 + RI_W && rmax >= r0 && rmin < r0 + RI_H)
-            atomicOr(&sh.t.mask[t >> 5], 1u << (t & 31));
+    // two triangles per thread and round, their loads issued together (tri -> X is a dependent pair of round trips)
+    for (int tb = tid; tb < m.T; tb += 512) {
+        const int ta = tb, tc = tb + 256;
+        const bool has2 = tc < m.T;
+        const int a0 = m.tri[3 * ta], a1 = m.tri[3 * ta + 1], a2 = m.tri[3 * ta + 2];
+        const int b0 = has2 ? m.tri[3 * tc] : a0, b1 = has2 ? m.tri[3 * tc + 1] : a1, b2 = has2 ? m.tri[3 * tc + 2] : a2;
+        const double ax0 = X[2 * a0], ay0 = X[2 * a0 + 1], ax1 = X[2 * a1], ay1 = X[2 * a1 + 1], ax2 = X[2 * a2], ay2 = X[2 * a2 + 1];
+        const double bx0 = X[2 * b0], by0 = X[2 * b0 + 1], bx1 = X[2 * b1], by1 = X[2 * b1 + 1], bx2 = X[2 * b2], by2 = X[2 * b2 + 1];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (k == 1 && !has2) break;
+            const int t = k ? tc : ta;
+            const double x0 = k ? bx0 : ax0, y0 = k ? by0 : ay0, x1 = k ? bx1 : ax1, y1 = k ? by1 : ay1, x2 = k ? bx2 : ax2, y2 = k ? by2 : ay2;
+            // pixel (c, r) can only be covered if its centre lies within the extent of the vertices (snapped to 1/256 px:
+            // half a pixel of slack would do); anything non-finite takes the exact test
+            const double lo_x = fmin(x0, fmin(x1, x2)) - 2.0, hi_x = fmax(x0, fmax(x1, x2)) + 2.0;
+            const double lo_y = fmin(y0, fmin(y1, y2)) - 2.0, hi_y = fmax(y0, fmax(y1, y2)) + 2.0;
+            if (hi_x < (double)c0 || lo_x > (double)(c0 + RI_W) || hi_y < (double)r0 || lo_y > (double)(r0 + RIH)) continue;
+            int cmin, cmax, rmin, rmax;
+            d_tri_bbox(d_snap(x0), d_snap(y0), d_snap(x1), d_snap(y1), d_snap(x2), d_snap(y2), m.W, m.H, cmin, cmax, rmin, rmax);
+            if (cmin <= cmax && cmax >= c0 && cmin < c0 + RI_W && rmax >= r0 && rmin < r0 + RIH)
+                atomicOr(&sh.t.mask[t >> 5], 1u << (t & 31));
+        }
     }
     __syncthreads();
+    HM_STAMP_AT(1);
     int total = 0;
     for (int w = 0; w < words; w++) total += __popc(sh.t.mask[w]);
     const int c = c0 + (tid & 63), rb = r0 + (tid >> 6);
-    int acc[RI_PX], cnt[RI_PX];
+    int acc[RI_PX], cnt[RI_PX], tadr[RI_PX];
     float fx[RI_PX], fy[RI_PX];
 #pragma unroll
-    for (int q = 0; q < RI_PX; q++) { acc[q] = 0; cnt[q] = 0; fx[q] = 0.0f; fy[q] = 0.0f; }
+    for (int q = 0; q < RI_PX; q++) { acc[q] = 0; cnt[q] = 0; fx[q] = 0.0f; fy[q] = 0.0f; tadr[q] = -1; }
     for (int base = 0; base < total; base += RI_CHUNK) {
         const int nch = min(RI_CHUNK, total - base);
-        if (tid < nch) {                           // the (base + tid)-th set bit, in ascending order
-            int k = base + tid, w = 0;
-            for (;; w++) {
-                const int pc = __popc(sh.t.mask[w]);
-                if (k < pc) break;
-                k -= pc;
-            }
-            unsigned bits = sh.t.mask[w];
-            for (; k > 0; k--) bits &= bits - 1;
-            const int t = w * 32 + __ffs(bits) - 1;
-            const int v0 = m.tri[3 * t], v1 = m.tri[3 * t + 1], v2 = m.tri[3 * t + 2];
+        // The candidates base .. base + nch - 1 (in ascending triangle order: the rank of a triangle among the set bits
+        // is its slot) are set up by the threads that tested them -- spread over all waves, each with its own triangles
+        // -- not by the lanes of one wave one after the other.  A candidate no pixel of the strip can lie in (E_k <= 0
+        // at all four corner pixels for one edge k: E is linear) is left with an empty box: the pixel loop passes it
+        // at its first comparison.
+        for (int tb = tid; tb < m.T; tb += 256) {
+            const unsigned word = sh.t.mask[tb >> 5], bit = 1u << (tb & 31);
+            if (!(word & bit)) continue;
+            int rank = __popc(word & (bit - 1u));
+            for (int w = 0; w < (tb >> 5); w++) rank += __popc(sh.t.mask[w]);
+            if (rank < base || rank >= base + nch) continue;
+            const int v0 = m.tri[3 * tb], v1 = m.tri[3 * tb + 1], v2 = m.tri[3 * tb + 2];
             TriSetup su;
             d_tri_setup(su, v0, v1, v2, d_snap(X[2 * v0]), d_snap(X[2 * v0 + 1]), d_snap(X[2 * v1]), d_snap(X[2 * v1 + 1]),
                         d_snap(X[2 * v2]), d_snap(X[2 * v2 + 1]), m.W, m.H);
             d_tri_attr(su, m.uv, X, m.N);
-            sh.t.cand[tid] = su;
+            {
+                const double xa = (double)c0, xb = (double)min(c0 + RI_W - 1, m.W - 1);
+                const double ya = (double)r0, yb = (double)min(r0 + RIH - 1, m.H - 1);
+                bool out = false;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const double e00 = fma(su.ea[k], xa, fma(su.eb[k], ya, su.ecb[k])), e10 = fma(su.ea[k], xb, fma(su.eb[k], ya, su.ecb[k]));
+                    const double e01 = fma(su.ea[k], xa, fma(su.eb[k], yb, su.ecb[k])), e11 = fma(su.ea[k], xb, fma(su.eb[k], yb, su.ecb[k]));
+                    out |= !(e00 > 0.0 || e10 > 0.0 || e01 > 0.0 || e11 > 0.0);
+                }
+                if (out) { su.cmin = 1; su.cmax = 0; }
+            }
+            sh.t.cand[rank - base] = su;
         }
         __syncthreads();
         if (c < m.W)
@@ -1087,13 +1121,26 @@ __global__ __launch_bounds__(256) void k_render_iter(IterRenderArgs r, MeasureAr
                 for (int j = 0; j < RI_PX; j++) {
                     float l1, l2;
                     if (!d_tri_eval(su, c, rb + 4 * j, l1, l2)) continue;    // (rows past the frame are outside the box)
-                    acc[j] += d_texel(m.tex, su, l1, l2, m.W, m.H);
+                    // the texel of the first covering triangle is fetched after the loop, all pixels' together (a
+                    // fetch here would be waited for before the next triangle is looked at); further ones (a folded
+                    // mesh) at once -- integer sums: the order does not matter
+                    const int at = d_texel_at(su, l1, l2, m.W, m.H);
+                    if (tadr[j] < 0) tadr[j] = at;
+                    else acc[j] += m.tex[at];
                     fx[j] = fx[j] + d_lerp(su.ax[0], su.ax[1], su.ax[2], l1, l2);
                     fy[j] = fy[j] + d_lerp(su.ay[0], su.ay[1], su.ay[2], l1, l2);
                     cnt[j]++;
                 }
             }
         __syncthreads();
+    }
+    HM_STAMP_AT(2);
+    {
+        int tx[RI_PX];
+#pragma unroll
+        for (int j = 0; j < RI_PX; j++) tx[j] = m.tex[tadr[j] < 0 ? 0 : tadr[j]];
+#pragma unroll
+        for (int j = 0; j < RI_PX; j++) acc[j] += tadr[j] < 0 ? 0 : tx[j];
     }
     double e[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -1115,8 +1162,10 @@ __global__ __launch_bounds__(256) void k_render_iter(IterRenderArgs r, MeasureAr
             e[3] += (double)((dm * dm) & 255u);
         }
     }
+    HM_STAMP_AT(3);
     if (!r.with_err) return;
     d_block_reduce<4, 256>(e, sh.t.red, r.partial + 4 * (size_t)tile);
+    HM_STAMP_AT(4);
 }
 
 // The four error sums from the per-tile partials, in a fixed order: thread g of RI_GROUPS adds the partials g,

@@ -1,53 +1,58 @@
 // KalmanFilter.projectmask (reference kalman.py:724-742) on the device (gfx950).
 //
-// The reference asks OpenCV for the signed distance of a vertex to the object contour
-// (imgproc.py:175-248, outside this path); the product defines it as the Euclidean distance
-// transform of the mask (object pixel -> nearest background pixel, negative; background pixel
-// -> nearest object pixel, positive), sampled bilinearly -- see oracle/ekf_ref.py:project_mask.
-// The nearest pixel of the other kind always touches the outline (has a 4-neighbour of the
-// other kind), so the transform is never formed: k_outline compacts the outline pixels of
-// either kind (a few thousand at 1024^2) and k_project_mask, one workgroup per vertex, takes
-// the exact integer minimum of dx^2+dy^2 over them for the four pixels around a sample point.
-// The arithmetic after that is the host's, operation by operation (no contraction), so the
-// projected state is the same f64 numbers.
+// The reference asks OpenCV for the signed distance of a vertex to the object's contour:
+// fd(p) = -cv2.pointPolygonTest(contour, p, True) with the contour cv2.findContours traces through
+// the border pixels of the mask (imgproc.py:195-235) -- the distance to the POLYGON THROUGH THE
+// CENTRES OF THE OBJECT'S BORDER PIXELS, negative inside.  Here:
+//   * k_outline marks and compacts the border pixels of the object: object pixels with a 4-neighbour
+//     that is background or lies outside the frame (findContours treats the frame as surrounded by
+//     background);
+//   * the polygon's sides are the segments between 8-adjacent border pixels (a traced contour uses a
+//     subset of them; the others are diagonal short cuts that lie on the object's side of the contour,
+//     so for a point outside the object -- the only place the walk below evaluates it, d > 1 -- the
+//     nearest point is the same).  k_project_mask, one workgroup per vertex, takes the exact minimum of
+//     the squared point-to-segment distance over all of them in binary64 (min does not depend on the
+//     order) and the sign from the 2x2 pixels around the point: inside iff all four are object, or
+//     three and the point lies on their side of the diagonal -- inside the polygon through the centres.
+// What is NOT applied per frame is the reference's contour pruning (imgproc.py:205-228: only the largest
+// object and its holes of at least 40 px): every border pixel of the mask counts.  For a mask with one object
+// and no small holes the numbers are those of imgproc.findObjectThreshold(mask).fd (tests).
+// The arithmetic is the oracle's (oracle/ekf_ref.py:outline_distance, project_mask), operation by
+// operation with contraction off, so the projected state is the same f64 numbers.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
 struct Outline {
-    int2 *pts;       // capacity cap = W*H: object pixels from the front, background pixels from the back
-    int *count;      // [0] object outline pixels, [1] background outline pixels, [2] vertices moved
+    int2 *pts;       // capacity W*H: border pixels of the object
+    int *count;      // [0] border pixels, [1] (unused), [2] vertices moved
     int cap;
+    uint8_t *flag;   // W*H: 1 at border pixels, else 0
 };
 
 #define OUTLINE_NT 256
-// one wave per 64-pixel row segment; one atomic per wave and kind
+// one wave per 64-pixel row segment; one atomic per wave
 __global__ __launch_bounds__(OUTLINE_NT) void k_outline(const uint8_t *__restrict__ ym, int W, int H, Outline o)
 {
     const int lane = threadIdx.x & 63;
     const int x = blockIdx.x * 64 + lane;
     const int y = blockIdx.y * (OUTLINE_NT / 64) + (threadIdx.x >> 6);
-    bool on = false, obj = false;
+    bool on = false;
     if (x < W && y < H) {
         const uint8_t *row = ym + (size_t)y * W;
-        obj = row[x] > 0;
-        if (x > 0) on |= (row[x - 1] > 0) != obj;
-        if (x + 1 < W) on |= (row[x + 1] > 0) != obj;
-        if (y > 0) on |= (row[x - W] > 0) != obj;
-        if (y + 1 < H) on |= (row[x + W] > 0) != obj;
+        if (row[x] > 0) {
+            on = x == 0 || x == W - 1 || y == 0 || y == H - 1;
+            if (!on) on = !(row[x - 1] > 0) || !(row[x + 1] > 0) || !(row[x - W] > 0) || !(row[x + W] > 0);
+        }
+        o.flag[(size_t)y * W + x] = on ? 1 : 0;
     }
-    const unsigned long long bo = __ballot(on && obj), bb = __ballot(on && !obj);
-    if (!(bo | bb)) return;
-    int base_o = 0, base_b = 0;
-    if (lane == 0) {
-        if (bo) base_o = atomicAdd(&o.count[0], __popcll(bo));
-        if (bb) base_b = atomicAdd(&o.count[1], __popcll(bb));
-    }
+    const unsigned long long bo = __ballot(on);
+    if (!bo) return;
+    int base_o = 0;
+    if (lane == 0) base_o = atomicAdd(&o.count[0], __popcll(bo));
     base_o = __shfl(base_o, 0);
-    base_b = __shfl(base_b, 0);
     const unsigned long long below = (1ull << lane) - 1ull;
-    if (on && obj) o.pts[base_o + __popcll(bo & below)] = make_int2(x, y);
-    if (on && !obj) o.pts[o.cap - 1 - (base_b + __popcll(bb & below))] = make_int2(x, y);
+    if (on) o.pts[base_o + __popcll(bo & below)] = make_int2(x, y);
 }
 
 struct ProjArgs {
@@ -58,56 +63,60 @@ struct ProjArgs {
 };
 
 #define PROJ_NT 256
-#define PROJ_NONE 0x7fffffffffffffffLL
 
-// signed distance at (x, y), uniform over the workgroup; red = PROJ_NT/64 * 4 LDS words
-static __device__ double d_mask_distance(const ProjArgs &a, double x, double y, long long *red)
+// signed distance at (x, y), uniform over the workgroup; red = PROJ_NT/64 * 3 doubles of LDS
+static __device__ double d_mask_distance(const ProjArgs &a, double x, double y, double *red)
 {
 #pragma clang fp contract(off)
     const int W = a.W, H = a.H;
-    const double xc = fmin(fmax(x, 0.0), (double)(W - 1)), yc = fmin(fmax(y, 0.0), (double)(H - 1));
-    const int px = (int)floor(xc), py = (int)floor(yc);
-    int qx[4], qy[4];
-    bool in[4];
-    for (int k = 0; k < 4; k++) {
-        qx[k] = min(px + (k & 1), W - 1);
-        qy[k] = min(py + (k >> 1), H - 1);
-        in[k] = a.ym[(size_t)qy[k] * W + qx[k]] > 0;
+    const int n_obj = a.o.count[0];
+    if (n_obj == 0) return 0.0;                        // a blank mask has no outline to be pulled to
+    double best_seg = 1e300, best_pt = 1e300, nseg = 0.0;
+    for (int i = threadIdx.x; i < n_obj; i += PROJ_NT) {
+        const int2 p = a.o.pts[i];
+        const double apx = x - (double)p.x, apy = y - (double)p.y;
+        best_pt = fmin(best_pt, apx * apx + apy * apy);
+        // each 8-adjacent pair once: right, lower left, lower, lower right
+        const int ddx[4] = {1, -1, 0, 1}, ddy[4] = {0, 1, 1, 1};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int qx = p.x + ddx[k], qy = p.y + ddy[k];
+            if (qx < 0 || qx >= W || qy >= H || !a.o.flag[(size_t)qy * W + qx]) continue;
+            const double abx = (double)ddx[k], aby = (double)ddy[k], den = abx * abx + aby * aby;
+            double t = (apx * abx + apy * aby) / den;
+            t = fmin(fmax(t, 0.0), 1.0);
+            const double ex = apx - t * abx, ey = apy - t * aby;
+            best_seg = fmin(best_seg, ex * ex + ey * ey);
+            nseg += 1.0;
+        }
     }
-    long long best[4] = {PROJ_NONE, PROJ_NONE, PROJ_NONE, PROJ_NONE};
-    const int n_obj = a.o.count[0], n_bg = a.o.count[1];
-    if (!(in[0] && in[1] && in[2] && in[3]))
-        for (int i = threadIdx.x; i < n_obj; i += PROJ_NT) {
-            const int2 p = a.o.pts[i];
-            for (int k = 0; k < 4; k++) {
-                const long long dx = p.x - qx[k], dy = p.y - qy[k];
-                if (!in[k]) best[k] = min(best[k], dx * dx + dy * dy);
-            }
-        }
-    if (in[0] || in[1] || in[2] || in[3])
-        for (int i = threadIdx.x; i < n_bg; i += PROJ_NT) {
-            const int2 p = a.o.pts[a.o.cap - 1 - i];
-            for (int k = 0; k < 4; k++) {
-                const long long dx = p.x - qx[k], dy = p.y - qy[k];
-                if (in[k]) best[k] = min(best[k], dx * dx + dy * dy);
-            }
-        }
-    for (int k = 0; k < 4; k++)
-        for (int s = 32; s > 0; s >>= 1) best[k] = min(best[k], __shfl_xor(best[k], s));
+    for (int s = 32; s > 0; s >>= 1) {
+        best_seg = fmin(best_seg, __shfl_xor(best_seg, s));
+        best_pt = fmin(best_pt, __shfl_xor(best_pt, s));
+        nseg += __shfl_xor(nseg, s);
+    }
     const int wv = threadIdx.x >> 6;
     __syncthreads();                                   // red may still be read from the previous call
-    if ((threadIdx.x & 63) == 0)
-        for (int k = 0; k < 4; k++) red[wv * 4 + k] = best[k];
+    if ((threadIdx.x & 63) == 0) { red[wv * 3] = best_seg; red[wv * 3 + 1] = best_pt; red[wv * 3 + 2] = nseg; }
     __syncthreads();
-    double q[4];
-    for (int k = 0; k < 4; k++) {
-        long long b = red[k];
-        for (int w = 1; w < PROJ_NT / 64; w++) b = min(b, red[w * 4 + k]);
-        const double r = b == PROJ_NONE ? 0.0 : sqrt((double)b);
-        q[k] = in[k] ? -r : r;
+    double bs = red[0], bp = red[1], ns = red[2];
+    for (int w = 1; w < PROJ_NT / 64; w++) { bs = fmin(bs, red[w * 3]); bp = fmin(bp, red[w * 3 + 1]); ns += red[w * 3 + 2]; }
+    const double dist = sqrt(ns > 0.0 ? bs : bp);      // a lone pixel is its own (degenerate) polygon
+    // inside the polygon through the pixel centres: the corners of the point's grid cell
+    bool ins = false;
+    if (!(x < 0.0 || y < 0.0 || x > (double)(W - 1) || y > (double)(H - 1))) {
+        const int x0 = min(max((int)floor(x), 0), W - 1), y0 = min(max((int)floor(y), 0), H - 1);
+        const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+        const double fx = fmin(fmax(x - (double)x0, 0.0), 1.0), fy = fmin(fmax(y - (double)y0, 0.0), 1.0);
+        const bool c00 = a.ym[(size_t)y0 * W + x0] > 0, c10 = a.ym[(size_t)y0 * W + x1] > 0;
+        const bool c01 = a.ym[(size_t)y1 * W + x0] > 0, c11 = a.ym[(size_t)y1 * W + x1] > 0;
+        const int n = (int)c00 + (int)c10 + (int)c01 + (int)c11;
+        ins = n == 4;
+        if (n == 3) {                                   // on the side of the diagonal away from the missing corner
+            ins = (!c00 && fx + fy >= 1.0) || (!c11 && fx + fy <= 1.0) || (!c10 && fy >= fx) || (!c01 && fy <= fx);
+        }
     }
-    const double ax = xc - (double)px, ay = yc - (double)py;
-    return (1.0 - ay) * ((1.0 - ax) * q[0] + ax * q[1]) + ay * ((1.0 - ax) * q[2] + ax * q[3]);
+    return ins ? -dist : dist;
 }
 
 // one workgroup per vertex: 10 steps p -= d g / |g|^2 with forward differences of 0.1 px; d is
@@ -116,7 +125,7 @@ static __device__ double d_mask_distance(const ProjArgs &a, double x, double y, 
 __global__ __launch_bounds__(PROJ_NT) void k_project_mask(ProjArgs a)
 {
 #pragma clang fp contract(off)
-    __shared__ long long red[PROJ_NT / 64 * 4];
+    __shared__ double red[PROJ_NT / 64 * 3];
     const int v = blockIdx.x;
     const double x0 = a.X[2 * v], y0 = a.X[2 * v + 1];
     const double fx = floor(x0), fy = floor(y0);

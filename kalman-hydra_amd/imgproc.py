@@ -132,6 +132,45 @@ class SignedDistance:
         return np.where(self._inside(p), -d, d)
 
 
+def outline_distance(mask):
+    """fd for a mask without contour pruning -- the per-frame form KalmanFilter.projectmask uses (reference kalman.py:725:
+    findObjectThreshold(y_m, 0.5)[2]): signed distance to the polygon through the centres of ALL border pixels of the
+    mask's object pixels (object pixels with a 4-neighbour that is background or off the frame), sides between
+    8-adjacent border pixels, exact minimum over every side in binary64 (no k-d tree: the same numbers
+    hm_project_mask computes on the device); sign as SignedDistance; a blank mask gives 0."""
+    m = np.asarray(mask) > 0.5
+    sd = SignedDistance(m)
+    if sd.empty:
+        return lambda p: np.zeros(len(np.atleast_2d(p)))
+    b = _boundary(m)
+    ys, xs = np.nonzero(b)
+    bp = np.pad(b, 1, constant_values=False)
+    A, B = [], []
+    for dx, dy in ((1, 0), (-1, 1), (0, 1), (1, 1)):
+        ok = bp[ys + 1 + dy, xs + 1 + dx]
+        A.append(np.column_stack((xs[ok], ys[ok])))
+        B.append(np.column_stack((xs[ok] + dx, ys[ok] + dy)))
+    A, B = np.concatenate(A).astype(np.float64), np.concatenate(B).astype(np.float64)
+    P = np.column_stack((xs, ys)).astype(np.float64)
+    abx, aby = B[:, 0] - A[:, 0], B[:, 1] - A[:, 1]
+    den = abx * abx + aby * aby
+
+    def fd(p):
+        p = np.atleast_2d(np.asarray(p, np.float64))
+        d = np.empty(len(p))
+        for i, (x, y) in enumerate(p):
+            if len(A):
+                apx, apy = x - A[:, 0], y - A[:, 1]
+                t = np.minimum(np.maximum((apx * abx + apy * aby) / den, 0.0), 1.0)
+                ex, ey = apx - t * abx, apy - t * aby
+                d[i] = np.sqrt((ex * ex + ey * ey).min())
+            else:
+                apx, apy = x - P[:, 0], y - P[:, 1]
+                d[i] = np.sqrt((apx * apx + apy * apy).min())
+        return np.where(sd._inside(p), -d, d)
+    return fd
+
+
 def findObjectThreshold(img, threshold=7):
     """reference imgproc.py:175-248 -> (mask u8 HxW, Contours, fd)."""
     gray = to_gray(img)

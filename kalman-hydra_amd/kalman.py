@@ -518,9 +518,10 @@ class KalmanFilter:
     def projectmask(self, y_m):
         """Vertices more than 1 px outside the object are pulled back onto its outline (:724-742).
 
-        The reference takes the signed distance from OpenCV contours (imgproc.py:175-248,
-        outside this path); here it is the Euclidean distance transform of the mask, sampled
-        bilinearly.  Steps, step size and the stale d / index set follow the reference."""
+        The signed distance is the reference's (imgproc.py:195-235): to the polygon through the centres of the
+        object's border pixels, negative inside (imgproc.outline_distance; on the device csrc/project_kernels.h);
+        the reference's per-frame pruning of small contours is not applied.  Steps, step size and the stale
+        d / index set follow the reference."""
         if y_m is None:
             return
         r = self.state.renderer
@@ -960,51 +961,8 @@ def _inside(y_m, p):
 
 
 def _mask_distance(y_m):
-    """Signed distance to the object outline: positive outside the mask, negative inside,
-    sampled bilinearly (see projectmask).
-
-    The numbers are those of the Euclidean distance transform of the mask (distance of an
-    object pixel to the nearest background pixel and vice versa), but the transform of a whole
-    1024^2 frame costs ~0.2 s on the host and only a few vertices ever ask.  The nearest pixel of
-    the other kind is always one that touches the outline (has a 4-neighbour of the other kind),
-    so the outline pixels of either kind go into two k-d trees (a few thousand points) and the
-    four pixels around each query look their distance up there: the same sqrt(integer) values,
-    at a cost that does not depend on how far the mesh has drifted from the object."""
-    from scipy.spatial import cKDTree
-    m = np.asarray(y_m) > 0.5
-    H, W = m.shape
-    mu = m.view(np.uint8)
-    dx = mu[:, 1:] ^ mu[:, :-1]
-    dy = mu[1:, :] ^ mu[:-1, :]
-    edge = np.zeros((H, W), np.uint8)
-    edge[:, 1:] |= dx
-    edge[:, :-1] |= dx
-    edge[1:, :] |= dy
-    edge[:-1, :] |= dy
-    flat = np.flatnonzero(edge)
-    if flat.size == 0:                    # blank or full mask: no outline to be pulled to
-        return lambda p: np.zeros(len(np.atleast_2d(p)))
-    ys, xs = np.divmod(flat, W)
-    obj = m.ravel()[flat]
-    pts = np.column_stack((xs, ys)).astype(np.float64)
-    tree_obj, tree_bg = cKDTree(pts[obj]), cKDTree(pts[~obj])
-
-    def fd(p):
-        p = np.atleast_2d(np.asarray(p, np.float64))
-        xc, yc = np.clip(p[:, 0], 0.0, W - 1.0), np.clip(p[:, 1], 0.0, H - 1.0)     # mode="nearest"
-        px, py = np.floor(xc).astype(np.int64), np.floor(yc).astype(np.int64)
-        q = np.empty((2, 2, len(p)))
-        for j in range(2):
-            for i in range(2):
-                xx, yy = np.minimum(px + i, W - 1), np.minimum(py + j, H - 1)
-                pix = np.column_stack((xx, yy)).astype(np.float64)
-                inside = m[yy, xx]
-                d = np.empty(len(p))
-                if inside.any():
-                    d[inside] = -tree_bg.query(pix[inside])[0]
-                if not inside.all():
-                    d[~inside] = tree_obj.query(pix[~inside])[0]
-                q[j, i] = d
-        ax, ay = xc - px, yc - py
-        return (1 - ay) * ((1 - ax) * q[0, 0] + ax * q[0, 1]) + ay * ((1 - ax) * q[1, 0] + ax * q[1, 1])
-    return fd
+    """Signed distance to the object's outline: positive outside the mask, negative inside -- the reference's fd
+    (imgproc.py:195-235: -cv2.pointPolygonTest of the contour through the object's border pixels), restated in
+    imgproc.outline_distance; what hm_project_mask evaluates on the device."""
+    from .imgproc import outline_distance
+    return outline_distance(y_m)

@@ -356,6 +356,10 @@ class FlowEKFPipeline:
         self._ready, self._buf, self._flying, self._thread_exc = (0, 0), 0, [], None
         self._end = self.F - 1
         self._cursor = 0                 # the oldest frame still needed (the pair the filter is at)
+        self._series_s = {}              # pairs -> seconds a series of that size took alone (first series of phases)
+        self._frame_s = None             # seconds per frame of the filter (running mean over the last phase)
+        self.adaptive_first = True       # size the first series of a phase from those measurements
+        self.first_series = 0            # > 0: fixed size of the first series of every phase
         self.profiled_handle = None
 
     # -- flow series ---------------------------------------------------------------------------------
@@ -388,9 +392,11 @@ class FlowEKFPipeline:
                 self.ring.ensure(min(nxt + 1, self._cursor + self.ring.R), self._cursor)
             except Exception as exc:                    # noqa: BLE001 -- re-raised by the thread that waits
                 self._thread_exc = exc
+        first = not self._flying and self._ready[0] == self._ready[1]       # the first series of a phase: nothing runs beside it
         t = threading.Thread(target=work)
+        t0 = time.perf_counter()
         t.start()
-        self._flying.append({"lo": k, "hi": k + nb, "buf": buf, "handle": h, "thread": t})
+        self._flying.append({"lo": k, "hi": k + nb, "buf": buf, "handle": h, "thread": t, "t0": t0, "alone": first})
 
     def _next_series(self, last):
         """Pairs of the series that follows one of `last` pairs.  A phase starts with two pairs and grows 2, 3, 5, 8: a
@@ -404,7 +410,38 @@ class FlowEKFPipeline:
         if self._thread_exc is not None:
             exc, self._thread_exc = self._thread_exc, None
             raise exc
+        t1 = time.perf_counter()
         self.bfs[f["handle"]].sync()
+        t2 = time.perf_counter()
+        if f.get("alone") and t2 - t1 > 2e-4:
+            # the caller really waited for this series and nothing ran beside it (the first series of a phase): launch ->
+            # completion is what a series of that many pairs takes -- kept for sizing the first series of later phases
+            n = f["hi"] - f["lo"]
+            self._series_s[n] = min(self._series_s.get(n, 1e9), t2 - f["t0"])
+
+    def _first_series(self):
+        """Pairs of the first series of a phase.  The filter waits for that series with nothing to do, so it should be
+        just large enough that the series after it (of B pairs, running beside the filter) is done by the time the
+        filter is through with these: n1 x (time of a frame of the filter) >= time of a series of B pairs.  Both times
+        are measured in earlier phases (a series of n pairs takes about a + b (n - 1): two first series of different
+        sizes give a and b, one gives a with b taken as a fifth of a two-pair series -- 1.45 of 7.2 ms at 1024^2; a
+        series beside the filter takes ~1.3 x as long as alone); without measurements a phase starts with two pairs."""
+        if len(self.bfs) > 1:
+            return 1
+        default = min(2, self.B)
+        if self.first_series:
+            return max(1, min(self.B, int(self.first_series)))
+        ts = self._series_s
+        if not ts or self._frame_s is None or not self.adaptive_first:
+            return default
+        (n_a, t_a), (n_b, t_b) = sorted(ts.items())[0], sorted(ts.items())[-1]
+        if n_b > n_a:
+            b = max(0.0, (t_b - t_a) / (n_b - n_a))
+        else:
+            b = 0.2 * t_a / (1.0 + 0.2 * (n_a - 2))
+        t_full = t_a + b * (self.B - n_a)
+        n1 = int(np.ceil(1.3 * t_full / max(self._frame_s, 1e-4)))
+        return max(default, min(self.B, n1))
 
     def flow_sync(self):
         """Wait for every series in flight (their results stay where they are)."""
@@ -430,7 +467,7 @@ class FlowEKFPipeline:
             if nxt >= self._end:
                 return
             size = (last["hi"] - last["lo"]) if last else (self._ready[1] - self._ready[0])
-            self._launch(nxt, self._end, self._next_series(size) if size else (1 if len(self.bfs) > 1 else min(2, self.B)))
+            self._launch(nxt, self._end, self._next_series(size) if size else self._first_series())
 
     def flow_ready(self, k):
         """Make the flow of pair (k, k+1) available -> (device pointer of u, of v)."""
@@ -475,6 +512,7 @@ class FlowEKFPipeline:
                                 y_m_host=self.source.frame_at(k + 1)[1])
         e = self.kf.compute(obs, None, None, maskflow=self.maskflow)
         t2 = time.perf_counter()
+        self._frame_s = (t2 - t1) if self._frame_s is None else 0.8 * self._frame_s + 0.2 * (t2 - t1)
         self.t_flow += t1 - t0
         self.t_ekf += t2 - t1
         self.iters += getattr(self.kf, "niter", 1)

@@ -470,27 +470,82 @@ def mask_flow(y_flow, y_m):
     return np.dstack((y_m * y_flow[:, :, 0], y_m * y_flow[:, :, 1])).astype(np.float32)
 
 
+def outline_distance(y_m):
+    """fd of reference imgproc.py:195-235 for a mask: -cv2.pointPolygonTest(contour, p, True) with the contour that
+    cv2.findContours traces through the border pixels of the object, i.e. the signed distance (negative inside) to the
+    polygon through the centres of the object's border pixels.  Restated without OpenCV:
+
+    * border pixels: object pixels with a 4-neighbour that is background or outside the frame (findContours treats the
+      frame as surrounded by background);
+    * sides of the polygon: the segments between 8-adjacent border pixels.  A traced contour uses a subset of them; the
+      rest are diagonal short cuts on the object's side of the contour, so outside the object (where projectmask
+      evaluates fd, kalman.py:728: d > 1) the nearest point of the outline is the same.  Exact minimum over all of them
+      in binary64; a mask whose border pixels have no 8-adjacent pair at all (a lone pixel) is its own degenerate
+      polygon (nearest border pixel); no border pixel at all (blank mask): 0;
+    * sign: a point is inside the polygon through the pixel centres iff the four pixels around it are all object, or
+      three are and it lies on their side of the diagonal; points off the frame are outside.
+
+    The reference's pruning of contours (imgproc.py:205-228: the largest object and its holes of >= 40 px only) is NOT
+    applied: every border pixel of the mask counts (as in the product's per-frame projection)."""
+    m = np.asarray(y_m) > 0.5
+    H, W = m.shape
+    pad = np.pad(m, 1, constant_values=False)
+    inner = pad[:-2, 1:-1] & pad[2:, 1:-1] & pad[1:-1, :-2] & pad[1:-1, 2:]
+    border = m & ~inner
+    ys, xs = np.nonzero(border)
+    A, B = [], []
+    bp = np.pad(border, 1, constant_values=False)
+    for dx, dy in ((1, 0), (-1, 1), (0, 1), (1, 1)):            # each 8-adjacent pair once
+        ok = bp[ys + 1 + dy, xs + 1 + dx]
+        A.append(np.column_stack((xs[ok], ys[ok])))
+        B.append(np.column_stack((xs[ok] + dx, ys[ok] + dy)))
+    A = np.concatenate(A).astype(np.float64) if len(xs) else np.zeros((0, 2))
+    B = np.concatenate(B).astype(np.float64) if len(xs) else np.zeros((0, 2))
+    P = np.column_stack((xs, ys)).astype(np.float64)
+
+    def inside(q):
+        x, y = q[:, 0], q[:, 1]
+        x0 = np.clip(np.floor(x).astype(np.int64), 0, W - 1)
+        y0 = np.clip(np.floor(y).astype(np.int64), 0, H - 1)
+        x1, y1 = np.minimum(x0 + 1, W - 1), np.minimum(y0 + 1, H - 1)
+        fx, fy = np.clip(x - x0, 0.0, 1.0), np.clip(y - y0, 0.0, 1.0)
+        c00, c10, c01, c11 = m[y0, x0], m[y0, x1], m[y1, x0], m[y1, x1]
+        n = c00.astype(int) + c10 + c01 + c11
+        ins = n == 4
+        three = n == 3
+        ins = ins | (three & ((~c00 & (fx + fy >= 1.0)) | (~c11 & (fx + fy <= 1.0)) | (~c10 & (fy >= fx)) | (~c01 & (fy <= fx))))
+        off = (x < 0) | (y < 0) | (x > W - 1) | (y > H - 1)
+        return ins & ~off
+
+    def fd(q):
+        q = np.atleast_2d(np.asarray(q, np.float64))
+        if len(P) == 0:
+            return np.zeros(len(q))
+        out = np.empty(len(q))
+        for i, (x, y) in enumerate(q):
+            if len(A):
+                apx, apy = x - A[:, 0], y - A[:, 1]
+                abx, aby = B[:, 0] - A[:, 0], B[:, 1] - A[:, 1]
+                den = abx * abx + aby * aby
+                t = np.minimum(np.maximum((apx * abx + apy * aby) / den, 0.0), 1.0)
+                ex, ey = apx - t * abx, apy - t * aby
+                out[i] = np.sqrt((ex * ex + ey * ey).min())
+            else:
+                apx, apy = x - P[:, 0], y - P[:, 1]
+                out[i] = np.sqrt((apx * apx + apy * apy).min())
+        return np.where(inside(q), -out, out)
+    return fd
+
+
 def project_mask(X, N, y_m, steps=10, ddeps=1e-1):
-    """KalmanFilter.projectmask, kalman.py:724-742.  The reference's distance function comes
-    from OpenCV contours (imgproc.py:175-248, outside the hot path and not available here);
-    as in the product, it is replaced by the Euclidean distance transform of the mask sampled
-    bilinearly.  Loop structure (10 steps, forward difference 0.1, d and the index set not
+    """KalmanFilter.projectmask, kalman.py:724-742, with fd = outline_distance(y_m) (the reference takes it from
+    findObjectThreshold(y_m, 0.5), :725).  Loop structure (10 steps, forward difference 0.1, d and the index set not
     refreshed inside the loop, displacement also added to the velocities) follows the reference."""
-    from scipy import ndimage
     X = np.array(X, np.float64).reshape(-1, 1)
     m = np.asarray(y_m) > 0.5
     if not m.any():
         return X
-    dist = ndimage.distance_transform_edt(~m) - ndimage.distance_transform_edt(m)
-    H, W = m.shape
-
-    def fd(q):      # bilinear, coordinates clamped to the frame (map_coordinates order=1 mode="nearest", spelt out)
-        xc, yc = np.clip(q[:, 0], 0.0, W - 1.0), np.clip(q[:, 1], 0.0, H - 1.0)
-        px, py = np.floor(xc).astype(int), np.floor(yc).astype(int)
-        px1, py1 = np.minimum(px + 1, W - 1), np.minimum(py + 1, H - 1)
-        ax, ay = xc - px, yc - py
-        return ((1 - ay) * ((1 - ax) * dist[py, px] + ax * dist[py, px1])
-                + ay * ((1 - ax) * dist[py1, px] + ax * dist[py1, px1]))
+    fd = outline_distance(m)
     p = X[:2 * N].reshape(-1, 2).copy()
     p0 = p.copy()
     d = fd(p)

@@ -153,6 +153,54 @@ def test_measure_equals_single_perturbation_operators(hm):
         assert R.j(st, 2.0, int(i), int(j)) == 0.0
 
 
+def test_dense_mesh_grows_the_difference_image_pool(hm):
+    """The parked difference images of the measurement live in a pool of 8 frames' worth of pixels that grows on
+    demand (the reference has no such limit: its renders are whole frames).  A fine mesh over most of a small frame --
+    106 vertices on 48^2, star regions padded to whole 8x8 tiles: ~40 000 pixels against 18 432 -- makes hm_measure,
+    hm_update_step and hm_update_run (each on a fresh context, so each meets the small pool) grow it and go on with the
+    numbers of the oracle / of each other."""
+    from oracle import ekf_c
+    n = 48
+    rng = np.random.default_rng(21)
+    outs = []
+    for path in ("measure", "step", "run"):
+        dm, N, tex, R, meas = _setup(hm, n, 3.0, seed=6)
+        assert N > 90
+        if path == "measure":
+            X = _state(dm, rng, pos_sigma=0.2)
+            y_im, flow, y_m = _observation(dm, meas, rng, n)
+            n4 = 4 * N
+            M = np.random.default_rng(2).normal(size=(n4, n4))
+            W = np.eye(n4) * 0.5 + 0.05 * (M @ M.T) / n4
+        st = _Flow()
+        st.X = X.reshape(-1, 1)
+        R.update_frame(y_im, flow, y_m)
+        if path == "measure":
+            Hz, HTH, Hzc = R.measure(st, y_im, flow, y_m)
+            cm = ekf_c.Measurement(N, dm.t, dm.p, tex, 1e-3, 1.0, 1.0, threads=min(8, os.cpu_count() or 1))
+            rHz, rHzc = cm.jacobian_all(X, y_im, flow, y_m)
+            assert np.abs(Hz - rHz).max() <= 1e-9 * np.abs(rHz).max()
+            _, J = ekf_ref.adjacency(N, dm.t)
+            pi, pj = np.nonzero(np.triu(J == 1))
+            sel = np.random.default_rng(3).choice(len(pi), 300, replace=False)
+            vals = cm.hessian_pairs(pi[sel], pj[sel], 2.0)
+            got = HTH[pi[sel], pj[sel]]
+            assert np.abs(got - vals).max() <= 1e-9 * np.abs(HTH).max()
+            assert np.all(HTH[J == 0] == 0) and np.array_equal(HTH, HTH.T)
+        elif path == "step":
+            R.update_begin(W, X)
+            s1, _, e1 = R.update_step(st, y_im, flow, y_m)
+            assert np.isfinite(s1).all()
+            outs.append((s1, np.array(e1)))
+        else:
+            run = R.update_run(W, X, y_im, flow, y_m, 1, 1e-12)
+            assert run[1]["niter"] == 1
+            outs.append((None if run[1]["reverted"] else run[0].reshape(-1) - X, np.array(run[2][0])))
+    assert np.array_equal(outs[0][1], outs[1][1])                      # the error sums of the first iterate
+    if outs[1][0] is not None:
+        assert np.allclose(outs[0][0].reshape(-1), outs[1][0], rtol=0, atol=1e-12 * np.abs(outs[0][0]).max())
+
+
 @pytest.mark.parametrize("case", ["outside", "folded", "blank", "saturated"])
 def test_measure_edge_cases_match_oracle(hm, case):
     """The fused measurement where the rasteriser's corner cases matter: a mesh partly outside the
@@ -548,6 +596,9 @@ def test_measure_split_changes_only_the_summation_order(hm):
 
 
 # ---- projectmask on the device (hm_project_mask) against oracle/ekf_ref.project_mask ---------------
+# (the distance function is the reference's fd, the signed distance to the polygon through the object's border pixels;
+# tests/test_host_cpu.py::test_mask_distance_is_the_polygon_distance_of_the_reference holds the oracle's restatement
+# against imgproc.findObjectThreshold(mask)[2] and against known answers)
 def _project_masks(n):
     yy, xx = np.mgrid[:n, :n]
     disk = ((xx - 0.5 * n) ** 2 + (yy - 0.45 * n) ** 2 < (0.3 * n) ** 2).astype(np.uint8)

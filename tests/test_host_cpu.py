@@ -284,25 +284,38 @@ def test_projectmask_pulls_outliers_back(hm):
     assert kf.state.X[0, 0] > X0[0, 0] - 1.5 and kf.state.X[8, 0] > 0     # pulled back, velocity follows
 
 
-def test_mask_distance_equals_whole_frame_transform(hm):
-    """_mask_distance answers from the outline pixels only; the numbers are those of the distance
-    transform of the whole mask, near the outline, far from it and for queries off the frame."""
-    from scipy import ndimage
-    from hydra_mi import kalman
+def test_mask_distance_is_the_polygon_distance_of_the_reference(hm):
+    """N3: the distance function of projectmask is the reference's fd (imgproc.py:195-235): the signed distance to the
+    polygon through the centres of the object's border pixels (-cv2.pointPolygonTest).  The product's host form
+    (imgproc.outline_distance, exact over all sides) equals the oracle's restatement bit for bit; for a mask the
+    reference's contour pruning leaves alone (one object, holes >= 40 px) it equals findObjectThreshold(mask).fd, the
+    restated reference function, for points outside the object; known answers on a square."""
+    from hydra_mi import imgproc, kalman
     rng = np.random.default_rng(5)
     H, W = 90, 120
     yy, xx = np.mgrid[:H, :W]
-    m = (((xx - 50) ** 2 + (yy - 40) ** 2 < 20 ** 2) | ((xx > 95) & (yy < 30))).astype(np.uint8)   # touches the border
-    m[38:43, 48:53] = 0                                                                        # and has a hole
-    full = ndimage.distance_transform_edt(m == 0) - ndimage.distance_transform_edt(m > 0)
-    p = np.column_stack((rng.uniform(-8, W + 8, 500), rng.uniform(-8, H + 8, 500)))
+    m = (((xx - 50) ** 2 + (yy - 40) ** 2 < 20 ** 2) | ((xx > 95) & (yy < 30) & (xx - 95 + 30 - yy > 8))).astype(np.uint8)
+    m[36:44, 46:54] = 0                                                                        # a hole of 64 px
+    p = np.column_stack((rng.uniform(-8, W + 8, 400), rng.uniform(-8, H + 8, 400)))
     p[:20] = np.round(p[:20])                                                                  # on pixel centres
-    want = ndimage.map_coordinates(full, [p[:, 1], p[:, 0]], order=1, mode="nearest")
     got = kalman._mask_distance(m)(p)
-    assert np.allclose(got, want, rtol=0, atol=1e-12)
-    on = (p[:20, 0] >= 0) & (p[:20, 0] <= W - 1) & (p[:20, 1] >= 0) & (p[:20, 1] <= H - 1)
-    assert np.array_equal(got[:20][on], full[p[:20, 1].astype(int)[on], p[:20, 0].astype(int)[on]])
-    for blank in (np.zeros_like(m), np.ones_like(m)):
+    want = ekf_ref.outline_distance(m)(p)
+    assert np.array_equal(got, want)
+    one = (xx - 50) ** 2 + (yy - 40) ** 2 < 20 ** 2                                            # a single object with its hole
+    one = one & ~((yy >= 36) & (yy < 44) & (xx >= 46) & (xx < 54))
+    ref_fd = imgproc.findObjectThreshold(np.where(one, 200, 0).astype(np.uint8), 7)[2]
+    mine = kalman._mask_distance(one.astype(np.uint8))
+    outside = mine(p) > 0
+    assert outside.sum() > 100
+    assert np.allclose(mine(p)[outside], ref_fd(p)[outside], rtol=0, atol=1e-12)
+    assert np.array_equal(np.sign(mine(p)), np.sign(ref_fd(p)))
+    # known answers: the square [20, 40]^2 of pixel centres
+    sq = np.zeros((64, 64), np.uint8)
+    sq[20:41, 20:41] = 1
+    fd = kalman._mask_distance(sq)
+    q = np.array([[10.0, 30.0], [30.0, 45.5], [17.0, 16.0], [30.0, 30.0], [20.0, 25.0], [42.0, 43.0], [-3.0, 30.0]])
+    assert np.allclose(fd(q), [10.0, 5.5, 5.0, -10.0, 0.0, np.sqrt(13.0), 23.0], rtol=0, atol=1e-12)
+    for blank in (np.zeros_like(m),):
         assert np.array_equal(kalman._mask_distance(blank)(p), np.zeros(len(p)))
 
 

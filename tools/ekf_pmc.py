@@ -16,6 +16,9 @@ for k in range(nf):
     bf.calc_dev(1, dv[k].data_ptr(), dv[k + 1].data_ptr(), U[k].data_ptr(), V[k].data_ptr())
 bf.sync()
 kf = kalman.IteratedMSKalmanFilter(dm, video[0], np.zeros((n, n, 2), np.float32), True)
+for key in ("render_rows", "measure_split", "edge_split"):            # A/B knobs: HYDRA_TUNE_render_rows=8 ...
+    if os.environ.get("HYDRA_TUNE_" + key):
+        kf.state.renderer.tune(key, int(os.environ["HYDRA_TUNE_" + key]))
 for k in range(nf):
     obs = DeviceObservation(dv[k + 1].data_ptr(), U[k].data_ptr(), V[k].data_ptr(), dmk[k + 1].data_ptr())
     kf.compute(obs, None, None)
