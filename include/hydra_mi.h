@@ -297,6 +297,12 @@ int hm_cov_predict(hm_ctx_t h, const double *W_in, int n_bars, const int32_t *ba
  * hm_update_prefactor does, queued by the calling thread while the state prediction runs. */
 int hm_ms_predict(hm_ctx_t h, int n_bars, const int32_t *bars, const double *l0, double kappa, double M, double dt,
                   int maxiter, double tol, double eps_F, double *X, int *newton_iterations, int prefactor);
+/* Renderer.error (renderer.py:485-501) of the state the last hm_update_run kept, against the observation as it was
+ * given (raw flow), WITHOUT another render: when that state is the update's last iterate, the iterate's own render
+ * produced these sums (KalmanFilter.compute ends with exactly this call, kalman.py:700).  X: the state asked about.
+ * Returns 0 and fills err, or 1 when the sums are not at hand (another state, a reverted update, a new observation or
+ * texture since): call hm_error then. */
+int hm_update_last_error(hm_ctx_t h, const double *X, double err[4]);
 /* tuning knobs: "measure_split" = workgroups per vertex job of the measurement (1..16, default 5),
  * "edge_split" = workgroups per mesh-edge job (1..16, default 2); the sums change in their last
  * bits with them (another summation order); "chol_flow" = 1/0 the blocked Cholesky factorisations of the update as one

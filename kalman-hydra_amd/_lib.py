@@ -82,6 +82,7 @@ SIGNATURES = {
     "hm_update_prefactor": (ctypes.c_int, [c_vp]),
     "hm_update_run": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                      ctypes.POINTER(ctypes.c_int), c_vp, c_vp, c_vp, c_vp]),
+    "hm_update_last_error": (ctypes.c_int, [c_vp, c_vp, c_f64p]),
     "hm_cov_fetch": (ctypes.c_int, [c_vp, c_vp]),
     "hm_project_mask": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "hm_cov_predict": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_vp, c_vp, ctypes.c_double, ctypes.c_double,

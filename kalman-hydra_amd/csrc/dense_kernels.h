@@ -476,22 +476,26 @@ __global__ __launch_bounds__(256) void k_assemble(const double *__restrict__ inv
 }
 
 // ---- end of one iteration of hm_update_run ---------------------------------------------------------------
-// res (host-visible, coherent) = [step (n) | the four error sums of the render's per-tile partials (fixed order:
-// d_tile_partial_sums) | overflow flag | ticket | (spare) | factorisation time-out].  One workgroup.  The ticket is
-// written last, after a system-scope fence: a host that sees it sees the rest.
+// res (host-visible, coherent) = [step (n) | the four error sums of the render's per-strip partials (fixed order:
+// d_tile_partial_sums) | overflow flag | ticket | (spare) | factorisation time-out | flow x, flow y error sums against
+// the raw flow | (2 spare)].  One workgroup.  The ticket is written last, after a system-scope fence: a host that
+// sees it sees the rest.
+#define RES_HEAD 12           // doubles behind the step in a result block
 __global__ __launch_bounds__(256) void k_iter_result(const double *__restrict__ step, int n, const double *__restrict__ partial,
                                                      int ntiles, const int *__restrict__ overflow,
                                                      const unsigned *__restrict__ flow_ctl, double *__restrict__ res, double ticket)
 {
-    __shared__ double sp[RI_GROUPS * 4];
+    __shared__ double sp[RI_GROUPS * RI_NV];
+    __shared__ double sums[RI_NV];
     const int t = threadIdx.x;
     for (int i = t; i < n; i += 256) res[i] = step[i];
-    d_tile_partial_sums(partial, ntiles, sp, res + n);
-    if (t == 4) {
-        res[n + 4] = (double)*overflow;
-    } else if (t == 5) {
-        res[n + 7] = (double)flow_ctl[1];             // a wait of the persistent factorisation launch timed out
-    }
+    d_tile_partial_sums(partial, ntiles, sp, sums);
+    __syncthreads();
+    if (t < 4) res[n + t] = sums[t];
+    else if (t == 4) res[n + 4] = (double)*overflow;
+    else if (t == 5) res[n + 7] = (double)flow_ctl[1];   // a wait of the persistent factorisation launch timed out
+    else if (t == 6) res[n + 8] = sums[4];
+    else if (t == 7) res[n + 9] = sums[5];
     __threadfence_system();
     __syncthreads();
     if (t == 0) {

@@ -54,6 +54,7 @@ struct hm_ctx {
     size_t pin_n;
     std::vector<int> sp_h_off, sp_h_bar, sp_h_other;   // host staging of the spring topology
     std::vector<double> sp_h_blk;
+    std::vector<int32_t> sp_bars_cached;   // the springs whose topology is on the device (d_sp_off / _bar / _other)
     std::vector<int> tri;            // host copy of the triangles (orientation test of hm_update_run)
     DPool pool;                      // parked difference images (see ekf_kernels.h)
     int *d_area;
@@ -68,6 +69,11 @@ struct hm_ctx {
     std::vector<double> h_tpart;
     int ntiles = 0;
     int render_rows = RI_H;          // strip height of k_render_iter (16 or 8)
+    // Renderer.error of the state hm_update_run kept, against the raw flow, from the render of its last iteration
+    // (hm_update_last_error): valid until the observation or anything else on the handle changes
+    bool last_err_valid = false;
+    double last_err[4] = {0, 0, 0, 0};
+    std::vector<double> last_err_X;
     long long run_ticket;            // sequence number of hm_update_run's per-iteration result blocks
     int vsplit, esplit;              // workgroups per vertex / per edge job of the measurement (hm_ctx_tune)
     // hm_update_arm_newton: what the next hm_update_run starts when its state is final
@@ -122,15 +128,17 @@ static void free_targets(Targets &t)
 // stream = one thread at a time, as far as the device can tell) and reports their failure, if any.
 static int ctx_join(hm_ctx *h)
 {
-    if (!h || !h->worker_active) return HM_OK;
-    h->worker.join();
-    h->worker_active = false;
-    if (h->worker_rc != HM_OK) {
-        const int rc = h->worker_rc;
-        h->worker_rc = HM_OK;
-        h->prefactored = false;
-        hm_set_error("%s", h->worker_err);
-        return rc;
+    if (!h) return HM_OK;
+    if (h->worker_active) {
+        h->worker.join();
+        h->worker_active = false;
+        if (h->worker_rc != HM_OK) {
+            const int rc = h->worker_rc;
+            h->worker_rc = HM_OK;
+            h->prefactored = false;
+            hm_set_error("%s", h->worker_err);
+            return rc;
+        }
     }
     return HM_OK;
 }
@@ -366,7 +374,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_Wprior, nn);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_gain, n4 * 3 * sizeof(double));
         // [step (n4) | four error sums | overflow flag] per iteration, then Hzc (n4 x 4) and the gains (3 x n4)
-        h->pin_n = n4 + 8 + n4 * 4 + n4 * 3;
+        h->pin_n = n4 + RES_HEAD + n4 * 4 + n4 * 3;
         if (e == hipSuccess) e = hipHostMalloc((void **)&h->pin, h->pin_n * sizeof(double), hipHostMallocCoherent);
         if (e == hipSuccess) memset(h->pin, 0, h->pin_n * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_X0, n4 * sizeof(double));
@@ -393,7 +401,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         return rc;
     }
     h->h_partial.resize((size_t)h->red_blocks * 4);
-    h->h_tpart.resize((size_t)h->ntiles * 4);
+    h->h_tpart.resize((size_t)h->ntiles * RI_NV);
     *out = h;
     return HM_OK;
 }
@@ -461,12 +469,14 @@ extern "C" int hm_set_texture(hm_ctx_t h, const uint8_t *tex)
     HM_HIP(hipSetDevice(h->device));
     HM_HIP(hipMemcpyAsync(h->d_tex, tex, (size_t)h->W * h->H, hipMemcpyHostToDevice, h->stream));
     HM_HIP(hipStreamSynchronize(h->stream));
+    h->last_err_valid = false;
     h->have_tex = true;
     return HM_OK;
 }
 
 static int finish_observation(hm_ctx *h)
 {
+    h->last_err_valid = false;
     const int n = h->W * h->H;
     hipLaunchKernelGGL(k_mask_flow, dim3(hm_cdiv(n, 256)), dim3(256), 0, h->stream, h->o_ym, h->o_yfx, h->o_yfy,
                        h->d_yfxm, h->d_yfym, n);
@@ -534,6 +544,7 @@ static int render_iter(hm_ctx *h, const double *dX, Targets t, bool with_err, in
     r.X = dX;
     r.out = t;
     r.o = Obs{h->o_yim, masked ? h->d_yfxm : h->o_yfx, masked ? h->d_yfym : h->o_yfy, h->o_ym};
+    r.raw_fx = h->o_yfx; r.raw_fy = h->o_yfy;
     r.partial = h->d_tpart;
     r.tiles_x = hm_cdiv(h->W, RI_W); r.tiles_y = hm_cdiv(h->H, h->render_rows);
     const int nstrips = r.tiles_x * r.tiles_y;
@@ -547,16 +558,18 @@ static int render_iter(hm_ctx *h, const double *dX, Targets t, bool with_err, in
     return HM_OK;
 }
 
-// the four sums of Renderer.error from the per-tile partials, added in the order of d_tile_partial_sums
-static void hm_tile_partial_sums(const double *p, int ntiles, double s[4])
+// the RI_NV sums of Renderer.error from the per-strip partials, added in the order of d_tile_partial_sums
+static void hm_tile_partial_sums(const double *p, int ntiles, double s[RI_NV])
 {
-    double g[RI_GROUPS][4];
+    static thread_local double g[RI_GROUPS][RI_NV];
     for (int t = 0; t < RI_GROUPS; t++) {
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        for (int i = t; i < ntiles; i += RI_GROUPS) { s0 += p[4 * (size_t)i]; s1 += p[4 * (size_t)i + 1]; s2 += p[4 * (size_t)i + 2]; s3 += p[4 * (size_t)i + 3]; }
-        g[t][0] = s0; g[t][1] = s1; g[t][2] = s2; g[t][3] = s3;
+        double a[RI_NV];
+        for (int k = 0; k < RI_NV; k++) a[k] = 0.0;
+        for (int i = t; i < ntiles; i += RI_GROUPS)
+            for (int k = 0; k < RI_NV; k++) a[k] += p[RI_NV * (size_t)i + k];
+        for (int k = 0; k < RI_NV; k++) g[t][k] = a[k];
     }
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < RI_NV; k++) {
         double v = 0.0;
         for (int t = 0; t < RI_GROUPS; t++) v += g[t][k];
         s[k] = v;
@@ -796,14 +809,20 @@ extern "C" int hm_error(hm_ctx_t h, const double *X, int masked, double err[4], 
     NEED_TEX(h, "hm_error");
     NEED_OBS(h, "hm_error");
     HM_HIP(hipSetDevice(h->device));
-    int rc = render_into(h, X, h->P);
+    // the launch and the order of additions of the update loop (k_render_iter, strip partials in the fixed two-level
+    // order): the error of a state is the same number whether an iteration of hm_update_run reports it or this call
+    HM_HIP(hipMemcpyAsync(h->d_X, X, (size_t)4 * h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    int rc = render_iter(h, h->d_X, h->P, true, masked, false, 2.0);
     if (rc) return rc;
     const int n = h->W * h->H;
-    hipLaunchKernelGGL(k_error, dim3(h->red_blocks), dim3(RED_NT), 0, h->stream, h->P, obs_of(h, masked), n,
-                       h->d_partial);
     if (fx) HM_HIP(hipMemcpyAsync(fx, h->P.fx, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     if (fy) HM_HIP(hipMemcpyAsync(fy, h->P.fy, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    return collect4(h, err);
+    HM_HIP(hipMemcpyAsync(h->h_tpart.data(), h->d_tpart, (size_t)render_strips(h) * RI_NV * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HM_HIP(stream_wait(h->stream));
+    double s6[RI_NV];
+    hm_tile_partial_sums(h->h_tpart.data(), render_strips(h), s6);
+    for (int k = 0; k < 4; k++) err[k] = s6[k];
+    return HM_OK;
 }
 
 // render X as the reference, run the fused perturb-and-reduce kernel, unpack into d_H / d_Hz / d_Hzc
@@ -897,8 +916,9 @@ static int aug_rows(int n) { return hm_cdiv(n, DNB) * DNB + DNB; }
 // below the matrix go through the elimination too (dense_kernels.h)
 // first_done: Lt[0] is there already (k_assemble)
 static void chol_factor(hm_ctx *h, double *A, double *L, double *Lt, double *T, double *M, int n, bool with_rhs,
-                        bool first_done = false)
+                        bool first_done = false, hipStream_t st = nullptr)
 {
+    if (!st) st = h->stream;
     const int nb = hm_cdiv(n, DNB);
     const int nrows = with_rhs ? aug_rows(n) : n;
     const int nbr = hm_cdiv(nrows, DNB);
@@ -907,24 +927,24 @@ static void chol_factor(hm_ctx *h, double *A, double *L, double *Lt, double *T, 
         // (chol_flow_kernels.h); the same bits as the launch-per-step form.  first_done: the caller's assembly pass
         // (k_assemble_flow) has pre-filled the outputs
         FlowArgs a = {A, L, Lt, T, h->d_flowP, n, nrows, nb, nbr, h->d_flowctl, h->flow_stall};
-        if (!first_done) hipLaunchKernelGGL(k_flow_fill, dim3(nrows + 1), dim3(256), 0, h->stream, a);
-        hipLaunchKernelGGL(k_chol_flow, dim3(h->flow_wgs), dim3(FLOW_NT), 0, h->stream, a);
+        if (!first_done) hipLaunchKernelGGL(k_flow_fill, dim3(nrows + 1), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_chol_flow, dim3(h->flow_wgs), dim3(FLOW_NT), 0, st, a);
         return;
     }
-    if (!first_done) hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(64), 0, h->stream, A, Lt, n);
+    if (!first_done) hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(64), 0, st, A, Lt, n);
     for (int k = 0; k < nb; k++) {
         const int mr = nbr - k - 1, mc = std::max(nb - k - 1, 1);
         // grid: mr block rows below the diagonal (update of A in columns < mc, of the inverse in the k+1
         // columns after them) and one more row that finishes row k of the inverse
-        hipLaunchKernelGGL(k_chol_step, dim3((mc + k + 1) * (mr + 1)), dim3(256), 0, h->stream, A, L, Lt, T, M, n, nrows, nb, k, mc, mc + k + 1, mr + 1);
+        hipLaunchKernelGGL(k_chol_step, dim3((mc + k + 1) * (mr + 1)), dim3(256), 0, st, A, L, Lt, T, M, n, nrows, nb, k, mc, mc + k + 1, mr + 1);
     }
 }
 
 // SPD inverse from the inverse T = L^-1 of the factor: inv = T^T T
-static void chol_inverse(hm_ctx *h, int n, const double *T, double *out)
+static void chol_inverse(hm_ctx *h, int n, const double *T, double *out, hipStream_t st = nullptr)
 {
     const int nb = hm_cdiv(n, DNB);
-    hipLaunchKernelGGL(k_ttt, dim3(nb, nb), dim3(256), 0, h->stream, T, n, out);
+    hipLaunchKernelGGL(k_ttt, dim3(nb, nb), dim3(256), 0, st ? st : h->stream, T, n, out);
 }
 
 // the time-out word of the persistent factorisation launches since the last hm_update_begin (stream must be idle)
@@ -972,21 +992,22 @@ static double *solve_step(hm_ctx *h, int slot, double deltaX)
 }
 
 // the covariance half of hm_update_begin: the prior into d_Wprior, its factor, inv(W) into d_invW0
-static int prior_inverse(hm_ctx *h, const double *W_prior)
+static int prior_inverse(hm_ctx *h, const double *W_prior, hipStream_t st = nullptr)
 {
+    if (!st) st = h->stream;
     const int n4 = 4 * h->N;
     // the prior stays in d_Wprior: it is the covariance to keep when no iterate is accepted
     const size_t nnb = (size_t)n4 * n4 * sizeof(double);
     if (W_prior)
-        HM_HIP(hipMemcpyAsync(h->d_Wprior, W_prior, nnb, hipMemcpyHostToDevice, h->stream));
+        HM_HIP(hipMemcpyAsync(h->d_Wprior, W_prior, nnb, hipMemcpyHostToDevice, st));
     else if (h->d_Wres != h->d_Wprior)
-        HM_HIP(hipMemcpyAsync(h->d_Wprior, h->d_Wres, nnb, hipMemcpyDeviceToDevice, h->stream));
+        HM_HIP(hipMemcpyAsync(h->d_Wprior, h->d_Wres, nnb, hipMemcpyDeviceToDevice, st));
     // the launch-per-step factorisation destroys its input: it gets a copy; the persistent launch only reads it
-    if (!h->chol_flow) HM_HIP(hipMemcpyAsync(h->d_Awork, h->d_Wprior, nnb, hipMemcpyDeviceToDevice, h->stream));
+    if (!h->chol_flow) HM_HIP(hipMemcpyAsync(h->d_Awork, h->d_Wprior, nnb, hipMemcpyDeviceToDevice, st));
     h->d_Wres = h->d_Wprior;                     // d_Wtmp is scratch from here on
-    HM_HIP(hipMemsetAsync(h->d_flowctl, 0, 4 * sizeof(unsigned), h->stream));      // a new sequence of factorisations
-    chol_factor(h, h->chol_flow ? h->d_Wprior : h->d_Awork, h->d_Af[0], h->d_Lt[0], h->d_Wtmp, h->d_invW0, n4, false);    // T in d_Wtmp
-    chol_inverse(h, n4, h->d_Wtmp, h->d_invW0);
+    HM_HIP(hipMemsetAsync(h->d_flowctl, 0, 4 * sizeof(unsigned), st));      // a new sequence of factorisations
+    chol_factor(h, h->chol_flow ? h->d_Wprior : h->d_Awork, h->d_Af[0], h->d_Lt[0], h->d_Wtmp, h->d_invW0, n4, false, false, st);    // T in d_Wtmp
+    chol_inverse(h, n4, h->d_Wtmp, h->d_invW0, st);
     HM_HIP(hipGetLastError());
     return HM_OK;
 }
@@ -1020,10 +1041,15 @@ extern "C" int hm_update_prefactor(hm_ctx_t h)
     return HM_OK;
 }
 
+static int update_begin(hm_ctx *h, const double *W_prior, const double *X0);
 extern "C" int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *X0)
 {
     HM_ARG(h && X0, "hm_update_begin: NULL argument");
     HM_JOIN(h);
+    return update_begin(h, W_prior, X0);
+}
+static int update_begin(hm_ctx *h, const double *W_prior, const double *X0)
+{
     if (!W_prior && !h->d_Wres) {
         hm_set_error("hm_update_begin: no prior given and none resident on the device");
         return HM_ERR_STATE;
@@ -1070,10 +1096,10 @@ extern "C" int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int ma
         // additions hm_update_run uses
         rc = render_iter(h, h->d_Xn, h->P, true, masked, false, deltaX);
         if (rc == HM_OK) {
-            hipError_t e = hipMemcpyAsync(h->h_tpart.data(), h->d_tpart, (size_t)render_strips(h) * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+            hipError_t e = hipMemcpyAsync(h->h_tpart.data(), h->d_tpart, (size_t)render_strips(h) * RI_NV * sizeof(double), hipMemcpyDeviceToHost, h->stream);
             if (e == hipSuccess) e = stream_wait(h->stream);
             if (e != hipSuccess) { hm_set_error("hm_update_step: %s", hipGetErrorString(e)); rc = HM_ERR_HIP; }
-            else hm_tile_partial_sums(h->h_tpart.data(), render_strips(h), err);
+            else { double s6[RI_NV]; hm_tile_partial_sums(h->h_tpart.data(), render_strips(h), s6); for (int k = 0; k < 4; k++) err[k] = s6[k]; }
         }
         if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }   // nothing of this call stays in flight
     } else {
@@ -1227,18 +1253,19 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
     HM_ARG(deltaX > 0 && max_iter >= 0, "hm_update_run: deltaX must be positive, max_iter >= 0");
     // what hm_update_arm_newton armed is for THIS call only: taken out of the handle before anything can fail, so that an
     // error return never leaves a worker pointer behind for a later call to start a job on
+    h->last_err_valid = false;
     const bool pn_go = h->pn_armed;
     void *const pn_worker = h->pn_worker;
     h->pn_armed = false;
     h->pn_worker = nullptr;
     NEED_TEX(h, "hm_update_run");
     NEED_OBS(h, "hm_update_run");
-    int rc = hm_update_begin(h, W_prior, X);
+    int rc = update_begin(h, W_prior, X);
     if (rc) return rc;
     const int N = h->N, n4 = 4 * N;
     std::vector<double> X0(X, X + n4), Xcur(X0), Xold(X0);
     HM_HIP(hipMemcpyAsync(h->d_X, h->d_X0, (size_t)n4 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    double *res = h->pin, *pin_hzc = h->pin + n4 + 8, *pin_gain = pin_hzc + (size_t)n4 * 4;
+    double *res = h->pin, *pin_hzc = h->pin + n4 + RES_HEAD, *pin_gain = pin_hzc + (size_t)n4 * 4;
     int niter = 0, accepted = 0;
     bool reverted = false, conv = false, ref_ready = false, regions_ahead = false, grown = false;
     double eold = 0.0;
@@ -1355,6 +1382,25 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
     }
     memcpy(X, Xcur.data(), (size_t)n4 * sizeof(double));
     info[0] = niter; info[1] = accepted; info[2] = reverted ? 1 : 0; info[3] = conv ? 1 : 0;
+    if (niter > 0 && !reverted) {
+        // the state that is kept is the last iterate: its render produced Renderer.error against the raw flow as well
+        h->last_err[0] = res[n4]; h->last_err[1] = res[n4 + 8]; h->last_err[2] = res[n4 + 9]; h->last_err[3] = res[n4 + 3];
+        h->last_err_X = Xcur;
+        h->last_err_valid = true;
+    }
+    return HM_OK;
+}
+
+// Renderer.error (renderer.py:485-501) of the state the last hm_update_run kept, against the observation as given
+// (the raw flow), when that state is its last iterate: the sums came out of that iterate's render (k_render_iter).
+// Returns HM_OK and fills err, or 1 when they are not at hand (another state, a reverted update, a new observation):
+// the caller then asks hm_error.
+extern "C" int hm_update_last_error(hm_ctx_t h, const double *X, double err[4])
+{
+    HM_ARG(h && X && err, "hm_update_last_error: NULL argument");
+    if (!h->last_err_valid || h->last_err_X.size() != (size_t)4 * h->N) return 1;
+    if (memcmp(X, h->last_err_X.data(), (size_t)4 * h->N * sizeof(double)) != 0) return 1;
+    for (int k = 0; k < 4; k++) err[k] = h->last_err[k];
     return HM_OK;
 }
 
@@ -1379,38 +1425,46 @@ extern "C" int hm_cov_predict(hm_ctx_t h, const double *W_in, int n_bars, const 
     const size_t nn = (size_t)n4 * n4 * sizeof(double);
     std::vector<int> &off = h->sp_h_off, &bar = h->sp_h_bar, &other = h->sp_h_other;   // live until the copies ran
     HM_HIP(stream_wait(h->stream));      // ... of the previous call
-    off.assign(N + 1, 0);
-    for (int i = 0; i < n_bars; i++) {
-        HM_ARG(bars[2 * i] >= 0 && bars[2 * i] < N && bars[2 * i + 1] >= 0 && bars[2 * i + 1] < N,
-               "hm_cov_predict: spring %d refers to a vertex outside 0..%d", i, N - 1);
-        off[bars[2 * i] + 1]++;
-        off[bars[2 * i + 1] + 1]++;
-    }
-    for (int v = 0; v < N; v++) off[v + 1] += off[v];
-    bar.resize(2 * (size_t)n_bars); other.resize(2 * (size_t)n_bars);
-    {
-        std::vector<int> fill(off.begin(), off.end() - 1);
+    // the springs' topology rarely changes between frames: its device copy is kept and only the per-spring blocks go up
+    const bool same_topo = h->d_sp_off && h->sp_bars_cached.size() == 2 * (size_t)n_bars &&
+                           (n_bars == 0 || memcmp(h->sp_bars_cached.data(), bars, 2 * (size_t)n_bars * sizeof(int32_t)) == 0);
+    if (!same_topo) {
+        off.assign(N + 1, 0);
         for (int i = 0; i < n_bars; i++) {
-            const int p = bars[2 * i], q = bars[2 * i + 1];
-            bar[fill[p]] = i; other[fill[p]++] = q;
-            bar[fill[q]] = i; other[fill[q]++] = p;
+            HM_ARG(bars[2 * i] >= 0 && bars[2 * i] < N && bars[2 * i + 1] >= 0 && bars[2 * i + 1] < N,
+                   "hm_cov_predict: spring %d refers to a vertex outside 0..%d", i, N - 1);
+            off[bars[2 * i] + 1]++;
+            off[bars[2 * i + 1] + 1]++;
         }
+        for (int v = 0; v < N; v++) off[v + 1] += off[v];
+        bar.resize(2 * (size_t)n_bars); other.resize(2 * (size_t)n_bars);
+        {
+            std::vector<int> fill(off.begin(), off.end() - 1);
+            for (int i = 0; i < n_bars; i++) {
+                const int p = bars[2 * i], q = bars[2 * i + 1];
+                bar[fill[p]] = i; other[fill[p]++] = q;
+                bar[fill[q]] = i; other[fill[q]++] = p;
+            }
+        }
+        if (!h->d_sp_off) HM_HIP(hipMalloc((void **)&h->d_sp_off, (size_t)(N + 1) * sizeof(int)));
+        if ((size_t)n_bars > h->sp_cap) {
+            if (h->d_sp_bar) (void)hipFree(h->d_sp_bar);
+            if (h->d_sp_other) (void)hipFree(h->d_sp_other);
+            if (h->d_sp_blk) (void)hipFree(h->d_sp_blk);
+            h->d_sp_bar = h->d_sp_other = nullptr; h->d_sp_blk = nullptr;
+            HM_HIP(hipMalloc((void **)&h->d_sp_bar, 2 * (size_t)n_bars * sizeof(int)));
+            HM_HIP(hipMalloc((void **)&h->d_sp_other, 2 * (size_t)n_bars * sizeof(int)));
+            HM_HIP(hipMalloc((void **)&h->d_sp_blk, 3 * (size_t)n_bars * sizeof(double)));
+            h->sp_cap = n_bars;
+        }
+        HM_HIP(hipMemcpyAsync(h->d_sp_off, off.data(), (size_t)(N + 1) * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        if (n_bars > 0) {
+            HM_HIP(hipMemcpyAsync(h->d_sp_bar, bar.data(), bar.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+            HM_HIP(hipMemcpyAsync(h->d_sp_other, other.data(), other.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        }
+        h->sp_bars_cached.assign(bars, bars + 2 * (size_t)n_bars);
     }
-    if (!h->d_sp_off) HM_HIP(hipMalloc((void **)&h->d_sp_off, (size_t)(N + 1) * sizeof(int)));
-    if ((size_t)n_bars > h->sp_cap) {
-        if (h->d_sp_bar) (void)hipFree(h->d_sp_bar);
-        if (h->d_sp_other) (void)hipFree(h->d_sp_other);
-        if (h->d_sp_blk) (void)hipFree(h->d_sp_blk);
-        h->d_sp_bar = h->d_sp_other = nullptr; h->d_sp_blk = nullptr;
-        HM_HIP(hipMalloc((void **)&h->d_sp_bar, 2 * (size_t)n_bars * sizeof(int)));
-        HM_HIP(hipMalloc((void **)&h->d_sp_other, 2 * (size_t)n_bars * sizeof(int)));
-        HM_HIP(hipMalloc((void **)&h->d_sp_blk, 3 * (size_t)n_bars * sizeof(double)));
-        h->sp_cap = n_bars;
-    }
-    HM_HIP(hipMemcpyAsync(h->d_sp_off, off.data(), (size_t)(N + 1) * sizeof(int), hipMemcpyHostToDevice, h->stream));
     if (n_bars > 0) {
-        HM_HIP(hipMemcpyAsync(h->d_sp_bar, bar.data(), bar.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-        HM_HIP(hipMemcpyAsync(h->d_sp_other, other.data(), other.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
         h->sp_h_blk.assign(blocks, blocks + 3 * (size_t)n_bars);
         HM_HIP(hipMemcpyAsync(h->d_sp_blk, h->sp_h_blk.data(), 3 * (size_t)n_bars * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }

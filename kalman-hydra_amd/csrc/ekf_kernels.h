@@ -332,27 +332,6 @@ __global__ __launch_bounds__(RED_NT) void k_j(Targets ref, Targets p, Targets q,
     d_block_reduce<4, RED_NT>(a, s_red, partial + 4 * blockIdx.x);
 }
 
-// Renderer.error (renderer.py:485-501).  The image and mask terms are computed in
-// uint8 there: difference and square both wrap modulo 256 before the sum.
-__global__ __launch_bounds__(RED_NT) void k_error(Targets ref, Obs o, int n, double *__restrict__ partial)
-{
-    __shared__ double s_red[(RED_NT / 64) * 4];
-    double a[4] = {0, 0, 0, 0};
-    for (int i = blockIdx.x * RED_NT + threadIdx.x; i < n; i += gridDim.x * RED_NT) {
-        unsigned rim = ref.acc[i] > 255 ? 255 : ref.acc[i];
-        unsigned rm = ref.cnt[i] > 0 ? 255 : 0;
-        unsigned d = ((unsigned)o.yim[i] - rim) & 255u;
-        unsigned dm = ((255u * (unsigned)o.ym[i]) - rm) & 255u;
-        float dfx = o.yfx[i] - ref.fx[i];
-        float dfy = o.yfy[i] + ref.fy[i];
-        a[0] += (double)((d * d) & 255u);
-        a[1] += (double)dfx * (double)dfx;
-        a[2] += (double)dfy * (double)dfy;
-        a[3] += (double)((dm * dm) & 255u);
-    }
-    d_block_reduce<4, RED_NT>(a, s_red, partial + 4 * blockIdx.x);
-}
-
 // ---- label-segmented reductions: the reference's multi-perturbation kernels ---------------------------------
 // histogram_jz / histogram_j (cuda_multi.py:81-248) attribute every pixel to a label -- the id the mask
 // render shows there, taken from the reference render where it covers the pixel, else from the (first, then
@@ -991,7 +970,7 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure_edge(MeasureArgs a)
 }
 
 // ---- the render of an iterate, with everything else that needs nothing but the iterate -----------------------
-// One launch per IEKF iteration in place of four (k_setup_all, k_render<0>, k_error, k_star_regions):
+// One launch per IEKF iteration in place of four (round 2: k_setup_all, k_render<0>, k_error, k_star_regions):
 //   blocks [0, n_regions)   the star regions of the measurement at this state (d_star_regions: they read the state only);
 //   the other blocks        one RI_W x RI_H strip of the render each, four pixels per thread (a wave covers a 64-pixel
 //       row: whole 256-byte lines of every target).  The triangle setups are not read from memory (69 KB per 16x16
@@ -1000,7 +979,8 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure_edge(MeasureArgs a)
 //       the box d_tri_setup keeps, a few instructions), then with that box itself (d_tri_bbox) -- the few that meet it
 //       are set up by one thread each into LDS, RI_CHUNK at a time, and visited by every pixel in ascending index
 //       order: the values of k_setup_all + k_render<0>, bit for bit.  With `with_err` the pixels' four terms of
-//       Renderer.error (k_error's arithmetic) are added up over the strip and stored as partial[strip]; the final sums
+//       Renderer.error (renderer.py:485-501: image and mask terms in uint8, difference and square both wrapping
+//       modulo 256 before the sum) are added up over the strip and stored as partial[strip]; the final sums
 //       are formed in a fixed two-level order (d_tile_partial_sums; hm_tile_partial_sums on the host).
 #define RI_CHUNK 32
 #define RI_GROUPS 256
@@ -1011,13 +991,16 @@ struct IterRenderArgs {
     const double *X;
     Targets out;
     Obs o;
-    double *partial;          // strips x 4
+    const float *raw_fx, *raw_fy;   // the observed flow before the mask was multiplied in (o.yfx / o.yfy may be either)
+    double *partial;          // strips x RI_NV
     int tiles_x, tiles_y, with_err, n_regions;
 };
+#define RI_NV 6               // image, flow x, flow y, mask terms against `o`, then flow x, flow y against the raw flow
 struct RenderShared {
     unsigned mask[EKF_MAX_TRI / 32];
     TriSetup cand[RI_CHUNK];
-    double red[(256 / 64) * 4];
+    double red[(256 / 64) * RI_NV];
+    unsigned band[RI_W / 8];  // per 8-column band: the candidates of the chunk that can reach it
 };
 
 #ifdef HM_STAMP
@@ -1114,9 +1097,31 @@ __global__ __launch_bounds__(256) void k_render_iter(IterRenderArgs r, MeasureAr
             sh.t.cand[rank - base] = su;
         }
         __syncthreads();
-        if (c < m.W)
-            for (int q = 0; q < nch; q++) {
+        {   // which candidates can reach which 8-column band of the strip (the same corner test, one (band, candidate)
+            // pair per thread): a pixel then looks at the one or two triangles of its band, not at all of the strip's
+            const int band = tid >> 5, q = tid & 31;
+            bool reach = false;
+            if (q < nch) {
                 const TriSetup &su = sh.t.cand[q];
+                const int xa_i = c0 + 8 * band, xb_i = min(xa_i + 7, m.W - 1), ya_i = r0, yb_i = min(r0 + RIH - 1, m.H - 1);
+                reach = su.cmin <= su.cmax && su.cmax >= xa_i && su.cmin <= xb_i && xa_i < m.W;
+                if (reach) {
+                    const double xa = (double)xa_i, xb = (double)xb_i, ya = (double)ya_i, yb = (double)yb_i;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const double e00 = fma(su.ea[k], xa, fma(su.eb[k], ya, su.ecb[k])), e10 = fma(su.ea[k], xb, fma(su.eb[k], ya, su.ecb[k]));
+                        const double e01 = fma(su.ea[k], xa, fma(su.eb[k], yb, su.ecb[k])), e11 = fma(su.ea[k], xb, fma(su.eb[k], yb, su.ecb[k]));
+                        reach &= (e00 > 0.0 || e10 > 0.0 || e01 > 0.0 || e11 > 0.0);
+                    }
+                }
+            }
+            const unsigned long long b = __ballot(reach);          // lanes 0..31: band 2 wave, lanes 32..63: band 2 wave + 1
+            if ((tid & 63) == 0) { sh.t.band[2 * (tid >> 6)] = (unsigned)b; sh.t.band[2 * (tid >> 6) + 1] = (unsigned)(b >> 32); }
+        }
+        __syncthreads();
+        if (c < m.W)
+            for (unsigned bm = sh.t.band[(tid & 63) >> 3]; bm != 0; bm &= bm - 1) {      // ascending triangle order
+                const TriSetup &su = sh.t.cand[__builtin_ctz(bm)];
 #pragma unroll
                 for (int j = 0; j < RI_PX; j++) {
                     float l1, l2;
@@ -1142,14 +1147,14 @@ __global__ __launch_bounds__(256) void k_render_iter(IterRenderArgs r, MeasureAr
 #pragma unroll
         for (int j = 0; j < RI_PX; j++) acc[j] += tadr[j] < 0 ? 0 : tx[j];
     }
-    double e[4] = {0.0, 0.0, 0.0, 0.0};
+    double e[RI_NV] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int j = 0; j < RI_PX; j++) {
         const int rr = rb + 4 * j;
         if (c >= m.W || rr >= m.H) continue;
         const int p = rr * m.W + c;
         r.out.acc[p] = acc[j]; r.out.fx[p] = fx[j]; r.out.fy[p] = fy[j]; r.out.cnt[p] = cnt[j];
-        if (r.with_err) {                          // Renderer.error (renderer.py:485-501), the arithmetic of k_error
+        if (r.with_err) {                          // Renderer.error (renderer.py:485-501): uint8 wrap-around of the image / mask terms
             const unsigned rim = acc[j] > 255 ? 255 : acc[j];
             const unsigned rm = cnt[j] > 0 ? 255 : 0;
             const unsigned d = ((unsigned)r.o.yim[p] - rim) & 255u;
@@ -1160,34 +1165,45 @@ __global__ __launch_bounds__(256) void k_render_iter(IterRenderArgs r, MeasureAr
             e[1] += (double)dfx * (double)dfx;
             e[2] += (double)dfy * (double)dfy;
             e[3] += (double)((dm * dm) & 255u);
+            // the same two terms against the flow as observed (KalmanFilter.compute updates on the masked flow and
+            // reports Renderer.error of the final state against the raw one, kalman.py:679-700): the report of the
+            // last iterate comes out of its own render
+            const float gfx = r.raw_fx[p] - fx[j];
+            const float gfy = r.raw_fy[p] + fy[j];
+            e[4] += (double)gfx * (double)gfx;
+            e[5] += (double)gfy * (double)gfy;
         }
     }
     HM_STAMP_AT(3);
     if (!r.with_err) return;
-    d_block_reduce<4, 256>(e, sh.t.red, r.partial + 4 * (size_t)tile);
+    d_block_reduce<RI_NV, 256>(e, sh.t.red, r.partial + RI_NV * (size_t)tile);
     HM_STAMP_AT(4);
 }
 
-// The four error sums from the per-tile partials, in a fixed order: thread g of RI_GROUPS adds the partials g,
+// The RI_NV error sums from the per-strip partials, in a fixed order: thread g of RI_GROUPS adds the partials g,
 // g + RI_GROUPS, ... in ascending order, then the group sums are added in ascending order (hm_tile_partial_sums on
-// the host does the same additions).  sp: RI_GROUPS x 4 doubles of LDS; out[0..3] written by threads 0..3 after a
-// barrier inside.
+// the host does the same additions).  sp: RI_GROUPS x RI_NV doubles of LDS; out[0..RI_NV-1] written by threads
+// 0..RI_NV-1 after a barrier inside.
 __device__ __forceinline__ void d_tile_partial_sums(const double *__restrict__ partial, int ntiles, double *sp, double *out)
 {
     const int t = threadIdx.x;
     if (t < RI_GROUPS) {
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        double s[RI_NV];
+#pragma unroll
+        for (int k = 0; k < RI_NV; k++) s[k] = 0.0;
 #pragma unroll 4
         for (int i = t; i < ntiles; i += RI_GROUPS) {
-            const double4 q = *(const double4 *)(partial + 4 * (size_t)i);
-            s0 += q.x; s1 += q.y; s2 += q.z; s3 += q.w;
+            const double2 *q = (const double2 *)(partial + RI_NV * (size_t)i);
+#pragma unroll
+            for (int k = 0; k < RI_NV / 2; k++) { const double2 v = q[k]; s[2 * k] += v.x; s[2 * k + 1] += v.y; }
         }
-        sp[4 * t] = s0; sp[4 * t + 1] = s1; sp[4 * t + 2] = s2; sp[4 * t + 3] = s3;
+#pragma unroll
+        for (int k = 0; k < RI_NV; k++) sp[RI_NV * t + k] = s[k];
     }
     __syncthreads();
-    if (t < 4) {
+    if (t < RI_NV) {
         double s = 0.0;
-        for (int g = 0; g < RI_GROUPS; g++) s += sp[4 * g + t];
+        for (int g = 0; g < RI_GROUPS; g++) s += sp[RI_NV * g + t];
         out[t] = s;
     }
 }

@@ -337,15 +337,27 @@ class FlowEKFPipeline:
         # vertices, 20 frames: 182 frames/s against 214 with one series at a time -- the filter's frames take 5.3 to
         # 13 ms beside two series (4.2 to 5.6 beside one) and the first pair of a phase is no sooner there (7.4 ms).
         # Off by default; the results are the same bits either way (tools/determinism_check.py).
-        self.bfs = [_brox.BroxOpticalFlow(self.W, self.H, max_batch=self.B, device=device, **(brox_params or {}))
-                    for _ in range(2 if concurrent_series else 1)]
-        self.bf = self.bfs[0]
-        for bf in self.bfs:
+        def make_handle():
+            bf = _brox.BroxOpticalFlow(self.W, self.H, max_batch=self.B, device=device, **(brox_params or {}))
             bf.tune("sor_threads", sor_threads)         # 0: chosen per series (1024 for one or two pairs, else 512)
             if cu_reserve:
                 # the flow streams leave some compute units alone: the filter's short dependent launches find room at
                 # once while a series fills the rest (bench: 250 -> 254 frames/s with 32 of 256 reserved)
                 bf.tune("cu_reserve", int(cu_reserve))
+            return bf
+        self._make_handle = make_handle
+        self.concurrent_series = bool(concurrent_series)
+        self.bfs = [make_handle() for _ in range(2 if concurrent_series else 1)]
+        self.bf = self.bfs[0]
+        # split_start: a phase whose series times are known (an earlier phase measured them) starts with TWO series side by
+        # side, on two handles -- a short one (two pairs) so that the filter, which has nothing to do until the first
+        # flow arrives, starts soon, and the one _first_series() sizes behind it.  A lone short series leaves most of the
+        # chip idle (it is a chain of ~500 short launches), so the second should cost the first little.  After that one
+        # series at a time, as before.  The second handle is created when it is first needed.  Measured at 1024^2 / 201
+        # vertices, 20 frames: 212 frames/s against 229 without (the two series slow each other and the filter's first
+        # frames more than the earlier start gains: 0.92 instead of 0.73 ms per frame of waiting for flow); 64 frames: 286
+        # against 292.  Off by default; the results are the same bits either way.
+        self.split_start = False
         self.t_flow = self.t_ekf = 0.0
         self.iters = 0
         self.frame_done = []             # perf_counter() at the end of every step (steady-state rates)
@@ -363,7 +375,7 @@ class FlowEKFPipeline:
         self.profiled_handle = None
 
     # -- flow series ---------------------------------------------------------------------------------
-    def _launch(self, k, end, most):
+    def _launch(self, k, end, most, alone=None):
         """Queue the series of pairs k .. k + nb - 1 on a handle and a buffer that are free."""
         nb = min(most, end - k)
         n, B = self._px, self.B
@@ -393,6 +405,8 @@ class FlowEKFPipeline:
             except Exception as exc:                    # noqa: BLE001 -- re-raised by the thread that waits
                 self._thread_exc = exc
         first = not self._flying and self._ready[0] == self._ready[1]       # the first series of a phase: nothing runs beside it
+        if alone is not None:
+            first = alone
         t = threading.Thread(target=work)
         t0 = time.perf_counter()
         t.start()
@@ -426,7 +440,7 @@ class FlowEKFPipeline:
         are measured in earlier phases (a series of n pairs takes about a + b (n - 1): two first series of different
         sizes give a and b, one gives a with b taken as a fifth of a two-pair series -- 1.45 of 7.2 ms at 1024^2; a
         series beside the filter takes ~1.3 x as long as alone); without measurements a phase starts with two pairs."""
-        if len(self.bfs) > 1:
+        if self.concurrent_series:
             return 1
         default = min(2, self.B)
         if self.first_series:
@@ -460,8 +474,20 @@ class FlowEKFPipeline:
             self.ring.reset(first)               # nothing of an earlier phase is assumed to be in the ring
 
     def _top_up(self):
-        """Keep as many series in flight as there are handles."""
-        while len(self._flying) < len(self.bfs):
+        """Keep as many series in flight as there are handles (one unless concurrent_series) -- two at the very start of
+        a phase when split_start applies."""
+        starting = not self._flying and self._ready[0] == self._ready[1]
+        if (starting and self.split_start and not self.concurrent_series and self._series_s and self._frame_s is not None
+                and self.B >= 3 and self._end - self._ready[1] >= 4 and not self.first_series):
+            if len(self.bfs) < 2:
+                self.bfs.append(self._make_handle())
+            k = self._ready[1]
+            n1 = max(3, self._first_series())
+            self._launch(k, self._end, 2, alone=False)
+            self._launch(k + 2, self._end, n1, alone=False)
+            return
+        limit = len(self.bfs) if self.concurrent_series else 1
+        while len(self._flying) < limit:
             last = self._flying[-1] if self._flying else None
             nxt = last["hi"] if last else self._ready[1]
             if nxt >= self._end:

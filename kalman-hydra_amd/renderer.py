@@ -359,6 +359,13 @@ class Renderer:
         masked = self._masked_flag(y_im, y_flow, y_m)
         err = (ctypes.c_double * 4)()
         fx = fy = None
+        if not want_flow and not masked:
+            # the state an update_run has just kept: the sums came out of the render of its last iterate
+            rc = _lib.lib().hm_update_last_error(self._h, _lib.ptr(self._X(state)), err)
+            if rc == 0:
+                return int(err[0]), err[1], err[2], int(err[3]), None, None
+            if rc < 0:
+                _lib.check(rc, "hm_update_last_error")
         if want_flow:
             fx = np.empty((self.ny, self.nx), np.float32)
             fy = np.empty_like(fx)

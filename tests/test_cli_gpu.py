@@ -133,5 +133,18 @@ def test_streaming_frame_ring_equals_resident_video(hm):
     assert np.array_equal(kf2.state.X, ref[5][0])
     with pytest.raises(IndexError):
         p2.flow_ready(F - 1)
-    for p in (pr, ps, pv, p2):
+    # with split_start a phase that follows a measured one starts with two series side by side on two handles (a short
+    # one so that the filter starts soon, the one sized from the measurements behind it): the same bits
+    kf3 = new_filter()
+    p3 = FlowEKFPipeline(kf3, video, masks, observed=video * masks, flow_batch=4)
+    p3.split_start = True                                     # (off by default: measured slower, pipeline.py)
+    got3 = []
+    p3.run(0, 2, on_frame=lambda k, e: got3.append((kf3.state.X.copy(), e[:4], kf3.niter)))
+    assert len(p3.bfs) == 1 and p3._series_s and p3._frame_s is not None
+    p3.run(2, F - 1, on_frame=lambda k, e: got3.append((kf3.state.X.copy(), e[:4], kf3.niter)))
+    assert len(p3.bfs) == 2                                   # the second handle was needed
+    assert len(got3) == F - 1
+    for k in range(F - 1):
+        assert np.array_equal(got3[k][0], ref[k][0]) and got3[k][1] == ref[k][1] and got3[k][2] == ref[k][2], k
+    for p in (pr, ps, pv, p2, p3):
         p.close()

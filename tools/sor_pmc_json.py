@@ -1,4 +1,4 @@
-"""profiles/r02_sor_pmc.json from the two PMC passes of tools/brox_pmc.py:
+"""profiles/r03_sor_pmc.json from the two PMC passes of tools/brox_pmc.py (tools/run_r3_profiles.sh):
 
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <dir>/fetch -o b -- python tools/brox_pmc.py
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d <dir>/write -o b -- python tools/brox_pmc.py
