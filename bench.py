@@ -475,6 +475,19 @@ def main():
     prof_bf = tracks[0].pipe.profiled_handle or tracks[0].bf
     levels = prof_bf.profile_levels()
     sor_ms, sor_launches, sor_pxit, sor_px = prof_bf.profile_read()
+    # the same series once more with nothing beside it (after the clock): what the kernel does when it has the chip
+    tr = tracks[0]
+    alone_pairs = min(B, len(tr.video) - 1)
+    tr.pipe.begin(0, alone_pairs)
+    tr.pipe.ring.ensure(alone_pairs + 1, 0)
+    tr.pipe.ring.sync()
+    torch.cuda.synchronize()
+    tr.bf.profile(True)
+    tr.bf.calc_dev(alone_pairs, tr.pipe.ring.run_ptr(0), tr.pipe.ring.run_ptr(0) + n * n, tr.pipe.d_u.ptr, tr.pipe.d_v.ptr)
+    tr.bf.sync()
+    alone_levels = tr.bf.profile_levels()
+    alone = tr.bf.profile_read()
+    tr.bf.profile(False)
     kf, video, masks, dm = tracks[0].kf, tracks[0].video, tracks[0].masks, tracks[0].dm
     N = kf.N
     t_flow = sum(tr.pipe.t_flow for tr in tracks) / V
@@ -520,8 +533,15 @@ def main():
                                       "iekf_iterations": iters / K},
             "roofline": sor_roofline(sor_ms, sor_launches, sor_pxit, sor_px,
                                      pmc_traffic() if (n == 1024 and prof_pairs == 8) else None,
-                                     "one flow series (%d pairs) %s" % (prof_pairs, prof_where), levels),
+                                     "one flow series (%d pairs) %s, the filter's kernels running beside it" % (prof_pairs, prof_where), levels),
         }
+        # ... and with the chip to itself (the figure the 40 % target of north_star is about)
+        ra = sor_roofline(alone[0], alone[1], alone[2], alone[3], pmc_traffic() if (n == 1024 and alone_pairs == 8) else None,
+                          "one flow series (%d pairs) after the timed region, nothing beside it" % alone_pairs, alone_levels)
+        out["roofline"]["alone"] = {k: ra[k] for k in ("achieved", "frac", "traffic", "traffic_source", "achieved_contract",
+                                                         "frac_contract", "launches", "avg_launch_us", "profiled") if k in ra}
+        if "finest_level" in ra:
+            out["roofline"]["alone"]["finest_level"] = ra["finest_level"]
         out["cpu_baseline"] = None                           # a reported baseline, timed at N = 1 only
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, video, masks, dm, max(1.0, iters / K))
