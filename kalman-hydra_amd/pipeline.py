@@ -45,11 +45,26 @@ def to_gray(a):
 
 def load_video(fn):
     """The whole video as gray frames (frames, H, W) uint8 -- shared by run_kalmanfilter.py and
-    optical_flow_ext.py, so that the tracker sees the frames its flow was computed on."""
-    a = np.load(fn)
-    if hasattr(a, "files"):
-        a = a[a.files[0]]
-    a = np.asarray(a)
+    optical_flow_ext.py, so that the tracker sees the frames its flow was computed on.  Sources (no OpenCV on this
+    path; reference renderer.py:745 opens anything cv2.VideoCapture can): a NumPy ``.npy`` / ``.npz`` array of shape
+    (frames, H, W[, 3]), or a multi-page TIFF stack (``.tif`` / ``.tiff``, 8-bit gray or RGB pages, read with PIL)."""
+    if str(fn).lower().endswith((".tif", ".tiff")):
+        from PIL import Image, ImageSequence
+        with Image.open(fn) as im:
+            pages = []
+            for page in ImageSequence.Iterator(im):
+                if page.mode not in ("L", "RGB"):
+                    raise ValueError("%s: expected 8-bit gray or RGB pages, found mode %s" % (fn, page.mode))
+                a = np.asarray(page)
+                pages.append(a[..., ::-1] if a.ndim == 3 else a)          # RGB -> BGR, the order cv2 hands out
+        if not pages or any(p.shape != pages[0].shape for p in pages):
+            raise ValueError("%s: expected pages of one size" % fn)
+        a = np.stack(pages)
+    else:
+        a = np.load(fn)
+        if hasattr(a, "files"):
+            a = a[a.files[0]]
+        a = np.asarray(a)
     if a.dtype != np.uint8 or a.ndim not in (3, 4) or (a.ndim == 4 and a.shape[-1] != 3):
         raise ValueError("%s: expected an 8-bit array of shape (frames, H, W[, 3])" % fn)
     return np.ascontiguousarray(to_gray(a))

@@ -44,6 +44,35 @@ def test_flow_tool_then_tracker(hm, tmp_path, oracle_brox):
     assert np.abs(res2["X"][-1][:2 * N] - res["X"][-1][:2 * N]).max() < 1.5   # flows with 10/10 vs 5/5 iterations
 
 
+def test_native_flow_tool_writes_the_files_of_the_python_tool(hm, tmp_path):
+    """The reference's flow tool is a C++ program (src/optical_flow_ext.cpp:333-507); csrc/optical_flow_ext.cpp is its
+    counterpart over the C-ABI (hm_brox_create / hm_brox_calc_batch): same positional arguments, same .mat files --
+    byte for byte those of optical_flow_ext.py, for a gray and for a BGR video, with non-default parameters and a series
+    size that does not divide the number of pairs."""
+    import subprocess
+    from hydra_mi import synth
+    sys.path.insert(0, ROOT)
+    import optical_flow_ext
+    exe = os.path.join(ROOT, "kalman-hydra_amd", "optical_flow_ext")
+    n, F = 80, 6
+    video, _, _, _ = synth.disk_video(n, F, "rotate", 3)
+    rng = np.random.default_rng(0)
+    colour = np.clip(video[..., None].astype(np.int32) + rng.integers(-20, 21, video.shape + (3,)), 0, 255).astype(np.uint8)
+    for name, arr, extra in (("gray", video, []), ("bgr", colour, ["0.3", "40", "0.75", "4", "50", "6"])):
+        fn = str(tmp_path / (name + ".npy"))
+        np.save(fn, arr)
+        assert optical_flow_ext.main(["optical_flow_ext.py", fn, str(tmp_path / (name + "_py"))] + extra) == 0
+        env = dict(os.environ, HYDRA_MI_FLOW_BATCH="2")
+        r = subprocess.run([exe, fn, str(tmp_path / (name + "_cc"))] + extra, capture_output=True, text=True, env=env, timeout=120)
+        assert r.returncode == 0 and "Finished." in r.stdout, r.stderr
+        for k in range(F - 1):
+            for c in "xy":
+                a = open(str(tmp_path / ("%s_py_%03d_%s.mat" % (name, k, c))), "rb").read()
+                b = open(str(tmp_path / ("%s_cc_%03d_%s.mat" % (name, k, c))), "rb").read()
+                assert a == b and len(a) == 12 + 4 * n * n, (name, k, c)
+        assert not os.path.exists(str(tmp_path / ("%s_cc_%03d_x.mat" % (name, F - 1))))
+
+
 def test_pipeline_equals_sequential_calls(hm):
     """hydra_mi.pipeline.FlowEKFPipeline (flow series of 1, 2, 4 pairs on the flow handle's stream, overlapped
     with the filter, flow handed over in device memory) gives bit for bit the states of the sequential

@@ -421,6 +421,36 @@ def test_videostream_and_shared_gray_conversion(hm, tmp_path):
         pipeline.load_video(fn)
 
 
+def test_video_sources_and_native_flow_tool_cpu_side(hm, tmp_path):
+    """N2: load_video reads .npy, .npz and multi-page TIFF stacks (gray and RGB) to the same gray frames; the native flow
+    tool (csrc/optical_flow_ext.cpp, the reference's C++ CLI over the C-ABI) is built, prints its usage with exit code
+    1 without arguments and refuses a missing / malformed video with the reference's kind of message."""
+    import subprocess
+    from PIL import Image
+    from hydra_mi import pipeline
+    rng = np.random.default_rng(4)
+    gray = rng.integers(0, 256, (3, 10, 12), dtype=np.uint8)
+    bgr = rng.integers(0, 256, (3, 10, 12, 3), dtype=np.uint8)
+    np.save(str(tmp_path / "g.npy"), gray)
+    np.savez(str(tmp_path / "g.npz"), gray)
+    pages = [Image.fromarray(f) for f in gray]
+    pages[0].save(str(tmp_path / "g.tif"), save_all=True, append_images=pages[1:])
+    pages = [Image.fromarray(np.ascontiguousarray(f[..., ::-1])) for f in bgr]              # TIFF pages are RGB
+    pages[0].save(str(tmp_path / "c.tiff"), save_all=True, append_images=pages[1:])
+    for fn in ("g.npy", "g.npz", "g.tif"):
+        assert np.array_equal(pipeline.load_video(str(tmp_path / fn)), gray), fn
+    assert np.array_equal(pipeline.load_video(str(tmp_path / "c.tiff")), pipeline.to_gray(bgr))
+    exe = os.path.join(ROOT, "kalman-hydra_amd", "optical_flow_ext")
+    assert os.access(exe, os.X_OK), "run `python __graft_entry__.py build`"
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage:" in r.stdout and "[alpha] [gamma] [scale_factor] [inner_it] [outer_it] [solver_it]" in r.stdout
+    r = subprocess.run([exe, str(tmp_path / "missing.npy"), str(tmp_path / "o")], capture_output=True, text=True)
+    assert r.returncode == 1 and "Failed to open the video" in r.stderr and "alpha = 0.197" in r.stdout
+    np.save(str(tmp_path / "f.npy"), gray.astype(np.float32))
+    r = subprocess.run([exe, str(tmp_path / "f.npy"), str(tmp_path / "o")], capture_output=True, text=True)
+    assert r.returncode == 1 and "uint8" in r.stderr
+
+
 # ---- sharding over ranks (gloo, world_size 2) ---------------------------------------------------
 def _worker(rank, world, port, out):
     import torch
