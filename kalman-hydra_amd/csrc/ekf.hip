@@ -38,6 +38,7 @@ struct hm_ctx {
     Targets ref, P, Q;
     TriSetup *d_setup, *d_cfgs;
     int4 *d_ubox;
+    unsigned *d_tmask = nullptr;     // per vertex and tile of its star region: the star triangles that can reach the tile (k_measure_vertex)
     double *d_X, *d_out, *d_partial;
     uint8_t *d_im8, *d_m8;
     std::vector<double> X0;          // state of the reference render
@@ -220,7 +221,7 @@ static int ctx_free(hm_ctx *h)
                     h->d_Wtmp, h->d_X0, h->d_Xn, h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk,
                     h->pool.hdr, h->pool.overflow, h->d_area,
                     h->d_outline, h->d_outline_cnt, h->d_pm_mask, h->d_pm_flag, h->d_pm_X, h->d_ids[0], h->d_ids[1], h->d_ids[2], h->d_labels, h->d_lbox,
-                    h->d_lout, h->d_tpart, h->d_nb_off, h->d_nb_u, h->d_nb_e, h->d_flowP, h->d_flowctl, h->d_nbars, h->d_nvoff, h->d_nvbar, h->d_ninfo, h->d_nl0, h->d_nX};
+                    h->d_lout, h->d_tpart, h->d_tmask, h->d_nb_off, h->d_nb_u, h->d_nb_e, h->d_flowP, h->d_flowctl, h->d_nbars, h->d_nvoff, h->d_nvbar, h->d_ninfo, h->d_nl0, h->d_nX};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     pool_release(h);
@@ -343,6 +344,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_setup, (size_t)T * sizeof(TriSetup));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_cfgs, (size_t)N * MEAS_NCFG * (EKF_MAX_STAR + 1) * sizeof(TriSetup));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_ubox, (size_t)N * UBOX_STRIDE * sizeof(int4));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_tmask, (size_t)N * TMASK_STRIDE * sizeof(unsigned));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_X, (size_t)4 * N * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_out, (size_t)h->njobs * MEAS_VSPLIT_MAX * MEAS_OUT * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_partial, (size_t)h->red_blocks * 4 * sizeof(double));
@@ -841,7 +843,7 @@ static int measure_dev(hm_ctx *h, const double *dX, bool ref_ready, double delta
     measure_args(h, dX, deltaX, masked, a);
     if (!regions_ready) hipLaunchKernelGGL(k_star_regions, dim3(h->N), dim3(REGION_NT), 0, h->stream, a, h->d_area);
     hipLaunchKernelGGL(k_measure_vertex, dim3(h->N, h->vsplit), dim3(MEAS_NT), 0, h->stream, a,
-                       (const TriSetup *)h->d_cfgs, (const int4 *)h->d_ubox);
+                       (const TriSetup *)h->d_cfgs, (const int4 *)h->d_ubox, (const unsigned *)h->d_tmask);
     if (h->E > 0) hipLaunchKernelGGL(k_measure_edge, dim3(h->E, h->esplit), dim3(MEAS_NT), 0, h->stream, a);
     if (scatter) {
         ScatterArgs s = {h->d_out, h->d_edges, h->N, h->E, h->vsplit, h->esplit, h->eps_Z, h->eps_J, h->eps_M, deltaX, h->d_HTH, h->d_Hz, h->d_Hzc};
@@ -866,6 +868,8 @@ static void measure_args(hm_ctx *h, const double *dX, double deltaX, int masked,
     a.iZ = 1.0 / h->eps_Z; a.iJ = 1.0 / h->eps_J; a.iM = 1.0 / h->eps_M;
     a.cfgs = h->d_cfgs;
     a.ubox = h->d_ubox;
+    a.tmask = h->d_tmask;
+    a.tmask_stride = TMASK_STRIDE;
 }
 
 static int measure_on_device(hm_ctx *h, const double *X, double deltaX, int masked, bool scatter = true)

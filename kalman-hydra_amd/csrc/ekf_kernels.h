@@ -602,6 +602,8 @@ struct MeasureArgs {
     double iZ, iJ, iM;        // 1 / eps_Z, 1 / eps_J, 1 / eps_M
     TriSetup *cfgs;           // N x MEAS_NCFG x (EKF_MAX_STAR + 1): the star setups, written by k_star_regions
     int4 *ubox;               // N x UBOX_STRIDE: per triangle of the star, its pixel box over all configurations
+    unsigned *tmask;          // N x tmask_stride: per tile of the region, the triangles of the star that can reach it
+    int tmask_stride;
 };
 
 #define MEAS_NT 256
@@ -631,6 +633,7 @@ enum {
 
 #define MEAS_NCFG 5            // reference, +x, -x, +y, -y of the vertex
 #define UBOX_STRIDE (EKF_MAX_STAR + 4)
+#define TMASK_STRIDE 1024       // tiles of a star region with a triangle word each (a region of up to 256 x 256 px)
 
 __device__ inline void d_vertex_cfgs(TriSetup (*cfg)[EKF_MAX_STAR + 1], int nsv, const int *trv, const Mesh &m,
                                      const double *X, int v, double d, int nthreads)
@@ -647,7 +650,9 @@ __device__ inline void d_vertex_cfgs(TriSetup (*cfg)[EKF_MAX_STAR + 1], int nsv,
 #define REGION_NT (64 * MEAS_NCFG)
 struct RegionShared {
     int4 tbox[MEAS_NCFG][EKF_MAX_STAR + 1];      // pixel box of every star triangle in every configuration (cmin, cmax, rmin, rmax)
+    double ea[MEAS_NCFG][EKF_MAX_STAR + 1][3], eb[MEAS_NCFG][EKF_MAX_STAR + 1][3], ecb[MEAS_NCFG][EKF_MAX_STAR + 1][3];   // their edge functions
     int box[MEAS_NCFG][4];
+    int reg[4];                                  // the region: c0, r0, rw, rh
 };
 template <int NT>
 __device__ inline void d_star_regions(const MeasureArgs &a, int *__restrict__ area, int v, RegionShared &sh)
@@ -668,6 +673,7 @@ __device__ inline void d_star_regions(const MeasureArgs &a, int *__restrict__ ar
             d_star_setup_one(su, trv[lane], m, a.X, v, dxs[cf], dys[cf]);
             dst[lane] = su;
             sh.tbox[cf][lane] = make_int4(su.cmin, su.cmax, su.rmin, su.rmax);
+            for (int k = 0; k < 3; k++) { sh.ea[cf][lane][k] = su.ea[k]; sh.eb[cf][lane][k] = su.eb[k]; sh.ecb[cf][lane][k] = su.ecb[k]; }
         }
         if ((nsv & 1) && lane == 0) {
             TriSetup pad;
@@ -702,16 +708,52 @@ __device__ inline void d_star_regions(const MeasureArgs &a, int *__restrict__ ar
         if (lane == 0) { sh.box[cf][0] = c0; sh.box[cf][1] = c1; sh.box[cf][2] = r0; sh.box[cf][3] = r1; }
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    int c0 = m.W, c1 = -1, r0 = m.H, r1 = -1;
-    for (int cfg = 0; cfg < MEAS_NCFG; cfg++) {
-        c0 = min(c0, sh.box[cfg][0]); c1 = max(c1, sh.box[cfg][1]);
-        r0 = min(r0, sh.box[cfg][2]); r1 = max(r1, sh.box[cfg][3]);
+    if (threadIdx.x == 0) {
+        int c0 = m.W, c1 = -1, r0 = m.H, r1 = -1;
+        for (int cfg = 0; cfg < MEAS_NCFG; cfg++) {
+            c0 = min(c0, sh.box[cfg][0]); c1 = max(c1, sh.box[cfg][1]);
+            r0 = min(r0, sh.box[cfg][2]); r1 = max(r1, sh.box[cfg][3]);
+        }
+        if (c1 >= c0) { c0 &= ~7; r0 &= ~7; }                         // whole tiles on the frame's 8x8 grid: see DPool
+        const int rw = c1 >= c0 ? (c1 - c0 + 8) & ~7 : 0, rh = (c1 >= c0 && r1 >= r0) ? (r1 - r0 + 8) & ~7 : 0;
+        a.pool.hdr[4 * v] = c0; a.pool.hdr[4 * v + 1] = r0; a.pool.hdr[4 * v + 2] = rw; a.pool.hdr[4 * v + 3] = rh;
+        area[v] = rw * rh;
+        sh.reg[0] = c0; sh.reg[1] = r0; sh.reg[2] = rw; sh.reg[3] = rh;
     }
-    if (c1 >= c0) { c0 &= ~7; r0 &= ~7; }                         // whole tiles on the frame's 8x8 grid: see DPool
-    const int rw = c1 >= c0 ? (c1 - c0 + 8) & ~7 : 0, rh = (c1 >= c0 && r1 >= r0) ? (r1 - r0 + 8) & ~7 : 0;
-    a.pool.hdr[4 * v] = c0; a.pool.hdr[4 * v + 1] = r0; a.pool.hdr[4 * v + 2] = rw; a.pool.hdr[4 * v + 3] = rh;
-    area[v] = rw * rh;
+    __syncthreads();
+    // Which triangles of the star can cover a pixel of which 8x8 tile of the region, in any configuration: bit k of the
+    // tile's word.  A triangle cannot if its box misses the tile or if one of its edge functions is <= 0 (with the
+    // top-left rule folded in: ecb) at all four corner pixels of the tile -- E is linear, whole numbers evaluated exactly
+    // in binary64 like the coverage test itself, so the word is a superset of the truth and a tight one: about a third
+    // of a region's tiles lie outside the star and get 0 -- k_measure_vertex evaluates nothing there.  (A region of
+    // more than tmask_stride tiles keeps the per-triangle boxes: k_measure_vertex tests those instead.)
+    const int ntx = sh.reg[2] >> 3, ntiles = ntx * (sh.reg[3] >> 3);
+    if (ntiles > a.tmask_stride) return;
+    for (int t = threadIdx.x; t < ntiles; t += NT) {
+        const int tc0 = sh.reg[0] + 8 * (t % ntx), tr0 = sh.reg[1] + 8 * (t / ntx);
+        const double xa = (double)tc0, xb = (double)min(tc0 + 7, m.W - 1), ya = (double)tr0, yb = (double)min(tr0 + 7, m.H - 1);
+        unsigned word = 0;
+#pragma unroll 1
+        for (int k = 0; k < nsv; k++) {
+            bool reach = false;
+#pragma unroll 1
+            for (int cf = 0; cf < MEAS_NCFG && !reach; cf++) {
+                const int4 b = sh.tbox[cf][k];
+                if ((b.x > b.y) | (b.y < tc0) | (b.x > tc0 + 7) | (b.w < tr0) | (b.z > tr0 + 7)) continue;
+                bool in = true;
+#pragma unroll 1
+                for (int e = 0; e < 3; e++) {
+                    const double A = sh.ea[cf][k][e], B = sh.eb[cf][k][e], C = sh.ecb[cf][k][e];
+                    const double e00 = fma(A, xa, fma(B, ya, C)), e10 = fma(A, xb, fma(B, ya, C));
+                    const double e01 = fma(A, xa, fma(B, yb, C)), e11 = fma(A, xb, fma(B, yb, C));
+                    in &= (e00 > 0.0) | (e10 > 0.0) | (e01 > 0.0) | (e11 > 0.0);
+                }
+                reach = in;
+            }
+            if (reach) word |= 1u << k;
+        }
+        a.tmask[(size_t)v * a.tmask_stride + t] = word;
+    }
 }
 
 __global__ __launch_bounds__(REGION_NT) void k_star_regions(MeasureArgs a, int *__restrict__ area)
@@ -750,7 +792,7 @@ __device__ inline void d_region_sums(const int *__restrict__ area, int N, int v,
 // around v (its star), so every sum runs over the bounding box of that star; the perturbed renders
 // are never materialised.  The forward difference images are parked in the pool for pass 2.
 __global__ __launch_bounds__(MEAS_NT, 4) void k_measure_vertex(MeasureArgs a, const TriSetup *__restrict__ cfgs,
-                                                                const int4 *__restrict__ ubox)
+                                                                const int4 *__restrict__ ubox, const unsigned *__restrict__ tmask)
 {
     __shared__ double s_red[(MEAS_NT / 64) * MEAS_OUT];
     __shared__ double s_k255[511];
@@ -790,9 +832,13 @@ __global__ __launch_bounds__(MEAS_NT, 4) void k_measure_vertex(MeasureArgs a, co
         const int tr0 = r0 + 8 * (tile / ntx), tc0 = c0 + 8 * (tile % ntx);
         const int r = tr0 + ly, c = tc0 + lx;
         unsigned mask = 0;                         // the triangles of the star that can reach this tile
-        for (int k = 0; k < nsv; k++) {
-            const int4 b = ubox[(size_t)v * UBOX_STRIDE + k];
-            if (!((b.y < tc0) | (b.x > tc0 + 7) | (b.w < tr0) | (b.z > tr0 + 7))) mask |= 1u << k;
+        if (ntiles <= a.tmask_stride) {
+            mask = tmask[(size_t)v * a.tmask_stride + tile];          // from the region pass: box and corner tests
+        } else {
+            for (int k = 0; k < nsv; k++) {
+                const int4 b = ubox[(size_t)v * UBOX_STRIDE + k];
+                if (!((b.y < tc0) | (b.x > tc0 + 7) | (b.w < tr0) | (b.z > tr0 + 7))) mask |= 1u << k;
+            }
         }
         const long long pp = base + (long long)tile * 64 + (threadIdx.x & 63);      // tile-major (DPool)
         if (c >= W || r >= m.H) {                  // the padding of a region may leave the frame
@@ -902,12 +948,14 @@ __global__ __launch_bounds__(MEAS_NT) void k_measure_edge(MeasureArgs a)
     const int tx0 = max(hv[0], hw[0]) >> 3, ty0 = max(hv[1], hw[1]) >> 3;
     const int tx1 = min(hv[0] + hv[2], hw[0] + hw[2]) >> 3, ty1 = min(hv[1] + hv[3], hw[1] + hw[3]) >> 3;
     const int ntx = tx1 - tx0, nty = ty1 - ty0;
-    const int nt = (ntx > 0 && nty > 0) ? ntx * nty : 0;
     const int vx0 = hv[0] >> 3, vy0 = hv[1] >> 3, vnx = hv[2] >> 3;
     const int wx0 = hw[0] >> 3, wy0 = hw[1] >> 3, wnx = hw[2] >> 3;
     __shared__ long long s_sum[(MEAS_NT / 64) * 3];
     long long bv, bw, total;
     d_region_sums<MEAS_NT>(a.pool.area, N, v, w, bv, bw, total, s_sum);
+    // regions that do not fit the pool were not parked (k_measure_vertex reported the overflow; the caller grows the pool
+    // and measures again): nothing of the pool is looked at, the places of these regions lie beyond its end
+    const int nt = (total <= a.pool.cap && ntx > 0 && nty > 0) ? ntx * nty : 0;
     double acc[B_NV];
 #pragma unroll
     for (int k = 0; k < B_NV; k++) acc[k] = 0.0;
@@ -1010,7 +1058,7 @@ __device__ long long *g_stamp;          // development builds only (tools/stamp_
 #define HM_STAMP_AT(k) do { } while (0)
 #endif
 template <int RIH>
-__global__ __launch_bounds__(256) void k_render_iter(IterRenderArgs r, MeasureArgs a, int *__restrict__ area)
+__global__ __launch_bounds__(256, 4) void k_render_iter(IterRenderArgs r, MeasureArgs a, int *__restrict__ area)
 {
     HM_STAMP_AT(0);
     constexpr int RI_PX = RI_W * RIH / 256;      // pixels per thread: rows r0 + (tid >> 6) + 4 q
