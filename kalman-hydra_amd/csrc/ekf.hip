@@ -38,6 +38,7 @@ struct hm_ctx {
     Targets ref, P, Q;
     TriSetup *d_setup, *d_cfgs;
     int4 *d_ubox;
+    int *d_tlist = nullptr, *d_tcount = nullptr;   // ... and the list / count of the tiles with a non-zero word
     unsigned *d_tmask = nullptr;     // per vertex and tile of its star region: the star triangles that can reach the tile (k_measure_vertex)
     double *d_X, *d_out, *d_partial;
     uint8_t *d_im8, *d_m8;
@@ -221,7 +222,7 @@ static int ctx_free(hm_ctx *h)
                     h->d_Wtmp, h->d_X0, h->d_Xn, h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk,
                     h->pool.hdr, h->pool.overflow, h->d_area,
                     h->d_outline, h->d_outline_cnt, h->d_pm_mask, h->d_pm_flag, h->d_pm_X, h->d_ids[0], h->d_ids[1], h->d_ids[2], h->d_labels, h->d_lbox,
-                    h->d_lout, h->d_tpart, h->d_tmask, h->d_nb_off, h->d_nb_u, h->d_nb_e, h->d_flowP, h->d_flowctl, h->d_nbars, h->d_nvoff, h->d_nvbar, h->d_ninfo, h->d_nl0, h->d_nX};
+                    h->d_lout, h->d_tpart, h->d_tmask, h->d_tlist, h->d_tcount, h->d_nb_off, h->d_nb_u, h->d_nb_e, h->d_flowP, h->d_flowctl, h->d_nbars, h->d_nvoff, h->d_nvbar, h->d_ninfo, h->d_nl0, h->d_nX};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     pool_release(h);
@@ -345,6 +346,8 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_cfgs, (size_t)N * MEAS_NCFG * (EKF_MAX_STAR + 1) * sizeof(TriSetup));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_ubox, (size_t)N * UBOX_STRIDE * sizeof(int4));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_tmask, (size_t)N * TMASK_STRIDE * sizeof(unsigned));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_tlist, (size_t)N * TMASK_STRIDE * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_tcount, (size_t)N * sizeof(int));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_X, (size_t)4 * N * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_out, (size_t)h->njobs * MEAS_VSPLIT_MAX * MEAS_OUT * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_partial, (size_t)h->red_blocks * 4 * sizeof(double));
@@ -869,6 +872,8 @@ static void measure_args(hm_ctx *h, const double *dX, double deltaX, int masked,
     a.cfgs = h->d_cfgs;
     a.ubox = h->d_ubox;
     a.tmask = h->d_tmask;
+    a.tlist = h->d_tlist;
+    a.tcount = h->d_tcount;
     a.tmask_stride = TMASK_STRIDE;
 }
 

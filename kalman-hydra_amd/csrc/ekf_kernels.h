@@ -603,6 +603,7 @@ struct MeasureArgs {
     TriSetup *cfgs;           // N x MEAS_NCFG x (EKF_MAX_STAR + 1): the star setups, written by k_star_regions
     int4 *ubox;               // N x UBOX_STRIDE: per triangle of the star, its pixel box over all configurations
     unsigned *tmask;          // N x tmask_stride: per tile of the region, the triangles of the star that can reach it
+    int *tlist, *tcount;      // N x tmask_stride: the tiles with a non-zero word, ascending; N: how many (-1: the region has more tiles than tmask_stride)
     int tmask_stride;
 };
 
@@ -653,6 +654,7 @@ struct RegionShared {
     double ea[MEAS_NCFG][EKF_MAX_STAR + 1][3], eb[MEAS_NCFG][EKF_MAX_STAR + 1][3], ecb[MEAS_NCFG][EKF_MAX_STAR + 1][3];   // their edge functions
     int box[MEAS_NCFG][4];
     int reg[4];                                  // the region: c0, r0, rw, rh
+    int wsum[8];                                 // live tiles per wave of a round
 };
 template <int NT>
 __device__ inline void d_star_regions(const MeasureArgs &a, int *__restrict__ area, int v, RegionShared &sh)
@@ -728,32 +730,50 @@ __device__ inline void d_star_regions(const MeasureArgs &a, int *__restrict__ ar
     // of a region's tiles lie outside the star and get 0 -- k_measure_vertex evaluates nothing there.  (A region of
     // more than tmask_stride tiles keeps the per-triangle boxes: k_measure_vertex tests those instead.)
     const int ntx = sh.reg[2] >> 3, ntiles = ntx * (sh.reg[3] >> 3);
-    if (ntiles > a.tmask_stride) return;
-    for (int t = threadIdx.x; t < ntiles; t += NT) {
-        const int tc0 = sh.reg[0] + 8 * (t % ntx), tr0 = sh.reg[1] + 8 * (t / ntx);
-        const double xa = (double)tc0, xb = (double)min(tc0 + 7, m.W - 1), ya = (double)tr0, yb = (double)min(tr0 + 7, m.H - 1);
-        unsigned word = 0;
-#pragma unroll 1
-        for (int k = 0; k < nsv; k++) {
-            bool reach = false;
-#pragma unroll 1
-            for (int cf = 0; cf < MEAS_NCFG && !reach; cf++) {
-                const int4 b = sh.tbox[cf][k];
-                if ((b.x > b.y) | (b.y < tc0) | (b.x > tc0 + 7) | (b.w < tr0) | (b.z > tr0 + 7)) continue;
-                bool in = true;
-#pragma unroll 1
-                for (int e = 0; e < 3; e++) {
-                    const double A = sh.ea[cf][k][e], B = sh.eb[cf][k][e], C = sh.ecb[cf][k][e];
-                    const double e00 = fma(A, xa, fma(B, ya, C)), e10 = fma(A, xb, fma(B, ya, C));
-                    const double e01 = fma(A, xa, fma(B, yb, C)), e11 = fma(A, xb, fma(B, yb, C));
-                    in &= (e00 > 0.0) | (e10 > 0.0) | (e01 > 0.0) | (e11 > 0.0);
-                }
-                reach = in;
-            }
-            if (reach) word |= 1u << k;
-        }
-        a.tmask[(size_t)v * a.tmask_stride + t] = word;
+    if (ntiles > a.tmask_stride) {                 // (uniform: the whole workgroup leaves)
+        if (threadIdx.x == 0) a.tcount[v] = -1;
+        return;
     }
+    // ... and the list of the tiles with a non-zero word, in ascending order (a ballot per wave, wave totals through LDS):
+    // k_measure_vertex walks that list and never touches the others
+    int listed = 0;
+    for (int t0 = 0; t0 < ntiles; t0 += NT) {
+        const int t = t0 + threadIdx.x;
+        unsigned word = 0;
+        if (t < ntiles) {
+            const int tc0 = sh.reg[0] + 8 * (t % ntx), tr0 = sh.reg[1] + 8 * (t / ntx);
+            const double xa = (double)tc0, xb = (double)min(tc0 + 7, m.W - 1), ya = (double)tr0, yb = (double)min(tr0 + 7, m.H - 1);
+#pragma unroll 1
+            for (int k = 0; k < nsv; k++) {
+                bool reach = false;
+#pragma unroll 1
+                for (int cf = 0; cf < MEAS_NCFG && !reach; cf++) {
+                    const int4 b = sh.tbox[cf][k];
+                    if ((b.x > b.y) | (b.y < tc0) | (b.x > tc0 + 7) | (b.w < tr0) | (b.z > tr0 + 7)) continue;
+                    bool in = true;
+#pragma unroll 1
+                    for (int e = 0; e < 3; e++) {
+                        const double A = sh.ea[cf][k][e], B = sh.eb[cf][k][e], C = sh.ecb[cf][k][e];
+                        const double e00 = fma(A, xa, fma(B, ya, C)), e10 = fma(A, xb, fma(B, ya, C));
+                        const double e01 = fma(A, xa, fma(B, yb, C)), e11 = fma(A, xb, fma(B, yb, C));
+                        in &= (e00 > 0.0) | (e10 > 0.0) | (e01 > 0.0) | (e11 > 0.0);
+                    }
+                    reach = in;
+                }
+                if (reach) word |= 1u << k;
+            }
+            a.tmask[(size_t)v * a.tmask_stride + t] = word;
+        }
+        const unsigned long long bal = __ballot(word != 0);
+        __syncthreads();                           // sh.wsum of the previous round has been read
+        if (lane == 0) sh.wsum[wv] = __popcll(bal);
+        __syncthreads();
+        int before = listed;
+        for (int w = 0; w < wv; w++) before += sh.wsum[w];
+        if (word != 0) a.tlist[(size_t)v * a.tmask_stride + before + __popcll(bal & ((1ull << lane) - 1ull))] = t;
+        for (int w = 0; w < NW; w++) listed += sh.wsum[w];
+    }
+    if (threadIdx.x == 0) a.tcount[v] = listed;
 }
 
 __global__ __launch_bounds__(REGION_NT) void k_star_regions(MeasureArgs a, int *__restrict__ area)
@@ -828,11 +848,16 @@ __global__ __launch_bounds__(MEAS_NT, 4) void k_measure_vertex(MeasureArgs a, co
     const int lx = threadIdx.x & 7, ly = (threadIdx.x & 63) >> 3;
     const int ntx = (rw + 7) >> 3, ntiles = ntx * ((rh + 7) >> 3);
     const int nwaves = (MEAS_NT / 64) * gridDim.y;
-    for (int tile = blockIdx.y * (MEAS_NT / 64) + wave; tile < ntiles; tile += nwaves) {
+    // The tiles some triangle of the star can reach (the region pass listed them); the others -- about a third of a
+    // region -- are not evaluated and not parked: their live word is cleared below and nobody reads their planes.
+    const int listed = a.tcount[v];
+    const int nwalk = listed >= 0 ? listed : ntiles;
+    for (int j = blockIdx.y * (MEAS_NT / 64) + wave; j < nwalk; j += nwaves) {
+        const int tile = listed >= 0 ? a.tlist[(size_t)v * a.tmask_stride + j] : j;
         const int tr0 = r0 + 8 * (tile / ntx), tc0 = c0 + 8 * (tile % ntx);
         const int r = tr0 + ly, c = tc0 + lx;
         unsigned mask = 0;                         // the triangles of the star that can reach this tile
-        if (ntiles <= a.tmask_stride) {
+        if (listed >= 0) {
             mask = tmask[(size_t)v * a.tmask_stride + tile];          // from the region pass: box and corner tests
         } else {
             for (int k = 0; k < nsv; k++) {
@@ -910,6 +935,9 @@ __global__ __launch_bounds__(MEAS_NT, 4) void k_measure_vertex(MeasureArgs a, co
             a.pool.vxfx[pp] = dvxp.fx; a.pool.vyfy[pp] = dvyp.fy;
         }
     }
+    if (park && listed >= 0)                       // the tiles nobody walked hold nothing
+        for (int t = blockIdx.y * MEAS_NT + threadIdx.x; t < ntiles; t += MEAS_NT * gridDim.y)
+            if (tmask[(size_t)v * a.tmask_stride + t] == 0) a.pool.live[base / 64 + t] = 0;
     d_block_reduce<A_NV, MEAS_NT>(acc, s_red, a.out + ((size_t)job * MEAS_VSPLIT_MAX + blockIdx.y) * MEAS_OUT);
 }
 
