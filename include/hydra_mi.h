@@ -93,8 +93,10 @@ int hm_brox_set_omega(hm_brox_t h, float omega);
  * "sor_deep" = 1/0 (default 1): with sor_fuse 0, a level whose tiles would not fill the device even with the halo of
  * all solver_iterations takes them in one launch, "coarse_max" = 0, 32 (default) or 64: pyramid levels of at most
  * that many pixels per side run in one launch per pair (k_coarse) instead of one launch per operator,
- * "cu_reserve" = n (default 0): the handle's stream is re-created with a compute-unit mask that leaves n CUs to
- * other streams (call it before hm_brox_stream's value is kept anywhere; the pipeline sets 32),
+ * "cu_reserve" = n (default 0): the handle gets a second stream with a compute-unit mask that leaves n CUs to
+ * other streams and uses it from now on (call it before hm_brox_stream's value is kept anywhere; the pipeline sets 32),
+ * "whole_chip" = 1/0: with a cu_reserve in force, the next calls go to the unmasked stream / back to the masked one
+ * (the stream that is left is drained first; the pipeline gives the first series of a phase the whole chip),
  * "coarse_stagger" = 1/0: test knob, delays some workgroups of k_coarse between phases,
  * "sor_threads" = 256, 512 or 1024 threads per SOR workgroup (0, the default: 1024 for calls of one or two pairs,
  * 512 for larger ones), "warp_window" =

@@ -261,7 +261,8 @@ struct hm_brox {
     int coarse_max;              // levels up to this many px per side run inside k_coarse: 0 (none), 32 or 64
     std::vector<Geo> geo;
     Taps taps;
-    hipStream_t stream;
+    hipStream_t stream;                 // the stream launches go to: `whole` or `masked`
+    hipStream_t whole = nullptr, masked = nullptr;
     float *arena;
     size_t arena_floats;
     std::vector<float *> pyr0, pyr1;
@@ -297,7 +298,8 @@ static int brox_free(hm_brox *h)
     if (h->d_f1) hipFree(h->d_f1);
     if (h->d_ox) hipFree(h->d_ox);
     if (h->d_oy) hipFree(h->d_oy);
-    if (h->stream) hipStreamDestroy(h->stream);
+    if (h->whole) hipStreamDestroy(h->whole);
+    if (h->masked) hipStreamDestroy(h->masked);
     delete h;
     return HM_OK;
 }
@@ -340,7 +342,8 @@ extern "C" int hm_brox_create(int device, int W, int H, int max_batch, float alp
     // padding columns are read (never used) by float2 loads: keep them finite.  The fill
     // goes on the handle's own stream: that stream is non-blocking, so a fill issued on the
     // null stream could still be running when the first calc starts.
-    e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    e = hipStreamCreateWithFlags(&h->whole, hipStreamNonBlocking);
+    h->stream = h->whole;
     if (e == hipSuccess) e = hipMemsetAsync(h->arena, 0, h->arena_floats * sizeof(float), h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_f0, B * W * H);
@@ -405,17 +408,25 @@ extern "C" int hm_brox_tune(hm_brox_t h, const char *key, int value)
         HM_ARG(value >= 0 && value < h->cus, "hm_brox_tune: cu_reserve must be in 0..%d", h->cus - 1);
         HM_HIP(hipSetDevice(h->device));
         HM_HIP(hipStreamSynchronize(h->stream));
-        hipStream_t ns = nullptr;
-        if (value == 0) {
-            HM_HIP(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
-        } else {
+        if (h->masked) { HM_HIP(hipStreamDestroy(h->masked)); h->masked = nullptr; }
+        if (value > 0) {
             const int words = (h->cus + 31) / 32;
             std::vector<uint32_t> mask(words, 0u);
             for (int i = 0; i < h->cus - value; i++) mask[i / 32] |= 1u << (i % 32);
-            HM_HIP(hipExtStreamCreateWithCUMask(&ns, (uint32_t)words, mask.data()));
+            HM_HIP(hipExtStreamCreateWithCUMask(&h->masked, (uint32_t)words, mask.data()));
         }
-        HM_HIP(hipStreamDestroy(h->stream));
-        h->stream = ns;
+        h->stream = h->masked ? h->masked : h->whole;
+    } else if (!strcmp(key, "whole_chip")) {
+        // 1: the next calls use all compute units whatever cu_reserve says (a series that runs with nothing beside it:
+        // the first of a phase of the streaming pipeline); 0: back to the masked stream.  Calls of one handle do not
+        // overlap, and the stream that is left is drained first.
+        HM_ARG(value == 0 || value == 1, "hm_brox_tune: whole_chip must be 0 or 1");
+        hipStream_t to = (value || !h->masked) ? h->whole : h->masked;
+        if (to != h->stream) {
+            HM_HIP(hipSetDevice(h->device));
+            HM_HIP(hipStreamSynchronize(h->stream));
+            h->stream = to;
+        }
     } else if (!strcmp(key, "sor_deep")) {
         HM_ARG(value >= 0 && value <= 8, "hm_brox_tune: sor_deep must be 0 .. 8");
         h->sor_deep = value;

@@ -37,6 +37,13 @@
 #include "dense_kernels.h"
 
 #define FLOW_NT 256
+#ifdef HM_STAMP
+// development builds only (tools/stamp_chol.py): clock stamps of the chain's columns, 8 words per column behind the
+// 4096 x 8 words k_render_iter uses
+#define HM_CHAIN_STAMP(c, k) do { if (g_stamp && (threadIdx.x & 63) == 0) g_stamp[(size_t)(4096 + (c)) * 8 + (k)] = clock64(); } while (0)
+#else
+#define HM_CHAIN_STAMP(c, k) do { } while (0)
+#endif
 #define FLOW_SENTINEL 0x7FF8DEADBEEF0001ull       // a quiet NaN with a payload the hardware never generates
 #define FLOW_POLL_LIMIT 4000000                   // polls of one wait before it gives up (~seconds)
 
@@ -158,21 +165,21 @@ __device__ __forceinline__ bool flow_fetch(const double *src, int ld, int nr, in
 }
 
 // Two blocks other tasks publish (DNB columns; rows < nr of the first, all of the second; what is not published
-// reads as 0; the second only if `two`) into LDS by the 192 threads of three waves (tt = 0 .. 191) that poll for
+// reads as 0; the second only if `two`) into LDS by the 128 threads of two waves (tt = 0 .. 127) that poll for
 // them on their own -- no workgroup barrier inside: every wave re-loads its elements of both until none is the
 // fill pattern.  false: gave up.
 __device__ __forceinline__ bool flow_prefetch2(const double *src0, int nr, double (*dst0)[DNB + 1], const double *src1,
                                                double (*dst1)[DNB + 1], bool two, int tt, unsigned *ctl)
 {
-    double v0[6], v1[6];
+    double v0[8], v1[8];
     for (int polls = 0;; polls++) {
         int ok = 1;
 #pragma unroll
-        for (int q = 0; q < 6; q++) {
-            const int e = tt + 192 * q, i = e / DNB;
+        for (int q = 0; q < 8; q++) {
+            const int e = tt + 128 * q, i = e / DNB;
             unsigned long long x0 = 0, x1 = 0;
-            if (e < DNB * DNB && i < nr) x0 = flow_ld_bits(src0 + e);
-            if (e < DNB * DNB && two) x1 = flow_ld_bits(src1 + e);
+            if (i < nr) x0 = flow_ld_bits(src0 + e);
+            if (two) x1 = flow_ld_bits(src1 + e);
             ok &= x0 != FLOW_SENTINEL && x1 != FLOW_SENTINEL;
             v0[q] = __longlong_as_double((long long)x0);
             v1[q] = __longlong_as_double((long long)x1);
@@ -182,53 +189,32 @@ __device__ __forceinline__ bool flow_prefetch2(const double *src0, int nr, doubl
         if (polls > FLOW_POLL_LIMIT) { __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
     }
 #pragma unroll
-    for (int q = 0; q < 6; q++) {
-        const int e = tt + 192 * q;
-        if (e < DNB * DNB) {
-            dst0[e / DNB][e % DNB] = v0[q];
-            if (two) dst1[e / DNB][e % DNB] = v1[q];
-        }
+    for (int q = 0; q < 8; q++) {
+        const int e = tt + 128 * q;
+        dst0[e / DNB][e % DNB] = v0[q];
+        if (two) dst1[e / DNB][e % DNB] = v1[q];
     }
     return true;
 }
 
-// chol32_tinv_wave with write-through stores, to Lt[c] and to the diagonal block of Tinv
-__device__ __forceinline__ void flow_chol32(double (*W)[DNB + 1], double *lt, double *tinv, int ld, int nc, int lane,
-                                            double (*keep)[DNB + 1])
+// wave T of the diagonal block (chol32_wave_t): the rows of T are published strip by strip, as soon as they are
+// final -- write-through stores to Lt[c] (the next tasks are waiting for it) and to the diagonal block of Tinv, a copy in
+// LDS for the chain's next block.  (Stored all at the end they cost the chain ~1 us per column: the stamps of
+// tools/stamp_chol.py show 2 600 clocks for 32 store instructions whose lines other workgroups are polling, 650 when
+// nobody does; spread over the strips they are issued while this wave waits for wave B.)
+__device__ __forceinline__ void flow_chol32_t(CholX &X, double *lt, double *tinv, int ld, int nc, int lane, double (*keep)[DNB + 1])
 {
-    d4_t b[2][2], t[2][2];
+    d4_t t[2][2];
     const int lr = lane >> 4, lc = lane & 15;
-#pragma unroll
-    for (int R = 0; R < 2; R++)
-#pragma unroll
-        for (int C = 0; C < 2; C++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int i = 16 * R + lr + 4 * e, jc = 16 * C + lc;
-                b[R][C][e] = W[i][jc];
-                t[R][C][e] = i == jc ? 1.0 : 0.0;
-            }
-    chol32_strip<0>(b, t, lane); chol32_strip<1>(b, t, lane); chol32_strip<2>(b, t, lane); chol32_strip<3>(b, t, lane);
-    chol32_strip<4>(b, t, lane); chol32_strip<5>(b, t, lane); chol32_strip<6>(b, t, lane); chol32_strip<7>(b, t, lane);
-    // T_c first: the next diagonal task is waiting for it; the copy into the inverse after it
-#pragma unroll
-    for (int R = 0; R < 2; R++)
-#pragma unroll
-        for (int C = 0; C < 2; C++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                flow_st(lt + (16 * R + lr + 4 * e) * DNB + 16 * C + lc, t[R][C][e]);
-                keep[16 * R + lr + 4 * e][16 * C + lc] = t[R][C][e];          // for the chain's next block
-            }
-#pragma unroll
-    for (int R = 0; R < 2; R++)
-#pragma unroll
-        for (int C = 0; C < 2; C++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int i = 16 * R + lr + 4 * e, j = 16 * C + lc;
-                if (i < nc && j < nc) flow_st(tinv + (size_t)i * ld + j, t[R][C][e]);
-            }
+    chol32_wave_t(t, X, lane, [&](int j, double u0, double u1) {
+        const int i = j + lr;
+        flow_st(lt + i * DNB + lc, u0);
+        flow_st(lt + i * DNB + 16 + lc, u1);
+        keep[i][lc] = u0;
+        keep[i][16 + lc] = u1;
+        if (i < nc && lc < nc) flow_st(tinv + (size_t)i * ld + lc, u0);
+        if (i < nc && 16 + lc < nc) flow_st(tinv + (size_t)i * ld + 16 + lc, u1);
+    });
 }
 
 __global__ __launch_bounds__(FLOW_NT) void k_chol_flow(FlowArgs a)
@@ -238,6 +224,7 @@ __global__ __launch_bounds__(FLOW_NT) void k_chol_flow(FlowArgs a)
     __shared__ double Bc[DNB][DNB + 1];
     __shared__ double Pn[DNB][DNB + 1];               // the chain's next operands, fetched while it factors
     __shared__ double Qn[DNB][DNB + 1];
+    __shared__ CholX Xs;                              // the chain's hand-off between its B wave and its T wave
     __shared__ unsigned s_task;
     __shared__ int s_fail;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -256,15 +243,17 @@ __global__ __launch_bounds__(FLOW_NT) void k_chol_flow(FlowArgs a)
         __syncthreads();
         if (first && s_task == 0) {
             // ---- the chain: D(0), D(1), ... ------------------------------------------------------------------
-            // While wave 0 factors block c (4.2 us, one wave), the other three waves fetch what block c + 1 starts
-            // from -- the block (c+1, c) before its triangular solve and Q_{c+1}; both appear about now -- so that
-            // the chain never waits for a load it could have issued earlier (a load of a block that is already
-            // there still takes 1.7 us).
+            // While waves 0 and 1 factor block c (dense_kernels.h: the B tiles in one, the T tiles in the other), the
+            // other two waves fetch what block c + 1 starts from -- the block (c+1, c) before its triangular solve and
+            // Q_{c+1}; both appear about now -- so that the chain never waits for a load it could have issued earlier
+            // (a load of a block that is already there still takes 1.7 us).
             __builtin_amdgcn_s_setprio(3);            // ahead of whatever shares its SIMDs
             if (t == 0) s_fail = 0;
+            chol32_x_clear(Xs, t, FLOW_NT);
             for (int c = 0; c < nb; c++) {
                 const int c0 = c * DNB, nc = min(DNB, n - c0);
                 for (int q = 0; q < a.stall; q++) __builtin_amdgcn_s_sleep(127);      // tests: everyone who waits for the chain waits long
+                if (wv == 0) HM_CHAIN_STAMP(c, 0);
                 double acc[4];
                 if (c < 2) {                          // Q_c is the block of A itself
 #pragma unroll
@@ -285,15 +274,23 @@ __global__ __launch_bounds__(FLOW_NT) void k_chol_flow(FlowArgs a)
                 }
 #pragma unroll
                 for (int e = 0; e < 4; e++) Br[mi[e]][mj] = (mi[e] < nc && mj < nc) ? acc[e] : (mi[e] == mj ? 1.0 : 0.0);
+                if (wv == 0) HM_CHAIN_STAMP(c, 1);
                 __syncthreads();
                 if (wv == 0) {
-                    flow_chol32(Br, a.Lt + (size_t)c * DNB * DNB, a.Tinv + (size_t)c0 * n + c0, n, nc, lane, Ts);
+                    HM_CHAIN_STAMP(c, 2);
+                    chol32_wave_b(Br, Xs, lane);
+                    HM_CHAIN_STAMP(c, 3);
+                } else if (wv == 1) {
+                    flow_chol32_t(Xs, a.Lt + (size_t)c * DNB * DNB, a.Tinv + (size_t)c0 * n + c0, n, nc, lane, Ts);
+                    HM_CHAIN_STAMP(c, 5);
                 } else if (c + 1 < nb) {
                     const int nr = min(DNB, n - (c0 + DNB));
                     const double *Pb = a.P + (size_t)(c + 1) * DNB * DNB, *Qb = a.P + (size_t)(nb + c + 1) * DNB * DNB;
-                    if (!flow_prefetch2(Pb, nr, Pn, Qb, Qn, c + 1 >= 2, t - 64, a.ctl)) s_fail = 1;
+                    if (!flow_prefetch2(Pb, nr, Pn, Qb, Qn, c + 1 >= 2, t - 128, a.ctl)) s_fail = 1;
+                    if (wv == 2) HM_CHAIN_STAMP(c, 7);
                 }
                 __syncthreads();
+                if (wv == 0) HM_CHAIN_STAMP(c, 6);
                 if (s_fail) return;
             }
             __builtin_amdgcn_s_setprio(0);

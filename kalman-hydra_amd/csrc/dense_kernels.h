@@ -131,6 +131,147 @@ __device__ __forceinline__ void chol32_strip(d4_t (&b)[2][2], d4_t (&t)[2][2], i
     if (tcol1) t[RJ][1][E] = uT1;
 }
 
+// ---- the same elimination split over two waves ---------------------------------------------------------------
+// Measured (tools/chol32_bench.hip, one block in a loop): 3.29 us in one wave, of which 0.78 are the 22 MFMAs that
+// are not on the way to the next pivot and 0.71 the eight 4x4 jobs; the MFMA pipe of ONE SIMD and in-order issue of
+// ONE wave carry all of it.  The T half never feeds back into the pivots: wave B keeps the B tiles (pivot, 4x4 job,
+// U of the B tiles, their updates; tile (1,0) is never read and is not kept at all), wave T keeps the T tiles and
+// gets, per strip, T44 in A-operand layout (`ta`) and the two A operands of the row updates (`xa`) through LDS.
+// Hand-off as between the tasks of k_chol_flow: a slot holds a NaN pattern no computation produces until its value
+// is stored; the T wave re-loads until all its lanes see values, and puts the pattern back when it has them (wave B
+// writes a slot once per block, and blocks are separated by workgroup barriers).  Every MFMA has the operands it has
+// in chol32_strip, so T has the same bits: 2.87 us per block.
+#define CHOL_X_SENTINEL 0x7FF8DEADBEEF0002ull
+struct CholX { double v[8][3][64]; };               // [strip][ta, xa of row tile 0, xa of row tile 1][lane]
+__device__ __forceinline__ void d_lds_put(double *slot, double v)
+{
+    __hip_atomic_store((unsigned long long *)slot, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ double d_lds_get(double *slot)
+{
+    unsigned long long x;
+    do {
+        x = __hip_atomic_load((unsigned long long *)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } while (!__all(x != CHOL_X_SENTINEL));
+    return __longlong_as_double((long long)x);
+}
+__device__ __forceinline__ void chol32_x_clear(CholX &X, int t, int nt)
+{
+    for (int e = t; e < 8 * 3 * 64; e += nt) (&X.v[0][0][0])[e] = __longlong_as_double((long long)CHOL_X_SENTINEL);
+}
+
+template <int G>
+__device__ __forceinline__ void chol32_strip_b(d4_t &b00, d4_t &b01, d4_t &b11, CholX &X, int lane)
+{
+    constexpr int j = 4 * G, RJ = G >> 2, E = G & 3, JJ = j & 15;
+    const double pv = RJ ? b11[E] : b00[E];
+    const double p00 = d_readlane(pv, JJ);
+    const double p10 = d_readlane(pv, 16 + JJ), p11 = d_readlane(pv, 16 + JJ + 1);
+    const double p20 = d_readlane(pv, 32 + JJ), p21 = d_readlane(pv, 32 + JJ + 1), p22 = d_readlane(pv, 32 + JJ + 2);
+    const double p30 = d_readlane(pv, 48 + JJ), p31 = d_readlane(pv, 48 + JJ + 1), p32 = d_readlane(pv, 48 + JJ + 2),
+                 p33 = d_readlane(pv, 48 + JJ + 3);
+    const double r0 = d_rsqrt(p00);
+    const double l10 = p10 * r0, l20 = p20 * r0, l30 = p30 * r0;
+    const double r1 = d_rsqrt(fma(-l10, l10, p11));
+    const double l21 = fma(-l20, l10, p21) * r1, l31 = fma(-l30, l10, p31) * r1;
+    const double r2 = d_rsqrt(fma(-l21, l21, fma(-l20, l20, p22)));
+    const double l32 = fma(-l31, l21, fma(-l30, l20, p32)) * r2;
+    const double r3 = d_rsqrt(fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, p33))));
+    double t10 = -(l10 * r0) * r1;
+    double t20 = -fma(l21, t10, l20 * r0) * r2, t21 = -(l21 * r1) * r2;
+    double t30 = -fma(l32, t20, fma(l31, t10, l30 * r0)) * r3, t31 = -fma(l32, t21, l31 * r1) * r3, t32 = -(l32 * r2) * r3;
+    asm volatile("" : "+v"(t10), "+v"(t20), "+v"(t21), "+v"(t30), "+v"(t31), "+v"(t32));
+    const int a = lane & 15, kq = lane >> 4;
+    const int idx = a < 4 ? 4 * a + kq : 16;
+    double ta = 0.0;
+    ta = idx == 0 ? r0 : ta;
+    ta = idx == 4 ? t10 : ta; ta = idx == 5 ? r1 : ta;
+    ta = idx == 8 ? t20 : ta; ta = idx == 9 ? t21 : ta; ta = idx == 10 ? r2 : ta;
+    ta = idx == 12 ? t30 : ta; ta = idx == 13 ? t31 : ta; ta = idx == 14 ? t32 : ta; ta = idx == 15 ? r3 : ta;
+    d_lds_put(&X.v[G][0][lane], ta);
+    const d4_t z = {0.0, 0.0, 0.0, 0.0};
+    constexpr bool live0 = j + 4 <= 15, live1 = j + 4 <= 31;
+    double uB0 = 0.0, uB1 = 0.0;
+    if (live0) uB0 = d_mfma4(ta, b00[E], z)[0];
+    if (live1) uB1 = d_mfma4(ta, (RJ ? b11 : b01)[E], z)[0];
+    if (live0) {
+        const double xa = a >= j + 4 ? -uB0 : 0.0;
+        d_lds_put(&X.v[G][1][lane], xa);
+        b00 = d_mfma4(xa, uB0, b00);
+        b01 = d_mfma4(xa, uB1, b01);
+    }
+    if (live1) {
+        const double xa = 16 + a >= j + 4 ? -uB1 : 0.0;
+        d_lds_put(&X.v[G][2][lane], xa);
+        b11 = d_mfma4(xa, uB1, b11);
+    }
+}
+
+// `rows_done(j, u0, u1)`: rows j .. j+3 of T are final -- lane holds row j + (lane >> 4), columns (lane & 15) and
+// 16 + (lane & 15); the caller publishes them while the wave waits for the next strip anyway
+template <int G, typename Done>
+__device__ __forceinline__ void chol32_strip_t(d4_t (&t)[2][2], CholX &X, int lane, Done &&rows_done)
+{
+    constexpr int j = 4 * G, RJ = G >> 2, E = G & 3;
+    constexpr bool live0 = j + 4 <= 15, live1 = j + 4 <= 31;
+    constexpr bool tcol1 = j >= 16;
+    const d4_t z = {0.0, 0.0, 0.0, 0.0};
+    const double sent = __longlong_as_double((long long)CHOL_X_SENTINEL);
+    const double ta = d_lds_get(&X.v[G][0][lane]);
+    double uT0, uT1 = 0.0;
+    uT0 = d_mfma4(ta, t[RJ][0][E], z)[0];
+    if (tcol1) uT1 = d_mfma4(ta, t[RJ][1][E], z)[0];
+    if (live0) {
+        const double xa = d_lds_get(&X.v[G][1][lane]);
+        t[0][0] = d_mfma4(xa, uT0, t[0][0]);
+        if (tcol1) t[0][1] = d_mfma4(xa, uT1, t[0][1]);
+        X.v[G][1][lane] = sent;
+    }
+    if (live1) {
+        const double xa = d_lds_get(&X.v[G][2][lane]);
+        t[1][0] = d_mfma4(xa, uT0, t[1][0]);
+        if (tcol1) t[1][1] = d_mfma4(xa, uT1, t[1][1]);
+        X.v[G][2][lane] = sent;
+    }
+    X.v[G][0][lane] = sent;
+    t[RJ][0][E] = uT0;
+    if (tcol1) t[RJ][1][E] = uT1;
+    rows_done(j, uT0, uT1);
+}
+
+// wave B of the pair: the B tiles of W (LDS, full symmetric block, identity padded) through the eight strips
+__device__ __forceinline__ void chol32_wave_b(double (*W)[DNB + 1], CholX &X, int lane)
+{
+    d4_t b00, b01, b11;
+    const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        b00[e] = W[lr + 4 * e][lc];
+        b01[e] = W[lr + 4 * e][16 + lc];
+        b11[e] = W[16 + lr + 4 * e][16 + lc];
+    }
+    chol32_strip_b<0>(b00, b01, b11, X, lane); chol32_strip_b<1>(b00, b01, b11, X, lane);
+    chol32_strip_b<2>(b00, b01, b11, X, lane); chol32_strip_b<3>(b00, b01, b11, X, lane);
+    chol32_strip_b<4>(b00, b01, b11, X, lane); chol32_strip_b<5>(b00, b01, b11, X, lane);
+    chol32_strip_b<6>(b00, b01, b11, X, lane); chol32_strip_b<7>(b00, b01, b11, X, lane);
+}
+
+// wave T of the pair: T = chol(B)^-1 in the registers of this wave (accumulator layout, 2 x 2 tiles)
+template <typename Done>
+__device__ __forceinline__ void chol32_wave_t(d4_t (&t)[2][2], CholX &X, int lane, Done &&rows_done)
+{
+    const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+    for (int R = 0; R < 2; R++)
+#pragma unroll
+        for (int C = 0; C < 2; C++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) t[R][C][e] = (16 * R + lr + 4 * e) == (16 * C + lc) ? 1.0 : 0.0;
+    chol32_strip_t<0>(t, X, lane, rows_done); chol32_strip_t<1>(t, X, lane, rows_done); chol32_strip_t<2>(t, X, lane, rows_done);
+    chol32_strip_t<3>(t, X, lane, rows_done); chol32_strip_t<4>(t, X, lane, rows_done); chol32_strip_t<5>(t, X, lane, rows_done);
+    chol32_strip_t<6>(t, X, lane, rows_done); chol32_strip_t<7>(t, X, lane, rows_done);
+}
+
 // One wave: B from LDS (W, full symmetric block, identity padded) -> T = chol(B)^-1 to global memory
 // (row-major 32x32 at `out`)
 __device__ __forceinline__ void chol32_tinv_wave(double (*W)[DNB + 1], double *__restrict__ out, int lane)

@@ -334,7 +334,15 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         step(upload(&h->d_nb_e, ne.data(), ne.size()));
     }
     if (rc == HM_OK) {
-        hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        // the filter's launches are a dependent chain of short kernels beside the flow's long ones on another stream:
+        // its queue gets the highest dispatch priority the device offers (HYDRA_MI_EKF_PRIORITY=0 turns that off)
+        int least = 0, greatest = 0;
+        const char *pe = getenv("HYDRA_MI_EKF_PRIORITY");
+        hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (e == hipSuccess && greatest != least && !(pe && atoi(pe) == 0))
+            e = hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, greatest);
+        else if (e == hipSuccess)
+            e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_tex, n);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_yim, n);
         if (e == hipSuccess) e = hipMalloc((void **)&h->d_ym, n);

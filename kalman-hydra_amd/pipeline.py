@@ -361,6 +361,7 @@ class FlowEKFPipeline:
                 bf.tune("cu_reserve", int(cu_reserve))
             return bf
         self._make_handle = make_handle
+        self.cu_reserve = int(cu_reserve or 0)
         self.concurrent_series = bool(concurrent_series)
         self.bfs = [make_handle() for _ in range(2 if concurrent_series else 1)]
         self.bf = self.bfs[0]
@@ -411,6 +412,10 @@ class FlowEKFPipeline:
                 # stream is waited for here, on the helper thread, before the flow stream is given work that reads them
                 self.ring.ensure(k + nb + 1, self._cursor)
                 self.ring.sync()
+                if self.cu_reserve:
+                    # a series the filter waits for with nothing to do (the first of a phase) gets the whole chip, the
+                    # others leave `cu_reserve` compute units to the filter
+                    bf.tune("whole_chip", 1 if first else 0)
                 bf.calc_dev(nb, self.ring.run_ptr(k), self.ring.run_ptr(k) + n,
                             self.d_u.ptr + buf * B * n * 4, self.d_v.ptr + buf * B * n * 4)
                 # ... and while this series runs, the frames of the next one go up (reference run_kalmanfilter.py:78-89

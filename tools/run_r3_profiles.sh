@@ -27,8 +27,18 @@ python tools/sor_sq_summary.py gpurun_out/r03/sorsq_*/b_counter_collection.csv >
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/r03/etraf_fetch -o b -- python tools/ekf_pmc.py 1 > gpurun_out/r03/etraf_fetch.log 2>&1 || echo etraf_fetch_fail
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/r03/etraf_write -o b -- python tools/ekf_pmc.py 1 > gpurun_out/r03/etraf_write.log 2>&1 || echo etraf_write_fail
 python tools/ekf_traffic_summary.py gpurun_out/r03 > gpurun_out/r03/r03_ekf_traffic.csv || echo etrafsum_fail
+# 5b. SQ counters of the filter's kernels
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU" \
+           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_WAIT_INST_LDS"; do
+  tag=$(echo $set | cut -d' ' -f1)
+  timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/r03/ekfsq_$tag -o b -- python tools/ekf_pmc.py 1 > gpurun_out/r03/ekfsq_$tag.log 2>&1 || echo fail_ekf_$tag
+done
+python tools/sor_sq_summary.py --prefix k_measure,k_render_iter,k_solve_prep,k_chol_flow,k_tvec,k_iter_result gpurun_out/r03/ekfsq_*/b_counter_collection.csv > gpurun_out/r03/r03_ekf_sq_counters.csv || echo ekfsqsum_fail
+# 5c. the chain of the factorisation: one 32x32 diagonal block in a loop (variants), clock stamps of the chain's columns
+timeout -k 10 120 ./build_exp/chol32_bench 2000 4 > gpurun_out/r03/r03_chol32_bench.txt 2>&1 || echo chol32_fail
+timeout -k 10 200 python tools/stamp_chol.py > gpurun_out/r03/r03_chol_chain_stamps.txt 2>&1 || echo stampchol_fail
 # 6. grid barrier against dependent launch
 timeout -k 10 200 python tools/gbar_bench.py > gpurun_out/r03/r03_grid_barrier.txt 2>&1 || echo gbar_fail
 # the raw traces are large: keep the summaries and the PMC collections
-rm -f gpurun_out/r03/benchprof/b_kernel_trace.csv gpurun_out/r03/alone/b_kernel_trace.csv gpurun_out/r03/sorsq_*/b_kernel_trace.csv gpurun_out/r03/pmc_*/b_kernel_trace.csv gpurun_out/r03/etraf_*/b_kernel_trace.csv
+rm -f gpurun_out/r03/benchprof/b_kernel_trace.csv gpurun_out/r03/alone/b_kernel_trace.csv gpurun_out/r03/sorsq_*/b_kernel_trace.csv gpurun_out/r03/pmc_*/b_kernel_trace.csv gpurun_out/r03/etraf_*/b_kernel_trace.csv gpurun_out/r03/ekfsq_*/b_kernel_trace.csv
 ls gpurun_out/r03; head -3 gpurun_out/r03/r03_sor_pmc.json; cat gpurun_out/r03/r03_iter_timeline.txt; cat gpurun_out/r03/r03_ekf_traffic.csv | head -12

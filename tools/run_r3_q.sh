@@ -1,8 +1,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for cfg in "5 2" "5 3" "5 4" "4 2" "6 2" "8 2" "6 4"; do
-  set -- $cfg
-  export HYDRA_TUNE_measure_split=$1 HYDRA_TUNE_edge_split=$2
-  timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r3q_$1_$2 -o b -- python tools/ekf_pmc.py 3 > gpurun_out/r3q_$1_$2.log 2>&1 || echo fail
-  echo "measure_split $1 edge_split $2: $(python tools/iter_timeline.py gpurun_out/r3q_$1_$2/b_kernel_trace.csv | grep -E 'k_measure_vertex|k_measure_edge|iterations' | tr '\n' ' ' | cut -c1-260)"
-  rm -f gpurun_out/r3q_$1_$2/b_kernel_trace.csv
-done
+timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r3q_alone -o b -- python tools/ekf_pmc.py 3 > gpurun_out/r3q_alone.log 2>&1 || echo fail
+python tools/iter_timeline.py gpurun_out/r3q_alone/b_kernel_trace.csv > gpurun_out/r3q_alone_timeline.txt; cat gpurun_out/r3q_alone_timeline.txt | cut -c1-220
+rm -f gpurun_out/r3q_alone/b_kernel_trace.csv
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r3q_bench -o b -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r3q_bench.log 2>&1 || echo fail
+python tools/iter_timeline.py gpurun_out/r3q_bench/b_kernel_trace.csv > gpurun_out/r3q_bench_timeline.txt; cat gpurun_out/r3q_bench_timeline.txt | cut -c1-220
+rm -f gpurun_out/r3q_bench/b_kernel_trace.csv

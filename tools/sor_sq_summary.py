@@ -1,16 +1,21 @@
 """Per-level SQ / LDS counters of k_sor from the passes of tools/run_sor_sq.sh
-(python tools/sor_sq_summary.py gpurun_out/sorsq_*/b_counter_collection.csv > profiles/r02_sor_sq_counters.csv)."""
+(python tools/sor_sq_summary.py gpurun_out/sorsq_*/b_counter_collection.csv > profiles/r02_sor_sq_counters.csv).
+With --prefix a,b,c as the first argument: the kernels whose names start with one of those instead (the filter's kernels:
+profiles/r03_ekf_sq_counters.csv)."""
 import collections
 import csv
 import sys
 
 rows = collections.OrderedDict()          # (kernel, grid) -> counter -> [values]; durations
 dur = collections.defaultdict(list)
-for path in sys.argv[1:]:
+prefixes, paths = ("k_sor",), sys.argv[1:]
+if paths and paths[0] == "--prefix":
+    prefixes, paths = tuple(paths[1].split(",")), paths[2:]
+for path in paths:
     seen = set()
     for r in csv.DictReader(open(path)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if not name.startswith("k_sor"):
+        if not name.startswith(prefixes):
             continue
         key = (name, int(r["Grid_Size"]), int(r["Workgroup_Size"]), int(r["VGPR_Count"]), int(r["LDS_Block_Size"]))
         rows.setdefault(key, collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
