@@ -323,6 +323,8 @@ def main():
     ap.add_argument("--flow-batch", type=int, default=8, help="consecutive frame pairs per Brox launch series")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--two-flow-handles", action="store_true", help="two flow series in flight (default: one at a time)")
+    ap.add_argument("--split-start", action="store_true", help="experiment: a phase starts with two flow series side by side (pipeline.split_start)")
+    ap.add_argument("--first-series", type=int, default=0, help="experiment: fixed size of the first flow series of a phase (default: sized from measurements)")
     ap.add_argument("--cu-reserve", type=int, default=None,
                     help="compute units the flow stream leaves to the filter (default: the pipeline's)")
     ap.add_argument("--workload", default="video", choices=["video", "flowbatch"],
@@ -401,6 +403,10 @@ def main():
                 extra["concurrent_series"] = True
             self.pipe = FlowEKFPipeline(self.kf, self.video, self.masks, flow_batch=B, device=dev, resident=args.resident, **extra)
             self.bf = self.pipe.bf
+            if args.split_start:
+                self.pipe.split_start = True
+            if args.first_series:
+                self.pipe.first_series = args.first_series
             if os.environ.get("HYDRA_MI_BENCH_TRACE"):
                 self.pipe.trace = lambda msg: print(msg, file=sys.stderr)
 

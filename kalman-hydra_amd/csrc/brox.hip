@@ -1,6 +1,7 @@
 // Brox optical flow on MI355X: host orchestration and C-ABI (include/hydra_mi.h).
 // Replaces cv::cuda::BroxOpticalFlow as called by processflow_gpu
 // (reference src/optical_flow_ext.cpp:294-331).
+#define HM_ALLOC_CLASS 2          // hm_malloc (HYDRA_MI_POISON): a flow handle's buffers
 #include "hm_common.h"
 #include <hip/hip_ext.h>
 #include "brox_kernels.h"
@@ -38,7 +39,7 @@ extern "C" int hm_dev_alloc(int device, uint64_t bytes, void **out)
     HM_ARG(out != nullptr && bytes > 0, "hm_dev_alloc: bad argument");
     *out = nullptr;
     HM_HIP(hipSetDevice(device));
-    HM_HIP(hipMalloc(out, (size_t)bytes));
+    HM_HIP(hm_malloc(out, (size_t)bytes, 4));
     return HM_OK;
 }
 extern "C" int hm_dev_free(int device, void *ptr)
@@ -333,7 +334,7 @@ extern "C" int hm_brox_create(int device, int W, int H, int max_batch, float alp
     for (const Geo &g : h->geo) pyr_floats += (size_t)g.plane * B;
     const int nfields = 2 + 7 + 8 + 7 + 4 + 4 + 1;
     h->arena_floats = 2 * pyr_floats + (size_t)nfields * plane0 * B;
-    hipError_t e = hipMalloc((void **)&h->arena, h->arena_floats * sizeof(float));
+    hipError_t e = hm_malloc((void **)&h->arena, h->arena_floats * sizeof(float));
     if (e != hipSuccess) {
         hm_set_error("hm_brox_create: hipMalloc of %zu MiB failed: %s", h->arena_floats * 4 >> 20, hipGetErrorString(e));
         brox_free(h);
@@ -346,10 +347,10 @@ extern "C" int hm_brox_create(int device, int W, int H, int max_batch, float alp
     h->stream = h->whole;
     if (e == hipSuccess) e = hipMemsetAsync(h->arena, 0, h->arena_floats * sizeof(float), h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->d_f0, B * W * H);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->d_f1, B * W * H);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->d_ox, B * W * H * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&h->d_oy, B * W * H * sizeof(float));
+    if (e == hipSuccess) e = hm_malloc((void **)&h->d_f0, B * W * H);
+    if (e == hipSuccess) e = hm_malloc((void **)&h->d_f1, B * W * H);
+    if (e == hipSuccess) e = hm_malloc((void **)&h->d_ox, B * W * H * sizeof(float));
+    if (e == hipSuccess) e = hm_malloc((void **)&h->d_oy, B * W * H * sizeof(float));
     if (e != hipSuccess) {
         hm_set_error("hm_brox_create: device setup failed: %s", hipGetErrorString(e));
         brox_free(h);
@@ -706,8 +707,9 @@ struct Scratch {      // pitched device planes with tight host I/O
     float *plane(const Geo &g)
     {
         float *p = nullptr;
-        if (hipMalloc((void **)&p, (size_t)g.plane * sizeof(float)) != hipSuccess) return nullptr;
+        if (hm_malloc((void **)&p, (size_t)g.plane * sizeof(float)) != hipSuccess) return nullptr;
         hipMemset(p, 0, (size_t)g.plane * sizeof(float));
+        hipDeviceSynchronize();          // the fill is on the null stream, the operators run on a non-blocking one
         bufs.push_back(p);
         return p;
     }
@@ -807,9 +809,9 @@ extern "C" int hm_op_add_prolong(const float *u, const float *v, const float *du
     OP_CHECK(a && b && c && d);
     if (wd == ws && hd == hs) {
         float *ox = nullptr, *oy = nullptr;
-        OP_CHECK(hipMalloc((void **)&ox, (size_t)ws * hs * sizeof(float)) == hipSuccess);
+        OP_CHECK(hm_malloc((void **)&ox, (size_t)ws * hs * sizeof(float)) == hipSuccess);
         sc.bufs.push_back(ox);
-        OP_CHECK(hipMalloc((void **)&oy, (size_t)ws * hs * sizeof(float)) == hipSuccess);
+        OP_CHECK(hm_malloc((void **)&oy, (size_t)ws * hs * sizeof(float)) == hipSuccess);
         sc.bufs.push_back(oy);
         hipLaunchKernelGGL(k_add_out, grid2d(gs, 1), kBlock2d, 0, 0, a, b, c, d, gs, ox, oy);
         HM_HIP(hipDeviceSynchronize());

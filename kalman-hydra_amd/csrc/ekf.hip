@@ -108,14 +108,18 @@ struct hm_ctx {
     uint8_t *d_pm_mask;
     uint8_t *d_pm_flag = nullptr;    // border-pixel flags of that mask (W*H)
     double *d_pm_X = nullptr;        // hm_project_mask's copy of the state (second stream)
+    double *pin_pm = nullptr;        // page-locked: [X | projected X | vertices moved | ticket] (k_project_mask_host)
+    int *d_pm_done = nullptr;        // workgroups of k_project_mask_host that have finished
+    long long pm_ticket = 0;
+    bool outline_ready = false;      // the outline of the resident mask (o_ym) has been queued on the second stream
 };
 
 static int alloc_targets(Targets &t, size_t n)
 {
-    HM_HIP(hipMalloc((void **)&t.acc, n * sizeof(int)));
-    HM_HIP(hipMalloc((void **)&t.fx, n * sizeof(float)));
-    HM_HIP(hipMalloc((void **)&t.fy, n * sizeof(float)));
-    HM_HIP(hipMalloc((void **)&t.cnt, n * sizeof(int)));
+    HM_HIP(hm_malloc((void **)&t.acc, n * sizeof(int)));
+    HM_HIP(hm_malloc((void **)&t.fx, n * sizeof(float)));
+    HM_HIP(hm_malloc((void **)&t.fy, n * sizeof(float)));
+    HM_HIP(hm_malloc((void **)&t.cnt, n * sizeof(int)));
     return HM_OK;
 }
 static void free_targets(Targets &t)
@@ -169,6 +173,29 @@ static hipError_t stream_wait(hipStream_t s)
     }
 }
 
+// Watch a ticket a kernel writes last into page-locked host memory (system-scope fence before it): a couple of
+// microseconds against ~20 for waking up from a stream synchronisation, which remains as the fallback.
+static int wait_ticket_on(hipStream_t st, const double *slot, double want)
+{
+    const volatile double *ticket = slot;
+    const auto t_start = std::chrono::steady_clock::now();
+    const auto t_yield = t_start + std::chrono::microseconds(700), t_give_up = t_start + std::chrono::milliseconds(20);
+    bool seen = false, polite = false;
+    for (int spin = 0;; spin++) {
+        if (*ticket == want) { seen = true; break; }
+        if (polite) std::this_thread::yield();
+        else __builtin_ia32_pause();
+        if ((spin & 255) == 255) {
+            const auto now = std::chrono::steady_clock::now();
+            if (now > t_give_up) break;
+            polite = now > t_yield;
+        }
+    }
+    if (!seen) HM_HIP(hipStreamSynchronize(st));
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return HM_OK;
+}
+
 // ---- the pool of parked difference images (DPool, ekf_kernels.h) -------------------------------------------------
 static void pool_release(hm_ctx *h)
 {
@@ -183,11 +210,11 @@ static int pool_alloc(hm_ctx *h, long long cap)
 {
     pool_release(h);
     const size_t pc = (size_t)cap;
-    HM_HIP(hipMalloc((void **)&h->pool.live, (pc / 64 + 1) * sizeof(int)));
+    HM_HIP(hm_malloc((void **)&h->pool.live, (pc / 64 + 1) * sizeof(int)));
     short2 **sp[] = {&h->pool.xi, &h->pool.yi};
-    for (short2 **q : sp) HM_HIP(hipMalloc((void **)q, pc * sizeof(short2)));
+    for (short2 **q : sp) HM_HIP(hm_malloc((void **)q, pc * sizeof(short2)));
     float **fp[] = {&h->pool.xfx, &h->pool.xfy, &h->pool.yfx, &h->pool.yfy, &h->pool.vxfx, &h->pool.vyfy};
-    for (float **q : fp) HM_HIP(hipMalloc((void **)q, pc * sizeof(float)));
+    for (float **q : fp) HM_HIP(hm_malloc((void **)q, pc * sizeof(float)));
     h->pool.cap = cap;
     return HM_OK;
 }
@@ -231,6 +258,8 @@ static int ctx_free(hm_ctx *h)
     free_targets(h->Q);
     if (h->pin) (void)hipHostFree(h->pin);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
+    if (h->pin_pm) (void)hipHostFree(h->pin_pm);
+    if (h->d_pm_done) (void)hipFree(h->d_pm_done);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return HM_OK;
@@ -239,7 +268,7 @@ static int ctx_free(hm_ctx *h)
 template <typename T>
 static int upload(T **dst, const T *src, size_t n)
 {
-    HM_HIP(hipMalloc((void **)dst, (n ? n : 1) * sizeof(T)));
+    HM_HIP(hm_malloc((void **)dst, (n ? n : 1) * sizeof(T)));
     if (n) HM_HIP(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
     return HM_OK;
 }
@@ -343,64 +372,64 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
             e = hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, greatest);
         else if (e == hipSuccess)
             e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_tex, n);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_yim, n);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_ym, n);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_yfx, n * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_yfy, n * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_yfxm, n * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_yfym, n * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_setup, (size_t)T * sizeof(TriSetup));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_cfgs, (size_t)N * MEAS_NCFG * (EKF_MAX_STAR + 1) * sizeof(TriSetup));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_ubox, (size_t)N * UBOX_STRIDE * sizeof(int4));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_tmask, (size_t)N * TMASK_STRIDE * sizeof(unsigned));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_tlist, (size_t)N * TMASK_STRIDE * sizeof(int));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_tcount, (size_t)N * sizeof(int));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_X, (size_t)4 * N * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_out, (size_t)h->njobs * MEAS_VSPLIT_MAX * MEAS_OUT * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_partial, (size_t)h->red_blocks * 4 * sizeof(double));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_tex, n);
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_yim, n);
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_ym, n);
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_yfx, n * sizeof(float));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_yfy, n * sizeof(float));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_yfxm, n * sizeof(float));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_yfym, n * sizeof(float));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_setup, (size_t)T * sizeof(TriSetup));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_cfgs, (size_t)N * MEAS_NCFG * (EKF_MAX_STAR + 1) * sizeof(TriSetup));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_ubox, (size_t)N * UBOX_STRIDE * sizeof(int4));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_tmask, (size_t)N * TMASK_STRIDE * sizeof(unsigned));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_tlist, (size_t)N * TMASK_STRIDE * sizeof(int));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_tcount, (size_t)N * sizeof(int));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_X, (size_t)4 * N * sizeof(double));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_out, (size_t)h->njobs * MEAS_VSPLIT_MAX * MEAS_OUT * sizeof(double));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_partial, (size_t)h->red_blocks * 4 * sizeof(double));
         h->ntiles = hm_cdiv(W, RI_W) * hm_cdiv(H, 8);           // most strips of k_render_iter (render_rows 8)
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_tpart, (size_t)h->ntiles * 4 * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_im8, n);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_m8, n);
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_tpart, (size_t)h->ntiles * 4 * sizeof(double));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_im8, n);
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_m8, n);
         const size_t n4 = (size_t)4 * N, nn = n4 * n4 * sizeof(double);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_H, nn);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_HTH, nn);
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_H, nn);
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_HTH, nn);
         if (e == hipSuccess) e = hipMemsetAsync(h->d_HTH, 0, nn, h->stream);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_invW0, nn);
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_invW0, nn);
         const size_t nn_aug = (size_t)(hm_cdiv((int)n4, DNB) * DNB + DNB) * n4 * sizeof(double);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Af[0], nn_aug);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Af[1], nn_aug);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Awork, nn_aug);
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_Af[0], nn_aug);
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_Af[1], nn_aug);
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_Awork, nn_aug);
         const size_t ld_bytes = (size_t)hm_cdiv((int)n4, DNB) * DNB * DNB * sizeof(double);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_T[0], nn);       // L^-1 of the factor in the same slot
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_T[1], nn);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_step, n4 * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Lt[0], ld_bytes);  // inverses of the factored diagonal blocks
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Lt[1], ld_bytes);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Wtmp, nn);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_flowP, 3 * ld_bytes);      // P, Q and Y blocks of k_chol_flow
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_flowctl, 4 * sizeof(unsigned));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_T[0], nn);       // L^-1 of the factor in the same slot
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_T[1], nn);
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_step, n4 * sizeof(double));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_Lt[0], ld_bytes);  // inverses of the factored diagonal blocks
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_Lt[1], ld_bytes);
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_Wtmp, nn);
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_flowP, 3 * ld_bytes);      // P, Q and Y blocks of k_chol_flow
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_flowctl, 4 * sizeof(unsigned));
         if (e == hipSuccess) e = hipMemsetAsync(h->d_flowctl, 0, 4 * sizeof(unsigned), h->stream);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Hz, n4 * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Hzc, n4 * 4 * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Wprior, nn);
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_gain, n4 * 3 * sizeof(double));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_Hz, n4 * sizeof(double));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_Hzc, n4 * 4 * sizeof(double));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_Wprior, nn);
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_gain, n4 * 3 * sizeof(double));
         // [step (n4) | four error sums | overflow flag] per iteration, then Hzc (n4 x 4) and the gains (3 x n4)
         h->pin_n = n4 + RES_HEAD + n4 * 4 + n4 * 3;
         if (e == hipSuccess) e = hipHostMalloc((void **)&h->pin, h->pin_n * sizeof(double), hipHostMallocCoherent);
         if (e == hipSuccess) memset(h->pin, 0, h->pin_n * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_X0, n4 * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->pool.hdr, (size_t)4 * N * sizeof(int));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->pool.overflow, sizeof(int));
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_area, (size_t)N * sizeof(int));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_X0, n4 * sizeof(double));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->pool.hdr, (size_t)4 * N * sizeof(int));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->pool.overflow, sizeof(int));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_area, (size_t)N * sizeof(int));
         h->pool.area = h->d_area;
         // pool of parked difference images (32 B per pixel): the star regions overlap about six times, so a mesh that
         // covers the whole frame needs about six frames' worth of pixels plus the padding of every region to whole 8x8
         // tiles (the bench's disk, a third of the frame: 1.6); it starts at 8 frames' worth = 268 MB at 1024^2 and grows
         // when a measurement reports that its regions do not fit (pool_grow)
         if (e == hipSuccess && pool_alloc(h, (long long)8 * W * H) != HM_OK) e = hipErrorOutOfMemory;
-        if (e == hipSuccess) e = hipMalloc((void **)&h->d_Xn, n4 * sizeof(double));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_Xn, n4 * sizeof(double));
         if (e != hipSuccess) {
             hm_set_error("hm_ctx_create: device allocation failed: %s", hipGetErrorString(e));
             rc = HM_ERR_HIP;
@@ -487,6 +516,45 @@ extern "C" int hm_set_texture(hm_ctx_t h, const uint8_t *tex)
     return HM_OK;
 }
 
+// The second stream (projectmask, hm_ms_predict): short launches beside the first stream's, same dispatch priority.
+static int ensure_stream2(hm_ctx *h)
+{
+    if (h->stream2) return HM_OK;
+    int least = 0, greatest = 0;
+    HM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    if (greatest != least) { HM_HIP(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, greatest)); }
+    else HM_HIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    return HM_OK;
+}
+
+// hm_project_mask's buffers and the outline of a mask in device memory, queued on the second stream
+static int project_buffers(hm_ctx *h)
+{
+    if (h->d_outline) return HM_OK;
+    const size_t n = (size_t)h->W * h->H, n4 = (size_t)4 * h->N;
+    HM_HIP(hm_malloc((void **)&h->d_outline, n * sizeof(int2)));
+    HM_HIP(hm_malloc((void **)&h->d_outline_cnt, 4 * sizeof(int)));
+    HM_HIP(hm_malloc((void **)&h->d_pm_flag, n));
+    HM_HIP(hm_malloc((void **)&h->d_pm_X, n4 * sizeof(double)));
+    HM_HIP(hm_malloc((void **)&h->d_pm_done, sizeof(int)));
+    // zeroed on the stream the kernel that counts in it runs on: a hipMemset on the null stream is not ordered with a
+    // non-blocking stream and may land in the middle of that kernel -- no workgroup is the last one then, the ticket
+    // never comes and the projection of a context's first frame was silently dropped (seen once in ~10 runs)
+    HM_HIP(hipMemsetAsync(h->d_pm_done, 0, sizeof(int), h->stream2));
+    HM_HIP(hipHostMalloc((void **)&h->pin_pm, (2 * n4 + 2) * sizeof(double), hipHostMallocCoherent));
+    memset(h->pin_pm, 0, (2 * n4 + 2) * sizeof(double));
+    return HM_OK;
+}
+static int queue_outline(hm_ctx *h, const uint8_t *mask)
+{
+    HM_HIP(hipMemsetAsync(h->d_outline_cnt, 0, 4 * sizeof(int), h->stream2));
+    Outline o = {h->d_outline, h->d_outline_cnt, h->W * h->H, h->d_pm_flag};
+    hipLaunchKernelGGL(k_outline, dim3(hm_cdiv(h->W, 64), hm_cdiv(h->H, OUTLINE_NT / 64)), dim3(OUTLINE_NT), 0, h->stream2,
+                       mask, h->W, h->H, o);
+    HM_HIP(hipGetLastError());
+    return HM_OK;
+}
+
 static int finish_observation(hm_ctx *h)
 {
     h->last_err_valid = false;
@@ -513,6 +581,12 @@ extern "C" int hm_set_observation(hm_ctx_t h, const uint8_t *y_im, const float *
     int rc = finish_observation(h);
     if (rc) return rc;
     HM_HIP(hipStreamSynchronize(h->stream));
+    h->outline_ready = false;
+    if (h->d_outline) {              // a tracker that projects onto the mask: its outline, ahead of hm_project_mask
+        rc = queue_outline(h, h->o_ym);
+        if (rc) return rc;
+        h->outline_ready = true;
+    }
     return HM_OK;
 }
 
@@ -523,7 +597,15 @@ extern "C" int hm_set_observation_dev(hm_ctx_t h, const uint8_t *d_y_im, const f
     HM_JOIN(h);
     HM_HIP(hipSetDevice(h->device));
     h->o_yim = d_y_im; h->o_ym = d_y_m; h->o_yfx = d_y_fx; h->o_yfy = d_y_fy;
-    return finish_observation(h);
+    int rc = finish_observation(h);
+    if (rc) return rc;
+    h->outline_ready = false;
+    if (h->d_outline) {              // as in hm_set_observation: the caller's mask is complete in device memory by contract
+        rc = queue_outline(h, h->o_ym);
+        if (rc) return rc;
+        h->outline_ready = true;
+    }
+    return HM_OK;
 }
 
 // render state X (host, 4N doubles) into target t on the handle's stream
@@ -697,15 +779,15 @@ static int multi_setup(hm_ctx *h, const int32_t *labels, int n_labels, const dou
 {
     const size_t n = (size_t)h->W * h->H;
     if (!h->d_ids[0]) {
-        for (int k = 0; k < 3; k++) HM_HIP(hipMalloc((void **)&h->d_ids[k], n * sizeof(int)));
-        HM_HIP(hipMalloc((void **)&h->d_labels, (size_t)h->T * sizeof(int)));
+        for (int k = 0; k < 3; k++) HM_HIP(hm_malloc((void **)&h->d_ids[k], n * sizeof(int)));
+        HM_HIP(hm_malloc((void **)&h->d_labels, (size_t)h->T * sizeof(int)));
     }
     if (n_labels > h->lcap) {
         if (h->d_lbox) (void)hipFree(h->d_lbox);
         if (h->d_lout) (void)hipFree(h->d_lout);
         h->d_lbox = nullptr; h->d_lout = nullptr; h->lcap = 0;
-        HM_HIP(hipMalloc((void **)&h->d_lbox, (size_t)n_labels * sizeof(int4)));
-        HM_HIP(hipMalloc((void **)&h->d_lout, (size_t)n_labels * 5 * sizeof(double)));
+        HM_HIP(hm_malloc((void **)&h->d_lbox, (size_t)n_labels * sizeof(int4)));
+        HM_HIP(hm_malloc((void **)&h->d_lout, (size_t)n_labels * 5 * sizeof(double)));
         h->lcap = n_labels;
     }
     std::vector<int4> box(n_labels, make_int4(1, 0, 1, 0));
@@ -1041,8 +1123,20 @@ extern "C" int hm_update_prefactor(hm_ctx_t h)
     HM_HIP(hipSetDevice(h->device));
     // (launched one by one: replaying this series as a hipGraph saved 0.08 ms of host time per frame, but
     // graph replays proved unreliable next to allocations by the caller -- see hm_brox_tune "graph")
-    // Queueing the ~30 launches takes the host about as long as the state prediction the caller does
-    // next (hm_ms_newton): a helper thread does it, and whatever is called next on this handle joins it.
+    // With the factorisation as one persistent launch this is a copy, a fill and three launches: queued right here
+    // (a helper thread started per call had them reach the device ~0.2 ms later -- thread start-up and the first
+    // runtime calls of a new thread -- and the first measurement of the frame waited for them: kernel trace of the
+    // bench, tools/frame_gap_timeline.py).
+    if (h->chol_flow) {
+        const int rc = prior_inverse(h, nullptr);
+        if (rc == HM_OK) {
+            h->prefactored = true;
+            h->upd_open = false;                  // the factor slots are being reused
+        }
+        return rc;
+    }
+    // The launch-per-step form: queueing its ~30 launches takes the host about as long as the state prediction the
+    // caller does next (hm_ms_newton): a helper thread does it, and whatever is called next on this handle joins it.
     h->worker_active = true;
     h->worker = std::thread([h]() {
         int rc = hipSetDevice(h->device) == hipSuccess ? HM_OK : HM_ERR_HIP;
@@ -1174,27 +1268,45 @@ extern "C" int hm_project_mask(hm_ctx_t h, const uint8_t *y_m, double *X, int *m
     // needs the mask and the predicted state only, and in a frame of the filter it comes while the covariance half of
     // the update (hm_update_prefactor: ~0.25 ms of launches) is still being queued and run on the first stream --
     // behind those it would have its caller wait for them.
-    if (!h->stream2) HM_HIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    int rc = ensure_stream2(h);
+    if (rc) return rc;
+    rc = project_buffers(h);
+    if (rc) return rc;
     hipStream_t s = h->stream2;
     const size_t n = (size_t)h->W * h->H;
-    const size_t xb = (size_t)4 * h->N * sizeof(double);
-    if (!h->d_outline) {
-        HM_HIP(hipMalloc((void **)&h->d_outline, n * sizeof(int2)));
-        HM_HIP(hipMalloc((void **)&h->d_outline_cnt, 4 * sizeof(int)));
-        HM_HIP(hipMalloc((void **)&h->d_pm_flag, n));
-        HM_HIP(hipMalloc((void **)&h->d_pm_X, xb));
-    }
-    const uint8_t *mask = h->o_ym;
-    if (y_m) {
-        if (!h->d_pm_mask) HM_HIP(hipMalloc((void **)&h->d_pm_mask, n));
-        HM_HIP(hipMemcpyAsync(h->d_pm_mask, y_m, n, hipMemcpyHostToDevice, s));
-        mask = h->d_pm_mask;
-    }
-    HM_HIP(hipMemsetAsync(h->d_outline_cnt, 0, 4 * sizeof(int), s));
-    HM_HIP(hipMemcpyAsync(h->d_pm_X, X, xb, hipMemcpyHostToDevice, s));
+    const size_t n4 = (size_t)4 * h->N, xb = n4 * sizeof(double);
     Outline o = {h->d_outline, h->d_outline_cnt, (int)n, h->d_pm_flag};
-    hipLaunchKernelGGL(k_outline, dim3(hm_cdiv(h->W, 64), hm_cdiv(h->H, OUTLINE_NT / 64)), dim3(OUTLINE_NT), 0, s,
-                       mask, h->W, h->H, o);
+    if (!y_m) {
+        // The mask of the resident observation: its outline was queued when the observation was set (or is now, the
+        // first time); the state goes through page-locked memory both ways and the host watches a ticket -- one
+        // launch and no copy operations on the way (0.15 -> ~0.03 ms per frame of the streaming pipeline).
+        if (!h->outline_ready) {
+            rc = queue_outline(h, h->o_ym);
+            if (rc) return rc;
+            h->outline_ready = true;
+        }
+        memcpy(h->pin_pm, X, xb);
+        ProjArgs a = {h->o_ym, h->W, h->H, h->N, o, nullptr};
+        hipLaunchKernelGGL(k_project_mask_host, dim3(h->N), dim3(PROJ_NT), 0, s, a, h->pin_pm, h->d_pm_done, (double)(++h->pm_ticket));
+        HM_HIP(hipGetLastError());
+        rc = wait_ticket_on(s, h->pin_pm + 2 * n4 + 1, (double)h->pm_ticket);
+        if (rc) return rc;
+        if (((const volatile double *)h->pin_pm)[2 * n4 + 1] != (double)h->pm_ticket) {      // the stream is idle and the ticket is not there
+            hm_set_error("hm_project_mask: the projection kernel finished without reporting (ticket %lld missing)", h->pm_ticket);
+            return HM_ERR_STATE;
+        }
+        const int nmoved = (int)h->pin_pm[2 * n4];
+        if (nmoved) memcpy(X, h->pin_pm + n4, xb);
+        if (moved) *moved = nmoved;
+        return HM_OK;
+    }
+    h->outline_ready = false;                    // the buffers are about to hold the outline of the caller's mask
+    if (!h->d_pm_mask) HM_HIP(hm_malloc((void **)&h->d_pm_mask, n));
+    HM_HIP(hipMemcpyAsync(h->d_pm_mask, y_m, n, hipMemcpyHostToDevice, s));
+    const uint8_t *mask = h->d_pm_mask;
+    rc = queue_outline(h, mask);
+    if (rc) return rc;
+    HM_HIP(hipMemcpyAsync(h->d_pm_X, X, xb, hipMemcpyHostToDevice, s));
     ProjArgs a = {mask, h->W, h->H, h->N, o, h->d_pm_X};
     hipLaunchKernelGGL(k_project_mask, dim3(h->N), dim3(PROJ_NT), 0, s, a);
     HM_HIP(hipGetLastError());
@@ -1228,26 +1340,7 @@ extern "C" int hm_cov_fetch(hm_ctx_t h, double *W_out)
 // A result block in pinned host memory carries a ticket that the kernel writes last (system-scope fence before it).
 // Watching it costs a couple of microseconds against ~20 for waking up from a stream synchronisation; the
 // synchronisation remains as the fallback.
-static int wait_ticket(hm_ctx *h, const double *slot, double want)
-{
-    const volatile double *ticket = slot;
-    const auto t_start = std::chrono::steady_clock::now();
-    const auto t_yield = t_start + std::chrono::microseconds(700), t_give_up = t_start + std::chrono::milliseconds(20);
-    bool seen = false, polite = false;          // an iteration takes ~0.4 ms: spin for that long, then yield between polls
-    for (int spin = 0;; spin++) {
-        if (*ticket == want) { seen = true; break; }
-        if (polite) std::this_thread::yield();
-        else __builtin_ia32_pause();
-        if ((spin & 255) == 255) {
-            const auto now = std::chrono::steady_clock::now();
-            if (now > t_give_up) break;
-            polite = now > t_yield;
-        }
-    }
-    if (!seen) HM_HIP(hipStreamSynchronize(h->stream));
-    std::atomic_thread_fence(std::memory_order_acquire);
-    return HM_OK;
-}
+static int wait_ticket(hm_ctx *h, const double *slot, double want) { return wait_ticket_on(h->stream, slot, want); }
 
 extern "C" int hm_update_arm_newton(hm_ctx_t h, void *worker, int n_bars, const int32_t *bars, const double *l0, double kappa,
                                     double M, double dt, int maxiter, double tol)
@@ -1463,15 +1556,15 @@ extern "C" int hm_cov_predict(hm_ctx_t h, const double *W_in, int n_bars, const 
                 bar[fill[q]] = i; other[fill[q]++] = p;
             }
         }
-        if (!h->d_sp_off) HM_HIP(hipMalloc((void **)&h->d_sp_off, (size_t)(N + 1) * sizeof(int)));
+        if (!h->d_sp_off) HM_HIP(hm_malloc((void **)&h->d_sp_off, (size_t)(N + 1) * sizeof(int)));
         if ((size_t)n_bars > h->sp_cap) {
             if (h->d_sp_bar) (void)hipFree(h->d_sp_bar);
             if (h->d_sp_other) (void)hipFree(h->d_sp_other);
             if (h->d_sp_blk) (void)hipFree(h->d_sp_blk);
             h->d_sp_bar = h->d_sp_other = nullptr; h->d_sp_blk = nullptr;
-            HM_HIP(hipMalloc((void **)&h->d_sp_bar, 2 * (size_t)n_bars * sizeof(int)));
-            HM_HIP(hipMalloc((void **)&h->d_sp_other, 2 * (size_t)n_bars * sizeof(int)));
-            HM_HIP(hipMalloc((void **)&h->d_sp_blk, 3 * (size_t)n_bars * sizeof(double)));
+            HM_HIP(hm_malloc((void **)&h->d_sp_bar, 2 * (size_t)n_bars * sizeof(int)));
+            HM_HIP(hm_malloc((void **)&h->d_sp_other, 2 * (size_t)n_bars * sizeof(int)));
+            HM_HIP(hm_malloc((void **)&h->d_sp_blk, 3 * (size_t)n_bars * sizeof(double)));
             h->sp_cap = n_bars;
         }
         HM_HIP(hipMemcpyAsync(h->d_sp_off, off.data(), (size_t)(N + 1) * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -1534,11 +1627,11 @@ extern "C" int hm_ms_predict(hm_ctx_t h, int n_bars, const int32_t *bars, const 
     const size_t lds = ((size_t)34 * N + (size_t)7 * n_bars + 8) * sizeof(double) + ((size_t)N + 1 + 4 * (size_t)n_bars) * sizeof(int);
     const bool on_device = lds <= 160 * 1024;
     if (on_device) {
-        if (!h->stream2) HM_HIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+        { const int rc2 = ensure_stream2(h); if (rc2) return rc2; }
         if (!h->d_nX) {
-            HM_HIP(hipMalloc((void **)&h->d_nX, (size_t)n4 * sizeof(double)));
-            HM_HIP(hipMalloc((void **)&h->d_nvoff, (size_t)(N + 1) * sizeof(int)));
-            HM_HIP(hipMalloc((void **)&h->d_ninfo, 2 * sizeof(int)));
+            HM_HIP(hm_malloc((void **)&h->d_nX, (size_t)n4 * sizeof(double)));
+            HM_HIP(hm_malloc((void **)&h->d_nvoff, (size_t)(N + 1) * sizeof(int)));
+            HM_HIP(hm_malloc((void **)&h->d_ninfo, 2 * sizeof(int)));
             HM_HIP(hipFuncSetAttribute((const void *)k_ms_newton, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
         if ((size_t)n_bars > h->ncap) {
@@ -1546,9 +1639,9 @@ extern "C" int hm_ms_predict(hm_ctx_t h, int n_bars, const int32_t *bars, const 
             if (h->d_nvbar) (void)hipFree(h->d_nvbar);
             if (h->d_nl0) (void)hipFree(h->d_nl0);
             h->d_nbars = h->d_nvbar = nullptr; h->d_nl0 = nullptr; h->ncap = 0;
-            HM_HIP(hipMalloc((void **)&h->d_nbars, 2 * (size_t)n_bars * sizeof(int)));
-            HM_HIP(hipMalloc((void **)&h->d_nvbar, 2 * (size_t)n_bars * sizeof(int)));
-            HM_HIP(hipMalloc((void **)&h->d_nl0, (size_t)n_bars * sizeof(double)));
+            HM_HIP(hm_malloc((void **)&h->d_nbars, 2 * (size_t)n_bars * sizeof(int)));
+            HM_HIP(hm_malloc((void **)&h->d_nvbar, 2 * (size_t)n_bars * sizeof(int)));
+            HM_HIP(hm_malloc((void **)&h->d_nl0, (size_t)n_bars * sizeof(double)));
             h->ncap = n_bars;
         }
         std::vector<int> off(N + 1, 0), vbar(2 * (size_t)n_bars);

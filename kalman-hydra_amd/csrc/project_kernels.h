@@ -121,22 +121,19 @@ static __device__ double d_mask_distance(const ProjArgs &a, double x, double y, 
 
 // one workgroup per vertex: 10 steps p -= d g / |g|^2 with forward differences of 0.1 px; d is
 // the distance before the first step throughout and only vertices with d > 1 move, as in the
-// reference; the displacement is added to the velocity
-__global__ __launch_bounds__(PROJ_NT) void k_project_mask(ProjArgs a)
+// reference; the displacement is added to the velocity.  Uniform over the workgroup: false = the vertex stays.
+static __device__ bool d_project_vertex(const ProjArgs &a, double x0, double y0, double *red, double &x, double &y)
 {
 #pragma clang fp contract(off)
-    __shared__ double red[PROJ_NT / 64 * 3];
-    const int v = blockIdx.x;
-    const double x0 = a.X[2 * v], y0 = a.X[2 * v + 1];
+    x = x0; y = y0;
     const double fx = floor(x0), fy = floor(y0);
     if (fx >= 0.0 && fy >= 0.0 && fx + 1.0 < (double)a.W && fy + 1.0 < (double)a.H) {
         const uint8_t *r = a.ym + (size_t)(int)fy * a.W + (int)fx;
-        if (r[0] > 0 && r[1] > 0 && r[a.W] > 0 && r[a.W + 1] > 0) return;      // d <= 0
+        if (r[0] > 0 && r[1] > 0 && r[a.W] > 0 && r[a.W + 1] > 0) return false;      // d <= 0
     }
     const double d = d_mask_distance(a, x0, y0, red);
-    if (!(d > 1.0)) return;
+    if (!(d > 1.0)) return false;
     const double eps = 1e-1;
-    double x = x0, y = y0;
     for (int it = 0; it < 10; it++) {
         const double gx = (d_mask_distance(a, x + eps, y + 0.0, red) - d) / eps;
         const double gy = (d_mask_distance(a, x + 0.0, y + eps, red) - d) / eps;
@@ -145,11 +142,52 @@ __global__ __launch_bounds__(PROJ_NT) void k_project_mask(ProjArgs a)
         x = x - step * gx;
         y = y - step * gy;
     }
+    return true;
+}
+
+// the state in device memory, in place (hm_project_mask with a host mask: the fine-grained path)
+__global__ __launch_bounds__(PROJ_NT) void k_project_mask(ProjArgs a)
+{
+#pragma clang fp contract(off)
+    __shared__ double red[PROJ_NT / 64 * 3];
+    const int v = blockIdx.x;
+    const double x0 = a.X[2 * v], y0 = a.X[2 * v + 1];
+    double x, y;
+    if (!d_project_vertex(a, x0, y0, red, x, y)) return;
     if (threadIdx.x == 0) {
         a.X[2 * v] = x;
         a.X[2 * v + 1] = y;
         a.X[2 * a.N + 2 * v] += x - x0;
         a.X[2 * a.N + 2 * v + 1] += y - y0;
         atomicAdd(&a.o.count[2], 1);
+    }
+}
+
+// The same with the state read from and written to page-locked host memory (a frame of the filter: the predicted
+// state comes from the host's Newton loop and goes back to it): `io` = [X (4N) | projected X (4N) | vertices moved |
+// ticket].  Every workgroup writes its vertex's four entries; the one that finishes last adds the count and, behind a
+// system-scope fence, the ticket the host is watching -- no copies, no stream synchronisation (hm_project_mask).
+__global__ __launch_bounds__(PROJ_NT) void k_project_mask_host(ProjArgs a, double *io, int *done, double ticket)
+{
+#pragma clang fp contract(off)
+    __shared__ double red[PROJ_NT / 64 * 3];
+    const int v = blockIdx.x, N = a.N;
+    const double x0 = io[2 * v], y0 = io[2 * v + 1];
+    double x, y;
+    const bool moved = d_project_vertex(a, x0, y0, red, x, y);
+    if (threadIdx.x != 0) return;
+    double *out = io + 4 * N;
+    out[2 * v] = x;
+    out[2 * v + 1] = y;
+    out[2 * N + 2 * v] = moved ? io[2 * N + 2 * v] + (x - x0) : io[2 * N + 2 * v];
+    out[2 * N + 2 * v + 1] = moved ? io[2 * N + 2 * v + 1] + (y - y0) : io[2 * N + 2 * v + 1];
+    if (moved) atomicAdd(&a.o.count[2], 1);
+    __threadfence_system();
+    if (atomicAdd(done, 1) == (int)gridDim.x - 1) {
+        __threadfence();
+        io[8 * N] = (double)atomicExch(&a.o.count[2], 0);        // (left clean for another projection onto the same mask)
+        *done = 0;
+        __threadfence_system();
+        io[8 * N + 1] = ticket;
     }
 }

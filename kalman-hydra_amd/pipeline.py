@@ -391,7 +391,7 @@ class FlowEKFPipeline:
         self.profiled_handle = None
 
     # -- flow series ---------------------------------------------------------------------------------
-    def _launch(self, k, end, most, alone=None):
+    def _launch(self, k, end, most, alone=None, whole=None):
         """Queue the series of pairs k .. k + nb - 1 on a handle and a buffer that are free."""
         nb = min(most, end - k)
         n, B = self._px, self.B
@@ -415,7 +415,7 @@ class FlowEKFPipeline:
                 if self.cu_reserve:
                     # a series the filter waits for with nothing to do (the first of a phase) gets the whole chip, the
                     # others leave `cu_reserve` compute units to the filter
-                    bf.tune("whole_chip", 1 if first else 0)
+                    bf.tune("whole_chip", 1 if (first if whole is None else whole) else 0)
                 bf.calc_dev(nb, self.ring.run_ptr(k), self.ring.run_ptr(k) + n,
                             self.d_u.ptr + buf * B * n * 4, self.d_v.ptr + buf * B * n * 4)
                 # ... and while this series runs, the frames of the next one go up (reference run_kalmanfilter.py:78-89
@@ -503,8 +503,8 @@ class FlowEKFPipeline:
                 self.bfs.append(self._make_handle())
             k = self._ready[1]
             n1 = max(3, self._first_series())
-            self._launch(k, self._end, 2, alone=False)
-            self._launch(k + 2, self._end, n1, alone=False)
+            self._launch(k, self._end, 2, alone=False, whole=True)
+            self._launch(k + 2, self._end, n1, alone=False, whole=True)
             return
         limit = len(self.bfs) if self.concurrent_series else 1
         while len(self._flying) < limit:

@@ -184,7 +184,9 @@ def test_calc_batch_and_tuning_do_not_change_results(hm, oracle_brox):
         ru, rv = oracle_brox.calc(F0[i], F1[i])
         assert np.array_equal(U[i], ru) and np.array_equal(V[i], rv)
     for key, val in [("sor_fuse", 1), ("sor_fuse", 2), ("sor_threads", 512), ("sor_fuse", 0), ("sor_threads", 1024),
-                     ("warp_window", 1), ("warp_window", 0), ("coarse_max", 0), ("coarse_max", 32), ("coarse_max", 64), ("sor_deep", 0), ("sor_fuse", 10)]:
+                     ("warp_window", 1), ("warp_window", 0), ("coarse_max", 0), ("coarse_max", 32), ("coarse_max", 64), ("sor_deep", 0), ("sor_fuse", 10),
+                     # the handle's two streams: compute-unit mask, the whole chip for one call, back, no mask
+                     ("whole_chip", 1), ("cu_reserve", 32), ("whole_chip", 1), ("whole_chip", 0), ("cu_reserve", 0), ("whole_chip", 0)]:
         bf.tune(key, val)
         U2, V2 = bf.calc_batch(F0, F1)
         assert np.array_equal(U, U2) and np.array_equal(V, V2), (key, val)

@@ -651,6 +651,20 @@ def test_project_mask_resident_observation_and_blank(hm):
     for blank in (np.zeros((n, n), np.uint8), np.ones((n, n), np.uint8)):
         same, moved = R.project_mask(X, blank)
         assert moved == 0 and np.array_equal(same, X)
+    # the resident path again, behind calls that left another mask's outline in the buffers, for other states (every
+    # vertex writes its entries, moved or not), and with the outline queued ahead by a new observation
+    for trial, spread in enumerate((0.3, 5.0, 20.0)):
+        X2 = _state(dm, rng, pos_sigma=spread)
+        got2, moved2 = R.project_mask(X2)
+        want2 = ekf_ref.project_mask(X2, N, y_m)[:, 0]
+        assert np.array_equal(got2, want2), trial
+        assert (moved2 == 0) == np.array_equal(got2, X2) or moved2 > 0
+    y_m3 = np.roll(y_m, 3, axis=1)
+    R.update_frame(y_im, flow, y_m3)
+    got3, moved3 = R.project_mask(X)
+    assert np.array_equal(got3, ekf_ref.project_mask(X, N, y_m3)[:, 0])
+    got4, moved4 = R.project_mask(X)                                # twice on the same outline: the counters are clean
+    assert moved4 == moved3 and np.array_equal(got4, got3)
     with pytest.raises(ValueError):
         R.project_mask(X, np.zeros((n, n + 1), np.uint8))
     with pytest.raises(ValueError):
