@@ -285,6 +285,19 @@ int hm_ms_newton_finish(void *worker, double *X, int *newton_iterations);
  * as that state is known -- before the covariance of the kept iterate is formed and fetched */
 int hm_update_arm_newton(hm_ctx_t h, void *worker, int n_bars, const int32_t *bars, const double *l0, double kappa,
                          double M, double dt, int maxiter, double tol);
+/* one-shot, with hm_update_arm_newton armed as well: the next hm_update_run also queues, right behind the covariance of
+ * the state it keeps, the covariance half of the NEXT frame's prediction (reference kalman.py:856-863: F at that state,
+ * W' = F W F^T + Weps -- hm_cov_predict with the spring blocks at that state) and the factorisation / inverse of W' the
+ * next update starts with (hm_update_prefactor): both depend on the finished update only, and the device has them
+ * done while the caller is still on its way back to predict().  hm_cov_fetch keeps returning the posterior;
+ * hm_update_cov is not available after such a run. */
+int hm_update_arm_cov(hm_ctx_t h, double eps_F);
+/* Makes what hm_update_run queued ahead (hm_update_arm_cov) current, as if hm_cov_predict(h, NULL, n_bars, bars,
+ * <blocks at X>, a, s, eps_F, NULL) and hm_update_prefactor(h) had just been called -- if it was made from exactly
+ * these inputs (X: the 4N state before the step; compared bit for bit).  Returns 0 when taken, 1 when there is nothing
+ * to take: the caller then makes the two calls itself (the posterior is still the resident covariance). */
+int hm_predict_take(hm_ctx_t h, const double *X, int n_bars, const int32_t *bars, const double *l0, double kappa,
+                    double a, double s, double eps_F);
 /* Covariance prediction W' = F W F^T + Weps (kalman.py:717 and :863) on the device, with
  * F = [[I, a I], [s dfdy, I]], dfdy given as one symmetric 2x2 block (Bxx, Bxy, Byy) per spring
  * (kalman.py:865-902; n_bars = 0: the constant-velocity model), Weps = eps_F [[I/4, I/2], [I/2, I]]

@@ -96,6 +96,9 @@ SIGNATURES = {
     "hm_ms_newton_finish": (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(ctypes.c_int)]),
     "hm_update_arm_newton": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_vp, c_vp, ctypes.c_double, ctypes.c_double,
                                             ctypes.c_double, ctypes.c_int, ctypes.c_double]),
+    "hm_update_arm_cov": (ctypes.c_int, [c_vp, ctypes.c_double]),
+    "hm_predict_take": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_vp, c_vp, ctypes.c_double, ctypes.c_double,
+                                       ctypes.c_double, ctypes.c_double]),
     "hm_ms_predict": (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                      ctypes.c_int, ctypes.c_double, ctypes.c_double, c_vp, ctypes.POINTER(ctypes.c_int),
                                      ctypes.c_int]),

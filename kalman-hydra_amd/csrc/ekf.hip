@@ -85,6 +85,15 @@ struct hm_ctx {
     std::vector<double> pn_l0;
     double pn_par[4] = {0, 0, 0, 0};
     int pn_maxiter = 0;
+    // hm_update_arm_cov: the covariance half of the next frame's prediction queued by hm_update_run itself (pq = "pre-queued")
+    bool pq_armed = false;           // the next hm_update_run is asked to queue it
+    double pq_eps_F = 0.0;
+    bool pq_valid = false;           // queued and not yet taken: d_Wprior / d_invW0 hold the prediction made from ...
+    std::vector<double> pq_X, pq_l0; // ... this state, these springs and parameters (kappa, a, s, eps_F)
+    std::vector<int32_t> pq_bars;
+    double pq_par[4] = {0, 0, 0, 0};
+    double *pin_blk = nullptr;       // page-locked staging of the spring blocks of that prediction
+    size_t pin_blk_cap = 0;
     std::thread worker;              // hm_update_prefactor queues its launches from here while the caller predicts the state
     bool worker_active;
     int worker_rc;
@@ -259,6 +268,7 @@ static int ctx_free(hm_ctx *h)
     if (h->pin) (void)hipHostFree(h->pin);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->pin_pm) (void)hipHostFree(h->pin_pm);
+    if (h->pin_blk) (void)hipHostFree(h->pin_blk);
     if (h->d_pm_done) (void)hipFree(h->d_pm_done);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1121,6 +1131,7 @@ extern "C" int hm_update_prefactor(hm_ctx_t h)
     HM_JOIN(h);
     if (!h->d_Wres) { hm_set_error("hm_update_prefactor: no covariance resident on the device"); return HM_ERR_STATE; }
     HM_HIP(hipSetDevice(h->device));
+    h->pq_valid = false;
     // (launched one by one: replaying this series as a hipGraph saved 0.08 ms of host time per frame, but
     // graph replays proved unreliable next to allocations by the caller -- see hm_brox_tune "graph")
     // With the factorisation as one persistent launch this is a copy, a fill and three launches: queued right here
@@ -1167,6 +1178,7 @@ static int update_begin(hm_ctx *h, const double *W_prior, const double *X0)
     }
     HM_HIP(hipSetDevice(h->device));
     const int n4 = 4 * h->N;
+    h->pq_valid = false;                         // (a prediction queued ahead that nobody took: d_Wres is still the posterior)
     if (!(h->prefactored && !W_prior && h->d_Wres == h->d_Wprior)) {
         int rc = prior_inverse(h, W_prior);
         if (rc) return rc;
@@ -1355,6 +1367,21 @@ extern "C" int hm_update_arm_newton(hm_ctx_t h, void *worker, int n_bars, const 
     return HM_OK;
 }
 
+// With hm_update_arm_newton armed as well: the next hm_update_run also queues the covariance half of the next frame's
+// prediction (queue_predict_ahead above; eps_F as for hm_cov_predict) behind the covariance of the state it keeps.
+// hm_update_cov is not available after such a run (the factor slots are reused); hm_cov_fetch still returns the
+// posterior until hm_predict_take.
+extern "C" int hm_update_arm_cov(hm_ctx_t h, double eps_F)
+{
+    HM_ARG(h != nullptr, "hm_update_arm_cov: NULL handle");
+    h->pq_armed = true;
+    h->pq_eps_F = eps_F;
+    return HM_OK;
+}
+
+static int queue_predict_ahead(hm_ctx *h, const double *X, int n_bars, const int32_t *bars, const double *l0, double kappa,
+                               double M, double dt, double eps_F);
+
 extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, double deltaX, int masked, int max_iter,
                              double reltol, int info[4], double *errs, double *Hzc, double *gains, double *W_out)
 {
@@ -1368,6 +1395,9 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
     void *const pn_worker = h->pn_worker;
     h->pn_armed = false;
     h->pn_worker = nullptr;
+    const bool pq_go = h->pq_armed && pn_go;
+    h->pq_armed = false;
+    h->pq_valid = false;
     NEED_TEX(h, "hm_update_run");
     NEED_OBS(h, "hm_update_run");
     int rc = update_begin(h, W_prior, X);
@@ -1477,6 +1507,13 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
     }
     if (W_out) HM_HIP(hipMemcpyAsync(W_out, h->d_Wres, (size_t)n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HM_HIP(hipGetLastError());
+    if (pq_go && h->chol_flow && which >= 0 && niter > 0 && !W_out) {
+        // the covariance half of the next frame's prediction, behind the launches above and before this thread waits
+        // for them (hm_update_arm_cov)
+        rc = queue_predict_ahead(h, Xcur.data(), (int)h->pn_l0.size(), h->pn_bars.data(), h->pn_l0.data(), h->pn_par[0],
+                                 h->pn_par[1], h->pn_par[2], h->pq_eps_F);
+        if (rc) return rc;
+    }
     if (niter > 0 && !W_out) {
         rc = wait_ticket(h, res + n4 + 5, (double)h->run_ticket);
         if (rc) return rc;
@@ -1521,20 +1558,17 @@ extern "C" int hm_update_last_error(hm_ctx_t h, const double *X, double err[4])
 //            Jacobian at the state before the step; n_bars = 0 gives the constant-velocity F (A = 0);
 //   a, s   : F = [[I, a I], [s dfdy, I]];  eps_F : Weps = eps_F [[I/4, I/2], [I/2, I]].
 // The result is copied to W_out and stays on the device as the prior of the next hm_update_begin(NULL).
-extern "C" int hm_cov_predict(hm_ctx_t h, const double *W_in, int n_bars, const int32_t *bars, const double *blocks,
-                              double a, double s, double eps_F, double *W_out)
+// ahead: called by hm_update_run for the NEXT frame, behind launches that are still running -- nothing here may wait for
+// the stream: the spring blocks go through page-locked memory (`blocks` is h->pin_blk), the result goes straight to
+// d_Wprior (where prior_inverse wants it) and the resident covariance (d_Wres, the posterior the caller may still
+// fetch) is left alone.
+static int cov_predict_core(hm_ctx *h, const double *W_in, int n_bars, const int32_t *bars, const double *blocks,
+                            double a, double s, double eps_F, double *W_out, bool ahead)
 {
-    HM_ARG(h && n_bars >= 0 && (n_bars == 0 || (bars && blocks)), "hm_cov_predict: bad argument");
-    HM_JOIN(h);
-    if (!W_in && !h->d_Wres) {
-        hm_set_error("hm_cov_predict: no covariance given and none resident on the device");
-        return HM_ERR_STATE;
-    }
-    HM_HIP(hipSetDevice(h->device));
     const int N = h->N, n4 = 4 * N;
     const size_t nn = (size_t)n4 * n4 * sizeof(double);
     std::vector<int> &off = h->sp_h_off, &bar = h->sp_h_bar, &other = h->sp_h_other;   // live until the copies ran
-    HM_HIP(stream_wait(h->stream));      // ... of the previous call
+    if (!ahead) HM_HIP(stream_wait(h->stream));      // ... of the previous call
     // the springs' topology rarely changes between frames: its device copy is kept and only the per-spring blocks go up
     const bool same_topo = h->d_sp_off && h->sp_bars_cached.size() == 2 * (size_t)n_bars &&
                            (n_bars == 0 || memcmp(h->sp_bars_cached.data(), bars, 2 * (size_t)n_bars * sizeof(int32_t)) == 0);
@@ -1575,8 +1609,12 @@ extern "C" int hm_cov_predict(hm_ctx_t h, const double *W_in, int n_bars, const 
         h->sp_bars_cached.assign(bars, bars + 2 * (size_t)n_bars);
     }
     if (n_bars > 0) {
-        h->sp_h_blk.assign(blocks, blocks + 3 * (size_t)n_bars);
-        HM_HIP(hipMemcpyAsync(h->d_sp_blk, h->sp_h_blk.data(), 3 * (size_t)n_bars * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        const double *from = blocks;
+        if (!ahead) {
+            h->sp_h_blk.assign(blocks, blocks + 3 * (size_t)n_bars);
+            from = h->sp_h_blk.data();
+        }
+        HM_HIP(hipMemcpyAsync(h->d_sp_blk, from, 3 * (size_t)n_bars * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
     const double *src = h->d_Wres;
     if (W_in) {
@@ -1588,13 +1626,100 @@ extern "C" int hm_cov_predict(hm_ctx_t h, const double *W_in, int n_bars, const 
     }
     SpringTopo tp = {h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk};
     double *P = h->d_Awork;                      // scratch
+    double *dst = ahead ? h->d_Wprior : h->d_Wtmp;
     hipLaunchKernelGGL(k_fw_rows, dim3(hm_cdiv(n4, 256), N), dim3(256), 0, h->stream, src, P, N, tp, a, s);
-    hipLaunchKernelGGL(k_pft_cols, dim3(hm_cdiv(n4, 256), N), dim3(256), 0, h->stream, P, h->d_Wtmp, N, tp, a, s, eps_F);
+    hipLaunchKernelGGL(k_pft_cols, dim3(hm_cdiv(n4, 256), N), dim3(256), 0, h->stream, P, dst, N, tp, a, s, eps_F);
     HM_HIP(hipGetLastError());
+    if (ahead) return HM_OK;
     if (W_out) HM_HIP(hipMemcpyAsync(W_out, h->d_Wtmp, nn, hipMemcpyDeviceToHost, h->stream));
     if (W_out) HM_HIP(stream_wait(h->stream));
     h->d_Wres = h->d_Wtmp;
     h->prefactored = false;
+    return HM_OK;
+}
+
+extern "C" int hm_cov_predict(hm_ctx_t h, const double *W_in, int n_bars, const int32_t *bars, const double *blocks,
+                              double a, double s, double eps_F, double *W_out)
+{
+    HM_ARG(h && n_bars >= 0 && (n_bars == 0 || (bars && blocks)), "hm_cov_predict: bad argument");
+    HM_JOIN(h);
+    if (!W_in && !h->d_Wres) {
+        hm_set_error("hm_cov_predict: no covariance given and none resident on the device");
+        return HM_ERR_STATE;
+    }
+    HM_HIP(hipSetDevice(h->device));
+    h->pq_valid = false;                         // a prediction queued ahead (hm_update_arm_cov) is not what this caller wants
+    return cov_predict_core(h, W_in, n_bars, bars, blocks, a, s, eps_F, W_out, false);
+}
+
+// The per-spring blocks (Bxx, Bxy, Byy) of the force Jacobian at the vertices of X (kalman.py:892-901): bar i between
+// a and b, d = y_a - y_b, l = |d|:  B = k I + c d d^T,  k = kappa (1 - l0/l),  c = kappa l0 / l^3.
+static void spring_blocks(int n_bars, const int32_t *bars, const double *l0, double kappa, const double *X, double *blk)
+{
+    for (int i = 0; i < n_bars; i++) {
+        const int a = bars[2 * i], b = bars[2 * i + 1];
+        const double dx = X[2 * a] - X[2 * b], dy = X[2 * a + 1] - X[2 * b + 1];
+        const double l = std::sqrt(dx * dx + dy * dy);
+        const double k = kappa * (1.0 - l0[i] / l), c = kappa * l0[i] / (l * l * l);
+        blk[3 * i] = k + c * dx * dx; blk[3 * i + 1] = c * dx * dy; blk[3 * i + 2] = k + c * dy * dy;
+    }
+}
+
+// hm_update_run, armed by hm_update_arm_newton + hm_update_arm_cov, when its state is final and the covariance of that
+// state (d_Wres) is queued: the covariance half of the NEXT frame's prediction -- W' = F W F^T + Weps with F at this
+// state (hm_cov_predict) and the factorisation / inverse of W' the next update starts with (hm_update_prefactor) --
+// goes onto the stream right behind it, ~0.3 ms before the caller could ask for it (it first has to get back to
+// IteratedMSKalmanFilter.predict).  Nothing is made current: hm_predict_take does that when the caller's inputs turn
+// out to be the ones used here; otherwise the caller's own hm_cov_predict starts from the posterior, which is intact.
+static int queue_predict_ahead(hm_ctx *h, const double *X, int n_bars, const int32_t *bars, const double *l0, double kappa,
+                               double M, double dt, double eps_F)
+{
+    for (int i = 0; i < 2 * n_bars; i++)
+        if (bars[i] < 0 || bars[i] >= h->N) return HM_OK;                 // the caller's own hm_cov_predict reports it
+    if ((size_t)n_bars > h->pin_blk_cap) {
+        if (h->pin_blk) (void)hipHostFree(h->pin_blk);
+        h->pin_blk = nullptr; h->pin_blk_cap = 0;
+        HM_HIP(hipHostMalloc((void **)&h->pin_blk, 3 * (size_t)n_bars * sizeof(double), hipHostMallocDefault));
+        h->pin_blk_cap = n_bars;
+    }
+    spring_blocks(n_bars, bars, l0, kappa, X, h->pin_blk);
+    double *const post = h->d_Wres;
+    int rc = cov_predict_core(h, nullptr, n_bars, bars, h->pin_blk, dt, dt / M, eps_F, nullptr, true);
+    if (rc) return rc;
+    h->d_Wres = h->d_Wprior;                     // (prior_inverse: the prior is where it belongs already)
+    rc = prior_inverse(h, nullptr);
+    h->d_Wres = post;
+    if (rc) return rc;
+    h->upd_open = false;                         // the factor slots and d_Wprior belong to the next update now
+    h->pq_X.assign(X, X + 4 * (size_t)h->N);
+    h->pq_bars.assign(bars, bars + 2 * (size_t)n_bars);
+    h->pq_l0.assign(l0, l0 + n_bars);
+    h->pq_par[0] = kappa; h->pq_par[1] = dt; h->pq_par[2] = dt / M; h->pq_par[3] = eps_F;
+    h->pq_valid = true;
+    return HM_OK;
+}
+
+// Makes the prediction hm_update_run queued ahead current -- as if hm_cov_predict(h, NULL, n_bars, bars, blocks at X, a, s,
+// eps_F, NULL) and hm_update_prefactor(h) had just been called -- when it was made from exactly these inputs (compared
+// bit for bit) and the posterior it started from is still the resident covariance.  Returns HM_OK when taken, 1 when
+// there is nothing to take (the caller then makes those two calls itself).
+extern "C" int hm_predict_take(hm_ctx_t h, const double *X, int n_bars, const int32_t *bars, const double *l0, double kappa,
+                               double a, double s, double eps_F)
+{
+    HM_ARG(h && X && n_bars >= 0 && (n_bars == 0 || (bars && l0)), "hm_predict_take: bad argument");
+    HM_JOIN(h);
+    if (!h->pq_valid) return 1;
+    h->pq_valid = false;
+    const size_t n4 = (size_t)4 * h->N;
+    const bool same = h->pq_X.size() == n4 && memcmp(h->pq_X.data(), X, n4 * sizeof(double)) == 0 &&
+                      h->pq_l0.size() == (size_t)n_bars &&
+                      (n_bars == 0 || (memcmp(h->pq_bars.data(), bars, 2 * (size_t)n_bars * sizeof(int32_t)) == 0 &&
+                                       memcmp(h->pq_l0.data(), l0, (size_t)n_bars * sizeof(double)) == 0)) &&
+                      h->pq_par[0] == kappa && h->pq_par[1] == a && h->pq_par[2] == s && h->pq_par[3] == eps_F;
+    if (!same || !h->d_Wres) return 1;
+    h->d_Wres = h->d_Wprior;
+    h->prefactored = true;
+    h->upd_open = false;
     return HM_OK;
 }
 
@@ -1617,13 +1742,7 @@ extern "C" int hm_ms_predict(hm_ctx_t h, int n_bars, const int32_t *bars, const 
     for (int i = 0; i < 2 * n_bars; i++) HM_ARG(bars[i] >= 0 && bars[i] < N, "hm_ms_predict: bar refers to vertex %d", bars[i]);
     // the spring blocks of dfdy at the state before the step (kalman.py:892-901)
     std::vector<double> blk(3 * (size_t)n_bars);
-    for (int i = 0; i < n_bars; i++) {
-        const int a = bars[2 * i], b = bars[2 * i + 1];
-        const double dx = X[2 * a] - X[2 * b], dy = X[2 * a + 1] - X[2 * b + 1];
-        const double l = std::sqrt(dx * dx + dy * dy);
-        const double k = kappa * (1.0 - l0[i] / l), c = kappa * l0[i] / (l * l * l);
-        blk[3 * i] = k + c * dx * dx; blk[3 * i + 1] = c * dx * dy; blk[3 * i + 2] = k + c * dy * dy;
-    }
+    spring_blocks(n_bars, bars, l0, kappa, X, blk.data());
     const size_t lds = ((size_t)34 * N + (size_t)7 * n_bars + 8) * sizeof(double) + ((size_t)N + 1 + 4 * (size_t)n_bars) * sizeof(int);
     const bool on_device = lds <= 160 * 1024;
     if (on_device) {

@@ -717,6 +717,11 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
         # True: the next frame's state prediction (hm_ms_newton, 0.42 ms of host time at 201 vertices) starts on a
         # worker thread as soon as the update has its final state, instead of at the top of the next compute()
         self.predict_ahead = True
+        # True (with predict_ahead): the update also queues the covariance half of the next frame's prediction -- F W F^T +
+        # Weps at the state it ends with, and the factorisation of the result -- behind its own last launches
+        # (hm_update_arm_cov); predict() takes it if the state, the springs and the parameters are still the same.
+        self.cov_ahead = True
+        self._cov_armed = False
         self._worker, self._ahead, self._armed = None, None, None
 
     def _jacobian(self):
@@ -750,7 +755,7 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
         l = np.sqrt((d * d).sum(axis=1))
         l0 = st.l0[:, 0]
         k = self.kappa * (1 - l0 / l)
-        c = self.kappa * l0 / l ** 3
+        c = self.kappa * l0 / (l * l * l)           # (the operations of the native spring_blocks, csrc/ekf.hip: same bits)
         return np.column_stack((k + c * d[:, 0] * d[:, 0], c * d[:, 0] * d[:, 1], k + c * d[:, 1] * d[:, 1]))
 
     def _bar_pattern(self):
@@ -795,11 +800,20 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
             # the covariance half first: it is queued on the device (prediction, then the
             # factorisation and inversion the update starts with) and runs while the host works
             # through the Newton iterations of the state
-            blocks = self._spring_blocks()
-            st.W = st.renderer.cov_predict(st._W, self._bars, blocks, self.deltat, self.deltat / self.M, st.eps_F,
-                                           fetch=False)
-            if self.fused_update and hasattr(st.renderer, "update_prefactor"):
-                st.renderer.update_prefactor(st._W)
+            taken = None
+            if self._cov_armed and hasattr(st.renderer, "predict_take"):
+                # the update of the last frame queued exactly this behind its own launches (hm_update_arm_cov)
+                taken = st.renderer.predict_take(st._W, st.X, self._bars, st.l0[:, 0], self.kappa, self.deltat,
+                                                 self.deltat / self.M, st.eps_F)
+            self._cov_armed = False
+            if taken is not None:
+                st.W = taken
+            else:
+                blocks = self._spring_blocks()
+                st.W = st.renderer.cov_predict(st._W, self._bars, blocks, self.deltat, self.deltat / self.M, st.eps_F,
+                                               fetch=False)
+                if self.fused_update and hasattr(st.renderer, "update_prefactor"):
+                    st.renderer.update_prefactor(st._W)
             self._newton()
         else:
             A = self._jacobian() * (self.deltat / self.M)
@@ -828,9 +842,13 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
             bars, l0, par = self._ahead_inputs()
             r.arm_newton(self._get_worker(), bars, l0, *par)
             self._armed = (bars, l0, par)
+            if self.cov_ahead and hasattr(r, "arm_cov"):
+                r.arm_cov(self.state.eps_F)
+                self._cov_armed = True
         try:
             IteratedKalmanFilter._update_fused(self, y_im, y_flow, y_m)
         except Exception:
+            self._cov_armed = False
             if self._armed is not None:          # whether the job was started is not known: wait for it if it was
                 self._armed = None
                 tmp = np.empty(4 * self.state.N)

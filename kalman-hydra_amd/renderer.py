@@ -332,6 +332,28 @@ class Renderer:
                                                    float(kappa), float(M), float(dt), int(maxiter), float(tol)),
                    "hm_update_arm_newton")
 
+    def arm_cov(self, eps_F):
+        """hm_update_arm_cov: the next update_run (armed with arm_newton as well) also queues the covariance half of the
+        next frame's prediction -- cov_predict at the state it ends with, then update_prefactor -- behind its own last
+        launches; predict_take makes them current."""
+        _lib.check(_lib.lib().hm_update_arm_cov(self._h, float(eps_F)), "hm_update_arm_cov")
+
+    def predict_take(self, W, X, bars, l0, kappa, a, s, eps_F):
+        """hm_predict_take: the DeviceCovariance of the prediction update_run queued ahead from the resident covariance W,
+        if it was made from exactly these inputs (its factorisation for the next update is queued as well, as after
+        update_prefactor) -- else None, and the caller calls cov_predict / update_prefactor itself."""
+        if not (isinstance(W, DeviceCovariance) and W.valid(self)):
+            return None
+        x = np.ascontiguousarray(np.asarray(X, np.float64).reshape(-1))
+        b = np.ascontiguousarray(bars, np.int32)
+        l0 = np.ascontiguousarray(np.asarray(l0, np.float64).reshape(-1))
+        rc = _lib.lib().hm_predict_take(self._h, _lib.ptr(x), int(b.shape[0]), _lib.ptr(b), _lib.ptr(l0), float(kappa),
+                                        float(a), float(s), float(eps_F))
+        if rc == 1:
+            return None
+        _lib.check(rc, "hm_predict_take")
+        return self._cov_result(False)
+
     def update_step(self, state, y_im, y_flow, y_m, deltaX=2.0, want_error=True):
         """hm_update_step: measurement at state.X, the solve and (want_error) Renderer.error of the new
         iterate X0 + step -> (step [4N,1], Hz_components [4N,4], (e_im, e_fx, e_fy, e_m) or None)."""

@@ -305,6 +305,45 @@ def test_prediction_started_ahead_changes_nothing(hm):
         assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
 
 
+def test_covariance_prediction_queued_ahead_changes_nothing(hm):
+    """IteratedMSKalmanFilter.cov_ahead (hm_update_arm_cov / hm_predict_take: the update queues F W F^T + Weps and the
+    factorisation of the result for the next frame behind its own launches): the same states and covariances, bit
+    for bit, with it and without; between frames the resident covariance is still the posterior; a state touched
+    between frames is noticed and the prediction made again from what it is."""
+    from hydra_mi import mesh, synth, kalman
+    video, flow = synth.test_data(128, 128)
+    g = np.load(os.path.join(GOLD, "config1_track.npz"))
+    tracks, taken = {}, {}
+    for ahead in (True, False):
+        kf = kalman.IteratedMSKalmanFilter(mesh.Mesh(g["p"], g["t"], 15.0), video[:, :, 0], flow[:, :, :, 0], True)
+        kf.cov_ahead = ahead
+        r = kf.state.renderer
+        took = []
+        take = r.predict_take
+        def spy(*a, _take=take, _took=took, **k):
+            out = _take(*a, **k)
+            _took.append(out is not None)
+            return out
+        r.predict_take = spy
+        out = []
+        for k in range(6):
+            frame = video[:, :, k]
+            if k == 3:
+                kf.state.X[0, 0] += 0.25                 # the caller moves a vertex between frames
+            kf.compute(frame, flow[:, :, :, k], (frame > 0).astype(np.uint8))
+            W = np.array(kf.state.W) if k in (1, 4) else None      # the posterior, fetched while the prediction is queued
+            out.append((kf.state.X.copy(), kf.niter, W))
+        out.append((np.array(kf.state.W), 0, None))
+        tracks[ahead], taken[ahead] = out, took
+        kf.close()
+    assert taken[False] == []
+    # asked from frame 1 on; frames 2 and 5: W had been fetched (a host array now), frame 3: the state was touched
+    assert taken[True] == [True, False, False, True, False], taken[True]
+    for a, b in zip(tracks[True], tracks[False]):
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1]
+        assert (a[2] is None) == (b[2] is None) and (a[2] is None or np.array_equal(a[2], b[2]))
+
+
 def test_state_errors_are_loud(hm):
     from hydra_mi import mesh, renderer
     dm = mesh.square4_mesh(10, 30)
