@@ -100,6 +100,7 @@ struct hm_ctx {
     char worker_err[512];
     int chol_flow, flow_wgs;         // the factorisation as one persistent launch (chol_flow_kernels.h) / its workgroups
     int flow_stall = 0;              // test knob: FlowArgs.stall
+    int speculate = 1;               // hm_update_run queues the next iteration's measurement before it knows that there is one
     double *d_flowP;                 // 3 x nb x 32 x 32 scratch of that launch
     unsigned *d_flowctl;             // its task counter and time-out word
     hipStream_t stream2;             // hm_ms_predict: the state prediction runs beside the covariance half of the update
@@ -491,6 +492,9 @@ extern "C" int hm_ctx_tune(hm_ctx_t h, const char *key, int value)
     } else if (!strcmp(key, "chol_flow_stall")) {      // tests only: results must not depend on it
         HM_ARG(value >= 0 && value <= 100000, "hm_ctx_tune: chol_flow_stall must be in 0..100000");
         h->flow_stall = value;
+    } else if (!strcmp(key, "speculate")) {            // same results either way
+        HM_ARG(value == 0 || value == 1, "hm_ctx_tune: speculate must be 0 or 1");
+        h->speculate = value;
     } else if (!strcmp(key, "edge_split")) {
         HM_ARG(value >= 1 && value <= MEAS_VSPLIT_MAX, "hm_ctx_tune: edge_split must be in 1..%d", MEAS_VSPLIT_MAX);
         h->esplit = value;
@@ -1409,9 +1413,22 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
     int niter = 0, accepted = 0;
     bool reverted = false, conv = false, ref_ready = false, regions_ahead = false, grown = false;
     double eold = 0.0;
+    // spec: the measurement at the new iterate has been queued already -- behind k_iter_result, before the host has seen
+    // that iteration's result, on the assumption that the loop goes on (it does 7 times out of 8): the device goes from
+    // one iteration into the next without the ~14 us it takes the host to notice the ticket, decide and launch.  ref / P
+    // and d_X / d_Xn are swapped when it is queued; an iteration that turns out to be the last swaps them back (the
+    // wasted measurement only wrote job sums and parked differences nobody reads, and the launches behind it on this
+    // stream -- the covariance of the kept state -- are not what the next frame waits for).
+    bool spec = false;
+    auto unspec = [&]() {
+        if (spec) { std::swap(h->ref, h->P); std::swap(h->d_X, h->d_Xn); spec = false; }
+    };
     for (int it = 0; it < max_iter; it++) {
-        rc = measure_dev(h, h->d_X, ref_ready, deltaX, masked, regions_ahead, false);
-        if (rc) return rc;
+        if (!spec) {
+            rc = measure_dev(h, h->d_X, ref_ready, deltaX, masked, regions_ahead, false);
+            if (rc) return rc;
+        }
+        spec = false;
         h->X0 = Xcur;                              // the state of the reference render (hm_jz / hm_j)
         h->have_ref = true;
         const int slot = h->upd_last == 0 ? 1 : 0;
@@ -1425,9 +1442,17 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
         hipLaunchKernelGGL(k_iter_result, dim3(1), dim3(256), 0, h->stream, rhs_row, n4, h->d_tpart,
                            render_strips(h), h->pool.overflow, (const unsigned *)h->d_flowctl, res, (double)(++h->run_ticket));
         HM_HIP(hipGetLastError());
+        if (h->speculate && regions_ahead) {
+            std::swap(h->ref, h->P);
+            std::swap(h->d_X, h->d_Xn);
+            spec = true;
+            rc = measure_dev(h, h->d_X, true, deltaX, masked, true, false);
+            if (rc) { unspec(); return rc; }
+        }
         rc = wait_ticket(h, res + n4 + 5, (double)h->run_ticket);
-        if (rc) return rc;
+        if (rc) { unspec(); return rc; }
         if (res[n4 + 4] != 0.0) {
+            unspec();
             // the star regions of this measurement did not fit the pool of difference images: grow it and take the
             // iteration again (nothing of it has been kept; the regions the failed pass computed for its -- meaningless
             // -- next iterate are computed anew)
@@ -1446,12 +1471,14 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
         h->upd_last = slot;
         niter++;
         if (res[n4 + 7] != 0.0) {
+            unspec();
             hm_set_error("hm_update_run: the factorisation launch gave up waiting for a block (chol_flow time-out)");
             return HM_ERR_HIP;
         }
         bool finite = true;
         for (int i = 0; i < n4; i++) finite = finite && std::isfinite(res[i]);
         if (!finite) {
+            unspec();
             hm_set_error("hm_update_run: the update system inv(W) + HTH is not positive definite "
                          "(non-finite state, covariance or observation?)");
             return HM_ERR_NUMERIC;
@@ -1467,6 +1494,7 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
             flipped = ax * by - ay * bx < 0.0;
         }
         if (flipped) {
+            unspec();
             Xcur = Xold;
             reverted = true;
             break;
@@ -1476,15 +1504,18 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
         const double e_im = std::trunc(res[n4]), e_m = std::trunc(res[n4 + 3]);
         const double enew = std::sqrt(e_im * e_im + res[n4 + 1] * res[n4 + 1] + res[n4 + 2] * res[n4 + 2] + e_m * e_m);
         accepted++;
-        if (std::fabs(enew - eold) / enew < reltol) { conv = true; break; }
+        if (std::fabs(enew - eold) / enew < reltol) { unspec(); conv = true; break; }
         eold = enew;
         Xold = Xcur;
         // the new iterate becomes the point of the next measurement; its render is already there
-        std::swap(h->ref, h->P);
-        std::swap(h->d_X, h->d_Xn);
+        if (!spec) {
+            std::swap(h->ref, h->P);
+            std::swap(h->d_X, h->d_Xn);
+        }
         ref_ready = true;
         h->X0 = Xcur;
     }
+    unspec();                                      // (max_iter reached: regions_ahead was false, nothing was queued)
     // the state is final: a caller that armed it gets the next frame's state prediction started now, on its worker
     // thread, beside the covariance launches below (hm_update_arm_newton)
     if (pn_go) {
