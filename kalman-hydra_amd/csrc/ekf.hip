@@ -243,6 +243,7 @@ static int pool_grow(hm_ctx *h, const char *who)
         hm_set_error("%s: the star regions need %lld pixels of difference images, more than the pool may hold", who, total);
         return HM_ERR_STATE;
     }
+    if (getenv("HYDRA_MI_TRACE")) fprintf(stderr, "[hydra_mi] %s: difference-image pool %lld -> %lld pixels\n", who, h->pool.cap, want);
     int rc = pool_alloc(h, want);
     if (rc) { hm_set_error("%s: cannot grow the difference-image pool to %lld pixels: %s", who, want, hm_last_error()); return rc; }
     return HM_OK;
@@ -1404,8 +1405,13 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
     h->pq_valid = false;
     NEED_TEX(h, "hm_update_run");
     NEED_OBS(h, "hm_update_run");
+    const bool dbg = getenv("HYDRA_MI_TRACE") != nullptr;
+    const auto dbg_a = std::chrono::steady_clock::now();
+    auto dbg_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_a).count(); };
+    double dbg_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int rc = update_begin(h, W_prior, X);
     if (rc) return rc;
+    dbg_stage[0] = dbg_ms();
     const int N = h->N, n4 = 4 * N;
     std::vector<double> X0(X, X + n4), Xcur(X0), Xold(X0);
     HM_HIP(hipMemcpyAsync(h->d_X, h->d_X0, (size_t)n4 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -1449,8 +1455,13 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
             rc = measure_dev(h, h->d_X, true, deltaX, masked, true, false);
             if (rc) { unspec(); return rc; }
         }
+        const auto dbg_t0 = std::chrono::steady_clock::now();
         rc = wait_ticket(h, res + n4 + 5, (double)h->run_ticket);
         if (rc) { unspec(); return rc; }
+        if (getenv("HYDRA_MI_TRACE")) {
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0).count();
+            if (ms > 1.5) fprintf(stderr, "[hydra_mi] hm_update_run: iteration %d waited %.2f ms for its result\n", it, ms);
+        }
         if (res[n4 + 4] != 0.0) {
             unspec();
             // the star regions of this measurement did not fit the pool of difference images: grow it and take the
@@ -1516,6 +1527,7 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
         h->X0 = Xcur;
     }
     unspec();                                      // (max_iter reached: regions_ahead was false, nothing was queued)
+    dbg_stage[1] = dbg_ms();
     // the state is final: a caller that armed it gets the next frame's state prediction started now, on its worker
     // thread, beside the covariance launches below (hm_update_arm_newton)
     if (pn_go) {
@@ -1523,6 +1535,7 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
                                 h->pn_par[1], h->pn_par[2], h->pn_maxiter, h->pn_par[3], Xcur.data());
         if (rc) return rc;
     }
+    dbg_stage[2] = dbg_ms();
     // covariance of the state that is kept (kalman.py:806-811, 826)
     int which = -1;                                // -1: the prior
     if (reverted) which = accepted == 0 ? -1 : 1;
@@ -1545,12 +1558,17 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
                                  h->pn_par[1], h->pn_par[2], h->pq_eps_F);
         if (rc) return rc;
     }
+    dbg_stage[3] = dbg_ms();
     if (niter > 0 && !W_out) {
         rc = wait_ticket(h, res + n4 + 5, (double)h->run_ticket);
         if (rc) return rc;
     } else {
         HM_HIP(stream_wait(h->stream));
     }
+    dbg_stage[4] = dbg_ms();
+    if (dbg && dbg_stage[4] > 5.0)
+        fprintf(stderr, "[hydra_mi] hm_update_run %d iterations: begin %.2f loop-end %.2f newton-started %.2f tail-queued %.2f tail-done %.2f ms\n",
+                niter, dbg_stage[0], dbg_stage[1], dbg_stage[2], dbg_stage[3], dbg_stage[4]);
     if (niter > 0) {
         if (Hzc) memcpy(Hzc, pin_hzc, (size_t)n4 * 4 * sizeof(double));
         if (gains) memcpy(gains, pin_gain, (size_t)n4 * 3 * sizeof(double));

@@ -389,6 +389,12 @@ class FlowEKFPipeline:
         self.adaptive_first = True       # size the first series of a phase from those measurements
         self.first_series = 0            # > 0: fixed size of the first series of every phase
         self.profiled_handle = None
+        self.gc_freeze = True            # see run()
+        # model_ramp: size every series of a phase from the measured series / frame times (_next_series) instead of the
+        # fixed 1.7 x ramp.  Measured on the driver's 20-frame bench, three runs each on one box: 246 frames/s against
+        # 250 (waiting for flow 0.86 against 0.77 ms per frame) although the last 12 frames run at 351 against 325
+        # frames/s -- off by default.
+        self.model_ramp = False
 
     # -- flow series ---------------------------------------------------------------------------------
     def _launch(self, k, end, most, alone=None, whole=None):
@@ -437,7 +443,29 @@ class FlowEKFPipeline:
         series of n 1024^2 pairs takes about 5.3 + 1.45 (n - 1) ms, a frame of the filter about 4 ms, and this ramp
         is the one with the least waiting for that pair of numbers (1, 2, 4, 8 waits 40 % longer); a ramp that is too
         steep only costs the wait for its larger series, once.  (With two handles: 1, 2, 3, 5, 8.)"""
-        return min(self.B, max(last + 1, int(1.7 * last)))
+        guess = min(self.B, max(last + 1, int(1.7 * last)))
+        model = self._series_model()
+        if model is None or not self.adaptive_first or not self.model_ramp:
+            return guess
+        # with measurements: the largest series that is done (beside the filter: ~1.3 x as long as alone) by the time the
+        # filter is through with the `last` frames it has just been given -- a steeper ramp has the filter wait for it
+        a, b, n_a = model
+        room = last * self._frame_s / 1.3
+        n = int(n_a + (room - a) / b) if b > 0 else self.B
+        return max(min(last, self.B), min(self.B, n, 2 * last))
+
+    def _series_model(self):
+        """(a, b, n_a): a series of n pairs alone takes about a + b (n - n_a) seconds, from the first series of earlier
+        phases (see _first_series); None without measurements."""
+        ts = self._series_s
+        if not ts or self._frame_s is None:
+            return None
+        (n_a, t_a), (n_b, t_b) = sorted(ts.items())[0], sorted(ts.items())[-1]
+        if n_b > n_a:
+            b = max(0.0, (t_b - t_a) / (n_b - n_a))
+        else:
+            b = 0.2 * t_a / (1.0 + 0.2 * (n_a - 2))
+        return t_a, b, n_a
 
     def _wait(self, f):
         f["thread"].join()
@@ -465,15 +493,12 @@ class FlowEKFPipeline:
         default = min(2, self.B)
         if self.first_series:
             return max(1, min(self.B, int(self.first_series)))
-        ts = self._series_s
-        if not ts or self._frame_s is None or not self.adaptive_first:
+        model = self._series_model()
+        if model is None or not self.adaptive_first:
             return default
-        (n_a, t_a), (n_b, t_b) = sorted(ts.items())[0], sorted(ts.items())[-1]
-        if n_b > n_a:
-            b = max(0.0, (t_b - t_a) / (n_b - n_a))
-        else:
-            b = 0.2 * t_a / (1.0 + 0.2 * (n_a - 2))
-        t_full = t_a + b * (self.B - n_a)
+        t_a, b, n_a = model
+        # the series after the first need not be a full one (_next_series ramps up to B): sized for one of at most 8 pairs
+        t_full = t_a + b * (min(self.B, 8) - n_a)
         n1 = int(np.ceil(1.3 * t_full / max(self._frame_s, 1e-4)))
         return max(default, min(self.B, n1))
 
@@ -570,8 +595,17 @@ class FlowEKFPipeline:
         return e
 
     def run(self, first=0, end=None, on_frame=None):
-        """compute() for the frames first+1 .. end; on_frame(k, error_tuple) after each."""
+        """compute() for the frames first+1 .. end; on_frame(k, error_tuple) after each.
+
+        gc_freeze (attribute, default True): the objects alive when the phase starts are moved to the collector's
+        permanent generation (gc.freeze) -- the interpreter's full collections, which the frame loop's allocations
+        trigger every ~17 frames, then have nothing old to walk through.  Measured at 1024^2 / 201 vertices: one
+        frame in 17 took 8.4 instead of 1.7 ms (a 6.7 ms pause inside the Python wrapper of hm_update_run with
+        numpy / scipy loaded; longer with torch)."""
         end = self.F - 1 if end is None else min(int(end), self.F - 1)
+        if self.gc_freeze:
+            import gc
+            gc.freeze()
         self.begin(first, end)
         for k in range(first, end):
             e = self.step(k)

@@ -1,5 +1,5 @@
 mkdir -p gpurun_out/sweep
-for args in "--flow-batch 8" "--flow-batch 12" "--flow-batch 16" "--cu-reserve 16" "--cu-reserve 0" "--flow-batch 12 --cu-reserve 16"; do
+for args in "--flow-batch 8" "--flow-batch 12" "--flow-batch 16"; do
   tag=$(echo $args | tr -d ' -')
   for steps in "--steps 20 --warmup 5" ""; do
     python bench.py $steps --no-cpu-baseline $args 2>/dev/null | tail -1 | python -c "
