@@ -281,6 +281,16 @@ int hm_ms_worker_destroy(void *worker);
 int hm_ms_newton_start(void *worker, int n_vertices, int n_bars, const int32_t *bars, const double *l0, double kappa,
                        double M, double dt, int maxiter, double tol, const double *X);
 int hm_ms_newton_finish(void *worker, double *X, int *newton_iterations);
+/* Jobs started on `worker` run as ONE launch on the device of the filter handle `ctx` (NULL: back to the worker's host
+ * thread) when the mesh fits the kernel (k_ms_newton4, csrc/predict_kernels.h: at most 256 vertices and 12 springs per
+ * vertex; four waves, a vertex per lane) -- the state goes in and out through page-locked memory, hm_ms_newton_finish
+ * watches a ticket; larger meshes keep the host loop.  Host and device agree to rounding (sums over the vector are
+ * added in another order).  The handle must outlive the worker's jobs. */
+int hm_ms_worker_attach(void *worker, hm_ctx_t ctx);
+/* what the attached worker calls; 1 = not for the device (mesh too large / inner solve gave up) */
+int hm_newton_dev_start(hm_ctx_t h, int N, int n_bars, const int32_t *bars, const double *l0, double kappa, double M,
+                        double dt, int maxiter, double tol, const double *X);
+int hm_newton_dev_finish(hm_ctx_t h, double *X, int *newton_iterations);
 /* one-shot: the next hm_update_run on h calls hm_ms_newton_start(worker, ..., X) with the state it ends with as soon
  * as that state is known -- before the covariance of the kept iterate is formed and fetched */
 int hm_update_arm_newton(hm_ctx_t h, void *worker, int n_bars, const int32_t *bars, const double *l0, double kappa,

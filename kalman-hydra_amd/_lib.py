@@ -94,6 +94,10 @@ SIGNATURES = {
     "hm_ms_newton_start": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_vp, ctypes.c_double, ctypes.c_double,
                                           ctypes.c_double, ctypes.c_int, ctypes.c_double, c_vp]),
     "hm_ms_newton_finish": (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(ctypes.c_int)]),
+    "hm_ms_worker_attach": (ctypes.c_int, [c_vp, c_vp]),
+    "hm_newton_dev_start": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_vp, ctypes.c_double, ctypes.c_double,
+                                           ctypes.c_double, ctypes.c_int, ctypes.c_double, c_vp]),
+    "hm_newton_dev_finish": (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(ctypes.c_int)]),
     "hm_update_arm_newton": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_vp, c_vp, ctypes.c_double, ctypes.c_double,
                                             ctypes.c_double, ctypes.c_int, ctypes.c_double]),
     "hm_update_arm_cov": (ctypes.c_int, [c_vp, ctypes.c_double]),

@@ -92,6 +92,17 @@ struct hm_ctx {
     std::vector<double> pq_X, pq_l0; // ... this state, these springs and parameters (kappa, a, s, eps_F)
     std::vector<int32_t> pq_bars;
     double pq_par[4] = {0, 0, 0, 0};
+    // hm_newton_dev_start / _finish: the state prediction's Newton loop as a four-wave kernel on a stream of its own
+    hipStream_t stream3 = nullptr;
+    int *d_n4nbr = nullptr, *d_n4nbb = nullptr, *d_n4bars = nullptr;
+    double *d_n4l0 = nullptr;
+    size_t n4cap = 0;                // bars the device arrays hold
+    int n4deg = 0;                   // padded degree of the table on the device (8 or 12), 0: this mesh does not fit the kernel
+    std::vector<int32_t> n4_bars;    // the springs the table was built for
+    std::vector<double> n4_l0;
+    double *pin_n4 = nullptr;        // page-locked: [X in | X out | iterations | failed | ticket]
+    long long n4_ticket = 0;
+    bool n4_pending = false;
     double *pin_blk = nullptr;       // page-locked staging of the spring blocks of that prediction
     size_t pin_blk_cap = 0;
     std::thread worker;              // hm_update_prefactor queues its launches from here while the caller predicts the state
@@ -271,6 +282,9 @@ static int ctx_free(hm_ctx *h)
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->pin_pm) (void)hipHostFree(h->pin_pm);
     if (h->pin_blk) (void)hipHostFree(h->pin_blk);
+    if (h->pin_n4) (void)hipHostFree(h->pin_n4);
+    if (h->stream3) { (void)hipStreamSynchronize(h->stream3); (void)hipStreamDestroy(h->stream3); }
+    { void *q[] = {h->d_n4nbr, h->d_n4nbb, h->d_n4bars, h->d_n4l0}; for (void *x : q) if (x) (void)hipFree(x); }
     if (h->d_pm_done) (void)hipFree(h->d_pm_done);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1849,4 +1863,106 @@ extern "C" int hm_ms_predict(hm_ctx_t h, int n_bars, const int32_t *bars, const 
     }
     if (rc) return rc;
     return hm_ms_newton(N, n_bars, bars, l0, kappa, M, dt, maxiter, tol, X, newton_iterations);
+}
+
+
+// ---- the state prediction's Newton loop on the device, started ahead (csrc/predict_kernels.h: k_ms_newton4) -----------------
+// hm_newton_dev_start queues ONE launch on a stream of its own: the state goes in and comes out through page-locked
+// memory, the host watches a ticket (hm_newton_dev_finish).  Called by the worker object of csrc/predict.cpp when a
+// handle is attached to it (hm_ms_worker_attach): from hm_update_run the moment its state is final, i.e. the kernel
+// runs beside the covariance launches of the frame that ends and the caller's way back to predict().  Returns 1 when
+// this mesh does not fit the kernel (more than 256 vertices, a vertex with more than 12 springs): the caller takes the
+// host loop.
+extern "C" int hm_newton_dev_start(hm_ctx_t h, int N, int n_bars, const int32_t *bars, const double *l0, double kappa, double M,
+                                   double dt, int maxiter, double tol, const double *X)
+{
+    HM_ARG(h && bars && l0 && X && n_bars >= 1, "hm_newton_dev_start: bad argument");
+    if (N != h->N || N > NEWTON4_NT) return 1;
+    HM_HIP(hipSetDevice(h->device));
+    if (h->n4_pending) {                          // a prediction nobody fetched: let it finish (its ticket is not waited for)
+        HM_HIP(hipStreamSynchronize(h->stream3));
+        h->n4_pending = false;
+    }
+    if (!h->stream3) {
+        int least = 0, greatest = 0;
+        HM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        if (greatest != least) { HM_HIP(hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, greatest)); }
+        else HM_HIP(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
+        HM_HIP(hipHostMalloc((void **)&h->pin_n4, ((size_t)8 * N + 4) * sizeof(double), hipHostMallocDefault));
+        memset(h->pin_n4, 0, ((size_t)8 * N + 4) * sizeof(double));
+    }
+    const bool same = h->n4_bars.size() == 2 * (size_t)n_bars && memcmp(h->n4_bars.data(), bars, 2 * (size_t)n_bars * sizeof(int32_t)) == 0;
+    if (!same) {
+        for (int i = 0; i < 2 * n_bars; i++) HM_ARG(bars[i] >= 0 && bars[i] < N, "hm_newton_dev_start: bar refers to vertex %d", bars[i]);
+        std::vector<int> deg(N, 0);
+        for (int i = 0; i < 2 * n_bars; i++) deg[bars[i]]++;
+        const int maxdeg = *std::max_element(deg.begin(), deg.end());
+        h->n4_bars.assign(bars, bars + 2 * (size_t)n_bars);
+        h->n4_l0.clear();
+        h->n4deg = maxdeg <= 8 ? 8 : maxdeg <= 12 ? 12 : 0;
+        if (h->n4deg) {
+            const int D = h->n4deg;
+            std::vector<int> nbr((size_t)N * D), nbb((size_t)N * D, n_bars), fill(N, 0);
+            for (int v = 0; v < N; v++)
+                for (int q = 0; q < D; q++) nbr[(size_t)v * D + q] = v;             // padding: the vertex itself, bar I (zero terms)
+            for (int i = 0; i < n_bars; i++) {                                        // ascending bar order per vertex
+                const int a = bars[2 * i], b = bars[2 * i + 1];
+                nbr[(size_t)a * D + fill[a]] = b; nbb[(size_t)a * D + fill[a]++] = i;
+                nbr[(size_t)b * D + fill[b]] = a; nbb[(size_t)b * D + fill[b]++] = i;
+            }
+            if ((size_t)n_bars > h->n4cap || !h->d_n4nbr) {
+                void *q[] = {h->d_n4nbr, h->d_n4nbb, h->d_n4bars, h->d_n4l0};
+                for (void *x : q) if (x) (void)hipFree(x);
+                h->d_n4nbr = h->d_n4nbb = h->d_n4bars = nullptr; h->d_n4l0 = nullptr; h->n4cap = 0;
+                HM_HIP(hm_malloc((void **)&h->d_n4nbr, (size_t)N * 12 * sizeof(int)));
+                HM_HIP(hm_malloc((void **)&h->d_n4nbb, (size_t)N * 12 * sizeof(int)));
+                HM_HIP(hm_malloc((void **)&h->d_n4bars, 2 * (size_t)n_bars * sizeof(int)));
+                HM_HIP(hm_malloc((void **)&h->d_n4l0, (size_t)n_bars * sizeof(double)));
+                h->n4cap = n_bars;
+            }
+            HM_HIP(hipMemcpy(h->d_n4nbr, nbr.data(), nbr.size() * sizeof(int), hipMemcpyHostToDevice));
+            HM_HIP(hipMemcpy(h->d_n4nbb, nbb.data(), nbb.size() * sizeof(int), hipMemcpyHostToDevice));
+            HM_HIP(hipMemcpy(h->d_n4bars, bars, 2 * (size_t)n_bars * sizeof(int), hipMemcpyHostToDevice));
+        }
+    }
+    if (!h->n4deg) return 1;
+    if (h->n4_l0.size() != (size_t)n_bars || memcmp(h->n4_l0.data(), l0, (size_t)n_bars * sizeof(double)) != 0) {
+        h->n4_l0.assign(l0, l0 + n_bars);
+        HM_HIP(hipMemcpy(h->d_n4l0, l0, (size_t)n_bars * sizeof(double), hipMemcpyHostToDevice));
+    }
+    const size_t n4 = (size_t)4 * N;
+    memcpy(h->pin_n4, X, n4 * sizeof(double));
+    Newton4Args a;
+    a.N = N; a.I = n_bars; a.deg_stride = h->n4deg;
+    a.bars = h->d_n4bars; a.l0 = h->d_n4l0; a.nbr = h->d_n4nbr; a.nbb = h->d_n4nbb;
+    a.kappa = kappa; a.M = M; a.dt = dt; a.tol = tol; a.maxiter = maxiter; a.steps = (int)std::ceil(1.0 / dt);
+    a.Xin = h->pin_n4; a.out = h->pin_n4 + n4; a.ticket = (double)(++h->n4_ticket);
+    const size_t lds = ((size_t)6 * NEWTON4_NT + 4 * ((size_t)n_bars + 1) + 4 * (NEWTON4_NT / 64)) * sizeof(double) + 2 * (size_t)n_bars * sizeof(int);
+    if (lds > 64 * 1024) return 1;
+    if (h->n4deg == 8) hipLaunchKernelGGL((k_ms_newton4<8>), dim3(1), dim3(NEWTON4_NT), lds, h->stream3, a);
+    else hipLaunchKernelGGL((k_ms_newton4<12>), dim3(1), dim3(NEWTON4_NT), lds, h->stream3, a);
+    HM_HIP(hipGetLastError());
+    h->n4_pending = true;
+    return HM_OK;
+}
+
+// Waits for the launch of hm_newton_dev_start; X (4N) receives the advanced state.  Returns 1 when the kernel's inner solve
+// did not converge (never observed): the caller repeats the prediction on the host.
+extern "C" int hm_newton_dev_finish(hm_ctx_t h, double *X, int *newton_iterations)
+{
+    HM_ARG(h && X, "hm_newton_dev_finish: bad argument");
+    if (!h->n4_pending) { hm_set_error("hm_newton_dev_finish: no prediction was started"); return HM_ERR_STATE; }
+    HM_HIP(hipSetDevice(h->device));
+    const size_t n4 = (size_t)4 * h->N;
+    int rc = wait_ticket_on(h->stream3, h->pin_n4 + 2 * n4 + 2, (double)h->n4_ticket);
+    h->n4_pending = false;
+    if (rc) return rc;
+    if (((const volatile double *)h->pin_n4)[2 * n4 + 2] != (double)h->n4_ticket) {
+        hm_set_error("hm_newton_dev_finish: the kernel finished without reporting (ticket %lld missing)", h->n4_ticket);
+        return HM_ERR_STATE;
+    }
+    if (h->pin_n4[2 * n4 + 1] != 0.0) return 1;
+    memcpy(X, h->pin_n4 + n4, n4 * sizeof(double));
+    if (newton_iterations) *newton_iterations = (int)h->pin_n4[2 * n4];
+    return HM_OK;
 }

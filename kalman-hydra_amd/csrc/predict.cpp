@@ -141,8 +141,11 @@ extern "C" int hm_ms_newton(int N, int I, const int32_t *bars, const double *l0,
 // the moment the update's last iteration has reported: hm_ms_newton for the NEXT frame can run on a host thread
 // while the device finishes the covariance of this one and the caller does its bookkeeping between frames.  One
 // persistent thread per worker object (posting a job costs a few microseconds; creating a thread per frame ~60).
+// (the device version of the loop: hm_newton_dev_start / _finish, csrc/ekf.hip; 1 = this job is for the host)
 namespace {
 struct NewtonWorker {
+    hm_ctx_t ctx = nullptr;          // hm_ms_worker_attach: jobs go to this handle's device when they fit its kernel
+    bool on_device = false;          // the job in flight is a launch, not a post to the thread
     std::thread th;
     std::mutex m;
     std::condition_variable cv;
@@ -182,6 +185,19 @@ extern "C" int hm_ms_worker_create(void **out)
     return HM_OK;
 }
 
+// Jobs started on this worker run as one launch on the device of the filter handle `ctx` (hm_ctx_t; NULL: back to the
+// host thread) whenever the mesh fits the kernel (k_ms_newton4: at most 256 vertices, 12 springs per vertex); the
+// handle must outlive the worker's jobs.
+extern "C" int hm_ms_worker_attach(void *worker, hm_ctx_t ctx)
+{
+    NewtonWorker *w = (NewtonWorker *)worker;
+    HM_ARG(w != nullptr, "hm_ms_worker_attach: NULL worker");
+    std::unique_lock<std::mutex> lk(w->m);
+    w->cv.wait(lk, [&] { return !w->busy; });
+    w->ctx = ctx;
+    return HM_OK;
+}
+
 extern "C" int hm_ms_worker_destroy(void *worker)
 {
     NewtonWorker *w = (NewtonWorker *)worker;
@@ -208,6 +224,12 @@ extern "C" int hm_ms_newton_start(void *worker, int N, int I, const int32_t *bar
     w->bars.assign(bars, bars + 2 * (size_t)I);
     w->l0.assign(l0, l0 + I);
     w->X.assign(X, X + 4 * (size_t)N);
+    w->on_device = false;
+    if (w->ctx && I >= 1) {
+        const int rc = hm_newton_dev_start(w->ctx, N, I, bars, l0, kappa, M, dt, maxiter, tol, X);
+        if (rc == HM_OK) { w->on_device = true; w->rc = HM_OK; return HM_OK; }
+        if (rc != 1) return rc;
+    }
     w->busy = true;
     w->posted = true;
     w->cv.notify_all();
@@ -221,6 +243,14 @@ extern "C" int hm_ms_newton_finish(void *worker, double *X, int *newton_iteratio
     HM_ARG(w && X, "hm_ms_newton_finish: bad argument");
     std::unique_lock<std::mutex> lk(w->m);
     if (w->X.empty()) { hm_set_error("hm_ms_newton_finish: no job was started"); return HM_ERR_STATE; }
+    if (w->on_device) {
+        w->on_device = false;
+        const int rc = hm_newton_dev_finish(w->ctx, X, newton_iterations);
+        if (rc != 1) return rc;
+        // the kernel's inner solve gave up: once more, here
+        memcpy(X, w->X.data(), w->X.size() * sizeof(double));
+        return hm_ms_newton(w->N, w->I, w->bars.data(), w->l0.data(), w->kappa, w->M, w->dt, w->maxiter, w->tol, X, newton_iterations);
+    }
     w->cv.wait(lk, [&] { return !w->busy && !w->posted; });
     if (w->rc != HM_OK) { hm_set_error("%s", w->err); return w->rc; }
     memcpy(X, w->X.data(), w->X.size() * sizeof(double));

@@ -722,6 +722,11 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
         # (hm_update_arm_cov); predict() takes it if the state, the springs and the parameters are still the same.
         self.cov_ahead = True
         self._cov_armed = False
+        # True: the prediction started ahead runs as one launch on the device (hm_ms_worker_attach: k_ms_newton4, four
+        # waves, a vertex per lane) instead of on the worker's host thread, when the mesh fits the kernel (<= 256
+        # vertices); the two agree to rounding
+        self.newton_on_device = True
+        self._worker_dev = None
         self._worker, self._ahead, self._armed = None, None, None
 
     def _jacobian(self):
@@ -832,6 +837,12 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
             w = ctypes.c_void_p()
             _lib.check(_lib.lib().hm_ms_worker_create(ctypes.byref(w)), "hm_ms_worker_create")
             self._worker = w
+            self._worker_dev = None
+        dev = bool(self.newton_on_device) and hasattr(self.state.renderer, "attach_worker")
+        if dev != self._worker_dev:
+            if hasattr(self.state.renderer, "attach_worker"):
+                self.state.renderer.attach_worker(self._worker, dev)
+            self._worker_dev = dev
         return self._worker
 
     def _update_fused(self, y_im, y_flow, y_m):
@@ -916,6 +927,17 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
         bars = np.ascontiguousarray(self._bars, np.int32)
         l0 = np.ascontiguousarray(st.l0[:, 0], np.float64)
         its = ctypes.c_int()
+        if self.newton_on_device and hasattr(st.renderer, "attach_worker"):
+            # the same launch a prediction started ahead would have been: the same bits with and without predict_ahead
+            w = self._get_worker()
+            L = _lib.lib()
+            _lib.check(L.hm_ms_newton_start(w, int(st.N), int(bars.shape[0]), _lib.ptr(bars), _lib.ptr(l0), float(self.kappa),
+                                            float(self.M), float(self.deltat), int(self.maxiter), float(self.tol), _lib.ptr(X)),
+                       "hm_ms_newton_start")
+            _lib.check(L.hm_ms_newton_finish(w, _lib.ptr(X), ctypes.byref(its)), "hm_ms_newton_finish")
+            self.newton_iterations = its.value
+            st.X = X.reshape(-1, 1)
+            return
         _lib.check(_lib.lib().hm_ms_newton(int(st.N), int(bars.shape[0]), _lib.ptr(bars), _lib.ptr(l0),
                                            float(self.kappa), float(self.M), float(self.deltat), int(self.maxiter),
                                            float(self.tol), _lib.ptr(X), ctypes.byref(its)), "hm_ms_newton")

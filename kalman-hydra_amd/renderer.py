@@ -332,6 +332,10 @@ class Renderer:
                                                    float(kappa), float(M), float(dt), int(maxiter), float(tol)),
                    "hm_update_arm_newton")
 
+    def attach_worker(self, worker, on=True):
+        """hm_ms_worker_attach: the state predictions started on `worker` run as a launch on this renderer's device."""
+        _lib.check(_lib.lib().hm_ms_worker_attach(worker, self._h if on else None), "hm_ms_worker_attach")
+
     def arm_cov(self, eps_F):
         """hm_update_arm_cov: the next update_run (armed with arm_newton as well) also queues the covariance half of the
         next frame's prediction -- cov_predict at the state it ends with, then update_prefactor -- behind its own last

@@ -305,6 +305,58 @@ def test_prediction_started_ahead_changes_nothing(hm):
         assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
 
 
+def test_newton_on_device_matches_host_loop(hm):
+    """The state prediction as one launch (hm_ms_worker_attach -> k_ms_newton4: four waves, a vertex per lane) against
+    the host loop (hm_ms_newton) and the oracle (reference kalman.py:923-960): the per-vertex operations are the host's,
+    the sums over the vector are added in another order -- 1e-12 relative, the same Newton iteration counts; a whole
+    track with it stays within 1e-9 of the track with the host loop."""
+    import ctypes
+    from hydra_mi import mesh, synth, kalman, _lib
+    video, flow = synth.test_data(128, 128)
+    g = np.load(os.path.join(GOLD, "config1_track.npz"))
+    kf = kalman.IteratedMSKalmanFilter(mesh.Mesh(g["p"], g["t"], 15.0), video[:, :, 0], flow[:, :, :, 0], True)
+    st = kf.state
+    rng = np.random.default_rng(5)
+    X0 = st.X.reshape(-1).copy()
+    n2 = 2 * st.N
+    X0[n2:] = rng.normal(0, 1.5, n2)                       # velocities: the springs get something to do
+    X0[:n2] += rng.normal(0, 0.4, n2)
+    bars = np.ascontiguousarray(kf._bars, np.int32)
+    l0 = np.ascontiguousarray(st.l0[:, 0], np.float64)
+    L = _lib.lib()
+    Xh = X0.copy()
+    ih = ctypes.c_int()
+    _lib.check(L.hm_ms_newton(int(st.N), int(bars.shape[0]), _lib.ptr(bars), _lib.ptr(l0), float(kf.kappa), float(kf.M),
+                              float(kf.deltat), int(kf.maxiter), float(kf.tol), _lib.ptr(Xh), ctypes.byref(ih)), "hm_ms_newton")
+    Xd = X0.copy()
+    idv = ctypes.c_int()
+    rc = L.hm_newton_dev_start(st.renderer._h, int(st.N), int(bars.shape[0]), _lib.ptr(bars), _lib.ptr(l0), float(kf.kappa),
+                               float(kf.M), float(kf.deltat), int(kf.maxiter), float(kf.tol), _lib.ptr(Xd))
+    assert rc == 0, rc                                       # this mesh fits the kernel
+    _lib.check(L.hm_newton_dev_finish(st.renderer._h, _lib.ptr(Xd), ctypes.byref(idv)), "hm_newton_dev_finish")
+    assert idv.value == ih.value
+    assert np.abs(Xd - Xh).max() <= 1e-12 * np.abs(Xh).max(), np.abs(Xd - Xh).max()
+    n4 = 4 * st.N
+    K = ekf_ref.incidence(st.N, bars)
+    ref, _ = ekf_ref.ms_predict(X0, np.eye(n4), np.zeros((n4, n4)), K, l0, kf.kappa, kf.M, kf.deltat, kf.maxiter, kf.tol)
+    assert np.abs(Xd - ref.reshape(-1)).max() <= 1e-9 * np.abs(ref).max()
+    kf.close()
+    tracks = {}
+    for dev in (True, False):
+        kf = kalman.IteratedMSKalmanFilter(mesh.Mesh(g["p"], g["t"], 15.0), video[:, :, 0], flow[:, :, :, 0], True)
+        kf.newton_on_device = dev
+        out = []
+        for k in range(5):
+            frame = video[:, :, k]
+            kf.compute(frame, flow[:, :, :, k], (frame > 0).astype(np.uint8))
+            out.append((kf.state.X.copy(), kf.niter, kf.newton_iterations))
+        tracks[dev] = out
+        kf.close()
+    for a, b in zip(tracks[True], tracks[False]):
+        assert a[1:] == b[1:]
+        assert np.abs(a[0] - b[0]).max() <= 1e-9 * np.abs(b[0]).max()
+
+
 def test_covariance_prediction_queued_ahead_changes_nothing(hm):
     """IteratedMSKalmanFilter.cov_ahead (hm_update_arm_cov / hm_predict_take: the update queues F W F^T + Weps and the
     factorisation of the result for the next frame behind its own launches): the same states and covariances, bit
