@@ -385,16 +385,17 @@ class FlowEKFPipeline:
         self._end = self.F - 1
         self._cursor = 0                 # the oldest frame still needed (the pair the filter is at)
         self._series_s = {}              # pairs -> seconds a series of that size took alone (first series of phases)
-        self._frame_s = None             # seconds per frame of the filter (running mean over the last phase)
+        self._frame_s = None             # seconds per frame of the filter (median of the last frames)
+        self._frame_hist = []
         self.adaptive_first = True       # size the first series of a phase from those measurements
         self.first_series = 0            # > 0: fixed size of the first series of every phase
         self.profiled_handle = None
         self.gc_freeze = True            # see run()
-        # model_ramp: size every series of a phase from the measured series / frame times (_next_series) instead of the
-        # fixed 1.7 x ramp.  Measured on the driver's 20-frame bench, three runs each on one box: 246 frames/s against
-        # 250 (waiting for flow 0.86 against 0.77 ms per frame) although the last 12 frames run at 351 against 325
-        # frames/s -- off by default.
-        self.model_ramp = False
+        # model_ramp: the first series of a phase and the ones after it are sized from the measured series / frame times
+        # (_first_series: the smallest first series the ramp can follow; _next_series: the largest series that is done when
+        # the filter is through with the previous one) instead of the fixed 1.7 x ramp.  Driver's 20-frame bench, three
+        # runs each on one box: 245.2 against 244.2 frames/s; the plain frame loop (tools/pipe_trace.py) 254 against 248.
+        self.model_ramp = True
 
     # -- flow series ---------------------------------------------------------------------------------
     def _launch(self, k, end, most, alone=None, whole=None):
@@ -497,9 +498,17 @@ class FlowEKFPipeline:
         if model is None or not self.adaptive_first:
             return default
         t_a, b, n_a = model
+        F = max(self._frame_s, 1e-4)
+        if self.model_ramp:
+            # the smallest first series the ramp of _next_series can follow without shrinking: a series of as many pairs,
+            # running beside the filter (1.3 x), is done when the filter is through with these
+            for n1 in range(default, self.B + 1):
+                if 1.3 * (t_a + b * (n1 - n_a)) <= n1 * F:
+                    return n1
+            return self.B
         # the series after the first need not be a full one (_next_series ramps up to B): sized for one of at most 8 pairs
         t_full = t_a + b * (min(self.B, 8) - n_a)
-        n1 = int(np.ceil(1.3 * t_full / max(self._frame_s, 1e-4)))
+        n1 = int(np.ceil(1.3 * t_full / F))
         return max(default, min(self.B, n1))
 
     def flow_sync(self):
@@ -583,7 +592,12 @@ class FlowEKFPipeline:
                                 y_m_host=self.source.frame_at(k + 1)[1])
         e = self.kf.compute(obs, None, None, maskflow=self.maskflow)
         t2 = time.perf_counter()
-        self._frame_s = (t2 - t1) if self._frame_s is None else 0.8 * self._frame_s + 0.2 * (t2 - t1)
+        # what a frame of the filter takes: the median of the last few (the first frames of a filter's life carry
+        # first-use costs -- allocations, the first launches -- that a running mean drags along for a whole phase)
+        self._frame_hist.append(t2 - t1)
+        if len(self._frame_hist) > 8:
+            self._frame_hist.pop(0)
+        self._frame_s = float(np.median(self._frame_hist))
         self.t_flow += t1 - t0
         self.t_ekf += t2 - t1
         self.iters += getattr(self.kf, "niter", 1)

@@ -1,6 +1,6 @@
 # A/B of environment knobs on the driver's 20-step bench, three runs each, interleaved
 for rep in 1 2 3; do
-  for cfg in "A HYDRA_MI_NEWTON_DEV=1" "B HYDRA_MI_NEWTON_DEV=0"; do
+  for cfg in "A HYDRA_MI_MODEL_RAMP=1" "B HYDRA_MI_MODEL_RAMP=0"; do
     set -- $cfg
     tag=$1; shift
     env "$@" python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
