@@ -180,6 +180,39 @@ class ArraySource:
             if observed.shape != video.shape:
                 raise ValueError("observed must have the shape of video")
         self.video, self.masks, self.observed = video, masks, observed
+        self.pinned = False
+
+    def pin(self):
+        """Page-lock the arrays (hm_host_register): the frame ring then copies straight out of them -- no staging pass
+        through page-locked memory of its own (0.4 ms of a host core per 1024^2 frame + mask, and the first flow series
+        of a phase waits for the staging of all its frames).  False when the memory cannot be registered."""
+        if self.pinned:
+            return True
+        done = []
+        for a in (self.video, self.masks, self.observed):
+            if a is None or any(a is d for d in done):
+                continue
+            if not a.flags["WRITEABLE"] or _lib.lib().hm_host_register(ctypes.c_void_p(a.ctypes.data), a.nbytes) != 0:
+                for d in done:
+                    _lib.lib().hm_host_unregister(ctypes.c_void_p(d.ctypes.data))
+                return False
+            done.append(a)
+        self._pinned_arrays = done
+        self.pinned = True
+        return True
+
+    def unpin(self):
+        if self.pinned:
+            for d in self._pinned_arrays:
+                _lib.lib().hm_host_unregister(ctypes.c_void_p(d.ctypes.data))
+            self._pinned_arrays = []
+            self.pinned = False
+
+    def __del__(self):
+        try:
+            self.unpin()
+        except Exception:               # noqa: BLE001 -- interpreter shutdown
+            pass
 
     def __len__(self):
         return self.video.shape[0]
@@ -226,6 +259,8 @@ class FrameRing:
         self._staged = 0
         self.lo = self.hi = 0                                    # frames [lo, hi) are in the ring (queued or there)
         self.bytes_uploaded = 0
+        if hasattr(source, "pin"):
+            source.pin()
 
     def reset(self, first):
         with self._lock:
@@ -259,15 +294,21 @@ class FrameRing:
                 if self.planes == 3:
                     parts.append((self.d_observed, fr if ob is None else ob))
                 s = f % self.R
+                direct = getattr(self.src, "pinned", False)
+                staged = False
                 for i, (buf, a) in enumerate(parts):
-                    st[i][:] = np.asarray(a, np.uint8).reshape(-1)
-                    src = self._stage.value + (self._staged * self.planes + i) * self.n
+                    if direct and a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]:
+                        src = a.ctypes.data                  # the source's own page-locked memory
+                    else:
+                        staged = True
+                        st[i][:] = np.asarray(a, np.uint8).reshape(-1)
+                        src = self._stage.value + (self._staged * self.planes + i) * self.n
                     _lib.check(L.hm_dev_upload_async(self.device, buf.ptr + s * self.n, src, self.n, self._stream), "hm_dev_upload_async")
                     if s < self.extra:                            # the mirror behind the ring
                         _lib.check(L.hm_dev_upload_async(self.device, buf.ptr + (self.R + s) * self.n, src, self.n, self._stream),
                                    "hm_dev_upload_async")
                     self.bytes_uploaded += self.n
-                self._staged += 1
+                self._staged += 1 if staged else 0
                 self.hi = f + 1
             self.lo = max(self.lo, self.hi - self.R)
 
@@ -387,14 +428,17 @@ class FlowEKFPipeline:
         self._series_s = {}              # pairs -> seconds a series of that size took alone (first series of phases)
         self._frame_s = None             # seconds per frame of the filter (median of the last frames)
         self._frame_hist = []
+        self._calibrated = False
         self.adaptive_first = True       # size the first series of a phase from those measurements
         self.first_series = 0            # > 0: fixed size of the first series of every phase
         self.profiled_handle = None
         self.gc_freeze = True            # see run()
-        # model_ramp: the first series of a phase and the ones after it are sized from the measured series / frame times
-        # (_first_series: the smallest first series the ramp can follow; _next_series: the largest series that is done when
-        # the filter is through with the previous one) instead of the fixed 1.7 x ramp.  Driver's 20-frame bench, three
-        # runs each on one box: 245.2 against 244.2 frames/s; the plain frame loop (tools/pipe_trace.py) 254 against 248.
+        # model_ramp: the first series of a phase and the ones after it are sized from measured series / frame times
+        # (calibrate: what a series of 2 and of B pairs takes alone; _first_series: the smallest first series the ramp can
+        # follow; _next_series: the largest series that is done when the filter is through with the previous one, at least
+        # one pair more than that one) instead of a fixed 1.7 x ramp from a first series sized for a full one behind it.
+        # Driver's 20-frame bench, three runs each on one box: 255.0 against 244.0 frames/s (waiting for flow 0.62
+        # against 0.92 ms per frame: a first series of 4 or 5 pairs instead of 8), 64 frames: 307.7 against 301.3.
         self.model_ramp = True
 
     # -- flow series ---------------------------------------------------------------------------------
@@ -449,11 +493,13 @@ class FlowEKFPipeline:
         if model is None or not self.adaptive_first or not self.model_ramp:
             return guess
         # with measurements: the largest series that is done (beside the filter: ~1.3 x as long as alone) by the time the
-        # filter is through with the `last` frames it has just been given -- a steeper ramp has the filter wait for it
+        # filter is through with the `last` frames it has just been given -- a steeper ramp has the filter wait for it --
+        # but at least one pair more than the last one: larger series cost less per pair, and the wait for a series that
+        # is one pair too large is a millisecond or two, once
         a, b, n_a = model
         room = last * self._frame_s / 1.3
         n = int(n_a + (room - a) / b) if b > 0 else self.B
-        return max(min(last, self.B), min(self.B, n, 2 * last))
+        return min(self.B, max(last + 1, min(n, 2 * last)))
 
     def _series_model(self):
         """(a, b, n_a): a series of n pairs alone takes about a + b (n - n_a) seconds, from the first series of earlier
@@ -517,6 +563,29 @@ class FlowEKFPipeline:
             self._wait(f)
             f["thread"] = _Done
 
+    def calibrate(self, first=0):
+        """What a flow series of 2 and of B pairs takes with nothing beside it (seconds, kept in _series_s for
+        _first_series / _next_series): three calls on the frames first .. first + B, the first of which also absorbs the
+        one-time costs of a handle's first launches (measured as part of a phase's first series they made a series of 2
+        pairs look like 9.7 instead of 6.8 ms, and every series after it was sized from that).  ~30 ms at 1024^2, once
+        per pipeline, at the start of its first phase."""
+        nb = min(self.B, self.F - 1 - first)
+        if nb < 2 or self.concurrent_series:
+            return
+        n, B = self._px, self.B
+        self.ring.ensure(first + nb + 1, first)
+        self.ring.sync()
+        bf = self.bfs[0]
+        if self.cu_reserve:
+            bf.tune("whole_chip", 1)
+        for pairs, keep in ((2, False), (2, True), (nb, True)):
+            t0 = time.perf_counter()
+            bf.calc_dev(pairs, self.ring.run_ptr(first), self.ring.run_ptr(first) + n, self.d_u.ptr, self.d_v.ptr)
+            bf.sync()
+            if keep:
+                self._series_s[pairs] = min(self._series_s.get(pairs, 1e9), time.perf_counter() - t0)
+        self._calibrated = True
+
     def begin(self, first=0, end=None):
         """Start a phase: the pairs first .. end-1 will be asked for in order."""
         self.flow_sync()
@@ -526,6 +595,10 @@ class FlowEKFPipeline:
         self._cursor = first
         if not self.resident:
             self.ring.reset(first)               # nothing of an earlier phase is assumed to be in the ring
+        if self.model_ramp and self.adaptive_first and not self._calibrated:
+            self.calibrate(first)
+            if not self.resident:
+                self.ring.reset(first)
 
     def _top_up(self):
         """Keep as many series in flight as there are handles (one unless concurrent_series) -- two at the very start of
@@ -597,7 +670,8 @@ class FlowEKFPipeline:
         self._frame_hist.append(t2 - t1)
         if len(self._frame_hist) > 8:
             self._frame_hist.pop(0)
-        self._frame_s = float(np.median(self._frame_hist))
+        # (with fewer than five on record the fastest one: the slow ones are the first-use frames)
+        self._frame_s = float(np.median(self._frame_hist)) if len(self._frame_hist) >= 5 else float(min(self._frame_hist))
         self.t_flow += t1 - t0
         self.t_ekf += t2 - t1
         self.iters += getattr(self.kf, "niter", 1)
