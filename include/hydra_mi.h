@@ -53,9 +53,6 @@ int hm_copy_stream_sync(int device, void *stream);
 int hm_host_alloc(uint64_t bytes, void **out);
 int hm_host_free(void *ptr);
 int hm_dev_upload_async(int device, void *dst, const void *src, uint64_t bytes, void *stream);
-/* page-lock / release memory the caller owns (frames that are already in host memory go up without a staging copy) */
-int hm_host_register(void *ptr, uint64_t bytes);
-int hm_host_unregister(void *ptr);
 
 /* ------------------------------------------------------------------------
  * Brox optical flow.  Replaces cv::cuda::BroxOpticalFlow as used by

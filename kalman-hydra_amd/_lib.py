@@ -28,8 +28,6 @@ SIGNATURES = {
     "hm_dev_free": (ctypes.c_int, [ctypes.c_int, c_vp]),
     "hm_dev_upload": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, ctypes.c_uint64]),
     "hm_dev_download": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, ctypes.c_uint64]),
-    "hm_host_register": (ctypes.c_int, [c_vp, ctypes.c_uint64]),
-    "hm_host_unregister": (ctypes.c_int, [c_vp]),
     "hm_copy_stream_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(c_vp)]),
     "hm_copy_stream_destroy": (ctypes.c_int, [ctypes.c_int, c_vp]),
     "hm_copy_stream_sync": (ctypes.c_int, [ctypes.c_int, c_vp]),

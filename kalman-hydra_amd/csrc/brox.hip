@@ -123,20 +123,6 @@ extern "C" int hm_host_free(void *ptr)
     HM_HIP(hipHostFree(ptr));
     return HM_OK;
 }
-// Page-lock memory the caller already owns (a decoded video, frames a capture library filled): copies from it by
-// hm_dev_upload_async are DMA transfers without a staging pass through hm_host_alloc memory.
-extern "C" int hm_host_register(void *ptr, uint64_t bytes)
-{
-    HM_ARG(ptr != nullptr && bytes > 0, "hm_host_register: bad argument");
-    HM_HIP(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
-    return HM_OK;
-}
-extern "C" int hm_host_unregister(void *ptr)
-{
-    if (!ptr) return HM_OK;
-    HM_HIP(hipHostUnregister(ptr));
-    return HM_OK;
-}
 extern "C" int hm_dev_upload_async(int device, void *dst, const void *src, uint64_t bytes, void *stream)
 {
     HM_ARG(dst && src && stream, "hm_dev_upload_async: NULL pointer");

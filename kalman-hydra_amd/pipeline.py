@@ -180,39 +180,6 @@ class ArraySource:
             if observed.shape != video.shape:
                 raise ValueError("observed must have the shape of video")
         self.video, self.masks, self.observed = video, masks, observed
-        self.pinned = False
-
-    def pin(self):
-        """Page-lock the arrays (hm_host_register): the frame ring then copies straight out of them -- no staging pass
-        through page-locked memory of its own (0.4 ms of a host core per 1024^2 frame + mask, and the first flow series
-        of a phase waits for the staging of all its frames).  False when the memory cannot be registered."""
-        if self.pinned:
-            return True
-        done = []
-        for a in (self.video, self.masks, self.observed):
-            if a is None or any(a is d for d in done):
-                continue
-            if not a.flags["WRITEABLE"] or _lib.lib().hm_host_register(ctypes.c_void_p(a.ctypes.data), a.nbytes) != 0:
-                for d in done:
-                    _lib.lib().hm_host_unregister(ctypes.c_void_p(d.ctypes.data))
-                return False
-            done.append(a)
-        self._pinned_arrays = done
-        self.pinned = True
-        return True
-
-    def unpin(self):
-        if self.pinned:
-            for d in self._pinned_arrays:
-                _lib.lib().hm_host_unregister(ctypes.c_void_p(d.ctypes.data))
-            self._pinned_arrays = []
-            self.pinned = False
-
-    def __del__(self):
-        try:
-            self.unpin()
-        except Exception:               # noqa: BLE001 -- interpreter shutdown
-            pass
 
     def __len__(self):
         return self.video.shape[0]
@@ -259,8 +226,6 @@ class FrameRing:
         self._staged = 0
         self.lo = self.hi = 0                                    # frames [lo, hi) are in the ring (queued or there)
         self.bytes_uploaded = 0
-        if hasattr(source, "pin"):
-            source.pin()
 
     def reset(self, first):
         with self._lock:
@@ -294,21 +259,15 @@ class FrameRing:
                 if self.planes == 3:
                     parts.append((self.d_observed, fr if ob is None else ob))
                 s = f % self.R
-                direct = getattr(self.src, "pinned", False)
-                staged = False
                 for i, (buf, a) in enumerate(parts):
-                    if direct and a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]:
-                        src = a.ctypes.data                  # the source's own page-locked memory
-                    else:
-                        staged = True
-                        st[i][:] = np.asarray(a, np.uint8).reshape(-1)
-                        src = self._stage.value + (self._staged * self.planes + i) * self.n
+                    st[i][:] = np.asarray(a, np.uint8).reshape(-1)
+                    src = self._stage.value + (self._staged * self.planes + i) * self.n
                     _lib.check(L.hm_dev_upload_async(self.device, buf.ptr + s * self.n, src, self.n, self._stream), "hm_dev_upload_async")
                     if s < self.extra:                            # the mirror behind the ring
                         _lib.check(L.hm_dev_upload_async(self.device, buf.ptr + (self.R + s) * self.n, src, self.n, self._stream),
                                    "hm_dev_upload_async")
                     self.bytes_uploaded += self.n
-                self._staged += 1 if staged else 0
+                self._staged += 1
                 self.hi = f + 1
             self.lo = max(self.lo, self.hi - self.R)
 
@@ -596,9 +555,7 @@ class FlowEKFPipeline:
         if not self.resident:
             self.ring.reset(first)               # nothing of an earlier phase is assumed to be in the ring
         if self.model_ramp and self.adaptive_first and not self._calibrated:
-            self.calibrate(first)
-            if not self.resident:
-                self.ring.reset(first)
+            self.calibrate(first)                # (the frames it uploads are the first ones of this phase: they stay)
 
     def _top_up(self):
         """Keep as many series in flight as there are handles (one unless concurrent_series) -- two at the very start of
