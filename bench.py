@@ -405,6 +405,8 @@ def main():
             self.bf = self.pipe.bf
             if args.split_start:
                 self.pipe.split_start = True
+                if len(self.pipe.bfs) < 2:               # (not inside the timed region)
+                    self.pipe.bfs.append(self.pipe._make_handle())
             if args.first_series:
                 self.pipe.first_series = args.first_series
             if os.environ.get("HYDRA_MI_BENCH_TRACE"):

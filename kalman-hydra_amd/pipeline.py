@@ -372,7 +372,8 @@ class FlowEKFPipeline:
         # series at a time, as before.  The second handle is created when it is first needed.  Measured at 1024^2 / 201
         # vertices, 20 frames: 212 frames/s against 229 without (the two series slow each other and the filter's first
         # frames more than the earlier start gains: 0.92 instead of 0.73 ms per frame of waiting for flow); 64 frames: 286
-        # against 292.  Off by default; the results are the same bits either way.
+        # against 292.  Again at the end of round 3 (calibrated series sizes, the second handle created before the timed region):
+        # 249.5 against 254.4 frames/s at 20 frames, three runs each.  Off by default; the results are the same bits either way.
         self.split_start = False
         self.t_flow = self.t_ekf = 0.0
         self.iters = 0

@@ -555,3 +555,32 @@ def test_newton_worker_equals_synchronous_call(hm):
             assert np.array_equal(X, Y) and its.value == its2.value
     finally:
         L.hm_ms_worker_destroy(w)
+
+
+def test_flow_series_are_sized_from_the_measured_model(hm):
+    """FlowEKFPipeline._first_series / _next_series (host logic, no GPU): with the calibrated times of a series of 2 and of B
+    pairs and the filter's frame time, a phase starts with the smallest series the ramp can follow and every next series
+    is the largest one that is done (beside the filter: 1.3 x) when the filter is through with the last, at least one
+    pair more, never more than B; without measurements the fixed ramp 2, 3, 5, 8."""
+    from hydra_mi.pipeline import FlowEKFPipeline
+    p = object.__new__(FlowEKFPipeline)
+    p.B, p.concurrent_series, p.first_series, p.adaptive_first, p.model_ramp = 8, False, 0, True, True
+    p._series_s, p._frame_s = {}, None
+    assert p._first_series() == 2 and [p._next_series(n) for n in (2, 3, 5, 8)] == [3, 5, 8, 8]
+    # a series of n pairs alone: 3.9 + 1.46 n ms (1024^2 on an MI355X), a frame of the filter 3.2 ms
+    p._series_s = {2: 6.82e-3, 8: 15.58e-3}
+    p._frame_s = 3.2e-3
+    n1 = p._first_series()
+    assert n1 == 4                                           # 1.3 x T(4) = 12.7 ms <= 4 x 3.2 ms, 1.3 x T(3) = 10.8 > 9.6
+    sizes = [n1]
+    while sizes[-1] < p.B:
+        sizes.append(p._next_series(sizes[-1]))
+    assert sizes == [4, 5, 6, 7, 8]
+    assert p._next_series(8) == 8
+    p._frame_s = 10e-3                                       # a slow filter: the flow is never waited for, series double
+    assert p._first_series() == 2 and p._next_series(2) == 4 and p._next_series(4) == 8
+    p.B = 16
+    p._frame_s = 3.2e-3
+    assert [p._next_series(n) for n in (8, 10, 14)] == [10, 14, 16]
+    p.model_ramp = False                                     # the fixed rule again
+    assert p._next_series(4) == 6
