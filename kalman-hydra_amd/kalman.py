@@ -134,6 +134,8 @@ def _rows_unique(a):
 
 
 class KFState:
+    _ori_stale = False
+
     def __init__(self, distmesh, im, flow, cuda, eps_F=1, eps_Z=1e-3, eps_J=1e-3, eps_M=1e-3, vel=None,
                  sparse=True, multi=True, verbose=False, renderer=None, device=0):
         self.multi = multi
@@ -315,6 +317,31 @@ class KFState:
         self.ori = np.sign(cr)
         with np.errstate(divide="ignore", invalid="ignore"):
             self.sineface = cr / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+
+    # ori / sineface (:410-414): the fused update tests the orientation of the faces natively (hm_update_run) and only
+    # marks these stale; they are formed from the state when somebody looks (eight NumPy passes over the faces, ~50 us of
+    # every frame otherwise)
+    @property
+    def ori(self):
+        if self._ori_stale:
+            self._ori_stale = False
+            self.update_orientation()
+        return self._ori
+
+    @ori.setter
+    def ori(self, value):
+        self._ori, self._ori_stale = value, False
+
+    @property
+    def sineface(self):
+        if self._ori_stale:
+            self._ori_stale = False
+            self.update_orientation()
+        return self._sineface
+
+    @sineface.setter
+    def sineface(self, value):
+        self._sineface = value
 
     def size(self):
         return self.X.shape[0]
@@ -602,7 +629,7 @@ class IteratedKalmanFilter(KalmanFilter):
                 self._say("-- e_im: %d, e_fx: %d, e_fy: %d, e_m: %d" % tuple(e))
         st.X = X
         st.W = W
-        st.update_orientation()
+        st._ori_stale = True             # (update_orientation when ori / sineface are next read)
         self.niter = info["niter"]
         stats.niter += self.niter
         self.reverted, self.converged = info["reverted"], info["converged"]
