@@ -57,6 +57,10 @@ class Renderer:
         self.velocities = np.array(vel, np.float64).reshape(self.vertices.shape)
         self._obs = None
         self._palette = None
+        for kv in os.environ.get("HYDRA_MI_TUNE", "").split(","):          # experiments: "key=value,..." for hm_ctx_tune
+            if "=" in kv:
+                k, v = kv.split("=")
+                _lib.check(L.hm_ctx_tune(h, k.strip().encode(), int(v)), "hm_ctx_tune")
         self.frame_in_place = False             # set by KalmanFilter.compute() while the frame it uploaded is current
         self._cov_serial = 0                    # names the covariance resident on the device (DeviceCovariance)
         self.current_frame = tex
