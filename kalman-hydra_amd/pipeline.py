@@ -508,8 +508,11 @@ class FlowEKFPipeline:
         if self.model_ramp:
             # the smallest first series the ramp of _next_series can follow without shrinking: a series of as many pairs,
             # running beside the filter (1.3 x), is done when the filter is through with these
+            # (1.25, not the 1.3 of the series that follow: at 1024^2 / 201 vertices the choice between 4 and 5 pairs sat
+            # exactly on the measured frame time -- 3.17 ms -- and fell either way from run to run: 258-260 frames/s with
+            # 4, 250-252 with 5 over the driver's 20 frames)
             for n1 in range(default, self.B + 1):
-                if 1.3 * (t_a + b * (n1 - n_a)) <= n1 * F:
+                if 1.25 * (t_a + b * (n1 - n_a)) <= n1 * F:
                     return n1
             return self.B
         # the series after the first need not be a full one (_next_series ramps up to B): sized for one of at most 8 pairs
