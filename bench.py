@@ -91,18 +91,22 @@ def _sor_figures(ms, launches, pxit, px, traffic_per_launch):
             "launches": launches, "avg_launch_us": 1e3 * ms / n}
 
 
-def sor_roofline(sor_ms, sor_launches, sor_pxit, sor_px, pmc, profiled, levels=None):
+def sor_roofline(sor_ms, sor_launches, sor_pxit, sor_px, pmc, profiled, levels=None, pairs=8):
     """The roofline block of the JSON line.  sor_pxit = sum over the timed launches of pixels x fused
     iterations, sor_px = sum of pixels (one pass over memory each); levels = hm_brox_profile_levels."""
     out = {"bound": "hbm", "kernel": "k_sor", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
            "bytes_per_pixel_iteration": SOR_BYTES_PER_PIXEL_ITERATION, "limited_by": SOR_LIMITED_BY,
            "profiled": profiled}
-    out.update(_sor_figures(sor_ms, sor_launches, sor_pxit, sor_px, float(pmc["traffic_bytes_per_launch"]) if pmc else None))
+    # the PMC passes were taken on series of 8 pairs; every launch's traffic is proportional to the pairs it covers
+    scale = pairs / 8.0
+    # (the series average only for the same launches: a series of fewer pairs takes more levels in one launch each)
+    same_mix = pmc is not None and 2 * sor_launches == int(pmc.get("launches", 0))
+    out.update(_sor_figures(sor_ms, sor_launches, sor_pxit, sor_px, scale * float(pmc["traffic_bytes_per_launch"]) if same_mix else None))
     if levels and levels[0]["launches"] > 0:
         l0 = levels[0]
         tl = None
-        if pmc and pmc.get("finest_level", {}).get("pixels_per_launch") == l0["pixels"] / l0["launches"]:
-            tl = float(pmc["finest_level"]["traffic_bytes_per_launch"])
+        if pmc and scale * pmc.get("finest_level", {}).get("pixels_per_launch", -1) == l0["pixels"] / l0["launches"]:
+            tl = scale * float(pmc["finest_level"]["traffic_bytes_per_launch"])
         f = _sor_figures(l0["ms"], l0["launches"], l0["pixel_iterations"], l0["pixels"], tl)
         f["level"] = "%dx%d" % (l0["w"], l0["h"])
         out["finest_level"] = f
@@ -438,6 +442,9 @@ def main():
     # the flow series of the timed region start small and grow to B pairs (pipeline.py: sized from what series and
     # frames have taken so far); the first one of B pairs is profiled (kernel start/stop events for every SOR launch)
     tracks[0].pipe.profile_full = True
+    # (with series sized from measurements a timed region of 20 frames has series of 4, 5 and 6 pairs: the first one of
+    # at least 5 that runs beside the filter is the one profiled; the PMC traffic per launch scales with the pairs)
+    tracks[0].pipe.profile_min_pairs = min(B, 5) if K < 40 else B      # (a full series only comes after ~30 frames)
 
     if world > 1:
         dist.barrier()
@@ -540,12 +547,14 @@ def main():
                                       "ekf_predict": 1e3 * predtime / K, "ekf_update": 1e3 * updatetime / K,
                                       "iekf_iterations": iters / K},
             "roofline": sor_roofline(sor_ms, sor_launches, sor_pxit, sor_px,
-                                     pmc_traffic() if (n == 1024 and prof_pairs == 8) else None,
-                                     "one flow series (%d pairs) %s, the filter's kernels running beside it" % (prof_pairs, prof_where), levels),
+                                     pmc_traffic() if n == 1024 else None,
+                                     "one flow series (%d pairs) %s, %s" % (prof_pairs, prof_where, "the filter's kernels running beside it"
+                                                                             if prof_where == "of the timed region" else "nothing beside it"),
+                                     levels, prof_pairs),
         }
         # ... and with the chip to itself (the figure the 40 % target of north_star is about)
-        ra = sor_roofline(alone[0], alone[1], alone[2], alone[3], pmc_traffic() if (n == 1024 and alone_pairs == 8) else None,
-                          "one flow series (%d pairs) after the timed region, nothing beside it" % alone_pairs, alone_levels)
+        ra = sor_roofline(alone[0], alone[1], alone[2], alone[3], pmc_traffic() if n == 1024 else None,
+                          "one flow series (%d pairs) after the timed region, nothing beside it" % alone_pairs, alone_levels, alone_pairs)
         out["roofline"]["alone"] = {k: ra[k] for k in ("achieved", "frac", "traffic", "traffic_source", "achieved_contract",
                                                          "frac_contract", "launches", "avg_launch_us", "profiled") if k in ra}
         if "finest_level" in ra:

@@ -379,6 +379,7 @@ class FlowEKFPipeline:
         self.iters = 0
         self.frame_done = []             # perf_counter() at the end of every step (steady-state rates)
         self.profile_full, self.profiled_pairs = False, 0    # set profile_full: the next series of flow_batch pairs is profiled
+        self.profile_min_pairs = None    # ... or of at least this many (a series that runs beside the filter, not a phase's first)
         self.trace = None                # callable(str) for per-frame scheduling messages
         # pairs [lo, hi) of `ready` have their flow in buffer `buf`; the series in `_flying` (oldest first; each a dict
         # lo, hi, buf, handle, thread) are being computed while the filter works on `ready`
@@ -414,7 +415,7 @@ class FlowEKFPipeline:
 
         def work():
             try:
-                if self.profile_full and self.profiled_pairs == 0 and nb == self.B:
+                if self.profile_full and self.profiled_pairs == 0 and nb >= (self.profile_min_pairs or self.B) and not first:
                     bf.profile(True)                    # hm_brox_profile around the first series of flow_batch pairs
                     self.profiled_pairs, self.profiled_handle, self.profile_full = nb, bf, False
                 elif bf is self.profiled_handle:
