@@ -273,6 +273,22 @@ __global__ __launch_bounds__(NEWTON4_NT) void k_ms_newton4(Newton4Args a)
         if (act) { P[pb * 2 * NEWTON4_NT + 2 * v] = sx; P[pb * 2 * NEWTON4_NT + 2 * v + 1] = sy; }
         __syncthreads();
     };
+    // publish a vector AND sum a value over the workgroup behind ONE barrier: the vector goes into the buffer nobody reads
+    // any more, the wave's partial sum into the half of `part` nobody reads any more, then everybody sees both
+    auto publish_sum = [&](const double sx, const double sy, double val) -> double {
+        pb ^= 1;
+        if (act) { P[pb * 2 * NEWTON4_NT + 2 * v] = sx; P[pb * 2 * NEWTON4_NT + 2 * v + 1] = sy; }
+        double unused2 = 0.0;
+        d_wave_sum2(val, unused2);
+        double *q = part + flip * 2 * (NEWTON4_NT / 64);
+        flip ^= 1;
+        if ((threadIdx.x & 63) == 63) q[2 * (threadIdx.x >> 6)] = val;
+        __syncthreads();
+        double sa = 0.0;
+#pragma unroll
+        for (int w = 0; w < NEWTON4_NT / 64; w++) sa += q[2 * w];
+        return sa;
+    };
     for (int st = 0; st < a.steps; st++) {
         const double xy[2] = {Xy[0], Xy[1]}, xw[2] = {Xw[0], Xw[1]};
         double py[2] = {Xy[0], Xy[1]}, pw[2] = {Xw[0], Xw[1]};
@@ -285,12 +301,12 @@ __global__ __launch_bounds__(NEWTON4_NT) void k_ms_newton4(Newton4Args a)
                 dn = ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
                 pn = ((py[0] * py[0] + py[1] * py[1]) + pw[0] * pw[0]) + pw[1] * pw[1];
             }
+            // (the positions the springs are evaluated at go to LDS behind the same barrier as the two sums)
+            if (act) { Y[2 * v] = Xy[0]; Y[2 * v + 1] = Xy[1]; }
             d_wg_sum2(dn, pn, part, flip);
             if (!(n < a.maxiter && sqrt(dn) > a.tol * sqrt(pn))) break;
             oy[0] = py[0]; oy[1] = py[1]; ow[0] = pw[0]; ow[1] = pw[1];
             // the springs at the current state X, bar by bar
-            if (act) { Y[2 * v] = Xy[0]; Y[2 * v + 1] = Xy[1]; }
-            __syncthreads();
             for (int b = t; b < I; b += NEWTON4_NT) {
                 const int va = bars[2 * b], vb = bars[2 * b + 1];
                 const double dx = Y[2 * va] - Y[2 * vb], dy = Y[2 * va + 1] - Y[2 * vb + 1];
@@ -313,28 +329,26 @@ __global__ __launch_bounds__(NEWTON4_NT) void k_ms_newton4(Newton4Args a)
             const double g1[2] = {py[0] - xy[0] - dt * Xw[0], py[1] - xy[1] - dt * Xw[1]};
             const double g2[2] = {pw[0] - xw[0] - dt * (f0 / M), pw[1] - xw[1] - dt * (f1 / M)};
             const double rhs[2] = {g1[0] + dt * g2[0], g1[1] + dt * g2[1]};
-            double bn = rhs[0] * rhs[0] + rhs[1] * rhs[1], unused = 0.0;
-            d_wg_sum2(bn, unused, part, flip);
-            bn = sqrt(bn);
+            // |rhs|, and rhs -- the first term of the series below -- published behind the same barrier
+            double bn = sqrt(publish_sum(rhs[0], rhs[1], rhs[0] * rhs[0] + rhs[1] * rhs[1]));
             double s1[2] = {0.0, 0.0};
             if (bn != 0.0) {
                 // S = I - a2 dfdy with |a2 dfdy| of a few percent: the series s = sum (a2 dfdy)^k rhs gains a digit and a
-                // half per term, and a term costs one gather and one sum over the workgroup -- the host's conjugate
-                // gradients take nine steps instead of twelve, but each with two sums and two divisions in its dependent
-                // chain (measured: 0.6 us per step here, a Newton iteration in 7.7 us; in this form 4.6).  Same stopping rule:
-                // the remainder below the rounding of the state the correction is subtracted from.
+                // half per term, and a term costs one gather of the neighbours' vector and ONE barrier (the next term is
+                // published and its norm summed behind the same one) -- the host's conjugate gradients take nine steps
+                // instead of twelve, but each with two sums and two divisions in its dependent chain (measured: a Newton
+                // iteration in 7.7 us with conjugate gradients, 6.7 with the series -- with two barriers per term and with
+                // one alike: the gather's dependent chain and the lane sums, not the barriers, are what a term costs).  Same
+                // stopping rule: the remainder below the rounding of the state the correction is subtracted from.
                 const double stop = fmax(1e-15 * bn, 1e-16 * sqrt(pn));
-                double r[2] = {rhs[0], rhs[1]};              // the term being added
+                double r[2] = {rhs[0], rhs[1]};              // the term being added (in P[pb] already)
                 bool ok = false;
                 for (int it = 0; it < 200; it++) {
                     s1[0] += r[0]; s1[1] += r[1];
-                    publish(r[0], r[1]);
                     double tx, ty;
                     apply(r[0], r[1], tx, ty);
                     r[0] = a2 * tx; r[1] = a2 * ty;
-                    double rs = r[0] * r[0] + r[1] * r[1];
-                    unused = 0.0;
-                    d_wg_sum2(rs, unused, part, flip);
+                    const double rs = publish_sum(r[0], r[1], r[0] * r[0] + r[1] * r[1]);
                     if (sqrt(rs) <= stop) { ok = true; break; }
                 }
                 if (!ok) bad = 1;
