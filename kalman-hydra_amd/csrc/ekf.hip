@@ -1888,7 +1888,10 @@ extern "C" int hm_newton_dev_start(hm_ctx_t h, int N, int n_bars, const int32_t 
         HM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
         if (greatest != least) { HM_HIP(hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, greatest)); }
         else HM_HIP(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
-        HM_HIP(hipHostMalloc((void **)&h->pin_n4, ((size_t)8 * N + 4) * sizeof(double), hipHostMallocDefault));
+        // coherent (fine-grained): the kernel reads what the host has just written and the host reads what the kernel wrote,
+        // launch after launch at the same addresses -- from a default (cacheable) allocation the kernel now and then read the
+        // previous frame's state out of the L2 (one track in fifty came out different)
+        HM_HIP(hipHostMalloc((void **)&h->pin_n4, ((size_t)8 * N + 4) * sizeof(double), hipHostMallocCoherent));
         memset(h->pin_n4, 0, ((size_t)8 * N + 4) * sizeof(double));
     }
     const bool same = h->n4_bars.size() == 2 * (size_t)n_bars && memcmp(h->n4_bars.data(), bars, 2 * (size_t)n_bars * sizeof(int32_t)) == 0;
@@ -1920,15 +1923,19 @@ extern "C" int hm_newton_dev_start(hm_ctx_t h, int N, int n_bars, const int32_t 
                 HM_HIP(hm_malloc((void **)&h->d_n4l0, (size_t)n_bars * sizeof(double)));
                 h->n4cap = n_bars;
             }
-            HM_HIP(hipMemcpy(h->d_n4nbr, nbr.data(), nbr.size() * sizeof(int), hipMemcpyHostToDevice));
-            HM_HIP(hipMemcpy(h->d_n4nbb, nbb.data(), nbb.size() * sizeof(int), hipMemcpyHostToDevice));
-            HM_HIP(hipMemcpy(h->d_n4bars, bars, 2 * (size_t)n_bars * sizeof(int), hipMemcpyHostToDevice));
+            // on the kernel's own stream: a copy on the null stream is not ordered before a launch on a non-blocking
+            // stream (the kernel now and then started on tables that had not arrived: wrong neighbours, one track in fifty)
+            HM_HIP(hipMemcpyAsync(h->d_n4nbr, nbr.data(), nbr.size() * sizeof(int), hipMemcpyHostToDevice, h->stream3));
+            HM_HIP(hipMemcpyAsync(h->d_n4nbb, nbb.data(), nbb.size() * sizeof(int), hipMemcpyHostToDevice, h->stream3));
+            HM_HIP(hipMemcpyAsync(h->d_n4bars, h->n4_bars.data(), 2 * (size_t)n_bars * sizeof(int), hipMemcpyHostToDevice, h->stream3));
+            HM_HIP(hipStreamSynchronize(h->stream3));            // (nbr / nbb are locals)
         }
     }
     if (!h->n4deg) return 1;
     if (h->n4_l0.size() != (size_t)n_bars || memcmp(h->n4_l0.data(), l0, (size_t)n_bars * sizeof(double)) != 0) {
         h->n4_l0.assign(l0, l0 + n_bars);
-        HM_HIP(hipMemcpy(h->d_n4l0, l0, (size_t)n_bars * sizeof(double), hipMemcpyHostToDevice));
+        HM_HIP(hipMemcpyAsync(h->d_n4l0, h->n4_l0.data(), (size_t)n_bars * sizeof(double), hipMemcpyHostToDevice, h->stream3));
+        HM_HIP(hipStreamSynchronize(h->stream3));
     }
     const size_t n4 = (size_t)4 * N;
     memcpy(h->pin_n4, X, n4 * sizeof(double));
@@ -1954,9 +1961,15 @@ extern "C" int hm_newton_dev_finish(hm_ctx_t h, double *X, int *newton_iteration
     if (!h->n4_pending) { hm_set_error("hm_newton_dev_finish: no prediction was started"); return HM_ERR_STATE; }
     HM_HIP(hipSetDevice(h->device));
     const size_t n4 = (size_t)4 * h->N;
-    int rc = wait_ticket_on(h->stream3, h->pin_n4 + 2 * n4 + 2, (double)h->n4_ticket);
+    // The stream's completion, not the ticket: the kernel's result is 4N doubles written by four waves in strided 8-byte
+    // stores, and the ticket -- although written behind a system-scope fence and a barrier -- was seen by the host before
+    // the last of them had landed (one track in a hundred: positions of this prediction with velocities of the last one, or
+    // the other way round; tools/stress_determinism.py).  A stream that has completed has made all its writes visible; the
+    // kernel is usually long done when this is called (it was started at the end of the previous update), so the query
+    // returns at once.
+    hipError_t e = stream_wait(h->stream3);
     h->n4_pending = false;
-    if (rc) return rc;
+    if (e != hipSuccess) { hm_set_error("hm_newton_dev_finish: %s", hipGetErrorString(e)); return HM_ERR_HIP; }
     if (((const volatile double *)h->pin_n4)[2 * n4 + 2] != (double)h->n4_ticket) {
         hm_set_error("hm_newton_dev_finish: the kernel finished without reporting (ticket %lld missing)", h->n4_ticket);
         return HM_ERR_STATE;
