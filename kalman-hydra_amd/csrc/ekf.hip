@@ -1327,7 +1327,12 @@ extern "C" int hm_project_mask(hm_ctx_t h, const uint8_t *y_m, double *X, int *m
             return HM_ERR_STATE;
         }
         const int nmoved = (int)h->pin_pm[2 * n4];
-        if (nmoved) memcpy(X, h->pin_pm + n4, xb);
+        if (nmoved) {
+            // the projected state is N workgroups' strided stores: before it is read, the stream's completion rather than
+            // the ticket alone (hm_newton_dev_finish has the story; a frame that moves a vertex is rare enough for the query)
+            HM_HIP(stream_wait(s));
+            memcpy(X, h->pin_pm + n4, xb);
+        }
         if (moved) *moved = nmoved;
         return HM_OK;
     }

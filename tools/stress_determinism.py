@@ -44,6 +44,7 @@ def once():
     W = np.array(kf.state.W)
     pipe.close()
     kf.close()
+    kf.state.renderer.close()
     return out, W
 
 
