@@ -177,3 +177,35 @@ def test_streaming_frame_ring_equals_resident_video(hm):
         assert np.array_equal(got3[k][0], ref[k][0]) and got3[k][1] == ref[k][1] and got3[k][2] == ref[k][2], k
     for p in (pr, ps, pv, p2, p3):
         p.close()
+
+
+def test_streaming_track_repeats_bit_for_bit(hm):
+    """The whole frame loop -- flow series beside the filter, state prediction as a launch started by the update,
+    covariance queued ahead, speculative measurement -- repeated: every repetition gives the first one's states, iteration
+    counts and covariance bit for bit (tools/stress_determinism.py is this at 1024^2, 1200 repetitions; it is what found
+    the prediction's result being read before all of it had landed)."""
+    from hydra_mi import kalman, mesh, synth
+    from hydra_mi.pipeline import FlowEKFPipeline, threshold_mask
+    n, F = 128, 12
+    video, _, c, r = synth.disk_video(n, F, "translate_leftup", 1)
+    masks = np.stack([threshold_mask(f, 9) for f in video])
+    zero = np.zeros((n, n, 2), np.float32)
+
+    def once():
+        kf = kalman.IteratedMSKalmanFilter(mesh.disk_mesh(c[0], c[1], r - 1.0, 12.0), video[0], zero, True)
+        pipe = FlowEKFPipeline(kf, video, masks, flow_batch=4)
+        out = []
+        pipe.run(on_frame=lambda k, e: out.append((kf.state.X.copy(), kf.niter, kf.newton_iterations, e[0], e[3])))
+        W = np.array(kf.state.W)
+        pipe.close()
+        kf.close()
+        kf.state.renderer.close()
+        return out, W
+
+    ref, Wref = once()
+    assert len(ref) == F - 1 and all(o[1] >= 1 for o in ref)
+    for rep in range(25):
+        got, W = once()
+        for k in range(F - 1):
+            assert np.array_equal(got[k][0], ref[k][0]) and got[k][1:] == ref[k][1:], (rep, k)
+        assert np.array_equal(W, Wref), rep
