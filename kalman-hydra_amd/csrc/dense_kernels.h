@@ -619,24 +619,54 @@ __global__ __launch_bounds__(256) void k_assemble(const double *__restrict__ inv
 // ---- end of one iteration of hm_update_run ---------------------------------------------------------------
 // res (host-visible, coherent) = [step (n) | the four error sums of the render's per-strip partials (fixed order:
 // d_tile_partial_sums) | overflow flag | ticket | (spare) | factorisation time-out | flow x, flow y error sums against
-// the raw flow | (2 spare)].  One workgroup.  The ticket is written last, after a system-scope fence: a host that
-// sees it sees the rest.
+// the raw flow | checksum of this block | checksum of the tail block].  One workgroup.  The ticket is written last,
+// after a system-scope fence -- a host that sees it normally sees the rest; that the rest HAS landed the host checks
+// with the checksum (xor of the bit patterns of everything but ticket and checksums, low 52 bits, as a whole number):
+// the state prediction's result block, written in strided stores, was seen by the host with its ticket there and half
+// of its data not (hm_newton_dev_finish), and a wrong step would go unnoticed.
 #define RES_HEAD 12           // doubles behind the step in a result block
+#define RES_CHK 10            // ... of which this one is the block's checksum, RES_CHK + 1 that of the tail block
+
+// xor of x over the workgroup (NT threads, a multiple of 64), the same value in every thread
+template <int NT>
+__device__ __forceinline__ unsigned long long d_wg_xor(unsigned long long x, unsigned long long *s_part)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)(x & 0xffffffffull), o, 64), hi = __shfl_xor((unsigned)(x >> 32), o, 64);
+        x ^= ((unsigned long long)hi << 32) | lo;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = x;
+    __syncthreads();
+    unsigned long long r = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; w++) r ^= s_part[w];
+    return r;
+}
+
 __global__ __launch_bounds__(256) void k_iter_result(const double *__restrict__ step, int n, const double *__restrict__ partial,
                                                      int ntiles, const int *__restrict__ overflow,
                                                      const unsigned *__restrict__ flow_ctl, double *__restrict__ res, double ticket)
 {
     __shared__ double sp[RI_GROUPS * RI_NV];
     __shared__ double sums[RI_NV];
+    __shared__ unsigned long long s_x[256 / 64];
     const int t = threadIdx.x;
-    for (int i = t; i < n; i += 256) res[i] = step[i];
+    unsigned long long x = 0;
+    for (int i = t; i < n; i += 256) { const double v = step[i]; res[i] = v; x ^= (unsigned long long)__double_as_longlong(v); }
     d_tile_partial_sums(partial, ntiles, sp, sums);
     __syncthreads();
-    if (t < 4) res[n + t] = sums[t];
-    else if (t == 4) res[n + 4] = (double)*overflow;
-    else if (t == 5) res[n + 7] = (double)flow_ctl[1];   // a wait of the persistent factorisation launch timed out
-    else if (t == 6) res[n + 8] = sums[4];
-    else if (t == 7) res[n + 9] = sums[5];
+    double v = 0.0;
+    int slot = -1;
+    if (t < 4) { slot = t; v = sums[t]; }
+    else if (t == 4) { slot = 4; v = (double)*overflow; }
+    else if (t == 5) { slot = 7; v = (double)flow_ctl[1]; }  // a wait of the persistent factorisation launch timed out
+    else if (t == 6) { slot = 8; v = sums[4]; }
+    else if (t == 7) { slot = 9; v = sums[5]; }
+    if (slot >= 0) { res[n + slot] = v; x ^= (unsigned long long)__double_as_longlong(v); }
+    x = d_wg_xor<256>(x, s_x);
+    if (t == 0) res[n + RES_CHK] = (double)(x & ((1ull << 52) - 1));
     __threadfence_system();
     __syncthreads();
     if (t == 0) {
@@ -678,13 +708,17 @@ __global__ __launch_bounds__(256) void k_gains(const double *__restrict__ W, con
 }
 
 // what the host wants of the end of an update -- Hz components (n x 4), gains (3 x n) -- into pinned host memory,
-// then the ticket (k_iter_result's protocol)
+// their checksum (k_iter_result's) into chk_slot, then the ticket
 __global__ __launch_bounds__(1024) void k_tail_result(const double *__restrict__ Hzc, const double *__restrict__ gain, int n,
                                                       double *__restrict__ pin_hzc, double *__restrict__ pin_gain,
-                                                      double *__restrict__ ticket_slot, double ticket)
+                                                      double *__restrict__ ticket_slot, double ticket, double *__restrict__ chk_slot)
 {
-    for (int i = threadIdx.x; i < 4 * n; i += 1024) pin_hzc[i] = Hzc[i];
-    for (int i = threadIdx.x; i < 3 * n; i += 1024) pin_gain[i] = gain[i];
+    __shared__ unsigned long long s_x[1024 / 64];
+    unsigned long long x = 0;
+    for (int i = threadIdx.x; i < 4 * n; i += 1024) { const double v = Hzc[i]; pin_hzc[i] = v; x ^= (unsigned long long)__double_as_longlong(v); }
+    for (int i = threadIdx.x; i < 3 * n; i += 1024) { const double v = gain[i]; pin_gain[i] = v; x ^= (unsigned long long)__double_as_longlong(v); }
+    x = d_wg_xor<1024>(x, s_x);
+    if (threadIdx.x == 0) *chk_slot = (double)(x & ((1ull << 52) - 1));
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {

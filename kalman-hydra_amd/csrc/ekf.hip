@@ -1378,6 +1378,31 @@ extern "C" int hm_cov_fetch(hm_ctx_t h, double *W_out)
 // synchronisation remains as the fallback.
 static int wait_ticket(hm_ctx *h, const double *slot, double want) { return wait_ticket_on(h->stream, slot, want); }
 
+// xor of the bit patterns of n doubles of host-visible memory (read as they are now), continued from x
+static unsigned long long xor_bits(const double *p, size_t n, unsigned long long x = 0)
+{
+    const volatile unsigned long long *q = (const volatile unsigned long long *)p;
+    for (size_t i = 0; i < n; i++) x ^= q[i];
+    return x;
+}
+// A result block whose ticket has arrived: has all of it?  `sum()` recomputes the block's checksum from what the host
+// sees now, `want` points at the one the kernel wrote.  The data of a block normally precedes its ticket; when it does
+// not (see k_iter_result) it is a matter of microseconds -- the block is looked at again, and after ~5 ms the stream is
+// waited for (everything queued behind the block included) before the last look.
+template <typename F>
+static int wait_block(hm_ctx *h, F sum, const double *want, const char *who)
+{
+    const volatile double *w = want;
+    for (int tries = 0; tries < 20000; tries++) {
+        if ((double)(sum() & ((1ull << 52) - 1)) == *w) return HM_OK;
+        __builtin_ia32_pause();
+    }
+    HM_HIP(hipStreamSynchronize(h->stream));
+    if ((double)(sum() & ((1ull << 52) - 1)) == *w) return HM_OK;
+    hm_set_error("%s: a result block of the device did not arrive whole (checksum)", who);
+    return HM_ERR_HIP;
+}
+
 extern "C" int hm_update_arm_newton(hm_ctx_t h, void *worker, int n_bars, const int32_t *bars, const double *l0, double kappa,
                                     double M, double dt, int maxiter, double tol)
 {
@@ -1476,6 +1501,11 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
         }
         const auto dbg_t0 = std::chrono::steady_clock::now();
         rc = wait_ticket(h, res + n4 + 5, (double)h->run_ticket);
+        if (rc == HM_OK)
+            rc = wait_block(h, [&]() {
+                unsigned long long x = xor_bits(res, (size_t)n4 + 5);
+                return xor_bits(res + n4 + 7, 3, x);
+            }, res + n4 + RES_CHK, "hm_update_run");
         if (rc) { unspec(); return rc; }
         if (getenv("HYDRA_MI_TRACE")) {
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0).count();
@@ -1566,7 +1596,7 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
         // results do: two blit launches and the wake-up from a stream synchronisation less per frame
         hipLaunchKernelGGL(k_gains, dim3(n4), dim3(256), 0, h->stream, h->d_Wres, h->d_Hzc, n4, h->d_gain);
         hipLaunchKernelGGL(k_tail_result, dim3(1), dim3(1024), 0, h->stream, h->d_Hzc, h->d_gain, n4, pin_hzc, pin_gain, res + n4 + 5,
-                           (double)(++h->run_ticket));
+                           (double)(++h->run_ticket), res + n4 + RES_CHK + 1);
     }
     if (W_out) HM_HIP(hipMemcpyAsync(W_out, h->d_Wres, (size_t)n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HM_HIP(hipGetLastError());
@@ -1580,6 +1610,8 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
     dbg_stage[3] = dbg_ms();
     if (niter > 0 && !W_out) {
         rc = wait_ticket(h, res + n4 + 5, (double)h->run_ticket);
+        if (rc == HM_OK)
+            rc = wait_block(h, [&]() { return xor_bits(pin_hzc, (size_t)n4 * 7); }, res + n4 + RES_CHK + 1, "hm_update_run");
         if (rc) return rc;
     } else {
         HM_HIP(stream_wait(h->stream));
