@@ -350,9 +350,23 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Asked for N ranks without a launcher: start them -- torch.distributed.run as a CHILD process, before this one
+        # has imported anything that touches the GPU (never an exec of a process that has) -- and leave with its exit code.
+        # A run that printed `n_gpus: 1` for --gpus 8 would be a wrong record.
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print("bench.py: --gpus %d without WORLD_SIZE: launching %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d (python -m torch.distributed.run --nproc-per-node %d ... "
+                         "bench.py --gpus %d ...)" % (args.gpus, world, args.gpus, args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -436,7 +450,29 @@ def main():
         def flow_sync(self):
             self.pipe.flow_sync()
 
+        def close(self):
+            """helper threads joined, copy stream / flow handles / filter handle (its streams, page-locked blocks and
+            worker thread) released: nothing native is alive when the interpreter and the HIP runtime finalise"""
+            self.pipe.close()
+            self.kf.close()
+
     tracks = [Track(seed) for seed in my_videos]
+    try:
+        run_video(args, tracks, rank, world, dev, coll_dev, info, V, K, Wm, B, n)
+    finally:
+        for tr in tracks:
+            tr.close()
+        from hydra_mi import _lib
+        _lib.close_all()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_video(args, tracks, rank, world, dev, coll_dev, info, V, K, Wm, B, n):
+    import threading
+    import torch
+    import torch.distributed as dist
+    from hydra_mi import batch
     for tr in tracks:
         tr.warmup()
     # the flow series of the timed region start small and grow to B pairs (pipeline.py: sized from what series and
@@ -563,8 +599,6 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, video, masks, dm, max(1.0, iters / K))
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -204,17 +204,17 @@ int hm_jz_multi(hm_ctx_t h, const double *Xp, int masked, const int32_t *labels,
                 double *hz, double *hzc);
 int hm_j_multi(hm_ctx_t h, const double *X, double deltaX, int n_pairs, const int32_t *ee,
                const int32_t *labels, int n_labels, double *hsum, double *nz, double *hcomp);
-/* KalmanFilter.projectmask (kalman.py:724-742): every vertex whose signed
- * distance d to the object outline exceeds 1 px takes 10 steps
- * p -= d g/|g|^2 (g: forward differences of 0.1 px; d and the set of vertices
- * are those before the first step) and its displacement is added to its
- * velocity.  The reference's distance comes from OpenCV contours
- * (imgproc.py:175-248, not on this path); here it is the Euclidean distance
- * transform of the mask sampled bilinearly, evaluated exactly from the outline
- * pixels.  y_m: W*H host mask (object where > 0), or NULL = the mask of the
- * observation in place.  X (4N) is updated in place; *moved (may be NULL) =
- * number of vertices that were outside. */
+/* KalmanFilter.projectmask (kalman.py:724-742) on the device: every vertex whose signed distance fd to the object's
+ * outline exceeds 1 px takes 10 steps p -= d g/|g|^2 (g: forward differences of 0.1 px; d and the set of vertices
+ * are those before the first step) and its displacement is added to its velocity.  fd is the reference's
+ * (findObjectThreshold(y_m, 0.5)[2], imgproc.py:175-248): the mask's contours pruned as there (:205-228: the largest
+ * object and its holes of cv2.contourArea >= 40; areas from pixel counts by Pick's theorem), then the distance to the
+ * polygon through the centres of the border pixels of what is left (-cv2.pointPolygonTest), negative inside.
+ * y_m: W*H host mask (object where > 0), or NULL = the mask of the observation in place.  X (4N) is updated in
+ * place; *moved (may be NULL) = number of vertices that were outside. */
 int hm_project_mask(hm_ctx_t h, const uint8_t *y_m, double *X, int *moved);
+/* the pruning step alone, for parity tests: out (W*H) = 1 where the pruned object is */
+int hm_prune_mask(hm_ctx_t h, const uint8_t *y_m, uint8_t *out);
 /* Renderer.error (renderer.py:485-501): SSE per channel of render(X) against the
  * observation, with the 8-bit wrap-around the reference's uint8 arithmetic has
  * for the image and mask terms.  err = e_im, e_fx, e_fy, e_m; fx/fy (may be NULL)
@@ -284,7 +284,7 @@ int hm_ms_newton_finish(void *worker, double *X, int *newton_iterations);
 /* Jobs started on `worker` run as ONE launch on the device of the filter handle `ctx` (NULL: back to the worker's host
  * thread) when the mesh fits the kernel (k_ms_newton4, csrc/predict_kernels.h: at most 256 vertices and 12 springs per
  * vertex; four waves, a vertex per lane) -- the state goes in and out through page-locked memory, hm_ms_newton_finish
- * watches a ticket; larger meshes keep the host loop.  Host and device agree to rounding (sums over the vector are
+ * takes the kernel's result block when it is whole (csrc/host_block.h); larger meshes keep the host loop.  Host and device agree to rounding (sums over the vector are
  * added in another order).  The handle must outlive the worker's jobs. */
 int hm_ms_worker_attach(void *worker, hm_ctx_t ctx);
 /* what the attached worker calls; 1 = not for the device (mesh too large / inner solve gave up) */
@@ -328,13 +328,29 @@ int hm_ms_predict(hm_ctx_t h, int n_bars, const int32_t *bars, const double *l0,
  * Returns 0 and fills err, or 1 when the sums are not at hand (another state, a reverted update, a new observation or
  * texture since): call hm_error then. */
 int hm_update_last_error(hm_ctx_t h, const double *X, double err[4]);
+/* KalmanFilter.compute's predict -> projectmask -> update (kalman.py:676-700) without a host round trip between the
+ * three, for a state prediction started on the device (hm_ms_worker_attach + hm_update_arm_newton / hm_ms_newton_start)
+ * and the new frame's observation in place: queues projectmask (kalman.py:724-742, mask of the resident observation) of
+ * the prediction in flight behind its kernel; the projected state stays in device memory as the prior mean of the NEXT
+ * hm_update_run on h, whose X argument is then output only (it must still point at 4N doubles).  Same numbers as
+ * hm_ms_newton_finish + hm_project_mask(h, NULL, ...) + hm_update_run.  Returns 0 when queued, 1 when there is nothing
+ * to chain (no device prediction in flight): the caller makes the three calls.  A chained hm_update_run returns 2 when
+ * the prediction's inner solve gave up (never observed): the caller predicts on the host and calls it again. */
+int hm_chain_project(hm_ctx_t h);
+/* what the last chained hm_update_run started from: the predicted state, the projected state (its prior mean), the Newton
+ * iterations of the prediction, the number of vertices projectmask moved; any pointer may be NULL */
+int hm_chain_states(hm_ctx_t h, double *predicted, double *projected, int *newton_iterations, int *moved);
 /* tuning knobs: "measure_split" = workgroups per vertex job of the measurement (1..16, default 5),
  * "edge_split" = workgroups per mesh-edge job (1..16, default 2); the sums change in their last
  * bits with them (another summation order); "chol_flow" = 1/0 the blocked Cholesky factorisations of the update as one
  * persistent launch whose block tasks hand their results over through memory, or one launch per 32-column block step
  * (same bits either way), "chol_flow_wgs" = workgroups of that launch (2..2048, default 256: the first becomes the chain of
  * the diagonal blocks, the others run the tasks it waits for), "chol_flow_stall" = n (test knob, default 0): that chain sleeps
- * ~4 us x n before every diagonal block, so that every wait for it takes the patient path */
+ * ~4 us x n before every diagonal block, so that every wait for it takes the patient path; "result_delay" = n microseconds
+ * (test knob, default 0): the kernels that hand result blocks to the host (csrc/host_block.h) publish a block's last word
+ * first and the rest n us later -- same results; "tail_split" = 1/0 the tail of hm_update_run (covariance of the kept
+ * state, gains, the next frame's covariance prediction) on a stream of its own or on the handle's (same results);
+ * "newton_fail" = 1 (test knob): device state predictions report a failed inner solve */
 int hm_ctx_tune(hm_ctx_t h, const char *key, int value);
 int hm_ctx_sync(hm_ctx_t h);
 void *hm_ctx_stream(hm_ctx_t h);

@@ -98,6 +98,9 @@ SIGNATURES = {
     "hm_newton_dev_start": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_vp, ctypes.c_double, ctypes.c_double,
                                            ctypes.c_double, ctypes.c_int, ctypes.c_double, c_vp]),
     "hm_newton_dev_finish": (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(ctypes.c_int)]),
+    "hm_prune_mask": (ctypes.c_int, [c_vp, c_vp, c_vp]),
+    "hm_chain_project": (ctypes.c_int, [c_vp]),
+    "hm_chain_states": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "hm_update_arm_newton": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_vp, c_vp, ctypes.c_double, ctypes.c_double,
                                             ctypes.c_double, ctypes.c_int, ctypes.c_double]),
     "hm_update_arm_cov": (ctypes.c_int, [c_vp, ctypes.c_double]),
@@ -171,6 +174,42 @@ def check(rc, what=""):
         msg = lib().hm_last_error()
         raise RuntimeError("%s failed (code %d): %s" % (what or "libhydra_mi call", rc,
                                                          msg.decode() if msg else "?"))
+
+
+# ---- lifetime -----------------------------------------------------------------------------------
+# Everything that owns native state (pipelines with their helper threads and copy streams, filters with their worker
+# thread, renderer / flow handles with their streams and page-locked blocks, device buffers) registers here and is
+# closed -- threads joined, streams drained and destroyed, page-locked memory released -- before the interpreter and
+# the HIP runtime finalise: a process that exits with helper threads alive and streams registered crashed inside
+# __cxa_finalize when a profiler's tool library was finalising beside it (rocprofv3 -- python bench.py, round 3).
+_live = {}          # id -> (order, serial, weakref): lower order closes first; within an order, newest first
+_serial = [0]
+
+
+def register(obj, order):
+    """order: 0 pipelines, 1 filters, 2 renderer handles, 3 flow handles, 4 device / page-locked buffers."""
+    import weakref
+    _serial[0] += 1
+    key = id(obj)
+    _live[key] = (order, _serial[0], weakref.ref(obj, lambda _r, k=key: _live.pop(k, None)))
+
+
+def close_all():
+    """Close every live native object (idempotent; runs at interpreter exit)."""
+    for order, serial, ref in sorted(_live.values(), key=lambda e: (e[0], -e[1])):
+        obj = ref()
+        if obj is None:
+            continue
+        try:
+            obj.close()
+        except Exception:          # noqa: BLE001 -- teardown goes on with the others
+            pass
+    _live.clear()
+
+
+import atexit  # noqa: E402
+
+atexit.register(close_all)
 
 
 def ptr(a):

@@ -29,6 +29,7 @@ class BroxOpticalFlow:
                                     scale_factor, int(inner_iterations), int(outer_iterations),
                                     int(solver_iterations), ctypes.byref(h)), "hm_brox_create")
         self._h = h
+        _lib.register(self, 3)
         self.width, self.height, self.max_batch, self.device = int(width), int(height), int(max_batch), int(device)
         self.params = dict(alpha=alpha, gamma=gamma, scale_factor=scale_factor, inner_iterations=inner_iterations,
                            outer_iterations=outer_iterations, solver_iterations=solver_iterations)

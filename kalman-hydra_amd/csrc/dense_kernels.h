@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "ekf_kernels.h"      // d_tile_partial_sums (k_iter_result)
+#include "host_block.h"
 
 #define DNB 32          // block size
 #define TTT_PF 3        // block products whose operands are in flight (k_ttt)
@@ -617,62 +618,39 @@ __global__ __launch_bounds__(256) void k_assemble(const double *__restrict__ inv
 }
 
 // ---- end of one iteration of hm_update_run ---------------------------------------------------------------
-// res (host-visible, coherent) = [step (n) | the four error sums of the render's per-strip partials (fixed order:
-// d_tile_partial_sums) | overflow flag | ticket | (spare) | factorisation time-out | flow x, flow y error sums against
-// the raw flow | checksum of this block | checksum of the tail block].  One workgroup.  The ticket is written last,
-// after a system-scope fence -- a host that sees it normally sees the rest; that the rest HAS landed the host checks
-// with the checksum (xor of the bit patterns of everything but ticket and checksums, low 52 bits, as a whole number):
-// the state prediction's result block, written in strided stores, was seen by the host with its ticket there and half
-// of its data not (hm_newton_dev_finish), and a wrong step would go unnoticed.
-#define RES_HEAD 12           // doubles behind the step in a result block
-#define RES_CHK 10            // ... of which this one is the block's checksum, RES_CHK + 1 that of the tail block
-
-// xor of x over the workgroup (NT threads, a multiple of 64), the same value in every thread
-template <int NT>
-__device__ __forceinline__ unsigned long long d_wg_xor(unsigned long long x, unsigned long long *s_part)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned lo = __shfl_xor((unsigned)(x & 0xffffffffull), o, 64), hi = __shfl_xor((unsigned)(x >> 32), o, 64);
-        x ^= ((unsigned long long)hi << 32) | lo;
-    }
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = x;
-    __syncthreads();
-    unsigned long long r = 0;
-#pragma unroll
-    for (int w = 0; w < NT / 64; w++) r ^= s_part[w];
-    return r;
-}
+// res (page-locked host memory, a block of host_block.h: every value a stamped pair of words) = [step (n) | the four
+// error sums of the render's per-strip partials (fixed order: d_tile_partial_sums) | overflow flag | the ticket |
+// (spare) | factorisation time-out | flow x, flow y error sums against the raw flow].  One workgroup.  The host takes
+// the block when every pair carries this launch's stamp; nothing depends on the order the words arrive in (delay_us,
+// the test knob "result_delay", has the LAST value published first and everything else that much later).
+#define RES_HEAD 10           // doubles behind the step in a result block
 
 __global__ __launch_bounds__(256) void k_iter_result(const double *__restrict__ step, int n, const double *__restrict__ partial,
                                                      int ntiles, const int *__restrict__ overflow,
-                                                     const unsigned *__restrict__ flow_ctl, double *__restrict__ res, double ticket)
+                                                     const unsigned *__restrict__ flow_ctl, double *__restrict__ res, double ticket,
+                                                     int delay_us)
 {
     __shared__ double sp[RI_GROUPS * RI_NV];
     __shared__ double sums[RI_NV];
-    __shared__ unsigned long long s_x[256 / 64];
     const int t = threadIdx.x;
-    unsigned long long x = 0;
-    for (int i = t; i < n; i += 256) { const double v = step[i]; res[i] = v; x ^= (unsigned long long)__double_as_longlong(v); }
+    const unsigned long long stamp = hb_stamp((long long)ticket);
     d_tile_partial_sums(partial, ntiles, sp, sums);
     __syncthreads();
     double v = 0.0;
     int slot = -1;
     if (t < 4) { slot = t; v = sums[t]; }
     else if (t == 4) { slot = 4; v = (double)*overflow; }
-    else if (t == 5) { slot = 7; v = (double)flow_ctl[1]; }  // a wait of the persistent factorisation launch timed out
-    else if (t == 6) { slot = 8; v = sums[4]; }
-    else if (t == 7) { slot = 9; v = sums[5]; }
-    if (slot >= 0) { res[n + slot] = v; x ^= (unsigned long long)__double_as_longlong(v); }
-    x = d_wg_xor<256>(x, s_x);
-    if (t == 0) res[n + RES_CHK] = (double)(x & ((1ull << 52) - 1));
-    __threadfence_system();
-    __syncthreads();
-    if (t == 0) {
-        *(volatile double *)(res + n + 5) = ticket;
-        __threadfence_system();
+    else if (t == 5) { slot = 5; v = ticket; }
+    else if (t == 6) { slot = 6; v = 0.0; }
+    else if (t == 7) { slot = 7; v = (double)flow_ctl[1]; }  // a wait of the persistent factorisation launch timed out
+    else if (t == 8) { slot = 8; v = sums[4]; }
+    else if (t == 9) { slot = 9; v = sums[5]; }
+    if (delay_us > 0) {
+        if (t == 9) hb_put(res, n + 9, v, stamp);
+        hb_delay(delay_us);
     }
+    for (int i = t; i < n; i += 256) hb_put(res, i, step[i], stamp);
+    if (slot >= 0) hb_put(res, n + slot, v, stamp);
 }
 
 // gains of the three measurement channels (kalman.py:828-830): out[0] = W c0, out[1] = W (c1 + c2),
@@ -707,24 +685,18 @@ __global__ __launch_bounds__(256) void k_gains(const double *__restrict__ W, con
     }
 }
 
-// what the host wants of the end of an update -- Hz components (n x 4), gains (3 x n) -- into pinned host memory,
-// their checksum (k_iter_result's) into chk_slot, then the ticket
+// what the host wants of the end of an update -- Hz components (n x 4), gains (3 x n) -- as one block of host_block.h
+// (7n values) in page-locked host memory
 __global__ __launch_bounds__(1024) void k_tail_result(const double *__restrict__ Hzc, const double *__restrict__ gain, int n,
-                                                      double *__restrict__ pin_hzc, double *__restrict__ pin_gain,
-                                                      double *__restrict__ ticket_slot, double ticket, double *__restrict__ chk_slot)
+                                                      double *__restrict__ blk, double ticket, int delay_us)
 {
-    __shared__ unsigned long long s_x[1024 / 64];
-    unsigned long long x = 0;
-    for (int i = threadIdx.x; i < 4 * n; i += 1024) { const double v = Hzc[i]; pin_hzc[i] = v; x ^= (unsigned long long)__double_as_longlong(v); }
-    for (int i = threadIdx.x; i < 3 * n; i += 1024) { const double v = gain[i]; pin_gain[i] = v; x ^= (unsigned long long)__double_as_longlong(v); }
-    x = d_wg_xor<1024>(x, s_x);
-    if (threadIdx.x == 0) *chk_slot = (double)(x & ((1ull << 52) - 1));
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        *(volatile double *)ticket_slot = ticket;
-        __threadfence_system();
+    const unsigned long long stamp = hb_stamp((long long)ticket);
+    if (delay_us > 0) {
+        if (threadIdx.x == 0) hb_put(blk, 7 * n - 1, gain[3 * n - 1], stamp);
+        hb_delay(delay_us);
     }
+    for (int i = threadIdx.x; i < 4 * n; i += 1024) hb_put(blk, i, Hzc[i], stamp);
+    for (int i = threadIdx.x; i < 3 * n; i += 1024) hb_put(blk, 4 * n + i, gain[i], stamp);
 }
 
 // ---- covariance prediction W' = F W F^T + Weps on the device -------------------------------------------

@@ -52,8 +52,13 @@ struct hm_ctx {
     double *d_Wres;                  // the covariance resident on the device (the result of the last
                                      // hm_cov_predict / hm_update_cov / hm_update_run): d_Wtmp, d_H or
                                      // d_Wprior, or NULL when that buffer has been reused since
-    double *pin;                     // host-visible (pinned, device-mapped) result block of hm_update_run
+    double *pin;                     // page-locked, device-mapped: hm_update_run's result blocks (host_block.h) -- per iteration
+                                     // [step (n4) | RES_HEAD values], then the tail block [Hzc (n4 x 4) | gains (3 x n4)], every value
+                                     // a pair of words -- and two words of scratch (pin_scratch)
     size_t pin_n;
+    int *pin_scratch;                // ... where hm_measure / hm_update_step have a flag copied to
+    std::vector<double> resv, tailv; // the host's copies of the two blocks, taken when whole (hb_wait)
+    int result_delay = 0;            // test knob: the result kernels publish a block's last word first, the rest this many us later
     std::vector<int> sp_h_off, sp_h_bar, sp_h_other;   // host staging of the spring topology
     std::vector<double> sp_h_blk;
     std::vector<int32_t> sp_bars_cached;   // the springs whose topology is on the device (d_sp_off / _bar / _other)
@@ -100,9 +105,18 @@ struct hm_ctx {
     int n4deg = 0;                   // padded degree of the table on the device (8 or 12), 0: this mesh does not fit the kernel
     std::vector<int32_t> n4_bars;    // the springs the table was built for
     std::vector<double> n4_l0;
-    double *pin_n4 = nullptr;        // page-locked: [X in | X out | iterations | failed | ticket]
+    double *pin_n4 = nullptr;        // page-locked: [X in (4N) | result block of 4N + 2 values (host_block.h): X out, iterations, failed]
+    double *d_n4X = nullptr;         // the same 4N + 2 values in device memory, for hm_chain_project
+    std::vector<double> n4v;         // the host's copy of that block
     long long n4_ticket = 0;
     bool n4_pending = false;
+    int newton_fail = 0;             // test knob: the next device predictions report a failed inner solve
+    hipEvent_t ev_n4 = nullptr, ev_pm = nullptr;     // the prediction's kernel / the chained projection have run
+    // hm_chain_project: projectmask of the prediction in flight queued behind it; the projected state (d_X0) is the
+    // prior mean of the next hm_update_run, which also collects what the two kernels report
+    bool chain_pending = false;
+    std::vector<double> chain_pred, chain_proj;     // ... the predicted / the projected state of the last chained update
+    int chain_its = 0, chain_moved = 0;
     double *pin_blk = nullptr;       // page-locked staging of the spring blocks of that prediction
     size_t pin_blk_cap = 0;
     std::thread worker;              // hm_update_prefactor queues its launches from here while the caller predicts the state
@@ -115,6 +129,15 @@ struct hm_ctx {
     double *d_flowP;                 // 3 x nb x 32 x 32 scratch of that launch
     unsigned *d_flowctl;             // its task counter and time-out word
     hipStream_t stream2;             // hm_ms_predict: the state prediction runs beside the covariance half of the update
+    // The tail of hm_update_run -- covariance of the kept state, gains, their result block, and the covariance half of the
+    // NEXT frame's prediction (queue_predict_ahead) -- runs on a stream of its own: beside the measurement hm_update_run
+    // queued for an iteration that did not happen, and beside the next frame's reference render and measurement, which
+    // need none of its buffers.  tail_on_stream4: it may still be running; `stream` waits for ev_tail (on the device)
+    // before anything there touches the dense buffers (ctx_join; hm_update_run itself only before its first solve).
+    hipStream_t stream4 = nullptr;
+    hipEvent_t ev_tail = nullptr, ev_post = nullptr;
+    bool tail_on_stream4 = false;
+    int tail_split = 1;              // hm_ctx_tune "tail_split": 0 keeps the tail on `stream` (same results either way)
     int *d_nbars, *d_nvoff, *d_nvbar, *d_ninfo;     // its spring topology (bars, CSR of the bars of every vertex), result words
     double *d_nl0, *d_nX;
     size_t ncap;                     // bars the buffers hold
@@ -128,8 +151,11 @@ struct hm_ctx {
     int *d_outline_cnt;
     uint8_t *d_pm_mask;
     uint8_t *d_pm_flag = nullptr;    // border-pixel flags of that mask (W*H)
+    uint8_t *d_pm_pruned = nullptr;  // the mask after the reference's contour pruning (k_ccl_*): what the outline and the walk use
+    Ccl ccl = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};     // its working arrays
     double *d_pm_X = nullptr;        // hm_project_mask's copy of the state (second stream)
-    double *pin_pm = nullptr;        // page-locked: [X | projected X | vertices moved | ticket] (k_project_mask_host)
+    double *pin_pm = nullptr;        // page-locked: [X in (4N) | result block of 4N + 1 values: projected X, vertices moved] (k_project_mask_host)
+    std::vector<double> pmv;         // the host's copy of that block
     int *d_pm_done = nullptr;        // workgroups of k_project_mask_host that have finished
     long long pm_ticket = 0;
     bool outline_ready = false;      // the outline of the resident mask (o_ym) has been queued on the second stream
@@ -153,9 +179,16 @@ static void free_targets(Targets &t)
 
 // Every entry point waits for the launches hm_update_prefactor is still queueing (one handle = one
 // stream = one thread at a time, as far as the device can tell) and reports their failure, if any.
-static int ctx_join(hm_ctx *h)
+static int ctx_join(hm_ctx *h, bool lazy = false)
 {
     if (!h) return HM_OK;
+    if (!lazy && h->tail_on_stream4) {
+        h->tail_on_stream4 = false;
+        if (hipSetDevice(h->device) != hipSuccess || hipStreamWaitEvent(h->stream, h->ev_tail, 0) != hipSuccess) {
+            hm_set_error("the handle's stream cannot wait for the tail of the last update");
+            return HM_ERR_HIP;
+        }
+    }
     if (h->worker_active) {
         h->worker.join();
         h->worker_active = false;
@@ -170,6 +203,8 @@ static int ctx_join(hm_ctx *h)
     return HM_OK;
 }
 #define HM_JOIN(h) do { int _j = ctx_join(h); if (_j) return _j; } while (0)
+// entry points of the frame loop that touch none of the tail's buffers (or wait for it themselves, where they do)
+#define HM_JOIN_LAZY(h) do { int _j = ctx_join(h, true); if (_j) return _j; } while (0)
 
 // Wait for the stream: poll it for a while (a few microseconds of latency) before falling back on
 // hipStreamSynchronize, whose wake-up costs ~20 us -- three of those per frame on the compute() path.
@@ -194,16 +229,20 @@ static hipError_t stream_wait(hipStream_t s)
     }
 }
 
-// Watch a ticket a kernel writes last into page-locked host memory (system-scope fence before it): a couple of
-// microseconds against ~20 for waking up from a stream synchronisation, which remains as the fallback.
-static int wait_ticket_on(hipStream_t st, const double *slot, double want)
+// Take values [first, first + n) of a result block in page-locked host memory (host_block.h) into `out` once every one of
+// their pairs carries the launch's stamp.  The last pair is looked at first (one pair of loads per poll while nothing is
+// there yet); a block of which some words are still missing is simply looked at again -- no order of arrival is assumed.
+// A couple of microseconds against ~20 for waking up from a stream synchronisation, which remains as the fallback: after
+// 20 ms the stream is waited for (everything queued behind the block's kernel included) and a block that is not whole
+// then is an error.
+static int hb_wait(hipStream_t st, const double *blk, size_t first, size_t n, unsigned long long stamp, double *out, const char *who)
 {
-    const volatile double *ticket = slot;
+    const volatile unsigned long long *canary = (const volatile unsigned long long *)blk + 2 * (first + n - 1);
     const auto t_start = std::chrono::steady_clock::now();
     const auto t_yield = t_start + std::chrono::microseconds(700), t_give_up = t_start + std::chrono::milliseconds(20);
-    bool seen = false, polite = false;
+    bool polite = false;
     for (int spin = 0;; spin++) {
-        if (*ticket == want) { seen = true; break; }
+        if ((canary[0] ^ canary[1]) == stamp && hb_take(blk, first, n, stamp, out)) return HM_OK;
         if (polite) std::this_thread::yield();
         else __builtin_ia32_pause();
         if ((spin & 255) == 255) {
@@ -212,9 +251,10 @@ static int wait_ticket_on(hipStream_t st, const double *slot, double want)
             polite = now > t_yield;
         }
     }
-    if (!seen) HM_HIP(hipStreamSynchronize(st));
-    std::atomic_thread_fence(std::memory_order_acquire);
-    return HM_OK;
+    HM_HIP(hipStreamSynchronize(st));
+    if (hb_take(blk, first, n, stamp, out)) return HM_OK;
+    hm_set_error("%s: a result block of the device is not whole although its stream has completed (stamp %016llx)", who, stamp);
+    return HM_ERR_HIP;
 }
 
 // ---- the pool of parked difference images (DPool, ekf_kernels.h) -------------------------------------------------
@@ -265,12 +305,15 @@ static int ctx_free(hm_ctx *h)
     if (!h) return HM_OK;
     (void)ctx_join(h);
     (void)hipSetDevice(h->device);
+    // every stream of the handle first: a state prediction started ahead is always pending after the last frame (it writes
+    // into pin_n4), and so may be launches of an update that ended in an error
+    { hipStream_t q[] = {h->stream, h->stream2, h->stream3, h->stream4}; for (hipStream_t x : q) if (x) (void)hipStreamSynchronize(x); }
     void *ptrs[] = {h->d_tri, h->d_star_off, h->d_star_tri, h->d_edges, h->d_uv, h->d_tex, h->d_yim, h->d_ym, h->d_yfx,
                     h->d_yfy, h->d_yfxm, h->d_yfym, h->d_setup, h->d_cfgs, h->d_ubox, h->d_X, h->d_out, h->d_partial, h->d_im8, h->d_m8,
                     h->d_HTH, h->d_H, h->d_Hz, h->d_Hzc, h->d_invW0, h->d_Af[0], h->d_Af[1], h->d_T[0], h->d_T[1], h->d_step, h->d_Wprior, h->d_gain, h->d_Awork, h->d_Lt[0], h->d_Lt[1],
                     h->d_Wtmp, h->d_X0, h->d_Xn, h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk,
                     h->pool.hdr, h->pool.overflow, h->d_area,
-                    h->d_outline, h->d_outline_cnt, h->d_pm_mask, h->d_pm_flag, h->d_pm_X, h->d_ids[0], h->d_ids[1], h->d_ids[2], h->d_labels, h->d_lbox,
+                    h->d_outline, h->d_outline_cnt, h->d_pm_mask, h->d_pm_flag, h->d_pm_X, h->d_pm_pruned, h->ccl.L, h->ccl.cnt, h->ccl.bnd, h->ccl.edge, h->ccl.best, h->d_ids[0], h->d_ids[1], h->d_ids[2], h->d_labels, h->d_lbox,
                     h->d_lout, h->d_tpart, h->d_tmask, h->d_tlist, h->d_tcount, h->d_nb_off, h->d_nb_u, h->d_nb_e, h->d_flowP, h->d_flowctl, h->d_nbars, h->d_nvoff, h->d_nvbar, h->d_ninfo, h->d_nl0, h->d_nX};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -278,14 +321,19 @@ static int ctx_free(hm_ctx *h)
     free_targets(h->ref);
     free_targets(h->P);
     free_targets(h->Q);
+    { void *q[] = {h->d_n4nbr, h->d_n4nbb, h->d_n4bars, h->d_n4l0, h->d_n4X, h->d_pm_done}; for (void *x : q) if (x) (void)hipFree(x); }
+    // (the streams were drained at the top: nothing writes into the page-locked blocks any more)
     if (h->pin) (void)hipHostFree(h->pin);
-    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->pin_pm) (void)hipHostFree(h->pin_pm);
     if (h->pin_blk) (void)hipHostFree(h->pin_blk);
     if (h->pin_n4) (void)hipHostFree(h->pin_n4);
-    if (h->stream3) { (void)hipStreamSynchronize(h->stream3); (void)hipStreamDestroy(h->stream3); }
-    { void *q[] = {h->d_n4nbr, h->d_n4nbb, h->d_n4bars, h->d_n4l0}; for (void *x : q) if (x) (void)hipFree(x); }
-    if (h->d_pm_done) (void)hipFree(h->d_pm_done);
+    if (h->ev_n4) (void)hipEventDestroy(h->ev_n4);
+    if (h->ev_pm) (void)hipEventDestroy(h->ev_pm);
+    if (h->ev_tail) (void)hipEventDestroy(h->ev_tail);
+    if (h->ev_post) (void)hipEventDestroy(h->ev_post);
+    if (h->stream4) (void)hipStreamDestroy(h->stream4);
+    if (h->stream3) (void)hipStreamDestroy(h->stream3);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return HM_OK;
@@ -441,10 +489,12 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         if (e == hipSuccess) e = hm_malloc((void **)&h->d_Hzc, n4 * 4 * sizeof(double));
         if (e == hipSuccess) e = hm_malloc((void **)&h->d_Wprior, nn);
         if (e == hipSuccess) e = hm_malloc((void **)&h->d_gain, n4 * 3 * sizeof(double));
-        // [step (n4) | four error sums | overflow flag] per iteration, then Hzc (n4 x 4) and the gains (3 x n4)
-        h->pin_n = n4 + RES_HEAD + n4 * 4 + n4 * 3;
+        h->pin_n = 2 * (n4 + RES_HEAD + n4 * 4 + n4 * 3) + 2;
         if (e == hipSuccess) e = hipHostMalloc((void **)&h->pin, h->pin_n * sizeof(double), hipHostMallocCoherent);
         if (e == hipSuccess) memset(h->pin, 0, h->pin_n * sizeof(double));
+        h->pin_scratch = (int *)(h->pin + h->pin_n - 2);
+        h->resv.assign(n4 + RES_HEAD, 0.0);
+        h->tailv.assign(n4 * 7, 0.0);
         if (e == hipSuccess) e = hm_malloc((void **)&h->d_X0, n4 * sizeof(double));
         if (e == hipSuccess) e = hm_malloc((void **)&h->pool.hdr, (size_t)4 * N * sizeof(int));
         if (e == hipSuccess) e = hm_malloc((void **)&h->pool.overflow, sizeof(int));
@@ -507,6 +557,15 @@ extern "C" int hm_ctx_tune(hm_ctx_t h, const char *key, int value)
     } else if (!strcmp(key, "chol_flow_stall")) {      // tests only: results must not depend on it
         HM_ARG(value >= 0 && value <= 100000, "hm_ctx_tune: chol_flow_stall must be in 0..100000");
         h->flow_stall = value;
+    } else if (!strcmp(key, "result_delay")) {         // tests only: results must not depend on it (host_block.h)
+        HM_ARG(value >= 0 && value <= 5000, "hm_ctx_tune: result_delay must be in 0..5000 (microseconds)");
+        h->result_delay = value;
+    } else if (!strcmp(key, "tail_split")) {           // same results either way
+        HM_ARG(value == 0 || value == 1, "hm_ctx_tune: tail_split must be 0 or 1");
+        h->tail_split = value;
+    } else if (!strcmp(key, "newton_fail")) {          // tests only: the device predictions report a failed inner solve
+        HM_ARG(value == 0 || value == 1, "hm_ctx_tune: newton_fail must be 0 or 1");
+        h->newton_fail = value;
     } else if (!strcmp(key, "speculate")) {            // same results either way
         HM_ARG(value == 0 || value == 1, "hm_ctx_tune: speculate must be 0 or 1");
         h->speculate = value;
@@ -564,22 +623,40 @@ static int project_buffers(hm_ctx *h)
     HM_HIP(hm_malloc((void **)&h->d_outline, n * sizeof(int2)));
     HM_HIP(hm_malloc((void **)&h->d_outline_cnt, 4 * sizeof(int)));
     HM_HIP(hm_malloc((void **)&h->d_pm_flag, n));
+    HM_HIP(hm_malloc((void **)&h->d_pm_pruned, n));
+    HM_HIP(hm_malloc((void **)&h->ccl.L, n * sizeof(int)));
+    HM_HIP(hm_malloc((void **)&h->ccl.cnt, n * sizeof(int)));
+    HM_HIP(hm_malloc((void **)&h->ccl.bnd, n * sizeof(int)));
+    HM_HIP(hm_malloc((void **)&h->ccl.edge, n));
+    HM_HIP(hm_malloc((void **)&h->ccl.best, sizeof(unsigned long long)));
+    h->ccl.W = h->W; h->ccl.H = h->H;
     HM_HIP(hm_malloc((void **)&h->d_pm_X, n4 * sizeof(double)));
     HM_HIP(hm_malloc((void **)&h->d_pm_done, sizeof(int)));
     // zeroed on the stream the kernel that counts in it runs on: a hipMemset on the null stream is not ordered with a
     // non-blocking stream and may land in the middle of that kernel -- no workgroup is the last one then, the ticket
     // never comes and the projection of a context's first frame was silently dropped (seen once in ~10 runs)
     HM_HIP(hipMemsetAsync(h->d_pm_done, 0, sizeof(int), h->stream2));
-    HM_HIP(hipHostMalloc((void **)&h->pin_pm, (2 * n4 + 2) * sizeof(double), hipHostMallocCoherent));
-    memset(h->pin_pm, 0, (2 * n4 + 2) * sizeof(double));
+    HM_HIP(hipHostMalloc((void **)&h->pin_pm, (n4 + 2 * (n4 + 1)) * sizeof(double), hipHostMallocCoherent));
+    memset(h->pin_pm, 0, (n4 + 2 * (n4 + 1)) * sizeof(double));
+    h->pmv.assign(n4 + 1, 0.0);
+    HM_HIP(hipEventCreateWithFlags(&h->ev_pm, hipEventDisableTiming));
     return HM_OK;
 }
+// the reference's contour pruning of the mask (imgproc.py:198-228: the largest object, its holes of area >= 40) into
+// d_pm_pruned, then the border pixels of what is left
 static int queue_outline(hm_ctx *h, const uint8_t *mask)
 {
     HM_HIP(hipMemsetAsync(h->d_outline_cnt, 0, 4 * sizeof(int), h->stream2));
+    const dim3 cg(hm_cdiv(h->W, 64), hm_cdiv(h->H, CCL_NT / 64)), cb(CCL_NT);
+    hipLaunchKernelGGL(k_ccl_runs, cg, cb, 0, h->stream2, mask, h->ccl);
+    hipLaunchKernelGGL(k_ccl_merge, cg, cb, 0, h->stream2, mask, h->ccl);
+    hipLaunchKernelGGL(k_ccl_flatten, cg, cb, 0, h->stream2, mask, h->ccl);
+    hipLaunchKernelGGL(k_ccl_stats, cg, cb, 0, h->stream2, mask, h->ccl);
+    hipLaunchKernelGGL(k_ccl_select, cg, cb, 0, h->stream2, mask, h->ccl);
+    hipLaunchKernelGGL(k_ccl_write, cg, cb, 0, h->stream2, mask, h->ccl, h->d_pm_pruned);
     Outline o = {h->d_outline, h->d_outline_cnt, h->W * h->H, h->d_pm_flag};
     hipLaunchKernelGGL(k_outline, dim3(hm_cdiv(h->W, 64), hm_cdiv(h->H, OUTLINE_NT / 64)), dim3(OUTLINE_NT), 0, h->stream2,
-                       mask, h->W, h->H, o);
+                       (const uint8_t *)h->d_pm_pruned, h->W, h->H, o);
     HM_HIP(hipGetLastError());
     return HM_OK;
 }
@@ -623,7 +700,7 @@ extern "C" int hm_set_observation_dev(hm_ctx_t h, const uint8_t *d_y_im, const f
                                       const uint8_t *d_y_m)
 {
     HM_ARG(h && d_y_im && d_y_fx && d_y_fy && d_y_m, "hm_set_observation_dev: NULL argument");
-    HM_JOIN(h);
+    HM_JOIN_LAZY(h);
     HM_HIP(hipSetDevice(h->device));
     h->o_yim = d_y_im; h->o_ym = d_y_m; h->o_yfx = d_y_fx; h->o_yfy = d_y_fy;
     int rc = finish_observation(h);
@@ -1013,7 +1090,7 @@ extern "C" int hm_measure(hm_ctx_t h, const double *X, double deltaX, int masked
     NEED_OBS(h, "hm_measure");
     HM_HIP(hipSetDevice(h->device));
     const size_t n4 = (size_t)4 * h->N;
-    int *ovf = (int *)(h->pin + n4 + 6);
+    int *ovf = h->pin_scratch;
     for (int attempt = 0;; attempt++) {              // (once more after the pool has been grown)
         int rc = measure_on_device(h, X, deltaX, masked);
         if (rc) return rc;
@@ -1187,8 +1264,10 @@ extern "C" int hm_update_begin(hm_ctx_t h, const double *W_prior, const double *
 {
     HM_ARG(h && X0, "hm_update_begin: NULL argument");
     HM_JOIN(h);
+    h->chain_pending = false;
     return update_begin(h, W_prior, X0);
 }
+// X0 == NULL: the prior mean is being left in d_X0 by hm_chain_project's kernel on the second stream
 static int update_begin(hm_ctx *h, const double *W_prior, const double *X0)
 {
     if (!W_prior && !h->d_Wres) {
@@ -1198,13 +1277,22 @@ static int update_begin(hm_ctx *h, const double *W_prior, const double *X0)
     HM_HIP(hipSetDevice(h->device));
     const int n4 = 4 * h->N;
     h->pq_valid = false;                         // (a prediction queued ahead that nobody took: d_Wres is still the posterior)
-    if (!(h->prefactored && !W_prior && h->d_Wres == h->d_Wprior)) {
+    const bool taken = h->prefactored && !W_prior && h->d_Wres == h->d_Wprior;
+    if (!taken) {
+        int rc = ctx_join(h);                    // (the tail of the last update is rewriting what prior_inverse rewrites)
+        if (rc) return rc;
+    }
+    if (!taken) {
         int rc = prior_inverse(h, W_prior);
         if (rc) return rc;
     }
     h->prefactored = false;
-    h->upd_X0.assign(X0, X0 + n4);
-    HM_HIP(hipMemcpyAsync(h->d_X0, h->upd_X0.data(), (size_t)n4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (X0) {
+        h->upd_X0.assign(X0, X0 + n4);
+        HM_HIP(hipMemcpyAsync(h->d_X0, h->upd_X0.data(), (size_t)n4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    } else {
+        HM_HIP(hipStreamWaitEvent(h->stream, h->ev_pm, 0));
+    }
     h->upd_last = h->upd_prev = -1;
     h->upd_open = true;
     return HM_OK;
@@ -1230,7 +1318,7 @@ extern "C" int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int ma
     HM_HIP(hipGetLastError());
     HM_HIP(hipMemcpyAsync(step, rhs_row, (size_t)n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (Hzc) HM_HIP(hipMemcpyAsync(Hzc, h->d_Hzc, (size_t)n4 * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    int *ovf = (int *)(h->pin + n4 + 6);                     // pinned, lives with the handle (see hm_measure)
+    int *ovf = h->pin_scratch;                               // pinned, lives with the handle (see hm_measure)
     *ovf = 0;
     HM_HIP(hipMemcpyAsync(ovf, h->pool.overflow, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (err) {
@@ -1259,10 +1347,15 @@ extern "C" int hm_update_step(hm_ctx_t h, const double *X, double deltaX, int ma
     return HM_OK;
 }
 
+static int update_cov_on(hm_ctx *h, int which, double *W_out, hipStream_t st);
 extern "C" int hm_update_cov(hm_ctx_t h, int which, double *W_out)
 {
     HM_ARG(h != nullptr, "hm_update_cov: NULL handle");
     HM_JOIN(h);
+    return update_cov_on(h, which, W_out, h->stream);
+}
+static int update_cov_on(hm_ctx *h, int which, double *W_out, hipStream_t st)
+{
     HM_ARG(which >= -1 && which <= 1, "hm_update_cov: which must be 0 (last step), 1 (the step before) or -1 (the prior)");
     if (!h->upd_open) { hm_set_error("hm_update_cov: hm_update_begin has not been called"); return HM_ERR_STATE; }
     HM_HIP(hipSetDevice(h->device));
@@ -1274,14 +1367,14 @@ extern "C" int hm_update_cov(hm_ctx_t h, int which, double *W_out)
         if (slot < 0) { hm_set_error("hm_update_cov: no such step"); return HM_ERR_STATE; }
         {   // T of this slot is there since its solve: inv = T^T T
             const int nb = hm_cdiv(n4, DNB);
-            hipLaunchKernelGGL(k_ttt, dim3(nb, nb), dim3(256), 0, h->stream, h->d_T[slot], n4, h->d_H);
+            hipLaunchKernelGGL(k_ttt, dim3(nb, nb), dim3(256), 0, st, h->d_T[slot], n4, h->d_H);
         }
         HM_HIP(hipGetLastError());
         h->d_Wres = h->d_H;
     }
     if (W_out) {
-        HM_HIP(hipMemcpyAsync(W_out, h->d_Wres, (size_t)n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HM_HIP(stream_wait(h->stream));
+        HM_HIP(hipMemcpyAsync(W_out, h->d_Wres, (size_t)n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, st));
+        HM_HIP(stream_wait(st));
     }
     return HM_OK;
 }
@@ -1309,30 +1402,22 @@ extern "C" int hm_project_mask(hm_ctx_t h, const uint8_t *y_m, double *X, int *m
     Outline o = {h->d_outline, h->d_outline_cnt, (int)n, h->d_pm_flag};
     if (!y_m) {
         // The mask of the resident observation: its outline was queued when the observation was set (or is now, the
-        // first time); the state goes through page-locked memory both ways and the host watches a ticket -- one
-        // launch and no copy operations on the way (0.15 -> ~0.03 ms per frame of the streaming pipeline).
+        // first time); the state goes through page-locked memory both ways, the result as a block the host takes when
+        // it is whole (host_block.h) -- one launch and no copy operations on the way (0.15 -> ~0.03 ms per frame of the streaming pipeline).
         if (!h->outline_ready) {
             rc = queue_outline(h, h->o_ym);
             if (rc) return rc;
             h->outline_ready = true;
         }
         memcpy(h->pin_pm, X, xb);
-        ProjArgs a = {h->o_ym, h->W, h->H, h->N, o, nullptr};
-        hipLaunchKernelGGL(k_project_mask_host, dim3(h->N), dim3(PROJ_NT), 0, s, a, h->pin_pm, h->d_pm_done, (double)(++h->pm_ticket));
+        ProjArgs a = {h->d_pm_pruned, h->W, h->H, h->N, o, nullptr};
+        hipLaunchKernelGGL(k_project_mask_host, dim3(h->N), dim3(PROJ_NT), 0, s, a, (const double *)h->pin_pm, h->pin_pm + n4, (double *)nullptr,
+                           h->d_pm_done, (double)(++h->pm_ticket), h->result_delay);
         HM_HIP(hipGetLastError());
-        rc = wait_ticket_on(s, h->pin_pm + 2 * n4 + 1, (double)h->pm_ticket);
+        rc = hb_wait(s, h->pin_pm + n4, 0, n4 + 1, hb_stamp(h->pm_ticket), h->pmv.data(), "hm_project_mask");
         if (rc) return rc;
-        if (((const volatile double *)h->pin_pm)[2 * n4 + 1] != (double)h->pm_ticket) {      // the stream is idle and the ticket is not there
-            hm_set_error("hm_project_mask: the projection kernel finished without reporting (ticket %lld missing)", h->pm_ticket);
-            return HM_ERR_STATE;
-        }
-        const int nmoved = (int)h->pin_pm[2 * n4];
-        if (nmoved) {
-            // the projected state is N workgroups' strided stores: before it is read, the stream's completion rather than
-            // the ticket alone (hm_newton_dev_finish has the story; a frame that moves a vertex is rare enough for the query)
-            HM_HIP(stream_wait(s));
-            memcpy(X, h->pin_pm + n4, xb);
-        }
+        const int nmoved = (int)h->pmv[n4];
+        if (nmoved) memcpy(X, h->pmv.data(), xb);
         if (moved) *moved = nmoved;
         return HM_OK;
     }
@@ -1343,7 +1428,7 @@ extern "C" int hm_project_mask(hm_ctx_t h, const uint8_t *y_m, double *X, int *m
     rc = queue_outline(h, mask);
     if (rc) return rc;
     HM_HIP(hipMemcpyAsync(h->d_pm_X, X, xb, hipMemcpyHostToDevice, s));
-    ProjArgs a = {mask, h->W, h->H, h->N, o, h->d_pm_X};
+    ProjArgs a = {h->d_pm_pruned, h->W, h->H, h->N, o, h->d_pm_X};
     hipLaunchKernelGGL(k_project_mask, dim3(h->N), dim3(PROJ_NT), 0, s, a);
     HM_HIP(hipGetLastError());
     int cnt[4] = {0, 0, 0, 0};
@@ -1351,6 +1436,28 @@ extern "C" int hm_project_mask(hm_ctx_t h, const uint8_t *y_m, double *X, int *m
     HM_HIP(hipMemcpyAsync(X, h->d_pm_X, xb, hipMemcpyDeviceToHost, s));
     HM_HIP(stream_wait(s));
     if (moved) *moved = cnt[2];
+    return HM_OK;
+}
+
+// The reference's contour pruning of a mask (imgproc.py:198-228: the largest object and its holes of area >= 40) as
+// hm_project_mask applies it -- fine-grained operator for the parity tests.  y_m: W*H host mask (object where > 0);
+// out: W*H, 1 where the pruned object is.
+extern "C" int hm_prune_mask(hm_ctx_t h, const uint8_t *y_m, uint8_t *out)
+{
+    HM_ARG(h && y_m && out, "hm_prune_mask: NULL argument");
+    HM_HIP(hipSetDevice(h->device));
+    int rc = ensure_stream2(h);
+    if (rc) return rc;
+    rc = project_buffers(h);
+    if (rc) return rc;
+    const size_t n = (size_t)h->W * h->H;
+    h->outline_ready = false;                    // the buffers are about to hold the outline of the caller's mask
+    if (!h->d_pm_mask) HM_HIP(hm_malloc((void **)&h->d_pm_mask, n));
+    HM_HIP(hipMemcpyAsync(h->d_pm_mask, y_m, n, hipMemcpyHostToDevice, h->stream2));
+    rc = queue_outline(h, h->d_pm_mask);
+    if (rc) return rc;
+    HM_HIP(hipMemcpyAsync(out, h->d_pm_pruned, n, hipMemcpyDeviceToHost, h->stream2));
+    HM_HIP(hipStreamSynchronize(h->stream2));
     return HM_OK;
 }
 
@@ -1373,36 +1480,6 @@ extern "C" int hm_cov_fetch(hm_ctx_t h, double *W_out)
 // that is kept.  Per iteration the host sees one small result block (step, the four error sums)
 // that the last kernel writes into pinned memory; the iterate itself never leaves the device, and
 // the render that gave an iterate's error is the reference render of the next measurement.
-// A result block in pinned host memory carries a ticket that the kernel writes last (system-scope fence before it).
-// Watching it costs a couple of microseconds against ~20 for waking up from a stream synchronisation; the
-// synchronisation remains as the fallback.
-static int wait_ticket(hm_ctx *h, const double *slot, double want) { return wait_ticket_on(h->stream, slot, want); }
-
-// xor of the bit patterns of n doubles of host-visible memory (read as they are now), continued from x
-static unsigned long long xor_bits(const double *p, size_t n, unsigned long long x = 0)
-{
-    const volatile unsigned long long *q = (const volatile unsigned long long *)p;
-    for (size_t i = 0; i < n; i++) x ^= q[i];
-    return x;
-}
-// A result block whose ticket has arrived: has all of it?  `sum()` recomputes the block's checksum from what the host
-// sees now, `want` points at the one the kernel wrote.  The data of a block normally precedes its ticket; when it does
-// not (see k_iter_result) it is a matter of microseconds -- the block is looked at again, and after ~5 ms the stream is
-// waited for (everything queued behind the block included) before the last look.
-template <typename F>
-static int wait_block(hm_ctx *h, F sum, const double *want, const char *who)
-{
-    const volatile double *w = want;
-    for (int tries = 0; tries < 20000; tries++) {
-        if ((double)(sum() & ((1ull << 52) - 1)) == *w) return HM_OK;
-        __builtin_ia32_pause();
-    }
-    HM_HIP(hipStreamSynchronize(h->stream));
-    if ((double)(sum() & ((1ull << 52) - 1)) == *w) return HM_OK;
-    hm_set_error("%s: a result block of the device did not arrive whole (checksum)", who);
-    return HM_ERR_HIP;
-}
-
 extern "C" int hm_update_arm_newton(hm_ctx_t h, void *worker, int n_bars, const int32_t *bars, const double *l0, double kappa,
                                     double M, double dt, int maxiter, double tol)
 {
@@ -1429,14 +1506,17 @@ extern "C" int hm_update_arm_cov(hm_ctx_t h, double eps_F)
 }
 
 static int queue_predict_ahead(hm_ctx *h, const double *X, int n_bars, const int32_t *bars, const double *l0, double kappa,
-                               double M, double dt, double eps_F);
+                               double M, double dt, double eps_F, hipStream_t st);
 
 extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, double deltaX, int masked, int max_iter,
                              double reltol, int info[4], double *errs, double *Hzc, double *gains, double *W_out)
 {
     HM_ARG(h && X && info, "hm_update_run: NULL argument");
-    HM_JOIN(h);
+    HM_JOIN_LAZY(h);                               // (the tail of the last update: waited for before the first solve below)
     HM_ARG(deltaX > 0 && max_iter >= 0, "hm_update_run: deltaX must be positive, max_iter >= 0");
+    // hm_chain_project: the prior mean is being left in d_X0 by the kernels of the state path; X is output only
+    const bool chained = h->chain_pending;
+    h->chain_pending = false;
     // what hm_update_arm_newton armed is for THIS call only: taken out of the handle before anything can fail, so that an
     // error return never leaves a worker pointer behind for a later call to start a job on
     h->last_err_valid = false;
@@ -1453,13 +1533,34 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
     const auto dbg_a = std::chrono::steady_clock::now();
     auto dbg_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_a).count(); };
     double dbg_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int rc = update_begin(h, W_prior, X);
+    int rc = update_begin(h, W_prior, chained ? nullptr : X);
     if (rc) return rc;
     dbg_stage[0] = dbg_ms();
     const int N = h->N, n4 = 4 * N;
-    std::vector<double> X0(X, X + n4), Xcur(X0), Xold(X0);
+    std::vector<double> X0, Xcur, Xold;
+    if (!chained) { X0.assign(X, X + n4); Xcur = X0; Xold = X0; }
+    // chained: what the prediction's and the projection's kernels report (host_block.h), taken while the first iteration
+    // runs.  2: the prediction's inner solve gave up (never observed) -- the caller predicts on the host and calls again.
+    auto chain_collect = [&]() -> int {
+        int r = hb_wait(h->stream3, h->pin_n4 + n4, 0, (size_t)n4 + 2, hb_stamp(h->n4_ticket), h->n4v.data(), "hm_update_run (state prediction)");
+        h->n4_pending = false;
+        if (r) return r;
+        r = hb_wait(h->stream2, h->pin_pm + n4, 0, (size_t)n4 + 1, hb_stamp(h->pm_ticket), h->pmv.data(), "hm_update_run (projectmask)");
+        if (r) return r;
+        h->chain_pred.assign(h->n4v.begin(), h->n4v.begin() + n4);
+        h->chain_proj.assign(h->pmv.begin(), h->pmv.begin() + n4);
+        h->chain_its = (int)h->n4v[n4];
+        h->chain_moved = (int)h->pmv[n4];
+        if (h->n4v[n4 + 1] != 0.0) return 2;
+        X0 = h->chain_proj; Xcur = X0; Xold = X0;
+        h->upd_X0 = X0;
+        h->X0 = X0;
+        return HM_OK;
+    };
+    bool collected = !chained;
     HM_HIP(hipMemcpyAsync(h->d_X, h->d_X0, (size_t)n4 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    double *res = h->pin, *pin_hzc = h->pin + n4 + RES_HEAD, *pin_gain = pin_hzc + (size_t)n4 * 4;
+    double *const pin_res = h->pin, *const pin_tail = h->pin + 2 * ((size_t)n4 + RES_HEAD);
+    const double *const res = h->resv.data();        // this call's copy of an iteration's block, taken when whole
     int niter = 0, accepted = 0;
     bool reverted = false, conv = false, ref_ready = false, regions_ahead = false, grown = false;
     double eold = 0.0;
@@ -1479,9 +1580,11 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
             if (rc) return rc;
         }
         spec = false;
-        h->X0 = Xcur;                              // the state of the reference render (hm_jz / hm_j)
+        if (collected) h->X0 = Xcur;               // the state of the reference render (hm_jz / hm_j)
         h->have_ref = true;
         const int slot = h->upd_last == 0 ? 1 : 0;
+        rc = ctx_join(h);                          // the tail of the last update may still be writing inv(W) and the factor slots
+        if (rc) return rc;
         double *rhs_row = solve_step(h, slot, deltaX);
         // the new iterate: its render, the partial sums of Renderer.error (kalman.py:813) and, as extra workgroups of
         // the same launch, the star regions of the next measurement (they need the new iterate only; wasted when the
@@ -1490,7 +1593,8 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
         rc = render_iter(h, h->d_Xn, h->P, true, masked, regions_ahead, deltaX);
         if (rc) return rc;
         hipLaunchKernelGGL(k_iter_result, dim3(1), dim3(256), 0, h->stream, rhs_row, n4, h->d_tpart,
-                           render_strips(h), h->pool.overflow, (const unsigned *)h->d_flowctl, res, (double)(++h->run_ticket));
+                           render_strips(h), h->pool.overflow, (const unsigned *)h->d_flowctl, pin_res, (double)(++h->run_ticket),
+                           h->result_delay);
         HM_HIP(hipGetLastError());
         if (h->speculate && regions_ahead) {
             std::swap(h->ref, h->P);
@@ -1500,12 +1604,12 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
             if (rc) { unspec(); return rc; }
         }
         const auto dbg_t0 = std::chrono::steady_clock::now();
-        rc = wait_ticket(h, res + n4 + 5, (double)h->run_ticket);
-        if (rc == HM_OK)
-            rc = wait_block(h, [&]() {
-                unsigned long long x = xor_bits(res, (size_t)n4 + 5);
-                return xor_bits(res + n4 + 7, 3, x);
-            }, res + n4 + RES_CHK, "hm_update_run");
+        if (!collected) {
+            rc = chain_collect();
+            if (rc) { unspec(); (void)hipStreamSynchronize(h->stream); return rc; }
+            collected = true;
+        }
+        rc = hb_wait(h->stream, pin_res, 0, (size_t)n4 + RES_HEAD, hb_stamp(h->run_ticket), h->resv.data(), "hm_update_run");
         if (rc) { unspec(); return rc; }
         if (getenv("HYDRA_MI_TRACE")) {
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0).count();
@@ -1517,6 +1621,14 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
             // iteration again (nothing of it has been kept; the regions the failed pass computed for its -- meaningless
             // -- next iterate are computed anew)
             if (grown) { hm_set_error("hm_update_run: the star regions do not fit the difference-image pool"); return HM_ERR_STATE; }
+            if (regions_ahead) {
+                // d_area no longer describes the measurement that overflowed: this iteration's render launch has put the
+                // regions of its (meaningless) new iterate there.  Those of the iterate that was measured, again:
+                MeasureArgs a;
+                measure_args(h, h->d_X, deltaX, masked, a);
+                hipLaunchKernelGGL(k_star_regions, dim3(h->N), dim3(REGION_NT), 0, h->stream, a, h->d_area);
+                HM_HIP(hipGetLastError());
+            }
             HM_HIP(hipStreamSynchronize(h->stream));
             rc = pool_grow(h, "hm_update_run");
             if (rc) return rc;
@@ -1576,6 +1688,10 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
         h->X0 = Xcur;
     }
     unspec();                                      // (max_iter reached: regions_ahead was false, nothing was queued)
+    if (!collected) {                              // (max_iter = 0)
+        rc = chain_collect();
+        if (rc) return rc;
+    }
     dbg_stage[1] = dbg_ms();
     // the state is final: a caller that armed it gets the next frame's state prediction started now, on its worker
     // thread, beside the covariance launches below (hm_update_arm_newton)
@@ -1589,40 +1705,64 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
     int which = -1;                                // -1: the prior
     if (reverted) which = accepted == 0 ? -1 : 1;
     else which = niter == 0 ? -1 : 0;
-    rc = hm_update_cov(h, which, nullptr);
+    // The tail runs on a stream of its own (stream4) when the caller does not want the covariance on the host: everything
+    // it reads is complete -- the host has seen the result block of the last iteration, whose kernel is behind all of
+    // them on `stream` -- and what is still queued on `stream` (the measurement of an iteration that does not happen)
+    // and what the next frame queues there first (reference render, measurement) touch none of its buffers; `stream` waits
+    // for its end (ev_tail, on the device) before the next solve (ctx_join).
+    hipStream_t ts = h->stream;
+    rc = ctx_join(h);                              // (a tail nobody has joined since: an update without iterations)
+    if (rc) return rc;
+    if (!W_out && h->tail_split) {
+        if (!h->stream4) {
+            int least = 0, greatest = 0;
+            HM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            if (greatest != least) { HM_HIP(hipStreamCreateWithPriority(&h->stream4, hipStreamNonBlocking, greatest)); }
+            else HM_HIP(hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking));
+            HM_HIP(hipEventCreateWithFlags(&h->ev_tail, hipEventDisableTiming));
+        }
+        ts = h->stream4;
+    }
+    rc = update_cov_on(h, which, nullptr, ts);
     if (rc) return rc;
     if (niter > 0) {
-        // gains and Hz components go to the pinned block by a kernel that ends with a ticket, as the iterations'
+        // gains and Hz components go to the host as a result block of their own (host_block.h), as the iterations'
         // results do: two blit launches and the wake-up from a stream synchronisation less per frame
-        hipLaunchKernelGGL(k_gains, dim3(n4), dim3(256), 0, h->stream, h->d_Wres, h->d_Hzc, n4, h->d_gain);
-        hipLaunchKernelGGL(k_tail_result, dim3(1), dim3(1024), 0, h->stream, h->d_Hzc, h->d_gain, n4, pin_hzc, pin_gain, res + n4 + 5,
-                           (double)(++h->run_ticket), res + n4 + RES_CHK + 1);
+        hipLaunchKernelGGL(k_gains, dim3(n4), dim3(256), 0, ts, h->d_Wres, h->d_Hzc, n4, h->d_gain);
+        hipLaunchKernelGGL(k_tail_result, dim3(1), dim3(1024), 0, ts, h->d_Hzc, h->d_gain, n4, pin_tail, (double)(++h->run_ticket),
+                           h->result_delay);
     }
-    if (W_out) HM_HIP(hipMemcpyAsync(W_out, h->d_Wres, (size_t)n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (W_out) HM_HIP(hipMemcpyAsync(W_out, h->d_Wres, (size_t)n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, ts));
     HM_HIP(hipGetLastError());
     if (pq_go && h->chol_flow && which >= 0 && niter > 0 && !W_out) {
         // the covariance half of the next frame's prediction, behind the launches above and before this thread waits
         // for them (hm_update_arm_cov)
         rc = queue_predict_ahead(h, Xcur.data(), (int)h->pn_l0.size(), h->pn_bars.data(), h->pn_l0.data(), h->pn_par[0],
-                                 h->pn_par[1], h->pn_par[2], h->pq_eps_F);
+                                 h->pn_par[1], h->pn_par[2], h->pq_eps_F, ts);
         if (rc) return rc;
+    }
+    if (ts != h->stream) {
+        HM_HIP(hipEventRecord(h->ev_tail, ts));
+        h->tail_on_stream4 = true;
     }
     dbg_stage[3] = dbg_ms();
     if (niter > 0 && !W_out) {
-        rc = wait_ticket(h, res + n4 + 5, (double)h->run_ticket);
-        if (rc == HM_OK)
-            rc = wait_block(h, [&]() { return xor_bits(pin_hzc, (size_t)n4 * 7); }, res + n4 + RES_CHK + 1, "hm_update_run");
+        rc = hb_wait(ts, pin_tail, 0, (size_t)n4 * 7, hb_stamp(h->run_ticket), h->tailv.data(), "hm_update_run");
         if (rc) return rc;
     } else {
-        HM_HIP(stream_wait(h->stream));
+        HM_HIP(stream_wait(ts));
+        if (niter > 0 && !hb_take(pin_tail, 0, (size_t)n4 * 7, hb_stamp(h->run_ticket), h->tailv.data())) {
+            hm_set_error("hm_update_run: the gains did not arrive although the stream has completed");
+            return HM_ERR_HIP;
+        }
     }
     dbg_stage[4] = dbg_ms();
     if (dbg && dbg_stage[4] > 5.0)
         fprintf(stderr, "[hydra_mi] hm_update_run %d iterations: begin %.2f loop-end %.2f newton-started %.2f tail-queued %.2f tail-done %.2f ms\n",
                 niter, dbg_stage[0], dbg_stage[1], dbg_stage[2], dbg_stage[3], dbg_stage[4]);
     if (niter > 0) {
-        if (Hzc) memcpy(Hzc, pin_hzc, (size_t)n4 * 4 * sizeof(double));
-        if (gains) memcpy(gains, pin_gain, (size_t)n4 * 3 * sizeof(double));
+        if (Hzc) memcpy(Hzc, h->tailv.data(), (size_t)n4 * 4 * sizeof(double));
+        if (gains) memcpy(gains, h->tailv.data() + (size_t)n4 * 4, (size_t)n4 * 3 * sizeof(double));
     } else {
         if (Hzc) memset(Hzc, 0, (size_t)n4 * 4 * sizeof(double));
         if (gains) memset(gains, 0, (size_t)n4 * 3 * sizeof(double));
@@ -1663,12 +1803,13 @@ extern "C" int hm_update_last_error(hm_ctx_t h, const double *X, double err[4])
 // d_Wprior (where prior_inverse wants it) and the resident covariance (d_Wres, the posterior the caller may still
 // fetch) is left alone.
 static int cov_predict_core(hm_ctx *h, const double *W_in, int n_bars, const int32_t *bars, const double *blocks,
-                            double a, double s, double eps_F, double *W_out, bool ahead)
+                            double a, double s, double eps_F, double *W_out, bool ahead, hipStream_t st = nullptr)
 {
+    if (!st) st = h->stream;
     const int N = h->N, n4 = 4 * N;
     const size_t nn = (size_t)n4 * n4 * sizeof(double);
     std::vector<int> &off = h->sp_h_off, &bar = h->sp_h_bar, &other = h->sp_h_other;   // live until the copies ran
-    if (!ahead) HM_HIP(stream_wait(h->stream));      // ... of the previous call
+    if (!ahead) HM_HIP(stream_wait(st));      // ... of the previous call
     // the springs' topology rarely changes between frames: its device copy is kept and only the per-spring blocks go up
     const bool same_topo = h->d_sp_off && h->sp_bars_cached.size() == 2 * (size_t)n_bars &&
                            (n_bars == 0 || memcmp(h->sp_bars_cached.data(), bars, 2 * (size_t)n_bars * sizeof(int32_t)) == 0);
@@ -1701,10 +1842,10 @@ static int cov_predict_core(hm_ctx *h, const double *W_in, int n_bars, const int
             HM_HIP(hm_malloc((void **)&h->d_sp_blk, 3 * (size_t)n_bars * sizeof(double)));
             h->sp_cap = n_bars;
         }
-        HM_HIP(hipMemcpyAsync(h->d_sp_off, off.data(), (size_t)(N + 1) * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HM_HIP(hipMemcpyAsync(h->d_sp_off, off.data(), (size_t)(N + 1) * sizeof(int), hipMemcpyHostToDevice, st));
         if (n_bars > 0) {
-            HM_HIP(hipMemcpyAsync(h->d_sp_bar, bar.data(), bar.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-            HM_HIP(hipMemcpyAsync(h->d_sp_other, other.data(), other.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+            HM_HIP(hipMemcpyAsync(h->d_sp_bar, bar.data(), bar.size() * sizeof(int), hipMemcpyHostToDevice, st));
+            HM_HIP(hipMemcpyAsync(h->d_sp_other, other.data(), other.size() * sizeof(int), hipMemcpyHostToDevice, st));
         }
         h->sp_bars_cached.assign(bars, bars + 2 * (size_t)n_bars);
     }
@@ -1714,25 +1855,25 @@ static int cov_predict_core(hm_ctx *h, const double *W_in, int n_bars, const int
             h->sp_h_blk.assign(blocks, blocks + 3 * (size_t)n_bars);
             from = h->sp_h_blk.data();
         }
-        HM_HIP(hipMemcpyAsync(h->d_sp_blk, from, 3 * (size_t)n_bars * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HM_HIP(hipMemcpyAsync(h->d_sp_blk, from, 3 * (size_t)n_bars * sizeof(double), hipMemcpyHostToDevice, st));
     }
     const double *src = h->d_Wres;
     if (W_in) {
-        HM_HIP(hipMemcpyAsync(h->d_H, W_in, nn, hipMemcpyHostToDevice, h->stream));
+        HM_HIP(hipMemcpyAsync(h->d_H, W_in, nn, hipMemcpyHostToDevice, st));
         src = h->d_H;
     } else if (src == h->d_Wtmp) {               // the output buffer: move the input out of the way
-        HM_HIP(hipMemcpyAsync(h->d_H, h->d_Wtmp, nn, hipMemcpyDeviceToDevice, h->stream));
+        HM_HIP(hipMemcpyAsync(h->d_H, h->d_Wtmp, nn, hipMemcpyDeviceToDevice, st));
         src = h->d_H;
     }
     SpringTopo tp = {h->d_sp_off, h->d_sp_bar, h->d_sp_other, h->d_sp_blk};
     double *P = h->d_Awork;                      // scratch
     double *dst = ahead ? h->d_Wprior : h->d_Wtmp;
-    hipLaunchKernelGGL(k_fw_rows, dim3(hm_cdiv(n4, 256), N), dim3(256), 0, h->stream, src, P, N, tp, a, s);
-    hipLaunchKernelGGL(k_pft_cols, dim3(hm_cdiv(n4, 256), N), dim3(256), 0, h->stream, P, dst, N, tp, a, s, eps_F);
+    hipLaunchKernelGGL(k_fw_rows, dim3(hm_cdiv(n4, 256), N), dim3(256), 0, st, src, P, N, tp, a, s);
+    hipLaunchKernelGGL(k_pft_cols, dim3(hm_cdiv(n4, 256), N), dim3(256), 0, st, P, dst, N, tp, a, s, eps_F);
     HM_HIP(hipGetLastError());
     if (ahead) return HM_OK;
-    if (W_out) HM_HIP(hipMemcpyAsync(W_out, h->d_Wtmp, nn, hipMemcpyDeviceToHost, h->stream));
-    if (W_out) HM_HIP(stream_wait(h->stream));
+    if (W_out) HM_HIP(hipMemcpyAsync(W_out, h->d_Wtmp, nn, hipMemcpyDeviceToHost, st));
+    if (W_out) HM_HIP(stream_wait(st));
     h->d_Wres = h->d_Wtmp;
     h->prefactored = false;
     return HM_OK;
@@ -1772,7 +1913,7 @@ static void spring_blocks(int n_bars, const int32_t *bars, const double *l0, dou
 // IteratedMSKalmanFilter.predict).  Nothing is made current: hm_predict_take does that when the caller's inputs turn
 // out to be the ones used here; otherwise the caller's own hm_cov_predict starts from the posterior, which is intact.
 static int queue_predict_ahead(hm_ctx *h, const double *X, int n_bars, const int32_t *bars, const double *l0, double kappa,
-                               double M, double dt, double eps_F)
+                               double M, double dt, double eps_F, hipStream_t st)
 {
     for (int i = 0; i < 2 * n_bars; i++)
         if (bars[i] < 0 || bars[i] >= h->N) return HM_OK;                 // the caller's own hm_cov_predict reports it
@@ -1784,10 +1925,10 @@ static int queue_predict_ahead(hm_ctx *h, const double *X, int n_bars, const int
     }
     spring_blocks(n_bars, bars, l0, kappa, X, h->pin_blk);
     double *const post = h->d_Wres;
-    int rc = cov_predict_core(h, nullptr, n_bars, bars, h->pin_blk, dt, dt / M, eps_F, nullptr, true);
+    int rc = cov_predict_core(h, nullptr, n_bars, bars, h->pin_blk, dt, dt / M, eps_F, nullptr, true, st);
     if (rc) return rc;
     h->d_Wres = h->d_Wprior;                     // (prior_inverse: the prior is where it belongs already)
-    rc = prior_inverse(h, nullptr);
+    rc = prior_inverse(h, nullptr, st);
     h->d_Wres = post;
     if (rc) return rc;
     h->upd_open = false;                         // the factor slots and d_Wprior belong to the next update now
@@ -1807,7 +1948,7 @@ extern "C" int hm_predict_take(hm_ctx_t h, const double *X, int n_bars, const in
                                double a, double s, double eps_F)
 {
     HM_ARG(h && X && n_bars >= 0 && (n_bars == 0 || (bars && l0)), "hm_predict_take: bad argument");
-    HM_JOIN(h);
+    HM_JOIN_LAZY(h);
     if (!h->pq_valid) return 1;
     h->pq_valid = false;
     const size_t n4 = (size_t)4 * h->N;
@@ -1925,11 +2066,14 @@ extern "C" int hm_newton_dev_start(hm_ctx_t h, int N, int n_bars, const int32_t 
         HM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
         if (greatest != least) { HM_HIP(hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, greatest)); }
         else HM_HIP(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
-        // coherent (fine-grained): the kernel reads what the host has just written and the host reads what the kernel wrote,
-        // launch after launch at the same addresses -- from a default (cacheable) allocation the kernel now and then read the
-        // previous frame's state out of the L2 (one track in fifty came out different)
-        HM_HIP(hipHostMalloc((void **)&h->pin_n4, ((size_t)8 * N + 4) * sizeof(double), hipHostMallocCoherent));
-        memset(h->pin_n4, 0, ((size_t)8 * N + 4) * sizeof(double));
+        // page-locked and coherent (hipHostMalloc without flags already is: the flag states the intent, it was not the
+        // cause of round 3's wrong tracks -- host_block.h has that story): [X in (4N) | a result block of 4N + 2 values]
+        const size_t words = (size_t)4 * N + 2 * ((size_t)4 * N + 2);
+        HM_HIP(hipHostMalloc((void **)&h->pin_n4, words * sizeof(double), hipHostMallocCoherent));
+        memset(h->pin_n4, 0, words * sizeof(double));
+        HM_HIP(hm_malloc((void **)&h->d_n4X, ((size_t)4 * N + 2) * sizeof(double)));
+        h->n4v.assign((size_t)4 * N + 2, 0.0);
+        HM_HIP(hipEventCreateWithFlags(&h->ev_n4, hipEventDisableTiming));
     }
     const bool same = h->n4_bars.size() == 2 * (size_t)n_bars && memcmp(h->n4_bars.data(), bars, 2 * (size_t)n_bars * sizeof(int32_t)) == 0;
     if (!same) {
@@ -1960,8 +2104,9 @@ extern "C" int hm_newton_dev_start(hm_ctx_t h, int N, int n_bars, const int32_t 
                 HM_HIP(hm_malloc((void **)&h->d_n4l0, (size_t)n_bars * sizeof(double)));
                 h->n4cap = n_bars;
             }
-            // on the kernel's own stream: a copy on the null stream is not ordered before a launch on a non-blocking
-            // stream (the kernel now and then started on tables that had not arrived: wrong neighbours, one track in fifty)
+            // on the kernel's own stream and waited for (nbr / nbb are locals): ordered before the launch by the stream
+            // itself rather than by hipMemcpy's return (that was not the cause of round 3's wrong tracks either -- a track
+            // uploads these tables once, the wrong predictions came at frame 13 -- but it is the form that needs no argument)
             HM_HIP(hipMemcpyAsync(h->d_n4nbr, nbr.data(), nbr.size() * sizeof(int), hipMemcpyHostToDevice, h->stream3));
             HM_HIP(hipMemcpyAsync(h->d_n4nbb, nbb.data(), nbb.size() * sizeof(int), hipMemcpyHostToDevice, h->stream3));
             HM_HIP(hipMemcpyAsync(h->d_n4bars, h->n4_bars.data(), 2 * (size_t)n_bars * sizeof(int), hipMemcpyHostToDevice, h->stream3));
@@ -1980,13 +2125,16 @@ extern "C" int hm_newton_dev_start(hm_ctx_t h, int N, int n_bars, const int32_t 
     a.N = N; a.I = n_bars; a.deg_stride = h->n4deg;
     a.bars = h->d_n4bars; a.l0 = h->d_n4l0; a.nbr = h->d_n4nbr; a.nbb = h->d_n4nbb;
     a.kappa = kappa; a.M = M; a.dt = dt; a.tol = tol; a.maxiter = maxiter; a.steps = (int)std::ceil(1.0 / dt);
-    a.Xin = h->pin_n4; a.out = h->pin_n4 + n4; a.ticket = (double)(++h->n4_ticket);
+    a.Xin = h->pin_n4; a.out = h->pin_n4 + n4; a.dev_out = h->d_n4X; a.ticket = (double)(++h->n4_ticket);
+    a.delay_us = h->result_delay; a.force_bad = h->newton_fail;
     const size_t lds = ((size_t)6 * NEWTON4_NT + 4 * ((size_t)n_bars + 1) + 4 * (NEWTON4_NT / 64)) * sizeof(double) + 2 * (size_t)n_bars * sizeof(int);
     if (lds > 64 * 1024) return 1;
     if (h->n4deg == 8) hipLaunchKernelGGL((k_ms_newton4<8>), dim3(1), dim3(NEWTON4_NT), lds, h->stream3, a);
     else hipLaunchKernelGGL((k_ms_newton4<12>), dim3(1), dim3(NEWTON4_NT), lds, h->stream3, a);
     HM_HIP(hipGetLastError());
+    HM_HIP(hipEventRecord(h->ev_n4, h->stream3));
     h->n4_pending = true;
+    h->chain_pending = false;
     return HM_OK;
 }
 
@@ -1998,21 +2146,67 @@ extern "C" int hm_newton_dev_finish(hm_ctx_t h, double *X, int *newton_iteration
     if (!h->n4_pending) { hm_set_error("hm_newton_dev_finish: no prediction was started"); return HM_ERR_STATE; }
     HM_HIP(hipSetDevice(h->device));
     const size_t n4 = (size_t)4 * h->N;
-    // The stream's completion, not the ticket: the kernel's result is 4N doubles written by four waves in strided 8-byte
-    // stores, and the ticket -- although written behind a system-scope fence and a barrier -- was seen by the host before
-    // the last of them had landed (one track in a hundred: positions of this prediction with velocities of the last one, or
-    // the other way round; tools/stress_determinism.py).  A stream that has completed has made all its writes visible; the
-    // kernel is usually long done when this is called (it was started at the end of the previous update), so the query
-    // returns at once.
-    hipError_t e = stream_wait(h->stream3);
+    // the kernel's result block, taken when it is whole (host_block.h); the kernel is usually long done when this is
+    // called (it was started at the end of the previous update)
+    const int rc = hb_wait(h->stream3, h->pin_n4 + n4, 0, n4 + 2, hb_stamp(h->n4_ticket), h->n4v.data(), "hm_newton_dev_finish");
     h->n4_pending = false;
-    if (e != hipSuccess) { hm_set_error("hm_newton_dev_finish: %s", hipGetErrorString(e)); return HM_ERR_HIP; }
-    if (((const volatile double *)h->pin_n4)[2 * n4 + 2] != (double)h->n4_ticket) {
-        hm_set_error("hm_newton_dev_finish: the kernel finished without reporting (ticket %lld missing)", h->n4_ticket);
-        return HM_ERR_STATE;
+    h->chain_pending = false;
+    if (rc) return rc;
+    if (h->n4v[n4 + 1] != 0.0) return 1;
+    memcpy(X, h->n4v.data(), n4 * sizeof(double));
+    if (newton_iterations) *newton_iterations = (int)h->n4v[n4];
+    return HM_OK;
+}
+
+
+// ---- the state path between two frames without host round trips ------------------------------------------------------
+// compute() (kalman.py:676-700) is predict -> projectmask -> update.  With the state prediction started on the device
+// by the update that precedes it (hm_newton_dev_start) every step's input is in device memory before the host needs
+// to know it: hm_chain_project queues projectmask (kalman.py:724-742, mask of the observation in place) of the
+// prediction in flight behind its kernel -- k_project_mask_host reads the kernel's device copy of the predicted state
+// and leaves the projected state in d_X0, where the update keeps its prior mean -- and marks the handle: the next
+// hm_update_run starts from d_X0 as it is (its X argument is output only), waits on the device for the projection
+// instead of uploading a state, and collects the two kernels' result blocks (predicted state, Newton iterations,
+// projected state, vertices moved: hm_chain_states) while its first iteration runs.  The numbers are those of the
+// three separate calls.  Returns 1 when there is nothing to chain (no prediction in flight): the caller takes the
+// three calls.
+extern "C" int hm_chain_project(hm_ctx_t h)
+{
+    HM_ARG(h != nullptr, "hm_chain_project: NULL handle");
+    NEED_OBS(h, "hm_chain_project");
+    if (!h->n4_pending || !h->d_n4X) return 1;
+    HM_HIP(hipSetDevice(h->device));
+    int rc = ensure_stream2(h);
+    if (rc) return rc;
+    rc = project_buffers(h);
+    if (rc) return rc;
+    if (!h->outline_ready) {
+        rc = queue_outline(h, h->o_ym);
+        if (rc) return rc;
+        h->outline_ready = true;
     }
-    if (h->pin_n4[2 * n4 + 1] != 0.0) return 1;
-    memcpy(X, h->pin_n4 + n4, n4 * sizeof(double));
-    if (newton_iterations) *newton_iterations = (int)h->pin_n4[2 * n4];
+    const size_t n4 = (size_t)4 * h->N;
+    Outline o = {h->d_outline, h->d_outline_cnt, h->W * h->H, h->d_pm_flag};
+    ProjArgs a = {h->d_pm_pruned, h->W, h->H, h->N, o, nullptr};
+    HM_HIP(hipStreamWaitEvent(h->stream2, h->ev_n4, 0));
+    hipLaunchKernelGGL(k_project_mask_host, dim3(h->N), dim3(PROJ_NT), 0, h->stream2, a, (const double *)h->d_n4X, h->pin_pm + n4, h->d_X0,
+                       h->d_pm_done, (double)(++h->pm_ticket), h->result_delay);
+    HM_HIP(hipGetLastError());
+    HM_HIP(hipEventRecord(h->ev_pm, h->stream2));
+    h->chain_pending = true;
+    return HM_OK;
+}
+
+// What the last chained hm_update_run started from: the predicted state, the projected state (its prior mean), the
+// Newton iterations of the prediction, the vertices projectmask moved.  Any pointer may be NULL.
+extern "C" int hm_chain_states(hm_ctx_t h, double *predicted, double *projected, int *newton_iterations, int *moved)
+{
+    HM_ARG(h != nullptr, "hm_chain_states: NULL handle");
+    const size_t n4 = (size_t)4 * h->N;
+    if (h->chain_pred.size() != n4 || h->chain_proj.size() != n4) { hm_set_error("hm_chain_states: no chained update has run"); return HM_ERR_STATE; }
+    if (predicted) memcpy(predicted, h->chain_pred.data(), n4 * sizeof(double));
+    if (projected) memcpy(projected, h->chain_proj.data(), n4 * sizeof(double));
+    if (newton_iterations) *newton_iterations = h->chain_its;
+    if (moved) *moved = h->chain_moved;
     return HM_OK;
 }

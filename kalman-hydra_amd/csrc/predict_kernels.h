@@ -8,6 +8,7 @@
 // gradients to the rounding floor.  Sums over the vector (norms, dot products) are block reductions in a fixed
 // order -- not the host's left-to-right order, so the two agree to rounding, not to the bit.
 #pragma once
+#include "host_block.h"
 #include <hip/hip_runtime.h>
 
 #define NEWTON_NT 512
@@ -182,10 +183,13 @@ struct Newton4Args {
     const int *nbr, *nbb;     // N x deg_stride: neighbour vertex / bar of slot q (padding: the vertex itself / bar I)
     double kappa, M, dt, tol;
     int maxiter, steps;
-    const double *Xin;        // 4N (page-locked host memory or device memory)
-    double *out;              // [0, 4N): the advanced state; [4N]: Newton iterations, [4N + 1]: 1 = inner solve failed,
-                              // [4N + 2]: the ticket, written last behind a system-scope fence
+    const double *Xin;        // 4N, page-locked host memory written before the launch was queued (system-scope loads)
+    double *out;              // a result block of host_block.h in page-locked host memory, 4N + 2 values: the advanced state,
+                              // the Newton iterations, 1 = inner solve failed
+    double *dev_out;          // 4N + 2 in device memory: the same for kernels queued behind this one (hm_chain_project), or NULL
     double ticket;
+    int delay_us;             // test knob "result_delay" (host_block.h)
+    int force_bad;            // test knob "newton_fail": report a failed inner solve
 };
 
 // wave-wide sums of a and b in lane 63 (row shifts, then the row broadcasts of gfx9)
@@ -251,7 +255,10 @@ __global__ __launch_bounds__(NEWTON4_NT) void k_ms_newton4(Newton4Args a)
     }
     // the state: X = [y; w] (positions, velocities); x = the sub-step's start, xp = the iterate, xo = the one before
     double Xy[2] = {0, 0}, Xw[2] = {0, 0};
-    if (act) { Xy[0] = a.Xin[2 * v]; Xy[1] = a.Xin[2 * v + 1]; Xw[0] = a.Xin[2 * N + 2 * v]; Xw[1] = a.Xin[2 * N + 2 * v + 1]; }
+    if (act) {
+        Xy[0] = hb_host_in(a.Xin + 2 * v); Xy[1] = hb_host_in(a.Xin + 2 * v + 1);
+        Xw[0] = hb_host_in(a.Xin + 2 * N + 2 * v); Xw[1] = hb_host_in(a.Xin + 2 * N + 2 * v + 1);
+    }
     const double dt = a.dt, M = a.M, a2 = dt * dt / M;
     int total = 0, bad = 0, flip = 0, pb = 0;
     // out = dfdy * s for this vertex, s of the neighbours from P[pb]
@@ -363,15 +370,22 @@ __global__ __launch_bounds__(NEWTON4_NT) void k_ms_newton4(Newton4Args a)
             total++;
         }
     }
+    const unsigned long long stamp = hb_stamp((long long)a.ticket);
+    bad |= a.force_bad;
+    if (a.dev_out) {
+        if (act) {
+            a.dev_out[2 * v] = Xy[0]; a.dev_out[2 * v + 1] = Xy[1];
+            a.dev_out[2 * N + 2 * v] = Xw[0]; a.dev_out[2 * N + 2 * v + 1] = Xw[1];
+        }
+        if (t == 0) { a.dev_out[4 * N] = (double)total; a.dev_out[4 * N + 1] = (double)bad; }
+    }
+    if (a.delay_us > 0) {
+        if (t == 0) hb_put(a.out, 4 * N + 1, (double)bad, stamp);
+        hb_delay(a.delay_us);
+    }
     if (act) {
-        a.out[2 * v] = Xy[0]; a.out[2 * v + 1] = Xy[1];
-        a.out[2 * N + 2 * v] = Xw[0]; a.out[2 * N + 2 * v + 1] = Xw[1];
+        hb_put(a.out, 2 * v, Xy[0], stamp); hb_put(a.out, 2 * v + 1, Xy[1], stamp);
+        hb_put(a.out, 2 * N + 2 * v, Xw[0], stamp); hb_put(a.out, 2 * N + 2 * v + 1, Xw[1], stamp);
     }
-    __threadfence_system();
-    __syncthreads();
-    if (t == 0) {
-        a.out[4 * N] = (double)total; a.out[4 * N + 1] = (double)bad;
-        __threadfence_system();
-        a.out[4 * N + 2] = a.ticket;
-    }
+    if (t == 0) { hb_put(a.out, 4 * N, (double)total, stamp); hb_put(a.out, 4 * N + 1, (double)bad, stamp); }
 }

@@ -14,14 +14,14 @@
 //     the squared point-to-segment distance over all of them in binary64 (min does not depend on the
 //     order) and the sign from the 2x2 pixels around the point: inside iff all four are object, or
 //     three and the point lies on their side of the diagonal -- inside the polygon through the centres.
-// What is NOT applied per frame is the reference's contour pruning (imgproc.py:205-228: only the largest
-// object and its holes of at least 40 px): every border pixel of the mask counts.  For a mask with one object
-// and no small holes the numbers are those of imgproc.findObjectThreshold(mask).fd (tests).
+// The reference's contour pruning (imgproc.py:205-228: only the largest object and its holes of area >= 40) is
+// applied to the mask first, per frame (k_ccl_* below); k_outline and the walk work on the pruned mask.
 // The arithmetic is the oracle's (oracle/ekf_ref.py:outline_distance, project_mask), operation by
 // operation with contraction off, so the projected state is the same f64 numbers.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include "host_block.h"
 
 struct Outline {
     int2 *pts;       // capacity W*H: border pixels of the object
@@ -53,6 +53,228 @@ __global__ __launch_bounds__(OUTLINE_NT) void k_outline(const uint8_t *__restric
     base_o = __shfl(base_o, 0);
     const unsigned long long below = (1ull << lane) - 1ull;
     if (on) o.pts[base_o + __popcll(bo & below)] = make_int2(x, y);
+}
+
+// ---- the reference's contour pruning on the device (imgproc.py:198-228 via kalman.py:725) --------------------------
+// findObjectThreshold keeps the outer contour of the LARGEST object (cv2.contourArea) and of its holes those of area
+// >= 40; smaller objects, smaller holes and everything nested deeper go (oracle/ekf_ref.py:pruned_object has the
+// restatement this follows, areas by Pick's theorem).  Per frame, on the mask in device memory:
+//   k_ccl_runs     every pixel points to the first pixel of its horizontal run inside a 64-pixel row segment; object
+//                  pixels and background pixels are labelled in the same pass (a pixel belongs to one of the two);
+//   k_ccl_merge    union-find over those labels (atomicMin towards the smaller index, so a component's root is its
+//                  first pixel in raster order): object pixels join their W / NW / N / NE neighbours (8-connected),
+//                  background pixels their W / N neighbours (4-connected);
+//   k_ccl_flatten  every pixel points to its root; background components that reach the frame edge are marked
+//                  (findContours treats the frame as surrounded by background: they are outside, not holes);
+//   k_ccl_stats    nesting comes from the roots: the pixel ABOVE a component's first pixel belongs to the component
+//                  that encloses it (an enclosed component cannot have pixels above whatever encloses it).  Every
+//                  pixel adds 1 to each contour it lies inside or on (its own object's outer contour, the hole that
+//                  object sits in, ...); object pixels 4-adjacent to the outside / to a hole of their own object count
+//                  the contours' boundary points;
+//   k_ccl_select   the level-0 object with the largest area (ties: first in raster order);
+//   k_ccl_write    the pruned mask: inside that object's outer contour and not inside one of its holes of area >= 40.
+// All counts are whole numbers, areas are compared doubled (2 A = 2 inside -/+ boundary - 2): same decisions as the oracle.
+struct Ccl {
+    int *L;          // W*H: labels (pixel indices)
+    int *cnt;        // W*H, used at roots: pixels inside or on the component's contour
+    int *bnd;        // W*H, used at roots: boundary points of the contour (object: pixels 4-adjacent to the outside;
+                     // hole: pixels of the enclosing object 4-adjacent to it)
+    uint8_t *edge;   // W*H, used at background roots: 1 = reaches the frame edge
+    unsigned long long *best;     // [0]: (2 A << 32) | ~root of the best level-0 object so far
+    int W, H;
+};
+
+__device__ __forceinline__ int d_ccl_find(int *L, int i)
+{
+    int r = i;
+    for (int p = L[r]; p != r; p = L[r]) r = p;
+    for (int p = L[i]; p != r && p != i; p = L[i]) { atomicMin(&L[i], r); i = p; }      // (labels only ever decrease)
+    return r;
+}
+__device__ __forceinline__ void d_ccl_unite(int *L, int a, int b)
+{
+    for (;;) {
+        a = d_ccl_find(L, a);
+        b = d_ccl_find(L, b);
+        if (a == b) return;
+        if (a > b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(&L[b], a);
+        if (old == b) return;
+        b = old;
+    }
+}
+
+#define CCL_NT 256
+// grid (ceil(W / 64), ceil(H / 4)): a wave per 64-pixel row segment
+__global__ __launch_bounds__(CCL_NT) void k_ccl_runs(const uint8_t *__restrict__ ym, Ccl c)
+{
+    const int lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 64 + lane, y = blockIdx.y * (CCL_NT / 64) + (threadIdx.x >> 6);
+    if (y >= c.H) return;
+    const bool in = x < c.W;
+    const bool fg = in && ym[(size_t)y * c.W + x] > 0;
+    const unsigned long long bf = __ballot(fg);
+    // lanes that start a run: lane 0, or a class different from the lane before
+    const unsigned long long prev = (bf << 1) | (bf & 1ull);
+    const unsigned long long starts = (bf ^ prev) | 1ull;
+    const unsigned long long upto = starts & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+    const int first = 63 - __clzll(upto);
+    if (in) {
+        const size_t p = (size_t)y * c.W + x;
+        c.L[p] = y * c.W + blockIdx.x * 64 + first;
+        c.cnt[p] = 0;
+        c.bnd[p] = 0;
+        c.edge[p] = 0;
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) c.best[0] = 0ull;
+}
+
+__global__ __launch_bounds__(CCL_NT) void k_ccl_merge(const uint8_t *__restrict__ ym, Ccl c)
+{
+    const int lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 64 + lane, y = blockIdx.y * (CCL_NT / 64) + (threadIdx.x >> 6);
+    if (x >= c.W || y >= c.H) return;
+    const int W = c.W, p = y * W + x;
+    const uint8_t *row = ym + (size_t)y * W;
+    const bool fg = row[x] > 0;
+    // the run start joins the run on its left (another segment) when that is of its class
+    if (lane == 0 && x > 0 && (row[x - 1] > 0) == fg) d_ccl_unite(c.L, p, p - 1);
+    if (y == 0) return;
+    const uint8_t *up = row - W;
+    const bool n = up[x] > 0;
+    if (fg) {
+        // the run above through N; when N is background, the (different) runs of NW and NE
+        if (n) d_ccl_unite(c.L, p, p - W);
+        else {
+            if (x > 0 && up[x - 1] > 0) d_ccl_unite(c.L, p, p - W - 1);
+            if (x + 1 < W && up[x + 1] > 0) d_ccl_unite(c.L, p, p - W + 1);
+        }
+    } else if (!n) {
+        d_ccl_unite(c.L, p, p - W);
+    }
+}
+
+__global__ __launch_bounds__(CCL_NT) void k_ccl_flatten(const uint8_t *__restrict__ ym, Ccl c)
+{
+    const int lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 64 + lane, y = blockIdx.y * (CCL_NT / 64) + (threadIdx.x >> 6);
+    if (x >= c.W || y >= c.H) return;
+    const int p = y * c.W + x;
+    const int r = d_ccl_find(c.L, p);
+    c.L[p] = r;
+    if (!(ym[p] > 0) && (x == 0 || y == 0 || x == c.W - 1 || y == c.H - 1)) c.edge[r] = 1;
+}
+
+// the component that encloses the component with root r (a pixel index): the one the pixel above r belongs to;
+// -1: the frame edge (r in row 0)
+__device__ __forceinline__ int d_ccl_parent(const Ccl &c, int r) { return r < c.W ? -1 : c.L[r - c.W]; }
+
+__global__ __launch_bounds__(CCL_NT) void k_ccl_stats(const uint8_t *__restrict__ ym, Ccl c)
+{
+    __shared__ int s_root, s_n, s_b;
+    if (threadIdx.x == 0) { s_root = -1; s_n = 0; s_b = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 64 + lane, y = blockIdx.y * (CCL_NT / 64) + (threadIdx.x >> 6);
+    const int W = c.W, H = c.H;
+    const bool in = x < W && y < H;
+    const int p = in ? y * W + x : 0;
+    const bool fg = in && ym[p] > 0;
+    const int r = in ? c.L[p] : -1;
+    // the workgroup's commonest object gathers its counts in LDS (one object covers most of a mask)
+    if (fg) atomicCAS(&s_root, -1, r);
+    __syncthreads();
+    const int hot = s_root;
+    if (in) {
+        // 1: the contours this pixel lies inside or on
+        int cur = r;
+        bool curfg = fg;
+        for (int depth = 0; depth < 64; depth++) {
+            if (curfg) {
+                if (cur == hot) atomicAdd(&s_n, 1); else atomicAdd(&c.cnt[cur], 1);
+                const int par = d_ccl_parent(c, cur);
+                if (par < 0 || c.edge[par]) break;              // level 0: outside is the frame or background that reaches it
+                cur = par; curfg = false;
+            } else {
+                if (c.edge[cur]) break;                          // outside
+                atomicAdd(&c.cnt[cur], 1);
+                cur = d_ccl_parent(c, cur);                      // (an enclosed background component is never in row 0)
+                curfg = true;
+            }
+        }
+        // 2: boundary points
+        if (fg) {
+            bool outer = x == 0 || y == 0 || x == W - 1 || y == H - 1;
+            int holes[4], nh = 0;
+            const int nbr[4] = {x > 0 ? p - 1 : -1, x + 1 < W ? p + 1 : -1, y > 0 ? p - W : -1, y + 1 < H ? p + W : -1};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (nbr[k] < 0 || ym[nbr[k]] > 0) continue;
+                const int b = c.L[nbr[k]];
+                if (c.edge[b]) { outer = true; continue; }
+                if (d_ccl_parent(c, b) != r) continue;           // this object sits IN that hole: the hole's contour runs elsewhere
+                bool seen = false;
+                for (int q = 0; q < nh; q++) seen = seen || holes[q] == b;
+                if (!seen) holes[nh++] = b;
+            }
+            if (outer) { if (r == hot) atomicAdd(&s_b, 1); else atomicAdd(&c.bnd[r], 1); }
+            for (int q = 0; q < nh; q++) atomicAdd(&c.bnd[holes[q]], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && hot >= 0) {
+        if (s_n) atomicAdd(&c.cnt[hot], s_n);
+        if (s_b) atomicAdd(&c.bnd[hot], s_b);
+    }
+}
+
+// doubled area of the outer contour of the object with root r / of the hole with root r
+__device__ __forceinline__ long long d_ccl_area2_object(const Ccl &c, int r) { return 2ll * c.cnt[r] - c.bnd[r] - 2; }
+__device__ __forceinline__ long long d_ccl_area2_hole(const Ccl &c, int r) { return 2ll * c.cnt[r] + c.bnd[r] - 2; }
+
+__global__ __launch_bounds__(CCL_NT) void k_ccl_select(const uint8_t *__restrict__ ym, Ccl c)
+{
+    const int lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 64 + lane, y = blockIdx.y * (CCL_NT / 64) + (threadIdx.x >> 6);
+    if (x >= c.W || y >= c.H) return;
+    const int p = y * c.W + x;
+    if (!(ym[p] > 0) || c.L[p] != p) return;                     // roots of objects only
+    const int par = d_ccl_parent(c, p);
+    if (par >= 0 && !c.edge[par]) return;                        // nested in a hole: not level 0
+    const long long a2 = d_ccl_area2_object(c, p);
+    if (a2 < 0) return;
+    atomicMax(c.best, ((unsigned long long)a2 << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)p));
+}
+
+// pruned mask: 1 inside the kept outer contour and outside every kept hole (doubled areas against 2 x 40)
+__global__ __launch_bounds__(CCL_NT) void k_ccl_write(const uint8_t *__restrict__ ym, Ccl c, uint8_t *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 64 + lane, y = blockIdx.y * (CCL_NT / 64) + (threadIdx.x >> 6);
+    if (x >= c.W || y >= c.H) return;
+    const int p = y * c.W + x;
+    const unsigned long long key = c.best[0];
+    const long long a2 = (long long)(key >> 32);
+    const int best = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+    uint8_t v = 0;
+    if (key != 0ull && a2 >= 80) {
+        int cur = c.L[p];
+        bool curfg = ym[p] > 0;
+        for (int depth = 0; depth < 64; depth++) {
+            if (curfg) {
+                if (cur == best) { v = 1; break; }
+                const int par = d_ccl_parent(c, cur);
+                if (par < 0 || c.edge[par]) break;               // another level-0 object
+                cur = par; curfg = false;
+            } else {
+                if (c.edge[cur]) break;                          // outside
+                const int own = d_ccl_parent(c, cur);
+                if (own == best) { v = d_ccl_area2_hole(c, cur) >= 80 ? 0 : 1; break; }    // a hole of the kept object: kept or filled
+                cur = own; curfg = true;
+            }
+        }
+    }
+    out[p] = v;
 }
 
 struct ProjArgs {
@@ -163,31 +385,37 @@ __global__ __launch_bounds__(PROJ_NT) void k_project_mask(ProjArgs a)
     }
 }
 
-// The same with the state read from and written to page-locked host memory (a frame of the filter: the predicted
-// state comes from the host's Newton loop and goes back to it): `io` = [X (4N) | projected X (4N) | vertices moved |
-// ticket].  Every workgroup writes its vertex's four entries; the one that finishes last adds the count and, behind a
-// system-scope fence, the ticket the host is watching -- no copies, no stream synchronisation (hm_project_mask).
-__global__ __launch_bounds__(PROJ_NT) void k_project_mask_host(ProjArgs a, double *io, int *done, double ticket)
+// The same for a frame of the filter, without copy operations and without a stream synchronisation (hm_project_mask,
+// hm_chain_project).  xin: the predicted state (4N) -- page-locked host memory written before the launch was queued, or
+// the device buffer the state prediction's kernel left it in; read with system-scope loads either way.  blk: a result
+// block of host_block.h in page-locked host memory, 4N + 1 values: the projected state and the number of vertices that
+// were moved (published by the workgroup that finishes last).  dev_out (may be NULL): the projected state in device
+// memory for the kernels queued behind this one (the prior mean of the update).
+__global__ __launch_bounds__(PROJ_NT) void k_project_mask_host(ProjArgs a, const double *xin, double *blk, double *dev_out, int *done,
+                                                               double ticket, int delay_us)
 {
 #pragma clang fp contract(off)
     __shared__ double red[PROJ_NT / 64 * 3];
     const int v = blockIdx.x, N = a.N;
-    const double x0 = io[2 * v], y0 = io[2 * v + 1];
+    const double x0 = hb_host_in(xin + 2 * v), y0 = hb_host_in(xin + 2 * v + 1);
     double x, y;
     const bool moved = d_project_vertex(a, x0, y0, red, x, y);
     if (threadIdx.x != 0) return;
-    double *out = io + 4 * N;
-    out[2 * v] = x;
-    out[2 * v + 1] = y;
-    out[2 * N + 2 * v] = moved ? io[2 * N + 2 * v] + (x - x0) : io[2 * N + 2 * v];
-    out[2 * N + 2 * v + 1] = moved ? io[2 * N + 2 * v + 1] + (y - y0) : io[2 * N + 2 * v + 1];
+    const unsigned long long stamp = hb_stamp((long long)ticket);
+    const double vx0 = hb_host_in(xin + 2 * N + 2 * v), vy0 = hb_host_in(xin + 2 * N + 2 * v + 1);
+    const double vx = moved ? vx0 + (x - x0) : vx0, vy = moved ? vy0 + (y - y0) : vy0;
+    if (dev_out) { dev_out[2 * v] = x; dev_out[2 * v + 1] = y; dev_out[2 * N + 2 * v] = vx; dev_out[2 * N + 2 * v + 1] = vy; }
+    if (delay_us > 0 && v == 0) {                            // test knob "result_delay": vertex 0's pairs come late
+        hb_put(blk, 2 * N, vx, stamp);
+        hb_delay(delay_us);
+    }
+    hb_put(blk, 2 * v, x, stamp); hb_put(blk, 2 * v + 1, y, stamp);
+    hb_put(blk, 2 * N + 2 * v, vx, stamp); hb_put(blk, 2 * N + 2 * v + 1, vy, stamp);
     if (moved) atomicAdd(&a.o.count[2], 1);
-    __threadfence_system();
+    __threadfence();
     if (atomicAdd(done, 1) == (int)gridDim.x - 1) {
         __threadfence();
-        io[8 * N] = (double)atomicExch(&a.o.count[2], 0);        // (left clean for another projection onto the same mask)
+        hb_put(blk, 4 * N, (double)atomicExch(&a.o.count[2], 0), stamp);        // (left clean for another projection onto the same mask)
         *done = 0;
-        __threadfence_system();
-        io[8 * N + 1] = ticket;
     }
 }

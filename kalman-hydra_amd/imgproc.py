@@ -46,22 +46,53 @@ class Contours:
 _EIGHT = ndimage.generate_binary_structure(2, 2)
 
 
-def _object_and_holes(mask, min_area=40):
-    """The region the reference's contour pruning keeps: the largest 8-connected object, with its holes
-    (4-connected background regions it encloses) of fewer than `min_area` pixels filled in."""
+def _touch4(region):
+    """pixels with a 4-neighbour in `region`"""
+    pad = np.pad(region, 1, constant_values=False)
+    return pad[:-2, 1:-1] | pad[2:, 1:-1] | pad[1:-1, :-2] | pad[1:-1, 2:]
+
+
+def _object_and_holes(mask, min_area=40.0):
+    """The region the reference's contour pruning keeps (imgproc.py:205-228): inside the outer contour of the level-0
+    object of largest cv2.contourArea, outside its holes of area >= 40 (smaller holes count as object; objects inside
+    a kept hole go with 'level > 1').  contourArea by Pick's theorem from pixel counts -- outer contour: pixels inside
+    or on it minus half the object's pixels next to the outside minus 1; hole: pixels inside it plus half the
+    enclosing object's pixels next to it minus 1 -- the rule csrc/project_kernels.h applies per frame on the device.
+    Nothing is kept when even the largest object has area < 40 (the reference fails there)."""
+    mask = np.asarray(mask, bool)
+    keep = np.zeros(mask.shape, bool)
     lab, n = ndimage.label(mask, structure=_EIGHT)
     if n == 0:
-        return np.zeros(mask.shape, bool)
-    sizes = np.bincount(lab.ravel())[1:]
-    obj = lab == (1 + int(np.argmax(sizes)))
-    bg, nb = ndimage.label(~obj)                           # 4-connected background regions
-    if nb:
-        edge = np.unique(np.concatenate((bg[0, :], bg[-1, :], bg[:, 0], bg[:, -1])))
-        areas = np.bincount(bg.ravel())
-        for k in range(1, nb + 1):
-            if k not in edge and areas[k] < min_area:      # an enclosed region too small to count as a hole
-                obj[bg == k] = True
-    return obj
+        return keep
+    bg, nb = ndimage.label(~mask)                          # 4-connected background regions
+    edge = set(np.unique(np.concatenate((bg[0, :], bg[-1, :], bg[:, 0], bg[:, -1])))) - {0}
+    outside = np.isin(bg, list(edge))                      # background that reaches the frame edge
+    frame = np.zeros(mask.shape, bool)
+    frame[0, :] = frame[-1, :] = frame[:, 0] = frame[:, -1] = True
+    next_out = _touch4(outside) | frame
+    best, best_a2 = 0, -1
+    fills = {}
+    for k in np.unique(lab[mask & next_out]):              # level-0 objects: they touch the outside
+        obj = lab == k
+        fill = ndimage.binary_fill_holes(obj)
+        a2 = 2 * int(fill.sum()) - int((obj & next_out).sum()) - 2
+        fills[k] = fill
+        if a2 > best_a2:                                   # (ascending labels: ties keep the first in raster order)
+            best, best_a2 = k, a2
+    if best == 0 or best_a2 < 2 * min_area:
+        return keep
+    obj = lab == best
+    keep = fills[best].copy()
+    holes, nh = ndimage.label(keep & ~mask)
+    near_obj = _touch4(obj)
+    for c in range(1, nh + 1):
+        hole = holes == c
+        if not (hole & near_obj).any():
+            continue                                        # a hole of something nested in a hole of the object
+        inside = ndimage.binary_fill_holes(hole)
+        if 2 * int(inside.sum()) + int((obj & _touch4(hole)).sum()) - 2 >= 2 * min_area:
+            keep &= ~inside
+    return keep
 
 
 def _boundary(region):
@@ -133,12 +164,12 @@ class SignedDistance:
 
 
 def outline_distance(mask):
-    """fd for a mask without contour pruning -- the per-frame form KalmanFilter.projectmask uses (reference kalman.py:725:
-    findObjectThreshold(y_m, 0.5)[2]): signed distance to the polygon through the centres of ALL border pixels of the
-    mask's object pixels (object pixels with a 4-neighbour that is background or off the frame), sides between
-    8-adjacent border pixels, exact minimum over every side in binary64 (no k-d tree: the same numbers
-    hm_project_mask computes on the device); sign as SignedDistance; a blank mask gives 0."""
-    m = np.asarray(mask) > 0.5
+    """fd of the per-frame form KalmanFilter.projectmask uses (reference kalman.py:725: findObjectThreshold(y_m, 0.5)[2]):
+    the mask pruned as the reference prunes its contours (_object_and_holes), then the signed distance to the polygon
+    through the centres of the border pixels of what is left (object pixels with a 4-neighbour that is background or off
+    the frame), sides between 8-adjacent border pixels, exact minimum over every side in binary64 (no k-d tree: the same
+    numbers hm_project_mask computes on the device); sign as SignedDistance; a blank mask gives 0."""
+    m = _object_and_holes(np.asarray(mask) > 0.5)
     sd = SignedDistance(m)
     if sd.empty:
         return lambda p: np.zeros(len(np.atleast_2d(p)))

@@ -475,6 +475,7 @@ class KalmanFilter:
         self.state = KFState(distmesh, im, flow, cuda, vel=vel, sparse=sparse, multi=multi, eps_F=eps_F,
                              eps_Z=eps_Z, eps_J=eps_J, eps_M=eps_M, verbose=verbose, renderer=renderer,
                              device=device)
+        _lib.register(self, 1)
         self.predtime = 0
         self.updatetime = 0
         self.projecttime = 0
@@ -485,6 +486,19 @@ class KalmanFilter:
 
     def size(self):
         return self.N * 4
+
+    def close(self):
+        """Releases the native state of the filter: its renderer handle (streams, page-locked blocks, device memory)."""
+        r = getattr(getattr(self, "state", None), "renderer", None)
+        if r is not None and hasattr(r, "close"):
+            r.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def _say(self, msg):
         if self.verbose:
@@ -508,11 +522,14 @@ class KalmanFilter:
         try:
             with _blas_cap(enabled=not hasattr(r, "update_run")):
                 t0 = time.time()
-                self.predict()
-                t1 = time.time()
-                self.projectmask(y_m)
-                t2 = time.time()
-                self.update(y_im, y_flow_mask, y_m)
+                if self._compute_chained(y_im, y_flow_mask, y_m):
+                    t1 = t2 = t0 + (self._chain_predict_s or 0.0)
+                else:
+                    self.predict()
+                    t1 = time.time()
+                    self.projectmask(y_m)
+                    t2 = time.time()
+                    self.update(y_im, y_flow_mask, y_m)
                 self._after_update()
                 t3 = time.time()
             self.predtime += t1 - t0
@@ -524,6 +541,13 @@ class KalmanFilter:
             return self.error(y_im, y_flow, y_m, want_flow=self.return_flow)
         finally:
             r.frame_in_place = False
+
+    _chain_predict_s = None
+
+    def _compute_chained(self, y_im, y_flow, y_m):
+        """Hook: predict -> projectmask -> update as one chain on the device, where a filter can (the mass-spring filter
+        with its prediction started ahead on the device); False: the three steps are taken one by one."""
+        return False
 
     def _after_update(self):
         """Hook for work that only needs the state the update ended with (the mass-spring filter starts the next
@@ -545,10 +569,10 @@ class KalmanFilter:
     def projectmask(self, y_m):
         """Vertices more than 1 px outside the object are pulled back onto its outline (:724-742).
 
-        The signed distance is the reference's (imgproc.py:195-235): to the polygon through the centres of the
-        object's border pixels, negative inside (imgproc.outline_distance; on the device csrc/project_kernels.h);
-        the reference's per-frame pruning of small contours is not applied.  Steps, step size and the stale
-        d / index set follow the reference."""
+        The signed distance is the reference's (imgproc.py:195-235): the mask's contours pruned as there (:205-228: the
+        largest object and its holes of area >= 40), then the distance to the polygon through the centres of the border
+        pixels of what is left, negative inside (imgproc.outline_distance; on the device csrc/project_kernels.h, k_ccl_*
+        + k_outline + k_project_mask).  Steps, step size and the stale d / index set follow the reference."""
         if y_m is None:
             return
         r = self.state.renderer
@@ -556,6 +580,7 @@ class KalmanFilter:
             X, moved = r.project_mask(self.state.X, None if isinstance(y_m, DeviceObservation) else y_m)
             if moved:
                 self.state.X = X
+            self.proj_x, self.moved = np.array(self.state.X), moved
             return
         if isinstance(y_m, DeviceObservation):
             y_m = y_m.y_m_host
@@ -753,6 +778,8 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
         # waves, a vertex per lane) instead of on the worker's host thread, when the mesh fits the kernel (<= 256
         # vertices); the two agree to rounding
         self.newton_on_device = True
+        # True: compute() chains predict -> projectmask -> update on the device when it can (_compute_chained)
+        self.chain = True
         self._worker_dev = None
         self._worker, self._ahead, self._armed = None, None, None
 
@@ -854,6 +881,62 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
         self.pred_x = st.X.copy()
         stats.statepredtime[0] += time.time() - t0
 
+    def _compute_chained(self, y_im, y_flow, y_m):
+        """predict -> projectmask -> update (reference kalman.py:676-700) without the host between them: the state
+        prediction started ahead on the device is still in flight or has just ended, projectmask of its result is queued
+        behind it (hm_chain_project), the update takes the projected state from device memory as its prior mean and reports
+        what the two kernels found (predicted / projected state, Newton iterations) with its own results.  The covariance
+        half of predict() is what it always is here (predict_take / cov_predict).  Same numbers as the three steps; taken
+        when every precondition of theirs holds: fused update, prediction started ahead on the device from exactly the
+        current state, springs and parameters, mask of the observation resident on the device.  chain = False switches it
+        off."""
+        st = self.state
+        r = st.renderer
+        if not (self.chain and self.fused_update and self.predict_ahead and self.newton_on_device and not self.device_predict
+                and self._ahead is not None and self._worker_dev and isinstance(y_m, DeviceObservation)
+                and hasattr(r, "chain_project") and isinstance(st._W, DeviceCovariance)):
+            return False
+        X0, bars0, l00, par0 = self._ahead
+        if not (np.array_equal(X0, np.asarray(st.X, np.float64).reshape(-1)) and np.array_equal(bars0, self._bars)
+                and np.array_equal(l00, st.l0[:, 0])
+                and par0 == (float(self.kappa), float(self.M), float(self.deltat), int(self.maxiter), float(self.tol))):
+            return False
+        t0 = time.time()
+        if not r.chain_project():            # nothing in flight after all
+            return False
+        self.orig_x = st.X.copy()
+        # covariance half of predict(), as there
+        taken = None
+        if self._cov_armed and hasattr(r, "predict_take"):
+            taken = r.predict_take(st._W, st.X, self._bars, st.l0[:, 0], self.kappa, self.deltat, self.deltat / self.M, st.eps_F)
+        self._cov_armed = False
+        if taken is not None:
+            st.W = taken
+        else:
+            st.W = r.cov_predict(st._W, self._bars, self._spring_blocks(), self.deltat, self.deltat / self.M, st.eps_F, fetch=False)
+            if hasattr(r, "update_prefactor"):
+                r.update_prefactor(st._W)
+        self._ahead = None
+        self._chain_predict_s = time.time() - t0
+        stats.statepredtime[0] += self._chain_predict_s
+        from .renderer import ChainedPredictionFailed
+        try:
+            self.update(y_im, y_flow, y_m)
+        except ChainedPredictionFailed:
+            # the prediction's inner solve gave up on the device (never observed; test knob newton_fail): on the host,
+            # then the three steps; the covariance prediction above stands
+            self._newton()
+            self.pred_x = st.X.copy()
+            self.projectmask(y_m)
+            self.update(y_im, y_flow, y_m)
+            return True
+        pred, proj, its, moved = r.chain_states()
+        self.pred_x = pred.reshape(-1, 1)
+        self.proj_x = proj.reshape(-1, 1)
+        self.newton_iterations = its
+        self.moved = moved
+        return True
+
     def _ahead_inputs(self):
         st = self.state
         return (np.ascontiguousarray(self._bars, np.int32).copy(), np.ascontiguousarray(st.l0[:, 0], np.float64).copy(),
@@ -930,9 +1013,13 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
 
     def close(self):
         if getattr(self, "_worker", None) is not None:
+            r = getattr(getattr(self, "state", None), "renderer", None)
+            if r is not None and hasattr(r, "detach_worker"):
+                r.detach_worker(self._worker)
             _lib.lib().hm_ms_worker_destroy(self._worker)
             self._worker = None
             self._ahead = None
+        KalmanFilter.close(self)
 
     def __del__(self):
         try:

@@ -143,6 +143,7 @@ class DeviceBuffer:
         p = _lib.c_vp()
         _lib.check(_lib.lib().hm_dev_alloc(self.device, self.nbytes, p), "hm_dev_alloc")
         self.ptr = p.value
+        _lib.register(self, 4)
 
     def upload(self, a, offset=0):
         a = np.ascontiguousarray(a)
@@ -224,6 +225,7 @@ class FrameRing:
         self._stage_np = np.ctypeslib.as_array(ctypes.cast(self._stage, ctypes.POINTER(ctypes.c_uint8)),
                                                shape=(self._nstage, self.planes, self.n))
         self._staged = 0
+        _lib.register(self, 4)
         self.lo = self.hi = 0                                    # frames [lo, hi) are in the ring (queued or there)
         self.bytes_uploaded = 0
 
@@ -346,6 +348,7 @@ class FlowEKFPipeline:
             self.ring.ensure(self.F, 0)
             self.ring.sync()
         self.resident = bool(resident)
+        _lib.register(self, 0)
         self.d_u = DeviceBuffer(3 * self.B * n * 4, device)          # flow planes: one buffer in use, two being filled
         self.d_v = DeviceBuffer(3 * self.B * n * 4, device)
         # concurrent_series: two flow handles (streams), two series in flight at a time.  Measured at 1024^2 / 201
@@ -647,27 +650,35 @@ class FlowEKFPipeline:
     def run(self, first=0, end=None, on_frame=None):
         """compute() for the frames first+1 .. end; on_frame(k, error_tuple) after each.
 
-        gc_freeze (attribute, default True): the objects alive when the phase starts are moved to the collector's
-        permanent generation (gc.freeze) -- the interpreter's full collections, which the frame loop's allocations
-        trigger every ~17 frames, then have nothing old to walk through.  Measured at 1024^2 / 201 vertices: one
-        frame in 17 took 8.4 instead of 1.7 ms (a 6.7 ms pause inside the Python wrapper of hm_update_run with
-        numpy / scipy loaded; longer with torch)."""
+        gc_freeze (attribute, default True; the name is round 3's): the interpreter's automatic collections are switched
+        off for the phase (gc.disable) and switched back on at its end if they were on -- a full collection, which the
+        frame loop's allocations trigger every ~17 frames, took 6.7 ms inside the Python wrapper of hm_update_run with
+        numpy / scipy loaded (one frame in 17 at 8.4 instead of 1.7 ms; longer with torch); the youngest generation is
+        collected by hand every 64 frames, which takes microseconds.  Nothing the caller froze or tuned is touched
+        (round 3 called gc.freeze() / gc.unfreeze() here, which unfroze the caller's objects as well)."""
         end = self.F - 1 if end is None else min(int(end), self.F - 1)
         import gc
-        frozen = bool(self.gc_freeze)
-        if frozen:
-            gc.freeze()
+        quiet = bool(self.gc_freeze) and gc.isenabled()
+        if quiet:
+            gc.disable()
         try:
             self.begin(first, end)
             for k in range(first, end):
                 e = self.step(k)
                 if on_frame is not None:
                     on_frame(k, e)
+                if quiet and (k - first) % 64 == 63:
+                    gc.collect(0)
         finally:
-            if frozen:
-                gc.unfreeze()            # (what was garbage before the phase can be collected after it)
+            if quiet:
+                gc.enable()
 
     def close(self):
+        """Joins the helper threads of the series in flight, drains and destroys the copy stream, frees the ring, the
+        flow planes and the flow handles (idempotent).  The filter is the caller's."""
+        if getattr(self, "_closed", False):
+            return
+        self._closed = True
         try:
             self.flow_sync()
         finally:
@@ -676,3 +687,10 @@ class FlowEKFPipeline:
                 b.close()
             for bf in self.bfs:
                 bf.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False

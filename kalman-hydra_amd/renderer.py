@@ -27,6 +27,11 @@ from . import _lib
 from . import matio
 
 
+class ChainedPredictionFailed(RuntimeError):
+    """hm_update_run, chained to a state prediction on the device (hm_chain_project), found that the prediction's inner
+    solve had given up: nothing was updated; predict on the host and update again."""
+
+
 class Renderer:
     def __init__(self, distmesh, vel, flow, nx, im1, cuda, eps_Z, eps_J, eps_M, labels=None, labels_hess=None,
                  Q=None, showtracking=False, force=None, multi=True, device=0):
@@ -52,6 +57,8 @@ class Renderer:
         _lib.check(L.hm_ctx_create(int(device), self.nx, self.ny, self.n, int(self.tri.shape[0]), _lib.ptr(self.tri),
                                    _lib.ptr(uv), eps_Z, eps_J, eps_M, ctypes.byref(h)), "hm_ctx_create")
         self._h = h
+        self._worker = None                     # a state-prediction worker attached to this handle (attach_worker)
+        _lib.register(self, 2)
         _lib.check(L.hm_set_texture(self._h, _lib.ptr(np.ascontiguousarray(tex, np.uint8))), "hm_set_texture")
         self.vertices = np.array(distmesh.p, np.float64)
         self.velocities = np.array(vel, np.float64).reshape(self.vertices.shape)
@@ -69,6 +76,11 @@ class Renderer:
     # -- lifetime -------------------------------------------------------------------------
     def close(self):
         if self._h is not None:
+            if self._worker is not None:        # the worker keeps a pointer to this handle: back to its host thread first
+                try:
+                    _lib.lib().hm_ms_worker_attach(self._worker, None)
+                finally:
+                    self._worker = None
             _lib.lib().hm_ctx_destroy(self._h)
             self._h = None
 
@@ -259,6 +271,15 @@ class Renderer:
                    "hm_project_mask")
         return Xp.reshape(np.shape(X)), moved.value
 
+    def prune_mask(self, y_m):
+        """hm_prune_mask: the reference's contour pruning of a mask (imgproc.py:198-228) as project_mask applies it."""
+        mask = np.ascontiguousarray(np.asarray(y_m) > 0.5).view(np.uint8)
+        if mask.shape != (self.ny, self.nx):
+            raise ValueError("mask of shape %r for frames of %r" % (mask.shape, (self.ny, self.nx)))
+        out = np.empty_like(mask)
+        _lib.check(_lib.lib().hm_prune_mask(self._h, _lib.ptr(mask), _lib.ptr(out)), "hm_prune_mask")
+        return out
+
     def cov_fetch(self):
         n4 = 4 * self.n
         W = np.empty((n4, n4))
@@ -323,6 +344,8 @@ class Renderer:
         self._cov_serial += 1
         if rc == _lib.HM_ERR_NUMERIC:
             raise FloatingPointError(_lib.lib().hm_last_error().decode())
+        if rc == 2:                                 # a chained run whose state prediction gave up: the caller predicts on the host
+            raise ChainedPredictionFailed()
         _lib.check(rc, "hm_update_run")
         out = dict(niter=info[0], accepted=info[1], reverted=bool(info[2]), converged=bool(info[3]))
         return X.reshape(-1, 1), out, errs[:info[0]], Hzc, gains, self._cov_result(fetch)
@@ -339,6 +362,32 @@ class Renderer:
     def attach_worker(self, worker, on=True):
         """hm_ms_worker_attach: the state predictions started on `worker` run as a launch on this renderer's device."""
         _lib.check(_lib.lib().hm_ms_worker_attach(worker, self._h if on else None), "hm_ms_worker_attach")
+        self._worker = worker if on else None
+
+    def detach_worker(self, worker):
+        """(the worker is about to be destroyed)"""
+        if self._worker is not None and self._h is not None:
+            _lib.lib().hm_ms_worker_attach(worker, None)
+        self._worker = None
+
+    def chain_project(self):
+        """hm_chain_project: projectmask of the state prediction in flight queued behind it, its result the prior mean
+        of the next update_run (whose X0 is then ignored) -- True when queued, False when there is nothing to chain."""
+        rc = _lib.lib().hm_chain_project(self._h)
+        if rc == 1:
+            return False
+        _lib.check(rc, "hm_chain_project")
+        return True
+
+    def chain_states(self):
+        """hm_chain_states -> (predicted state, projected state, Newton iterations, vertices moved) of the last chained
+        update_run."""
+        n4 = 4 * self.n
+        pred, proj = np.empty(n4), np.empty(n4)
+        its, moved = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(_lib.lib().hm_chain_states(self._h, _lib.ptr(pred), _lib.ptr(proj), ctypes.byref(its), ctypes.byref(moved)),
+                   "hm_chain_states")
+        return pred, proj, its.value, moved.value
 
     def arm_cov(self, eps_F):
         """hm_update_arm_cov: the next update_run (armed with arm_newton as well) also queues the covariance half of the

@@ -470,7 +470,79 @@ def mask_flow(y_flow, y_m):
     return np.dstack((y_m * y_flow[:, :, 0], y_m * y_flow[:, :, 1])).astype(np.float32)
 
 
-def outline_distance(y_m):
+def pruned_object(mask, min_area=40.0):
+    """The region whose outline the reference's fd describes: imgproc.py:198-228 restated without OpenCV.
+
+    cv2.findContours(mask, RETR_TREE) gives the outer contour of every 8-connected object (level 0), the contour of every
+    hole in it (4-connected background enclosed by it, level 1), of objects inside holes (level 2), ...; the frame counts
+    as surrounded by background, so background that reaches the frame edge is outside, not a hole.  The reference then
+    removes (:205-228) every level-0 contour whose cv2.contourArea is below the largest area (with everything inside it),
+    every contour of area < 40 (with everything inside it) and every contour deeper than level 1, and builds
+    fd = ddiff(outer, dunion(holes)) (:232-235) from what is left: the largest object with its holes of area >= 40 --
+    smaller holes count as object, and so does whatever lies inside a kept hole's contour ... no: whatever lies inside a
+    kept hole belongs to the hole (objects inside it went with 'level > 1').
+
+    cv2.contourArea is the area of the polygon through the centres of the pixels the contour visits.  By Pick's theorem
+    (area = interior lattice points + boundary lattice points / 2 - 1) for a contour that visits no pixel twice:
+      outer contour of an object:  (pixels inside or on it: the object, its holes, everything in them)
+                                   - (object pixels 4-adjacent to the outside or on the frame edge) / 2 - 1
+      contour of a hole:           (pixels inside it: the hole's background pixels and every object nested in it)
+                                   + (pixels of the enclosing object 4-adjacent to the hole) / 2 - 1
+    (a hole's contour runs through the pixels of the enclosing object around it).  Those are the areas used here; where a
+    contour visits a pixel twice (one-pixel-wide bridges) OpenCV's value differs by the doubly counted boundary points.
+    Ties between level-0 areas: the object whose first pixel in raster order comes first (the reference would keep both
+    and treat the second as a hole -- not restated).  If even the largest object has area < 40 nothing is left (the
+    reference then fails with an IndexError): the result is empty.
+
+    -> bool HxW: inside the kept outer contour and not inside a kept hole."""
+    m = np.asarray(mask) > 0.5
+    H, W = m.shape
+    out = np.zeros((H, W), bool)
+    if not m.any():
+        return out
+    from scipy import ndimage
+    eight = np.ones((3, 3), bool)
+    lab, n = ndimage.label(m, structure=eight)
+
+    def touches4(region, of):
+        """pixels of `of` with a 4-neighbour in `region`"""
+        pad = np.pad(region, 1, constant_values=False)
+        nb = pad[:-2, 1:-1] | pad[2:, 1:-1] | pad[1:-1, :-2] | pad[1:-1, 2:]
+        return of & nb
+
+    filled = []
+    for k in range(1, n + 1):
+        filled.append(ndimage.binary_fill_holes(lab == k))          # 4-connected background that cannot reach the frame edge
+    best, best_area = -1, -1.0
+    for k in range(1, n + 1):
+        obj = lab == k
+        nested = any(j != k and filled[j - 1][obj].all() for j in range(1, n + 1))
+        if nested:                                                   # level >= 2: inside a hole of another object
+            continue
+        outside = np.pad(~filled[k - 1], 1, constant_values=True)    # ... including beyond the frame edge
+        nb = outside[:-2, 1:-1] | outside[2:, 1:-1] | outside[1:-1, :-2] | outside[1:-1, 2:]
+        b_outer = int((obj & nb).sum())
+        area = float(filled[k - 1].sum()) - b_outer / 2.0 - 1.0
+        if area > best_area:                                         # (ascending labels = ascending first pixels: ties keep the first)
+            best, best_area = k, area
+    if best < 0 or best_area < min_area:
+        return out
+    obj = lab == best
+    out = filled[best - 1].copy()
+    holes, nh = ndimage.label(out & ~m)                              # background inside the outer contour, 4-connected
+    for c in range(1, nh + 1):
+        hole = holes == c
+        ring = touches4(hole, obj)
+        if not ring.any():
+            continue                                                 # a hole of an object nested deeper: goes with its level-1 ancestor
+        inside = ndimage.binary_fill_holes(hole)                     # the hole and everything nested in it
+        area = float(inside.sum()) + int(ring.sum()) / 2.0 - 1.0
+        if area >= min_area:
+            out &= ~inside
+    return out
+
+
+def outline_distance(y_m, prune=True):
     """fd of reference imgproc.py:195-235 for a mask: -cv2.pointPolygonTest(contour, p, True) with the contour that
     cv2.findContours traces through the border pixels of the object, i.e. the signed distance (negative inside) to the
     polygon through the centres of the object's border pixels.  Restated without OpenCV:
@@ -485,9 +557,12 @@ def outline_distance(y_m):
     * sign: a point is inside the polygon through the pixel centres iff the four pixels around it are all object, or
       three are and it lies on their side of the diagonal; points off the frame are outside.
 
-    The reference's pruning of contours (imgproc.py:205-228: the largest object and its holes of >= 40 px only) is NOT
-    applied: every border pixel of the mask counts (as in the product's per-frame projection)."""
+    The reference's pruning of contours (imgproc.py:205-228: the largest object and its holes of area >= 40 only) is
+    applied first (pruned_object; prune=False: every border pixel of the raw mask counts -- round 3's form, kept for the
+    comparison in the tests)."""
     m = np.asarray(y_m) > 0.5
+    if prune:
+        m = pruned_object(m)
     H, W = m.shape
     pad = np.pad(m, 1, constant_values=False)
     inner = pad[:-2, 1:-1] & pad[2:, 1:-1] & pad[1:-1, :-2] & pad[1:-1, 2:]

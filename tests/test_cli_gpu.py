@@ -179,33 +179,70 @@ def test_streaming_frame_ring_equals_resident_video(hm):
         p.close()
 
 
-def test_streaming_track_repeats_bit_for_bit(hm):
-    """The whole frame loop -- flow series beside the filter, state prediction as a launch started by the update,
-    covariance queued ahead, speculative measurement -- repeated: every repetition gives the first one's states, iteration
-    counts and covariance bit for bit (tools/stress_determinism.py is this at 1024^2, 1200 repetitions; it is what found
-    the prediction's result being read before all of it had landed)."""
+def _short_track(hm, tune=(), attrs=(), F=8, n=128):
+    """The whole frame loop on a small video -- flow series beside the filter, state prediction as a launch started by the
+    update, covariance queued ahead, speculative measurement, predict -> projectmask -> update chained on the device --
+    with hm_ctx_tune knobs / filter attributes set; -> (per frame: state, iterations, Newton iterations, the four error
+    terms, predicted state, projected state), final covariance, seconds."""
+    import time
     from hydra_mi import kalman, mesh, synth
     from hydra_mi.pipeline import FlowEKFPipeline, threshold_mask
-    n, F = 128, 12
     video, _, c, r = synth.disk_video(n, F, "translate_leftup", 1)
     masks = np.stack([threshold_mask(f, 9) for f in video])
+    masks[3:, 2:6, 2:9] = 1                                     # (a second object far from the mesh from frame 3 on)
     zero = np.zeros((n, n, 2), np.float32)
-
-    def once():
-        kf = kalman.IteratedMSKalmanFilter(mesh.disk_mesh(c[0], c[1], r - 1.0, 12.0), video[0], zero, True)
-        pipe = FlowEKFPipeline(kf, video, masks, flow_batch=4)
-        out = []
-        pipe.run(on_frame=lambda k, e: out.append((kf.state.X.copy(), kf.niter, kf.newton_iterations, e[0], e[3])))
+    kf = kalman.IteratedMSKalmanFilter(mesh.disk_mesh(c[0] + 2.5, c[1], r + 1.5, 12.0), video[0], zero, True)
+    for key, value in tune:
+        kf.state.renderer.tune(key, value)
+    for key, value in attrs:
+        setattr(kf, key, value)
+    out = []
+    with FlowEKFPipeline(kf, video, masks, flow_batch=4) as pipe:
+        t0 = time.perf_counter()
+        pipe.run(on_frame=lambda k, e: out.append((kf.state.X.copy(), kf.niter, kf.newton_iterations, tuple(e[:4]),
+                                                   np.array(kf.pred_x).reshape(-1), np.array(getattr(kf, "proj_x", kf.pred_x)).reshape(-1))))
+        dt = time.perf_counter() - t0
         W = np.array(kf.state.W)
-        pipe.close()
-        kf.close()
-        kf.state.renderer.close()
-        return out, W
+    kf.close()
+    return out, W, dt
 
-    ref, Wref = once()
-    assert len(ref) == F - 1 and all(o[1] >= 1 for o in ref)
-    for rep in range(25):
-        got, W = once()
-        for k in range(F - 1):
-            assert np.array_equal(got[k][0], ref[k][0]) and got[k][1:] == ref[k][1:], (rep, k)
-        assert np.array_equal(W, Wref), rep
+
+def _same_track(a, b, upto=4):
+    assert len(a[0]) == len(b[0])
+    for k, (x, y) in enumerate(zip(a[0], b[0])):
+        for i in range(upto):
+            assert np.array_equal(x[i], y[i]) if isinstance(x[i], np.ndarray) else x[i] == y[i], (k, i)
+    assert np.array_equal(a[1], b[1])
+
+
+def test_result_blocks_do_not_depend_on_the_order_their_words_arrive_in(hm):
+    """Result blocks in page-locked host memory (csrc/host_block.h: the IEKF iterations' step + error sums that drive
+    reference kalman.py:792-822, the gains, the state prediction, projectmask).  Round 3 trusted a block once its ticket
+    was visible and one track in a hundred took half of a block from the launch before.  Now every word carries its
+    launch's stamp and the host takes a block when all of it is there -- so a kernel that publishes the block's LAST word
+    first and everything else 1000 us later (hm_ctx_tune "result_delay") must give exactly the track of an undelayed
+    run, only slower.  One run, deterministic: the delayed path is taken for every block of every frame."""
+    ref = _short_track(hm)
+    assert all(o[1] >= 1 for o in ref[0])
+    late = _short_track(hm, tune=[("result_delay", 1000)])
+    _same_track(ref, late, upto=6)
+    blocks = sum(o[1] + 1 for o in ref[0])                        # one per iteration, one with the gains per frame
+    assert late[2] - ref[2] >= 0.5 * blocks * 1000e-6, (ref[2], late[2], blocks)        # (the knob was in effect)
+
+
+def test_chained_state_path_equals_the_three_calls(hm):
+    """compute() = predict -> projectmask -> update (reference kalman.py:676-700).  Chained on the device
+    (hm_chain_project: the projection queued behind the prediction's kernel, the update starting from the projected state
+    in device memory) it gives the bits of the three separate calls -- states, iteration counts, error terms, the
+    predicted and the projected state (vertices start outside the object here, so projectmask does move some) -- and so
+    does the update's tail on the handle's own stream instead of a second one; a device prediction that reports a failed
+    inner solve (test knob) is repeated on the host: the track of a filter that predicts on the host."""
+    chained = _short_track(hm)
+    three = _short_track(hm, attrs=[("chain", False)])
+    _same_track(chained, three, upto=6)
+    assert any(not np.array_equal(o[4], o[5]) for o in chained[0])        # projectmask moved something
+    one_stream = _short_track(hm, tune=[("tail_split", 0)])
+    _same_track(chained, one_stream, upto=6)
+    failed = _short_track(hm, tune=[("newton_fail", 1)])
+    host = _short_track(hm, attrs=[("newton_on_device", False)])
+    _same_track(failed, host, upto=6)

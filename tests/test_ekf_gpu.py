@@ -700,10 +700,40 @@ def _project_masks(n):
     specks = disk.copy()
     specks[3, 5] = 1                                                # single far pixel
     specks[n - 2, n - 2] = 1
-    return {"disk": disk, "holed": holed, "edge": edge, "specks": specks}
+    # what the reference's contour pruning (imgproc.py:205-228) decides: a second, smaller object close to the mesh; a
+    # 5 x 5 hole (contour area 34 < 40: counts as object) and a 5 x 6 one (40: stays a hole) with an island in it
+    second = disk.copy()
+    second[int(0.8 * n):int(0.8 * n) + 9, int(0.3 * n):int(0.3 * n) + 14] = 1
+    pinholes = disk.copy()
+    cy, cx = int(0.45 * n), int(0.5 * n)
+    pinholes[cy - 12:cy - 7, cx - 10:cx - 5] = 0
+    pinholes[cy + 4:cy + 9, cx + 3:cx + 9] = 0
+    pinholes[cy + 6, cx + 5] = 1
+    return {"disk": disk, "holed": holed, "edge": edge, "specks": specks, "second": second, "pinholes": pinholes}
 
 
-@pytest.mark.parametrize("kind", ["disk", "holed", "edge", "specks"])
+def test_contour_pruning_matches_oracle(hm):
+    """reference imgproc.py:198-228 on the device (k_ccl_*, csrc/project_kernels.h) against oracle/ekf_ref.pruned_object:
+    the hand-made cases and random masks with specks, pinholes, islands and objects on the frame edge -- the same pixels."""
+    from mask_cases import blobs as _blobs
+    n = 96
+    dm, N, tex, R, meas = _setup(hm, n, 9.0)
+    for kind, mask in _project_masks(n).items():
+        assert np.array_equal(R.prune_mask(mask).astype(bool), ekf_ref.pruned_object(mask)), kind
+    rng = np.random.default_rng(23)
+    for trial in range(60):
+        mm = _blobs(rng, n, n, int(rng.integers(1, 6)))
+        assert np.array_equal(R.prune_mask(mm).astype(bool), ekf_ref.pruned_object(mm)), trial
+    ring = np.zeros((n, n), bool)
+    ring[5:35, 5:35] = True
+    ring[7:33, 7:33] = False                                        # contour area 841 beats the 400 solid pixels below
+    ring[40:60, 50:70] = True
+    assert np.array_equal(R.prune_mask(ring).astype(bool), ekf_ref.pruned_object(ring))
+    for blank in (np.zeros((n, n), bool), np.ones((n, n), bool)):
+        assert np.array_equal(R.prune_mask(blank).astype(bool), ekf_ref.pruned_object(blank))
+
+
+@pytest.mark.parametrize("kind", ["disk", "holed", "edge", "specks", "second", "pinholes"])
 def test_project_mask_matches_oracle(hm, kind):
     n = 96
     dm, N, tex, R, meas = _setup(hm, n, 9.0)

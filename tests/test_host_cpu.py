@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import ekf_ref, partitions_ref
+from mask_cases import blobs as _blobs
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -317,6 +318,60 @@ def test_mask_distance_is_the_polygon_distance_of_the_reference(hm):
     assert np.allclose(fd(q), [10.0, 5.5, 5.0, -10.0, 0.0, np.sqrt(13.0), 23.0], rtol=0, atol=1e-12)
     for blank in (np.zeros_like(m),):
         assert np.array_equal(kalman._mask_distance(blank)(p), np.zeros(len(p)))
+
+
+def test_contour_pruning_follows_the_reference(hm):
+    """N3, reference imgproc.py:198-228 (called per frame from kalman.py:725): of the contours cv2.findContours(RETR_TREE)
+    finds, the largest level-0 one stays with its level-1 holes of cv2.contourArea >= 40; smaller objects, smaller holes
+    and everything deeper go.  Known answers for oracle/ekf_ref.pruned_object (areas of polygons through pixel centres,
+    worked out by hand), and the product's host form (imgproc._object_and_holes, written independently) equal to it on
+    random masks with specks, pinholes, holes with islands and objects on the frame edge."""
+    from hydra_mi import imgproc
+    m = np.zeros((60, 80), bool)
+    m[5:45, 5:55] = True                       # the object: 40 x 50 pixels
+    m[10:15, 10:15] = False                    # 5 x 5 hole: contour through the 20 pixels around it, area 6 x 6 - 4 / 2 = 34 -> filled
+    m[12, 12] = True                           # ... with an island in it: filled with the hole
+    m[20:25, 10:16] = False                    # 5 x 6 hole: area 6 x 7 - 2 = 40 -> kept
+    m[30:38, 30:40] = False                    # 8 x 10 hole, kept, with an object inside: the object goes (level 2)
+    m[33:35, 33:36] = True
+    m[50:58, 60:78] = True                     # a second object, 8 x 18 = 144 px (contour area 7 x 17 = 119): goes
+    m[2, 70] = True                            # a speck
+    want = np.zeros_like(m)
+    want[5:45, 5:55] = True
+    want[20:25, 10:16] = False
+    want[30:38, 30:40] = False
+    assert np.array_equal(ekf_ref.pruned_object(m), want)
+    assert np.array_equal(imgproc._object_and_holes(m), want)
+    # cv2.contourArea of the OUTER contour decides, not the pixel count: a ring of 232 pixels around 784 pixels of
+    # background (area 29 x 29 = 841) beats a solid square of 400 pixels (area 19 x 19 = 361) -- and its inside is a kept hole
+    r = np.zeros((70, 90), bool)
+    r[5:35, 5:35] = True
+    r[7:33, 7:33] = False
+    r[40:60, 50:70] = True
+    want = np.zeros_like(r)
+    want[5:35, 5:35] = True
+    want[7:33, 7:33] = False
+    assert np.array_equal(ekf_ref.pruned_object(r), want) and np.array_equal(imgproc._object_and_holes(r), want)
+    # background that reaches the frame edge is outside, not a hole (findContours: the frame is surrounded by background)
+    u = np.zeros((40, 40), bool)
+    u[0:30, 5:35] = True
+    u[0:20, 12:28] = False                     # a pocket open towards the top edge
+    assert np.array_equal(ekf_ref.pruned_object(u), u) and np.array_equal(imgproc._object_and_holes(u), u)
+    # nothing of area >= 40: nothing is kept (the reference fails with an IndexError there)
+    tiny = np.zeros((20, 20), bool)
+    tiny[3:9, 3:9] = True                      # 36 px, area 25
+    assert not ekf_ref.pruned_object(tiny).any() and not imgproc._object_and_holes(tiny).any()
+    assert not ekf_ref.pruned_object(np.zeros((9, 9), bool)).any()
+    rng = np.random.default_rng(11)
+    for trial in range(40):
+        H, W = int(rng.integers(24, 90)), int(rng.integers(24, 130))
+        mm = _blobs(rng, H, W, int(rng.integers(1, 5)))
+        assert np.array_equal(imgproc._object_and_holes(mm), ekf_ref.pruned_object(mm)), trial
+    # and the distance functions built on them agree, pruning included
+    mm = _blobs(np.random.default_rng(5), 70, 100, 3)
+    p = np.column_stack((rng.uniform(-5, 105, 200), rng.uniform(-5, 75, 200)))
+    assert np.array_equal(imgproc.outline_distance(mm)(p), ekf_ref.outline_distance(mm)(p))
+    assert not np.array_equal(ekf_ref.outline_distance(mm)(p), ekf_ref.outline_distance(mm, prune=False)(p))      # (it matters here)
 
 
 def test_signed_distance_and_distmesh(hm, tmp_path):

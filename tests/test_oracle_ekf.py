@@ -71,6 +71,50 @@ def test_ones_jz_velocity_only(hm):
     assert abs(total) < 1e-7
 
 
+def test_ones_get_pixel_data(hm):
+    """test_cuda.py:128-150 (get_pixel_data on the "ones" fixture, recipe test/createtestdata_kalmanfilter.py:52-54): the
+    render itself, not only sums over it -- the texture target holds 128 on exactly (end - start)^2 pixels
+    (np.sum(a) == (end - start)^2 * 128), the x-velocity target 1.534 inside the square to 1e-7, the y-velocity target
+    -1.534 (renderer.py:513 draws -v_y: "Why negative?? Because I flipped it")."""
+    nx, start, end, dm, frame, flow, X, meas = _ones_case(hm)
+    a, b, c, d = meas.render(X)
+    side = end - start
+    assert int(np.sum(a.astype(np.int64))) == side * side * 128
+    assert abs(float(b[start + 1, start + 1]) - 1.534) < 1e-7
+    assert abs(-float(c[start + 1, start + 1]) - 1.534) < 1e-7
+    assert abs(float(np.sum(c.astype(np.float64))) + side * side * 1.534) < side * side * 1e-7      # (:150, commented out there)
+    assert int((d == 255).sum()) == side * side and int((d == 0).sum()) == nx * nx - side * side   # the mask target (:937)
+
+
+def test_zeros_fixture(hm):
+    """test_cuda.py:30-56 (the "zeros" fixture, recipe test/createtestdata_kalmanfilter.py:46-48: frame 0, flow 0, velocity
+    0, the same 4-vertex square): every render target sums to exactly 0 (:53-56) and jz of any perturbation is exactly 0
+    (:38-39) -- a black texture on a black frame with no flow carries no information."""
+    from hydra_mi import mesh
+    nx = 680
+    start, end = nx // 3, 2 * nx // 3
+    dm = mesh.square4_mesh(start, end)
+    frame = np.zeros((nx, nx), np.uint8)
+    flow = np.zeros((nx, nx, 2), np.float32)
+    X = np.concatenate((dm.p.reshape(-1), np.zeros(8)))
+    meas = ekf_ref.Measurement(4, dm.t, dm.p, frame, 1.0, 1.0, 1.0)
+    a, b, c, d = meas.render(X)
+    assert np.sum(a) == 0 and np.sum(b) == 0 and np.sum(c) == 0
+    # the reference's observed mask term did not exist when that test was written: against the mask the render itself
+    # covers (z_m = 0 everywhere) the whole of jz is 0, exactly, for position and velocity perturbations alike
+    y_m = (d // 255).astype(np.uint8)
+    meas.initjacobian(X, frame, flow, y_m)
+    for k, delta in ((0, 3.0), (1, -3.0), (5, 3.0), (8, 3.0), (15, 3.0)):
+        Xp = X.copy()
+        Xp[k] += delta
+        total, comp = meas.jz(Xp)
+        assert comp[0] == 0.0 and comp[1] == 0.0 and comp[2] == 0.0
+    Xp = X.copy()
+    Xp[8:] += 1.0
+    total, comp = meas.jz(Xp)
+    assert total == 0.0
+
+
 def test_square_coverage_and_shared_edge(hm):
     from hydra_mi import mesh
     dm = mesh.square4_mesh(10, 30)
