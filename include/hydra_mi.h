@@ -337,6 +337,18 @@ int hm_update_last_error(hm_ctx_t h, const double *X, double err[4]);
  * to chain (no device prediction in flight): the caller makes the three calls.  A chained hm_update_run returns 2 when
  * the prediction's inner solve gave up (never observed): the caller predicts on the host and calls it again. */
 int hm_chain_project(hm_ctx_t h);
+/* The contour pruning and outline of a mask in DEVICE memory queued ahead of the hm_set_observation_dev that will name it
+ * as d_y_m (a streaming caller holds the next frame's mask a frame early): that call then finds the outline done instead
+ * of queueing ~0.2 ms of kernels the projection waits for.  The mask must not change until then; any other observation
+ * or a projection onto a host mask discards the preparation. */
+int hm_prepare_mask(hm_ctx_t h, const uint8_t *d_y_m);
+/* one-shot: the next hm_update_run on h calls hm_prepare_mask(h, d_y_m) the moment its state is final, so that the next
+ * frame's outline is computed beside the state prediction and the update's tail */
+int hm_update_arm_mask(hm_ctx_t h, const uint8_t *d_y_m);
+/* Hz components (4N x 4) and gains (3 x 4N; kalman.py:826-828) of the last hm_update_run that was called with
+ * Hzc = gains = NULL: such a call does not wait for the kernels that form them.  Either may be NULL.  Available until the
+ * next hm_update_run on h. */
+int hm_update_tail(hm_ctx_t h, double *Hzc, double *gains);
 /* what the last chained hm_update_run started from: the predicted state, the projected state (its prior mean), the Newton
  * iterations of the prediction, the number of vertices projectmask moved; any pointer may be NULL */
 int hm_chain_states(hm_ctx_t h, double *predicted, double *projected, int *newton_iterations, int *moved);

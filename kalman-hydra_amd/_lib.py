@@ -100,6 +100,9 @@ SIGNATURES = {
     "hm_newton_dev_finish": (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(ctypes.c_int)]),
     "hm_prune_mask": (ctypes.c_int, [c_vp, c_vp, c_vp]),
     "hm_chain_project": (ctypes.c_int, [c_vp]),
+    "hm_prepare_mask": (ctypes.c_int, [c_vp, c_vp]),
+    "hm_update_arm_mask": (ctypes.c_int, [c_vp, c_vp]),
+    "hm_update_tail": (ctypes.c_int, [c_vp, c_vp, c_vp]),
     "hm_chain_states": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "hm_update_arm_newton": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_vp, c_vp, ctypes.c_double, ctypes.c_double,
                                             ctypes.c_double, ctypes.c_int, ctypes.c_double]),

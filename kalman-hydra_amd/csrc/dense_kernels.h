@@ -646,11 +646,12 @@ __global__ __launch_bounds__(256) void k_iter_result(const double *__restrict__ 
     else if (t == 8) { slot = 8; v = sums[4]; }
     else if (t == 9) { slot = 9; v = sums[5]; }
     if (delay_us > 0) {
-        if (t == 9) hb_put(res, n + 9, v, stamp);
+        if (t == 9) { hb_put(res, n + 9, v, stamp); hb_flush(); }
         hb_delay(delay_us);
     }
     for (int i = t; i < n; i += 256) hb_put(res, i, step[i], stamp);
     if (slot >= 0) hb_put(res, n + slot, v, stamp);
+    hb_flush();
 }
 
 // gains of the three measurement channels (kalman.py:828-830): out[0] = W c0, out[1] = W (c1 + c2),
@@ -692,11 +693,12 @@ __global__ __launch_bounds__(1024) void k_tail_result(const double *__restrict__
 {
     const unsigned long long stamp = hb_stamp((long long)ticket);
     if (delay_us > 0) {
-        if (threadIdx.x == 0) hb_put(blk, 7 * n - 1, gain[3 * n - 1], stamp);
+        if (threadIdx.x == 0) { hb_put(blk, 7 * n - 1, gain[3 * n - 1], stamp); hb_flush(); }
         hb_delay(delay_us);
     }
     for (int i = threadIdx.x; i < 4 * n; i += 1024) hb_put(blk, i, Hzc[i], stamp);
     for (int i = threadIdx.x; i < 3 * n; i += 1024) hb_put(blk, 4 * n + i, gain[i], stamp);
+    hb_flush();
 }
 
 // ---- covariance prediction W' = F W F^T + Weps on the device -------------------------------------------

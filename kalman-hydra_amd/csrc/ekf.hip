@@ -11,14 +11,77 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <set>
 #include <thread>
 #include <utility>
 #include <vector>
 
+// A persistent helper thread of a handle: it queues launches the calling thread does not have to wait for (the tail of
+// hm_update_run: ~20 launches, ~80 us of host time at a frame boundary, where the caller's way to the NEXT frame's first
+// launches is what the device ends up waiting for).  One job at a time; every entry point joins it first (ctx_join).
+struct Helper {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool posted = false, busy = false, quit = false;
+    int rc = HM_OK;
+    char err[512] = "";
+    void run()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return quit || posted; });
+            if (quit) return;
+            posted = false;
+            std::function<int()> f = std::move(job);
+            lk.unlock();
+            const int r = f();
+            if (r != HM_OK) snprintf(err, sizeof err, "%s", hm_last_error());
+            lk.lock();
+            rc = r;
+            busy = false;
+            cv.notify_all();
+        }
+    }
+    void post(std::function<int()> f)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        if (!th.joinable()) th = std::thread([this] { run(); });
+        job = std::move(f);
+        posted = busy = true;
+        cv.notify_all();
+    }
+    // waits for the job in flight; its return code (reported once)
+    int wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return !busy; });
+        const int r = rc;
+        rc = HM_OK;
+        return r;
+    }
+    void stop()
+    {
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return !busy; });
+            quit = true;
+            cv.notify_all();
+        }
+        if (th.joinable()) th.join();
+    }
+};
+
 struct hm_ctx {
     int device, W, H, N, T, E, njobs;
+    Helper helper;
+    bool helper_used = false;
+    int tail_async = 1;              // hm_ctx_tune "tail_async": the tail of hm_update_run queued by the helper thread (same results)
     double eps_Z, eps_J, eps_M;
     hipStream_t stream;
     // mesh
@@ -59,6 +122,12 @@ struct hm_ctx {
     int *pin_scratch;                // ... where hm_measure / hm_update_step have a flag copied to
     std::vector<double> resv, tailv; // the host's copies of the two blocks, taken when whole (hb_wait)
     int result_delay = 0;            // test knob: the result kernels publish a block's last word first, the rest this many us later
+    // the tail block of the last hm_update_run (Hz components, gains): taken by hm_update_tail, or by hm_update_run itself
+    // when its caller wants them at once
+    bool tail_pending = false;
+    long long tail_ticket = 0;
+    hipStream_t tail_stream = nullptr;
+    const uint8_t *armed_mask = nullptr;     // hm_update_arm_mask: the next hm_update_run queues this mask's outline when its state is final
     std::vector<int> sp_h_off, sp_h_bar, sp_h_other;   // host staging of the spring topology
     std::vector<double> sp_h_blk;
     std::vector<int32_t> sp_bars_cached;   // the springs whose topology is on the device (d_sp_off / _bar / _other)
@@ -159,6 +228,8 @@ struct hm_ctx {
     int *d_pm_done = nullptr;        // workgroups of k_project_mask_host that have finished
     long long pm_ticket = 0;
     bool outline_ready = false;      // the outline of the resident mask (o_ym) has been queued on the second stream
+    const uint8_t *prepared_mask = nullptr;   // hm_prepare_mask: the outline in the buffers is that of this mask (device memory)
+    hipEvent_t ev_outline = nullptr; // ... recorded behind every outline queued on the second stream
 };
 
 static int alloc_targets(Targets &t, size_t n)
@@ -182,6 +253,10 @@ static void free_targets(Targets &t)
 static int ctx_join(hm_ctx *h, bool lazy = false)
 {
     if (!h) return HM_OK;
+    if (h->helper_used) {                        // launches the helper thread is still queueing (the tail of the last update)
+        const int rc = h->helper.wait();
+        if (rc != HM_OK) { hm_set_error("%s", h->helper.err); return rc; }
+    }
     if (!lazy && h->tail_on_stream4) {
         h->tail_on_stream4 = false;
         if (hipSetDevice(h->device) != hipSuccess || hipStreamWaitEvent(h->stream, h->ev_tail, 0) != hipSuccess) {
@@ -304,6 +379,7 @@ static int ctx_free(hm_ctx *h)
 {
     if (!h) return HM_OK;
     (void)ctx_join(h);
+    if (h->helper_used) h->helper.stop();
     (void)hipSetDevice(h->device);
     // every stream of the handle first: a state prediction started ahead is always pending after the last frame (it writes
     // into pin_n4), and so may be launches of an update that ended in an error
@@ -329,6 +405,7 @@ static int ctx_free(hm_ctx *h)
     if (h->pin_n4) (void)hipHostFree(h->pin_n4);
     if (h->ev_n4) (void)hipEventDestroy(h->ev_n4);
     if (h->ev_pm) (void)hipEventDestroy(h->ev_pm);
+    if (h->ev_outline) (void)hipEventDestroy(h->ev_outline);
     if (h->ev_tail) (void)hipEventDestroy(h->ev_tail);
     if (h->ev_post) (void)hipEventDestroy(h->ev_post);
     if (h->stream4) (void)hipStreamDestroy(h->stream4);
@@ -560,6 +637,9 @@ extern "C" int hm_ctx_tune(hm_ctx_t h, const char *key, int value)
     } else if (!strcmp(key, "result_delay")) {         // tests only: results must not depend on it (host_block.h)
         HM_ARG(value >= 0 && value <= 5000, "hm_ctx_tune: result_delay must be in 0..5000 (microseconds)");
         h->result_delay = value;
+    } else if (!strcmp(key, "tail_async")) {           // same results either way
+        HM_ARG(value == 0 || value == 1, "hm_ctx_tune: tail_async must be 0 or 1");
+        h->tail_async = value;
     } else if (!strcmp(key, "tail_split")) {           // same results either way
         HM_ARG(value == 0 || value == 1, "hm_ctx_tune: tail_split must be 0 or 1");
         h->tail_split = value;
@@ -640,6 +720,7 @@ static int project_buffers(hm_ctx *h)
     memset(h->pin_pm, 0, (n4 + 2 * (n4 + 1)) * sizeof(double));
     h->pmv.assign(n4 + 1, 0.0);
     HM_HIP(hipEventCreateWithFlags(&h->ev_pm, hipEventDisableTiming));
+    HM_HIP(hipEventCreateWithFlags(&h->ev_outline, hipEventDisableTiming));
     return HM_OK;
 }
 // the reference's contour pruning of the mask (imgproc.py:198-228: the largest object, its holes of area >= 40) into
@@ -648,8 +729,8 @@ static int queue_outline(hm_ctx *h, const uint8_t *mask)
 {
     HM_HIP(hipMemsetAsync(h->d_outline_cnt, 0, 4 * sizeof(int), h->stream2));
     const dim3 cg(hm_cdiv(h->W, 64), hm_cdiv(h->H, CCL_NT / 64)), cb(CCL_NT);
-    hipLaunchKernelGGL(k_ccl_runs, cg, cb, 0, h->stream2, mask, h->ccl);
-    hipLaunchKernelGGL(k_ccl_merge, cg, cb, 0, h->stream2, mask, h->ccl);
+    hipLaunchKernelGGL(k_ccl_local, dim3(hm_cdiv(h->W, CCL_TW), hm_cdiv(h->H, CCL_TH)), cb, 0, h->stream2, mask, h->ccl);
+    hipLaunchKernelGGL(k_ccl_border, cg, cb, 0, h->stream2, mask, h->ccl);
     hipLaunchKernelGGL(k_ccl_flatten, cg, cb, 0, h->stream2, mask, h->ccl);
     hipLaunchKernelGGL(k_ccl_stats, cg, cb, 0, h->stream2, mask, h->ccl);
     hipLaunchKernelGGL(k_ccl_select, cg, cb, 0, h->stream2, mask, h->ccl);
@@ -658,6 +739,8 @@ static int queue_outline(hm_ctx *h, const uint8_t *mask)
     hipLaunchKernelGGL(k_outline, dim3(hm_cdiv(h->W, 64), hm_cdiv(h->H, OUTLINE_NT / 64)), dim3(OUTLINE_NT), 0, h->stream2,
                        (const uint8_t *)h->d_pm_pruned, h->W, h->H, o);
     HM_HIP(hipGetLastError());
+    HM_HIP(hipEventRecord(h->ev_outline, h->stream2));
+    h->prepared_mask = nullptr;
     return HM_OK;
 }
 
@@ -706,11 +789,14 @@ extern "C" int hm_set_observation_dev(hm_ctx_t h, const uint8_t *d_y_im, const f
     int rc = finish_observation(h);
     if (rc) return rc;
     h->outline_ready = false;
-    if (h->d_outline) {              // as in hm_set_observation: the caller's mask is complete in device memory by contract
+    if (h->d_outline && h->prepared_mask == d_y_m) {      // hm_prepare_mask queued the outline of exactly this mask ahead
+        h->outline_ready = true;
+    } else if (h->d_outline) {       // as in hm_set_observation: the caller's mask is complete in device memory by contract
         rc = queue_outline(h, h->o_ym);
         if (rc) return rc;
         h->outline_ready = true;
     }
+    h->prepared_mask = nullptr;
     return HM_OK;
 }
 
@@ -1386,6 +1472,7 @@ static int update_cov_on(hm_ctx *h, int which, double *W_out, hipStream_t st)
 extern "C" int hm_project_mask(hm_ctx_t h, const uint8_t *y_m, double *X, int *moved)
 {
     HM_ARG(h && X, "hm_project_mask: NULL argument");
+    HM_JOIN_LAZY(h);
     if (!y_m) { NEED_OBS(h, "hm_project_mask"); }
     HM_HIP(hipSetDevice(h->device));
     // On the handle's second stream, with buffers of its own, and without joining the helper thread: the projection
@@ -1412,7 +1499,7 @@ extern "C" int hm_project_mask(hm_ctx_t h, const uint8_t *y_m, double *X, int *m
         memcpy(h->pin_pm, X, xb);
         ProjArgs a = {h->d_pm_pruned, h->W, h->H, h->N, o, nullptr};
         hipLaunchKernelGGL(k_project_mask_host, dim3(h->N), dim3(PROJ_NT), 0, s, a, (const double *)h->pin_pm, h->pin_pm + n4, (double *)nullptr,
-                           h->d_pm_done, (double)(++h->pm_ticket), h->result_delay);
+                           (double *)nullptr, h->d_pm_done, (double)(++h->pm_ticket), h->result_delay);
         HM_HIP(hipGetLastError());
         rc = hb_wait(s, h->pin_pm + n4, 0, n4 + 1, hb_stamp(h->pm_ticket), h->pmv.data(), "hm_project_mask");
         if (rc) return rc;
@@ -1445,6 +1532,7 @@ extern "C" int hm_project_mask(hm_ctx_t h, const uint8_t *y_m, double *X, int *m
 extern "C" int hm_prune_mask(hm_ctx_t h, const uint8_t *y_m, uint8_t *out)
 {
     HM_ARG(h && y_m && out, "hm_prune_mask: NULL argument");
+    HM_JOIN_LAZY(h);
     HM_HIP(hipSetDevice(h->device));
     int rc = ensure_stream2(h);
     if (rc) return rc;
@@ -1484,6 +1572,7 @@ extern "C" int hm_update_arm_newton(hm_ctx_t h, void *worker, int n_bars, const 
                                     double M, double dt, int maxiter, double tol)
 {
     HM_ARG(h && worker && n_bars >= 0 && bars && l0, "hm_update_arm_newton: bad argument");
+    HM_JOIN_LAZY(h);                               // (the tail of the last update still reads what this call replaces)
     h->pn_worker = worker;
     h->pn_bars.assign(bars, bars + 2 * (size_t)n_bars);
     h->pn_l0.assign(l0, l0 + n_bars);
@@ -1507,6 +1596,36 @@ extern "C" int hm_update_arm_cov(hm_ctx_t h, double eps_F)
 
 static int queue_predict_ahead(hm_ctx *h, const double *X, int n_bars, const int32_t *bars, const double *l0, double kappa,
                                double M, double dt, double eps_F, hipStream_t st);
+static int prepare_mask(hm_ctx *h, const uint8_t *d_y_m);
+
+// one-shot: when the next hm_update_run on h has its final state it also queues hm_prepare_mask(h, d_y_m) -- the contour
+// pruning and outline of the NEXT frame's mask run beside the state prediction and the update's tail instead of at the
+// start of the next frame, where the projection would wait for them
+extern "C" int hm_update_arm_mask(hm_ctx_t h, const uint8_t *d_y_m)
+{
+    HM_ARG(h != nullptr, "hm_update_arm_mask: NULL handle");
+    h->armed_mask = d_y_m;
+    return HM_OK;
+}
+
+// Hz components (4N x 4) and gains (3 x 4N) of the last hm_update_run that was called with Hzc = gains = NULL (such a
+// call does not wait for the kernels that form them: the caller gets on with the next frame); either may be NULL.
+// Available until the next hm_update_run on h; zeros for an update without iterations.
+extern "C" int hm_update_tail(hm_ctx_t h, double *Hzc, double *gains)
+{
+    HM_ARG(h != nullptr, "hm_update_tail: NULL handle");
+    HM_JOIN_LAZY(h);                               // (the helper thread may still be queueing the kernels that form them)
+    const size_t n4 = (size_t)4 * h->N;
+    if (h->tail_pending) {
+        HM_HIP(hipSetDevice(h->device));
+        const int rc = hb_wait(h->tail_stream, h->pin + 2 * (n4 + RES_HEAD), 0, n4 * 7, hb_stamp(h->tail_ticket), h->tailv.data(), "hm_update_tail");
+        if (rc) return rc;
+        h->tail_pending = false;
+    }
+    if (Hzc) memcpy(Hzc, h->tailv.data(), n4 * 4 * sizeof(double));
+    if (gains) memcpy(gains, h->tailv.data() + n4 * 4, n4 * 3 * sizeof(double));
+    return HM_OK;
+}
 
 extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, double deltaX, int masked, int max_iter,
                              double reltol, int info[4], double *errs, double *Hzc, double *gains, double *W_out)
@@ -1527,6 +1646,9 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
     const bool pq_go = h->pq_armed && pn_go;
     h->pq_armed = false;
     h->pq_valid = false;
+    const uint8_t *const next_mask = h->armed_mask;
+    h->armed_mask = nullptr;
+    h->tail_pending = false;                       // (the block of the last update is about to be overwritten)
     NEED_TEX(h, "hm_update_run");
     NEED_OBS(h, "hm_update_run");
     const bool dbg = getenv("HYDRA_MI_TRACE") != nullptr;
@@ -1545,7 +1667,7 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
         int r = hb_wait(h->stream3, h->pin_n4 + n4, 0, (size_t)n4 + 2, hb_stamp(h->n4_ticket), h->n4v.data(), "hm_update_run (state prediction)");
         h->n4_pending = false;
         if (r) return r;
-        r = hb_wait(h->stream2, h->pin_pm + n4, 0, (size_t)n4 + 1, hb_stamp(h->pm_ticket), h->pmv.data(), "hm_update_run (projectmask)");
+        r = hb_wait(h->stream3, h->pin_pm + n4, 0, (size_t)n4 + 1, hb_stamp(h->pm_ticket), h->pmv.data(), "hm_update_run (projectmask)");
         if (r) return r;
         h->chain_pred.assign(h->n4v.begin(), h->n4v.begin() + n4);
         h->chain_proj.assign(h->pmv.begin(), h->pmv.begin() + n4);
@@ -1558,7 +1680,8 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
         return HM_OK;
     };
     bool collected = !chained;
-    HM_HIP(hipMemcpyAsync(h->d_X, h->d_X0, (size_t)n4 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    // (chained: the projection's kernel has written the first iterate, d_X, next to the prior mean)
+    if (!chained) HM_HIP(hipMemcpyAsync(h->d_X, h->d_X0, (size_t)n4 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     double *const pin_res = h->pin, *const pin_tail = h->pin + 2 * ((size_t)n4 + RES_HEAD);
     const double *const res = h->resv.data();        // this call's copy of an iteration's block, taken when whole
     int niter = 0, accepted = 0;
@@ -1723,35 +1846,64 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
         }
         ts = h->stream4;
     }
-    rc = update_cov_on(h, which, nullptr, ts);
-    if (rc) return rc;
-    if (niter > 0) {
-        // gains and Hz components go to the host as a result block of their own (host_block.h), as the iterations'
-        // results do: two blit launches and the wake-up from a stream synchronisation less per frame
-        hipLaunchKernelGGL(k_gains, dim3(n4), dim3(256), 0, ts, h->d_Wres, h->d_Hzc, n4, h->d_gain);
-        hipLaunchKernelGGL(k_tail_result, dim3(1), dim3(1024), 0, ts, h->d_Hzc, h->d_gain, n4, pin_tail, (double)(++h->run_ticket),
-                           h->result_delay);
-    }
-    if (W_out) HM_HIP(hipMemcpyAsync(W_out, h->d_Wres, (size_t)n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, ts));
-    HM_HIP(hipGetLastError());
-    if (pq_go && h->chol_flow && which >= 0 && niter > 0 && !W_out) {
-        // the covariance half of the next frame's prediction, behind the launches above and before this thread waits
-        // for them (hm_update_arm_cov)
-        rc = queue_predict_ahead(h, Xcur.data(), (int)h->pn_l0.size(), h->pn_bars.data(), h->pn_l0.data(), h->pn_par[0],
-                                 h->pn_par[1], h->pn_par[2], h->pq_eps_F, ts);
-        if (rc) return rc;
-    }
-    if (ts != h->stream) {
-        HM_HIP(hipEventRecord(h->ev_tail, ts));
-        h->tail_on_stream4 = true;
-    }
+    const long long tail_ticket = niter > 0 ? ++h->run_ticket : h->run_ticket;
+    const double eps_F = h->pq_eps_F;
+    const bool ahead = pq_go && h->chol_flow && which >= 0 && niter > 0 && !W_out;
+    // the launches of the tail; Xk: the state that is kept
+    auto tail = [h, next_mask, which, ts, niter, n4, pin_tail, tail_ticket, W_out, ahead, eps_F](const std::vector<double> &Xk) -> int {
+        HM_HIP(hipSetDevice(h->device));
+        int r = HM_OK;
+        if (next_mask) {                           // the next frame's outline, beside the prediction (hm_update_arm_mask)
+            r = prepare_mask(h, next_mask);
+            if (r) return r;
+        }
+        r = update_cov_on(h, which, nullptr, ts);
+        if (r) return r;
+        if (niter > 0) {
+            // gains and Hz components go to the host as a result block of their own (host_block.h), as the iterations'
+            // results do: two blit launches and the wake-up from a stream synchronisation less per frame
+            hipLaunchKernelGGL(k_gains, dim3(n4), dim3(256), 0, ts, h->d_Wres, h->d_Hzc, n4, h->d_gain);
+            hipLaunchKernelGGL(k_tail_result, dim3(1), dim3(1024), 0, ts, h->d_Hzc, h->d_gain, n4, pin_tail, (double)tail_ticket,
+                               h->result_delay);
+        }
+        if (W_out) HM_HIP(hipMemcpyAsync(W_out, h->d_Wres, (size_t)n4 * n4 * sizeof(double), hipMemcpyDeviceToHost, ts));
+        HM_HIP(hipGetLastError());
+        if (ahead) {
+            // the covariance half of the next frame's prediction, behind the launches above (hm_update_arm_cov)
+            r = queue_predict_ahead(h, Xk.data(), (int)h->pn_l0.size(), h->pn_bars.data(), h->pn_l0.data(), h->pn_par[0],
+                                    h->pn_par[1], h->pn_par[2], eps_F, ts);
+            if (r) return r;
+        }
+        if (ts != h->stream) {
+            HM_HIP(hipEventRecord(h->ev_tail, ts));
+            h->tail_on_stream4 = true;
+        }
+        return HM_OK;
+    };
     dbg_stage[3] = dbg_ms();
-    if (niter > 0 && !W_out) {
-        rc = hb_wait(ts, pin_tail, 0, (size_t)n4 * 7, hb_stamp(h->run_ticket), h->tailv.data(), "hm_update_run");
+    if (niter > 0 && !W_out && !Hzc && !gains) {
+        // nobody wants the gains now: they are taken when asked for (hm_update_tail) and the caller gets on with its next
+        // frame -- the tail's ~20 launches are queued by the handle's helper thread (every entry point joins it first)
+        h->tail_pending = true;
+        h->tail_ticket = tail_ticket;
+        h->tail_stream = ts;
+        if (h->tail_async) {
+            h->helper_used = true;
+            h->helper.post([tail, Xk = Xcur]() { return tail(Xk); });
+        } else {
+            rc = tail(Xcur);
+            if (rc) return rc;
+        }
+    } else if (niter > 0 && !W_out) {
+        rc = tail(Xcur);
+        if (rc) return rc;
+        rc = hb_wait(ts, pin_tail, 0, (size_t)n4 * 7, hb_stamp(tail_ticket), h->tailv.data(), "hm_update_run");
         if (rc) return rc;
     } else {
+        rc = tail(Xcur);
+        if (rc) return rc;
         HM_HIP(stream_wait(ts));
-        if (niter > 0 && !hb_take(pin_tail, 0, (size_t)n4 * 7, hb_stamp(h->run_ticket), h->tailv.data())) {
+        if (niter > 0 && !hb_take(pin_tail, 0, (size_t)n4 * 7, hb_stamp(tail_ticket), h->tailv.data())) {
             hm_set_error("hm_update_run: the gains did not arrive although the stream has completed");
             return HM_ERR_HIP;
         }
@@ -1766,6 +1918,7 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
     } else {
         if (Hzc) memset(Hzc, 0, (size_t)n4 * 4 * sizeof(double));
         if (gains) memset(gains, 0, (size_t)n4 * 3 * sizeof(double));
+        std::fill(h->tailv.begin(), h->tailv.end(), 0.0);
     }
     memcpy(X, Xcur.data(), (size_t)n4 * sizeof(double));
     info[0] = niter; info[1] = accepted; info[2] = reverted ? 1 : 0; info[3] = conv ? 1 : 0;
@@ -2173,6 +2326,7 @@ extern "C" int hm_newton_dev_finish(hm_ctx_t h, double *X, int *newton_iteration
 extern "C" int hm_chain_project(hm_ctx_t h)
 {
     HM_ARG(h != nullptr, "hm_chain_project: NULL handle");
+    HM_JOIN_LAZY(h);
     NEED_OBS(h, "hm_chain_project");
     if (!h->n4_pending || !h->d_n4X) return 1;
     HM_HIP(hipSetDevice(h->device));
@@ -2188,12 +2342,41 @@ extern "C" int hm_chain_project(hm_ctx_t h)
     const size_t n4 = (size_t)4 * h->N;
     Outline o = {h->d_outline, h->d_outline_cnt, h->W * h->H, h->d_pm_flag};
     ProjArgs a = {h->d_pm_pruned, h->W, h->H, h->N, o, nullptr};
-    HM_HIP(hipStreamWaitEvent(h->stream2, h->ev_n4, 0));
-    hipLaunchKernelGGL(k_project_mask_host, dim3(h->N), dim3(PROJ_NT), 0, h->stream2, a, (const double *)h->d_n4X, h->pin_pm + n4, h->d_X0,
-                       h->d_pm_done, (double)(++h->pm_ticket), h->result_delay);
+    // on the prediction's own stream, right behind its kernel (no hop between streams there); the outline of the mask was
+    // queued on the second stream when the observation was set, or a frame ahead (hm_prepare_mask)
+    HM_HIP(hipStreamWaitEvent(h->stream3, h->ev_outline, 0));
+    hipLaunchKernelGGL(k_project_mask_host, dim3(h->N), dim3(PROJ_NT), 0, h->stream3, a, (const double *)h->d_n4X, h->pin_pm + n4, h->d_X0,
+                       h->d_X, h->d_pm_done, (double)(++h->pm_ticket), h->result_delay);
     HM_HIP(hipGetLastError());
-    HM_HIP(hipEventRecord(h->ev_pm, h->stream2));
+    HM_HIP(hipEventRecord(h->ev_pm, h->stream3));
     h->chain_pending = true;
+    return HM_OK;
+}
+
+// The pruning + outline of a mask in device memory queued AHEAD of the hm_set_observation_dev that will name it (a
+// streaming caller has the next frame's mask in device memory a frame early): ~0.2 ms of kernels on the second stream
+// that would otherwise start when the next frame does and keep its projection waiting.  Queued behind whatever the
+// second stream still has to do with the current outline.  The mask must not change until that hm_set_observation_dev;
+// any other observation, or a projection onto a host mask, simply discards the preparation.
+extern "C" int hm_prepare_mask(hm_ctx_t h, const uint8_t *d_y_m)
+{
+    HM_ARG(h && d_y_m, "hm_prepare_mask: NULL argument");
+    HM_JOIN_LAZY(h);
+    return prepare_mask(h, d_y_m);
+}
+static int prepare_mask(hm_ctx *h, const uint8_t *d_y_m)
+{
+    HM_HIP(hipSetDevice(h->device));
+    int rc = ensure_stream2(h);
+    if (rc) return rc;
+    rc = project_buffers(h);
+    if (rc) return rc;
+    // the projection of the CURRENT frame may still be reading the outline buffers on the prediction's stream
+    if (h->ev_pm && h->pm_ticket > 0) HM_HIP(hipStreamWaitEvent(h->stream2, h->ev_pm, 0));
+    rc = queue_outline(h, d_y_m);
+    if (rc) return rc;
+    h->outline_ready = false;                    // (the buffers no longer hold the outline of the observation in place)
+    h->prepared_mask = d_y_m;
     return HM_OK;
 }
 

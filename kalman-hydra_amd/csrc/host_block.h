@@ -22,7 +22,11 @@
 //   * a block of n doubles is 2n naturally aligned 8-byte words: word 2i is value i, word 2i + 1 is its bit pattern
 //     XOR the STAMP of the launch, hb_stamp(ticket) = ticket * an odd constant -- distinct for every ticket of a
 //     handle (tickets count from 1; a fresh block is all zeros, the pair of ticket 0);
-//   * the kernel stores every word write-through at system scope (sc0 sc1), in any order, no fence, no barrier;
+//   * the kernel stores the pairs with plain 16-byte stores, in any order, and every storing wave ends with ONE
+//     system-scope release fence (hb_flush: buffer_wbl2 sc0 sc1 + s_waitcnt), which writes the lines back to host
+//     memory -- the fence is there so that the words ARRIVE, not to order them.  (Measured this round: storing every
+//     word write-through instead, sc0 sc1, costs 100-300 ns per 8-byte store over PCIe -- k_tail_result 1.28 ms instead
+//     of 12 us, the state prediction 0.77 instead of 0.27 ms: the L2 has to gather the lines);
 //   * the host takes the block when EVERY pair satisfies a ^ b == stamp, into memory of its own, and works on that
 //     copy.  A word of an earlier launch fails the test whatever its value (its pair carries another stamp), a pair
 //     of which one word is new and one old fails it unless the two values differ by exactly the difference of the
@@ -44,14 +48,18 @@
 
 static inline __host__ __device__ unsigned long long hb_stamp(long long ticket) { return (unsigned long long)ticket * HB_MUL; }
 
-// value i of a block
+// value i of a block (a plain 16-byte store; hb_flush behind the wave's last one)
 __device__ __forceinline__ void hb_put(double *blk, int i, double v, unsigned long long stamp)
 {
+    typedef unsigned long long hb_u64x2 __attribute__((ext_vector_type(2)));
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    unsigned long long *w = (unsigned long long *)blk + 2 * (size_t)i;
-    __hip_atomic_store(w, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(w + 1, b ^ stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    hb_u64x2 w;
+    w.x = b;
+    w.y = b ^ stamp;
+    *((hb_u64x2 *)blk + i) = w;
 }
+// every wave that has stored into a block, once, after its last store: the lines go back to host memory
+__device__ __forceinline__ void hb_flush() { __threadfence_system(); }
 
 // a double the host wrote into page-locked memory before this launch was queued
 __device__ __forceinline__ double hb_host_in(const double *p)

@@ -380,7 +380,7 @@ __global__ __launch_bounds__(NEWTON4_NT) void k_ms_newton4(Newton4Args a)
         if (t == 0) { a.dev_out[4 * N] = (double)total; a.dev_out[4 * N + 1] = (double)bad; }
     }
     if (a.delay_us > 0) {
-        if (t == 0) hb_put(a.out, 4 * N + 1, (double)bad, stamp);
+        if (t == 0) { hb_put(a.out, 4 * N + 1, (double)bad, stamp); hb_flush(); }
         hb_delay(a.delay_us);
     }
     if (act) {
@@ -388,4 +388,5 @@ __global__ __launch_bounds__(NEWTON4_NT) void k_ms_newton4(Newton4Args a)
         hb_put(a.out, 2 * N + 2 * v, Xw[0], stamp); hb_put(a.out, 2 * N + 2 * v + 1, Xw[1], stamp);
     }
     if (t == 0) { hb_put(a.out, 4 * N, (double)total, stamp); hb_put(a.out, 4 * N + 1, (double)bad, stamp); }
+    hb_flush();
 }

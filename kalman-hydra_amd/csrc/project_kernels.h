@@ -59,11 +59,11 @@ __global__ __launch_bounds__(OUTLINE_NT) void k_outline(const uint8_t *__restric
 // findObjectThreshold keeps the outer contour of the LARGEST object (cv2.contourArea) and of its holes those of area
 // >= 40; smaller objects, smaller holes and everything nested deeper go (oracle/ekf_ref.py:pruned_object has the
 // restatement this follows, areas by Pick's theorem).  Per frame, on the mask in device memory:
-//   k_ccl_runs     every pixel points to the first pixel of its horizontal run inside a 64-pixel row segment; object
-//                  pixels and background pixels are labelled in the same pass (a pixel belongs to one of the two);
-//   k_ccl_merge    union-find over those labels (atomicMin towards the smaller index, so a component's root is its
-//                  first pixel in raster order): object pixels join their W / NW / N / NE neighbours (8-connected),
-//                  background pixels their W / N neighbours (4-connected);
+//   k_ccl_local    a 64 x 16 tile per workgroup, labelled in LDS: runs of a row by ballot, rows joined by a union-find
+//                  (atomicMin towards the smaller index, so a component's root is its first pixel in raster order):
+//                  object pixels join their W / NW / N / NE neighbours (8-connected), background pixels their W / N
+//                  neighbours (4-connected) -- both kinds in the same pass, a pixel belongs to one of the two;
+//   k_ccl_border   the same unions across tile borders, on the labels in memory;
 //   k_ccl_flatten  every pixel points to its root; background components that reach the frame edge are marked
 //                  (findContours treats the frame as surrounded by background: they are outside, not holes);
 //   k_ccl_stats    nesting comes from the roots: the pixel ABOVE a component's first pixel belongs to the component
@@ -105,23 +105,79 @@ __device__ __forceinline__ void d_ccl_unite(int *L, int a, int b)
 }
 
 #define CCL_NT 256
-// grid (ceil(W / 64), ceil(H / 4)): a wave per 64-pixel row segment
-__global__ __launch_bounds__(CCL_NT) void k_ccl_runs(const uint8_t *__restrict__ ym, Ccl c)
+#define CCL_TW 64
+#define CCL_TH 16
+// the same union-find on a tile's labels in LDS (local pixel indices)
+__device__ __forceinline__ int d_ccl_find_lds(int *L, int i)
 {
-    const int lane = threadIdx.x & 63;
-    const int x = blockIdx.x * 64 + lane, y = blockIdx.y * (CCL_NT / 64) + (threadIdx.x >> 6);
-    if (y >= c.H) return;
-    const bool in = x < c.W;
-    const bool fg = in && ym[(size_t)y * c.W + x] > 0;
-    const unsigned long long bf = __ballot(fg);
-    // lanes that start a run: lane 0, or a class different from the lane before
-    const unsigned long long prev = (bf << 1) | (bf & 1ull);
-    const unsigned long long starts = (bf ^ prev) | 1ull;
-    const unsigned long long upto = starts & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
-    const int first = 63 - __clzll(upto);
-    if (in) {
-        const size_t p = (size_t)y * c.W + x;
-        c.L[p] = y * c.W + blockIdx.x * 64 + first;
+    int r = i;
+    for (int p = L[r]; p != r; p = L[r]) r = p;
+    return r;
+}
+__device__ __forceinline__ void d_ccl_unite_lds(int *L, int a, int b)
+{
+    for (;;) {
+        a = d_ccl_find_lds(L, a);
+        b = d_ccl_find_lds(L, b);
+        if (a == b) return;
+        if (a > b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(&L[b], a);
+        if (old == b) return;
+        b = old;
+    }
+}
+
+// grid (ceil(W / 64), ceil(H / 16)): a workgroup labels a 64 x 16 tile in LDS -- runs of a row by ballot, the rows of
+// the tile joined by the union-find above -- and writes, per pixel, the GLOBAL index of its component's first pixel
+// inside the tile: flat trees, one hop deep, for the unions across tile borders that follow (k_ccl_border).  (One
+// union-find over the whole frame from single pixels took 0.6 ms at 1024^2: chains as long as the object is high.)
+__global__ __launch_bounds__(CCL_NT) void k_ccl_local(const uint8_t *__restrict__ ym, Ccl c)
+{
+    __shared__ int sl[CCL_TH * CCL_TW];
+    __shared__ signed char scls[CCL_TH][CCL_TW];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x0 = blockIdx.x * CCL_TW, y0 = blockIdx.y * CCL_TH, x = x0 + lane;
+    const int W = c.W, H = c.H;
+#pragma unroll
+    for (int q = 0; q < CCL_TH / 4; q++) {
+        const int r = wv * (CCL_TH / 4) + q, y = y0 + r;
+        const bool in = x < W && y < H;
+        const bool fg = in && ym[(size_t)y * W + x] > 0;
+        const unsigned long long bf = __ballot(fg), bi = __ballot(in);
+        // lanes that start a run: lane 0, a class different from the lane before, the first lane off the frame
+        const unsigned long long prev_f = (bf << 1) | (bf & 1ull), prev_i = (bi << 1) | (bi & 1ull);
+        const unsigned long long starts = (bf ^ prev_f) | (bi ^ prev_i) | 1ull;
+        const unsigned long long upto = starts & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+        sl[r * CCL_TW + lane] = r * CCL_TW + (63 - __clzll(upto));
+        scls[r][lane] = in ? (fg ? 1 : 0) : -1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < CCL_TH / 4; q++) {
+        const int r = wv * (CCL_TH / 4) + q;
+        if (r == 0) continue;
+        const int cl = scls[r][lane], me = r * CCL_TW + lane, up = me - CCL_TW;
+        if (cl < 0) continue;
+        const bool n = scls[r - 1][lane] == 1;
+        if (cl == 1) {
+            // the run above through N; when N is background, the (different) runs of NW and NE
+            if (n) d_ccl_unite_lds(sl, me, up);
+            else {
+                if (lane > 0 && scls[r - 1][lane - 1] == 1) d_ccl_unite_lds(sl, me, up - 1);
+                if (lane < 63 && scls[r - 1][lane + 1] == 1) d_ccl_unite_lds(sl, me, up + 1);
+            }
+        } else if (scls[r - 1][lane] == 0) {
+            d_ccl_unite_lds(sl, me, up);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < CCL_TH / 4; q++) {
+        const int r = wv * (CCL_TH / 4) + q, y = y0 + r;
+        if (x >= W || y >= H) continue;
+        const int root = d_ccl_find_lds(sl, r * CCL_TW + lane);
+        const size_t p = (size_t)y * W + x;
+        c.L[p] = (y0 + root / CCL_TW) * W + x0 + (root % CCL_TW);
         c.cnt[p] = 0;
         c.bnd[p] = 0;
         c.edge[p] = 0;
@@ -129,27 +185,28 @@ __global__ __launch_bounds__(CCL_NT) void k_ccl_runs(const uint8_t *__restrict__
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) c.best[0] = 0ull;
 }
 
-__global__ __launch_bounds__(CCL_NT) void k_ccl_merge(const uint8_t *__restrict__ ym, Ccl c)
+// the unions across tile borders: grid (ceil(W / 64), ceil(H / 4)), a wave per 64-pixel row segment
+__global__ __launch_bounds__(CCL_NT) void k_ccl_border(const uint8_t *__restrict__ ym, Ccl c)
 {
     const int lane = threadIdx.x & 63;
     const int x = blockIdx.x * 64 + lane, y = blockIdx.y * (CCL_NT / 64) + (threadIdx.x >> 6);
     if (x >= c.W || y >= c.H) return;
+    const bool top = (y % CCL_TH) == 0, left = lane == 0, right = lane == 63;
+    if (!top && !left && !right) return;
     const int W = c.W, p = y * W + x;
     const uint8_t *row = ym + (size_t)y * W;
     const bool fg = row[x] > 0;
-    // the run start joins the run on its left (another segment) when that is of its class
-    if (lane == 0 && x > 0 && (row[x - 1] > 0) == fg) d_ccl_unite(c.L, p, p - 1);
+    if (left && x > 0 && (row[x - 1] > 0) == fg) d_ccl_unite(c.L, p, p - 1);
     if (y == 0) return;
     const uint8_t *up = row - W;
     const bool n = up[x] > 0;
     if (fg) {
-        // the run above through N; when N is background, the (different) runs of NW and NE
-        if (n) d_ccl_unite(c.L, p, p - W);
+        if (n) { if (top) d_ccl_unite(c.L, p, p - W); }
         else {
-            if (x > 0 && up[x - 1] > 0) d_ccl_unite(c.L, p, p - W - 1);
-            if (x + 1 < W && up[x + 1] > 0) d_ccl_unite(c.L, p, p - W + 1);
+            if ((top || left) && x > 0 && up[x - 1] > 0) d_ccl_unite(c.L, p, p - W - 1);
+            if ((top || right) && x + 1 < W && up[x + 1] > 0) d_ccl_unite(c.L, p, p - W + 1);
         }
-    } else if (!n) {
+    } else if (!n && top) {
         d_ccl_unite(c.L, p, p - W);
     }
 }
@@ -390,9 +447,10 @@ __global__ __launch_bounds__(PROJ_NT) void k_project_mask(ProjArgs a)
 // the device buffer the state prediction's kernel left it in; read with system-scope loads either way.  blk: a result
 // block of host_block.h in page-locked host memory, 4N + 1 values: the projected state and the number of vertices that
 // were moved (published by the workgroup that finishes last).  dev_out (may be NULL): the projected state in device
-// memory for the kernels queued behind this one (the prior mean of the update).
-__global__ __launch_bounds__(PROJ_NT) void k_project_mask_host(ProjArgs a, const double *xin, double *blk, double *dev_out, int *done,
-                                                               double ticket, int delay_us)
+// memory for the kernels queued behind this one (the prior mean of the update; dev_out2: a second copy, the update's first
+// iterate).
+__global__ __launch_bounds__(PROJ_NT) void k_project_mask_host(ProjArgs a, const double *xin, double *blk, double *dev_out, double *dev_out2,
+                                                               int *done, double ticket, int delay_us)
 {
 #pragma clang fp contract(off)
     __shared__ double red[PROJ_NT / 64 * 3];
@@ -405,17 +463,20 @@ __global__ __launch_bounds__(PROJ_NT) void k_project_mask_host(ProjArgs a, const
     const double vx0 = hb_host_in(xin + 2 * N + 2 * v), vy0 = hb_host_in(xin + 2 * N + 2 * v + 1);
     const double vx = moved ? vx0 + (x - x0) : vx0, vy = moved ? vy0 + (y - y0) : vy0;
     if (dev_out) { dev_out[2 * v] = x; dev_out[2 * v + 1] = y; dev_out[2 * N + 2 * v] = vx; dev_out[2 * N + 2 * v + 1] = vy; }
+    if (dev_out2) { dev_out2[2 * v] = x; dev_out2[2 * v + 1] = y; dev_out2[2 * N + 2 * v] = vx; dev_out2[2 * N + 2 * v + 1] = vy; }
     if (delay_us > 0 && v == 0) {                            // test knob "result_delay": vertex 0's pairs come late
         hb_put(blk, 2 * N, vx, stamp);
+        hb_flush();
         hb_delay(delay_us);
     }
     hb_put(blk, 2 * v, x, stamp); hb_put(blk, 2 * v + 1, y, stamp);
     hb_put(blk, 2 * N + 2 * v, vx, stamp); hb_put(blk, 2 * N + 2 * v + 1, vy, stamp);
     if (moved) atomicAdd(&a.o.count[2], 1);
-    __threadfence();
+    hb_flush();                                              // (system scope: also orders the count before the arrival below)
     if (atomicAdd(done, 1) == (int)gridDim.x - 1) {
         __threadfence();
         hb_put(blk, 4 * N, (double)atomicExch(&a.o.count[2], 0), stamp);        // (left clean for another projection onto the same mask)
         *done = 0;
+        hb_flush();
     }
 }

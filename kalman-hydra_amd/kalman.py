@@ -637,13 +637,35 @@ class IteratedKalmanFilter(KalmanFilter):
         self.nI = nI
         self.reltol = 1e-4
         self.fused_update = True         # hm_update_run; False: the same loop in Python over hm_update_step
+        # the diagnostics of reference kalman.py:826-828 (tv, fv, mv = W Hzc[:, 0], W (Hzc[:, 1] + Hzc[:, 2]), W Hzc[:, 3])
+        # are formed on the device by the fused update; True: they cross to the host when they are read, not every frame
+        self.lazy_gains = True
+        self._gains = (None, None, None)
+
+    def _gain(self, k):
+        if self._gains is None:
+            _, g = self.state.renderer.update_tail()
+            self._gains = (g[0], g[1], g[2])
+        return self._gains[k]
+
+    def _set_gain(self, k, v):
+        g = list(self._gains) if self._gains is not None else [None, None, None]
+        g[k] = v
+        self._gains = tuple(g)
+
+    tv = property(lambda self: self._gain(0), lambda self, v: self._set_gain(0, v))
+    fv = property(lambda self: self._gain(1), lambda self, v: self._set_gain(1, v))
+    mv = property(lambda self: self._gain(2), lambda self, v: self._set_gain(2, v))
+
 
     def _update_fused(self, y_im, y_flow, y_m):
         """The whole loop below in one native call (hm_update_run): same numbers, the iterate and
         the covariance stay on the device."""
         st = self.state
         t0 = time.time()
-        X, info, errs, Hzc, gains, W = st.renderer.update_run(st._W, st.X, y_im, y_flow, y_m, self.nI, self.reltol)
+        # (the gains -- tv, fv, mv below -- are fetched when somebody reads them: the call does not wait for their kernels)
+        lazy = bool(self.lazy_gains) and hasattr(st.renderer, "update_tail")
+        X, info, errs, Hzc, gains, W = st.renderer.update_run(st._W, st.X, y_im, y_flow, y_m, self.nI, self.reltol, tail=not lazy)
         stats.stateupdatetc[0] += time.time() - t0
         stats.stateupdatetc[1] += info["niter"]
         for i, e in enumerate(errs):
@@ -658,7 +680,10 @@ class IteratedKalmanFilter(KalmanFilter):
         self.niter = info["niter"]
         stats.niter += self.niter
         self.reverted, self.converged = info["reverted"], info["converged"]
-        self.tv, self.fv, self.mv = gains[0], gains[1], gains[2]
+        if lazy:
+            self._gains = None                # tv / fv / mv: renderer.update_tail() on first access
+        else:
+            self._gains = (gains[0], gains[1], gains[2])
 
     def update(self, y_im, y_flow, y_m):
         """Iterated EKF in information form (:774-831).
@@ -966,6 +991,8 @@ class IteratedMSKalmanFilter(IteratedKalmanFilter):
             if self.cov_ahead and hasattr(r, "arm_cov"):
                 r.arm_cov(self.state.eps_F)
                 self._cov_armed = True
+        if getattr(y_m, "next_mask", None) and hasattr(r, "arm_mask"):
+            r.arm_mask(y_m.next_mask)        # the next frame's outline: queued when this update has its final state
         try:
             IteratedKalmanFilter._update_fused(self, y_im, y_flow, y_m)
         except Exception:

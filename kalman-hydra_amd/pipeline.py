@@ -225,6 +225,7 @@ class FrameRing:
         self._stage_np = np.ctypeslib.as_array(ctypes.cast(self._stage, ctypes.POINTER(ctypes.c_uint8)),
                                                shape=(self._nstage, self.planes, self.n))
         self._staged = 0
+        self.synced_hi = 0
         _lib.register(self, 4)
         self.lo = self.hi = 0                                    # frames [lo, hi) are in the ring (queued or there)
         self.bytes_uploaded = 0
@@ -232,7 +233,7 @@ class FrameRing:
     def reset(self, first):
         with self._lock:
             self.sync()
-            self.lo = self.hi = int(first)
+            self.lo = self.hi = self.synced_hi = int(first)
 
     def ptr(self, plane, f):
         """Device address of frame f in plane 0 (raw), 1 (mask) or 2 (shown to the filter)."""
@@ -275,8 +276,10 @@ class FrameRing:
 
     def sync(self):
         with self._lock:
+            hi = self.hi
             _lib.check(_lib.lib().hm_copy_stream_sync(self.device, self._stream), "hm_copy_stream_sync")
             self._staged = 0
+            self.synced_hi = hi              # frames below this are in device memory for certain
 
     def close(self):
         if getattr(self, "_stream", None) is not None and self._stream:
@@ -626,8 +629,11 @@ class FlowEKFPipeline:
         pu, pv = self.flow_ready(k)
         t1 = time.perf_counter()
         n = self._px
+        # the next frame's mask, when its upload has been waited for already (every flow series is launched behind a wait
+        # for the uploads of its frames): the filter queues that mask's outline a frame ahead
+        nxt = self.ring.ptr(1, k + 2) if (k + 2 < self.F and self.ring.lo <= k + 2 < self.ring.synced_hi) else None
         obs = DeviceObservation(self.ring.ptr(2, k + 1), pu, pv, self.ring.ptr(1, k + 1),
-                                y_m_host=self.source.frame_at(k + 1)[1])
+                                y_m_host=self.source.frame_at(k + 1)[1], next_mask=nxt)
         e = self.kf.compute(obs, None, None, maskflow=self.maskflow)
         t2 = time.perf_counter()
         # what a frame of the filter takes: the median of the last few (the first frames of a filter's life carry
@@ -636,7 +642,8 @@ class FlowEKFPipeline:
         if len(self._frame_hist) > 8:
             self._frame_hist.pop(0)
         # (with fewer than five on record the fastest one: the slow ones are the first-use frames)
-        self._frame_s = float(np.median(self._frame_hist)) if len(self._frame_hist) >= 5 else float(min(self._frame_hist))
+        hist = sorted(self._frame_hist)
+        self._frame_s = (0.5 * (hist[(len(hist) - 1) // 2] + hist[len(hist) // 2])) if len(hist) >= 5 else hist[0]
         self.t_flow += t1 - t0
         self.t_ekf += t2 - t1
         self.iters += getattr(self.kf, "niter", 1)

@@ -328,24 +328,26 @@ class Renderer:
         if W is not None:
             self._cov_serial += 1
 
-    def update_run(self, W_prior, X0, y_im, y_flow, y_m, max_iter, reltol, deltaX=2.0, fetch=False):
+    def update_run(self, W_prior, X0, y_im, y_flow, y_m, max_iter, reltol, deltaX=2.0, fetch=False, tail=True):
         """hm_update_run: the whole iterated update (kalman.py:774-831) ->
-        (X kept [4N,1], info dict, errs [niter,4], Hz_components [4N,4], gains [3,4N], covariance)."""
+        (X kept [4N,1], info dict, errs [niter,4], Hz_components [4N,4], gains [3,4N], covariance).
+        tail=False: the call does not wait for the kernels that form the Hz components and the gains (None in their place);
+        update_tail() fetches them, until the next update_run."""
         masked = self._masked_flag(y_im, y_flow, y_m)
         W = self._cov_arg(W_prior, "update_run")
         n4 = 4 * self.n
         X = np.ascontiguousarray(np.asarray(X0, np.float64).reshape(-1)).copy()
         info = (ctypes.c_int * 4)()
         errs = np.zeros((max(int(max_iter), 1), 4))
-        Hzc = np.empty((n4, 4))
-        gains = np.empty((3, n4))
+        Hzc = np.empty((n4, 4)) if tail else None
+        gains = np.empty((3, n4)) if tail else None
         rc = _lib.lib().hm_update_run(self._h, _lib.ptr(W), _lib.ptr(X), float(deltaX), masked, int(max_iter),
                                       float(reltol), info, _lib.ptr(errs), _lib.ptr(Hzc), _lib.ptr(gains), None)
+        if rc == 2:                                 # a chained run whose state prediction gave up: the caller predicts on the host
+            raise ChainedPredictionFailed()         # (nothing was updated: the predicted covariance is still the resident one)
         self._cov_serial += 1
         if rc == _lib.HM_ERR_NUMERIC:
             raise FloatingPointError(_lib.lib().hm_last_error().decode())
-        if rc == 2:                                 # a chained run whose state prediction gave up: the caller predicts on the host
-            raise ChainedPredictionFailed()
         _lib.check(rc, "hm_update_run")
         out = dict(niter=info[0], accepted=info[1], reverted=bool(info[2]), converged=bool(info[3]))
         return X.reshape(-1, 1), out, errs[:info[0]], Hzc, gains, self._cov_result(fetch)
@@ -378,6 +380,22 @@ class Renderer:
             return False
         _lib.check(rc, "hm_chain_project")
         return True
+
+    def update_tail(self):
+        """hm_update_tail -> (Hz components [4N,4], gains [3,4N]) of the last update_run(tail=False)."""
+        n4 = 4 * self.n
+        Hzc, gains = np.empty((n4, 4)), np.empty((3, n4))
+        _lib.check(_lib.lib().hm_update_tail(self._h, _lib.ptr(Hzc), _lib.ptr(gains)), "hm_update_tail")
+        return Hzc, gains
+
+    def arm_mask(self, d_mask):
+        """hm_update_arm_mask: the next update_run queues the outline of this mask (device address: the NEXT frame's) when
+        its state is final."""
+        _lib.check(_lib.lib().hm_update_arm_mask(self._h, ctypes.c_void_p(int(d_mask))), "hm_update_arm_mask")
+
+    def prepare_mask(self, d_mask):
+        """hm_prepare_mask: pruning + outline of the NEXT observation's mask (device address) queued a frame ahead."""
+        _lib.check(_lib.lib().hm_prepare_mask(self._h, ctypes.c_void_p(int(d_mask))), "hm_prepare_mask")
 
     def chain_states(self):
         """hm_chain_states -> (predicted state, projected state, Newton iterations, vertices moved) of the last chained
@@ -481,9 +499,10 @@ class DeviceObservation:
         def __init__(self, name):
             self.name = name
 
-    def __init__(self, d_y_im, d_flowx, d_flowy, d_y_m, y_m_host=None):
+    def __init__(self, d_y_im, d_flowx, d_flowy, d_y_m, y_m_host=None, next_mask=None):
         self.d_y_im, self.d_flowx, self.d_flowy, self.d_y_m = d_y_im, d_flowx, d_flowy, d_y_m
         self.y_m_host = y_m_host
+        self.next_mask = next_mask      # device address of the NEXT frame's mask when it is resident already (hm_prepare_mask)
         self.raw = DeviceObservation._Token("raw")
         self.masked = DeviceObservation._Token("masked")
 
