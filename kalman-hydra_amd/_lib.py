@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libhydra_mi.so")
+# (HYDRA_MI_SO: another build of the same library, for A/B experiments -- tools/ only)
+SO_PATH = os.environ.get("HYDRA_MI_SO") or os.path.join(_HERE, "libhydra_mi.so")
 
 c_f32p = ctypes.POINTER(ctypes.c_float)
 c_f64p = ctypes.POINTER(ctypes.c_double)

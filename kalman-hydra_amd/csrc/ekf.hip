@@ -713,8 +713,8 @@ static int project_buffers(hm_ctx *h)
     HM_HIP(hm_malloc((void **)&h->d_pm_X, n4 * sizeof(double)));
     HM_HIP(hm_malloc((void **)&h->d_pm_done, sizeof(int)));
     // zeroed on the stream the kernel that counts in it runs on: a hipMemset on the null stream is not ordered with a
-    // non-blocking stream and may land in the middle of that kernel -- no workgroup is the last one then, the ticket
-    // never comes and the projection of a context's first frame was silently dropped (seen once in ~10 runs)
+    // non-blocking stream and may land in the middle of that kernel -- no workgroup is the last one then, the count of
+    // moved vertices never comes and the projection of a context's first frame was silently dropped (seen once in ~10 runs)
     HM_HIP(hipMemsetAsync(h->d_pm_done, 0, sizeof(int), h->stream2));
     HM_HIP(hipHostMalloc((void **)&h->pin_pm, (n4 + 2 * (n4 + 1)) * sizeof(double), hipHostMallocCoherent));
     memset(h->pin_pm, 0, (n4 + 2 * (n4 + 1)) * sizeof(double));
@@ -1689,7 +1689,7 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
     double eold = 0.0;
     // spec: the measurement at the new iterate has been queued already -- behind k_iter_result, before the host has seen
     // that iteration's result, on the assumption that the loop goes on (it does 7 times out of 8): the device goes from
-    // one iteration into the next without the ~14 us it takes the host to notice the ticket, decide and launch.  ref / P
+    // one iteration into the next without the ~14 us it takes the host to notice the result block, decide and launch.  ref / P
     // and d_X / d_Xn are swapped when it is queued; an iteration that turns out to be the last swaps them back (the
     // wasted measurement only wrote job sums and parked differences nobody reads, and the launches behind it on this
     // stream -- the covariance of the kept state -- are not what the next frame waits for).
@@ -2210,7 +2210,7 @@ extern "C" int hm_newton_dev_start(hm_ctx_t h, int N, int n_bars, const int32_t 
     HM_ARG(h && bars && l0 && X && n_bars >= 1, "hm_newton_dev_start: bad argument");
     if (N != h->N || N > NEWTON4_NT) return 1;
     HM_HIP(hipSetDevice(h->device));
-    if (h->n4_pending) {                          // a prediction nobody fetched: let it finish (its ticket is not waited for)
+    if (h->n4_pending) {                          // a prediction nobody fetched: let it finish (its result block is dropped)
         HM_HIP(hipStreamSynchronize(h->stream3));
         h->n4_pending = false;
     }

@@ -811,7 +811,10 @@ __device__ inline void d_region_sums(const int *__restrict__ area, int N, int v,
 // workgroups per vertex; a perturbation of vertex v changes the render only inside the triangles
 // around v (its star), so every sum runs over the bounding box of that star; the perturbed renders
 // are never materialised.  The forward difference images are parked in the pool for pass 2.
-__global__ __launch_bounds__(MEAS_NT, 4) void k_measure_vertex(MeasureArgs a, const TriSetup *__restrict__ cfgs,
+#ifndef MEAS_OCC
+#define MEAS_OCC 4        // waves per SIMD the kernel is compiled for (experiments: -DMEAS_OCC=5 caps it at 96 VGPRs, with spills)
+#endif
+__global__ __launch_bounds__(MEAS_NT, MEAS_OCC) void k_measure_vertex(MeasureArgs a, const TriSetup *__restrict__ cfgs,
                                                                 const int4 *__restrict__ ubox, const unsigned *__restrict__ tmask)
 {
     __shared__ double s_red[(MEAS_NT / 64) * MEAS_OUT];

@@ -479,8 +479,8 @@ def pruned_object(mask, min_area=40.0):
     removes (:205-228) every level-0 contour whose cv2.contourArea is below the largest area (with everything inside it),
     every contour of area < 40 (with everything inside it) and every contour deeper than level 1, and builds
     fd = ddiff(outer, dunion(holes)) (:232-235) from what is left: the largest object with its holes of area >= 40 --
-    smaller holes count as object, and so does whatever lies inside a kept hole's contour ... no: whatever lies inside a
-    kept hole belongs to the hole (objects inside it went with 'level > 1').
+    smaller holes count as object (with whatever was inside them), and whatever lies inside a kept hole belongs to the
+    hole (objects inside it went with 'level > 1').
 
     cv2.contourArea is the area of the polygon through the centres of the pixels the contour visits.  By Pick's theorem
     (area = interior lattice points + boundary lattice points / 2 - 1) for a contour that visits no pixel twice:

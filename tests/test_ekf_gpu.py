@@ -199,6 +199,16 @@ def test_dense_mesh_grows_the_difference_image_pool(hm):
     assert np.array_equal(outs[0][1], outs[1][1])                      # the error sums of the first iterate
     if outs[1][0] is not None:
         assert np.allclose(outs[0][0].reshape(-1), outs[1][0], rtol=0, atol=1e-12 * np.abs(outs[0][0]).max())
+    # the overflow inside a LOOP of iterations: by the time hm_update_run sees it, the render launch of that iteration has
+    # put the star regions of its (meaningless) next iterate where the pool's new size is taken from -- the regions of the
+    # measured iterate are computed again first.  Same iterations as on a context whose pool has grown already.
+    dm, N, tex, R, meas = _setup(hm, n, 3.0, seed=6)
+    R.update_frame(y_im, flow, y_m)
+    first = R.update_run(W, X, y_im, flow, y_m, 3, 1e-12)              # grows the pool in its first iteration
+    again = R.update_run(W, X, y_im, flow, y_m, 3, 1e-12)              # the pool is large enough now
+    assert first[1]["niter"] == again[1]["niter"] >= 1
+    assert np.array_equal(first[0], again[0]) and np.array_equal(first[2], again[2])
+    assert np.array_equal(first[2][0], outs[0][1])
 
 
 @pytest.mark.parametrize("case", ["outside", "folded", "blank", "saturated"])
