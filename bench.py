@@ -16,7 +16,7 @@ uploaded inside it (the pipeline's frame ring: one frame + one mask per step ove
 SURVEY.md 8d asks.  `roofline` is the SOR kernel: kernel start/stop events of every SOR launch of one
 full flow series inside the timed region.
   frac / achieved    PHYSICAL: HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE x 2 +
-                     WRITE_SIZE, profiles/r03_sor_pmc.json, valid for the kernel sources it names) over the
+                     WRITE_SIZE, profiles/r04_sor_pmc.json, valid for the kernel sources it names) over the
                      launch time measured here, against 8 TB/s.  When the PMC file was taken for other
                      kernel sources the lower bound 52 B/px per LAUNCH stands in (traffic: null).
   *_contract         the contract's figure, 52 B per pixel per red-black ITERATION.  k_sor
@@ -43,7 +43,7 @@ SOR_BYTES_PER_PIXEL_ITERATION = 52.0      # 11 f32 fields read +
 HBM_PEAK_GBPS = 8000.0                    # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-SOR_PMC = os.path.join(ROOT, "profiles", "r03_sor_pmc.json")
+SOR_PMC = os.path.join(ROOT, "profiles", "r04_sor_pmc.json")
 SOR_LIMITED_BY = ("tile load phase (seven coefficient planes per tile through the L2 -> CU path) not overlapped with the "
                   "sweeps of the same workgroup, then vector issue and barrier waits: profiles/r03_sor_sq_counters.csv")
 

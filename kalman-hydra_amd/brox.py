@@ -9,6 +9,7 @@ parameters and defaults (:453-488), ``calc`` on two gray frames returning
 (flowx, flowy).  All arithmetic runs in libhydra_mi.so (csrc/brox.hip).
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -30,6 +31,10 @@ class BroxOpticalFlow:
                                     int(solver_iterations), ctypes.byref(h)), "hm_brox_create")
         self._h = h
         _lib.register(self, 3)
+        for kv in os.environ.get("HYDRA_MI_BROX_TUNE", "").split(","):     # experiments: "key=value,..." for hm_brox_tune
+            if "=" in kv:
+                k, v = kv.split("=")
+                _lib.check(L.hm_brox_tune(h, k.strip().encode(), int(v)), "hm_brox_tune")
         self.width, self.height, self.max_batch, self.device = int(width), int(height), int(max_batch), int(device)
         self.params = dict(alpha=alpha, gamma=gamma, scale_factor=scale_factor, inner_iterations=inner_iterations,
                            outer_iterations=outer_iterations, solver_iterations=solver_iterations)

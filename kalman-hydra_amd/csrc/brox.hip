@@ -187,17 +187,23 @@ static const dim3 kBlock2d(64, 4, 1);
 struct SorPlan {
     int K;                      // iterations per launch
     int threads;                // 256 (8 rows per thread) or 512 (4 rows per thread)
+    int tw;                     // tile width: SOR_TW, or 2 * SOR_TW (1024 threads, 4 rows per thread: the halo's share of a
+                                // tile drops from 2.12 to 1.72 of its interior at K = 5)
     int tiles_x, tiles_y, step_x, step_y, halo_x, halo_y;
 };
 
 // iterations fused per launch: everything when the level fits one tile (no halo
 // needed); otherwise the largest divisor of `solver` up to 5 (halo 2K = 10 px of a
 // 64-px tile is where redundant work starts to outweigh the saved traffic)
-static SorPlan sor_plan(const Geo &g, int solver, int fuse, int threads, int n = 1, long long slots = 0)
+static SorPlan sor_plan(const Geo &g, int solver, int fuse, int threads, int n = 1, long long slots = 0, int wide = 0)
 {
     SorPlan p;
     p.threads = threads;
-    bool fitx = g.w <= SOR_TW, fity = g.h <= SOR_TH;
+    // the wide tile: levels of at least `wide` pixels per side (0: never)
+    p.tw = (wide > 0 && g.w >= wide && g.h >= wide) ? 2 * SOR_TW : SOR_TW;
+    if (p.tw != SOR_TW) p.threads = threads = 1024;
+    const int TWp = p.tw;
+    bool fitx = g.w <= TWp, fity = g.h <= SOR_TH;
     int K;
     if (fuse > 0) K = fuse;
     else if (fitx && fity) K = solver;
@@ -208,7 +214,7 @@ static SorPlan sor_plan(const Geo &g, int solver, int fuse, int threads, int n =
         // A level whose tiles do not fill the chip even with the halo of all `solver` iterations (a small interior:
         // many more tiles) is bound by the latency of one launch after the other, not by work: one launch instead
         // of solver / K (a dependent launch costs ~8 us on the device whatever it does).
-        const int step = SOR_TW - 4 * solver;
+        const int step = TWp - 4 * solver;
         if (step >= 16 && solver <= 15) {
             const long long tiles = (long long)(fitx ? 1 : hm_cdiv(g.w, step)) * (fity ? 1 : hm_cdiv(g.h, SOR_TH - 4 * solver)) * n;
             if (tiles * threads <= slots * 1024) K = solver;
@@ -217,7 +223,7 @@ static SorPlan sor_plan(const Geo &g, int solver, int fuse, int threads, int n =
     p.K = K;
     p.halo_x = fitx ? 0 : 2 * K;
     p.halo_y = fity ? 0 : 2 * K;
-    p.step_x = SOR_TW - 2 * p.halo_x;
+    p.step_x = TWp - 2 * p.halo_x;
     p.step_y = SOR_TH - 2 * p.halo_y;
     p.tiles_x = fitx ? 1 : hm_cdiv(g.w, p.step_x);
     p.tiles_y = fity ? 1 : hm_cdiv(g.h, p.step_y);
@@ -233,6 +239,11 @@ static void sor_launch(const SorPlan &p, SorArgs a, int n, hipStream_t s, hipEve
     a.step_x = p.step_x; a.step_y = p.step_y;
     a.halo_x = p.halo_x; a.halo_y = p.halo_y;
     dim3 grid(p.tiles_x * p.tiles_y, 1, n);
+    if (p.tw == 2 * SOR_TW) {
+        if (e0 && e1) hipExtLaunchKernelGGL((k_sor<2 * SOR_TW, SOR_TH, 1024>), grid, dim3(1024), 0, s, e0, e1, 0, a, p.K);
+        else hipLaunchKernelGGL((k_sor<2 * SOR_TW, SOR_TH, 1024>), grid, dim3(1024), 0, s, a, p.K);
+        return;
+    }
     if (e0 && e1) {
         if (p.threads == 1024)
             hipExtLaunchKernelGGL((k_sor<SOR_TW, SOR_TH, 1024>), grid, dim3(1024), 0, s, e0, e1, 0, a, p.K);
@@ -258,6 +269,7 @@ struct hm_brox {
     int sor_dry;                 // development knob: SOR launches load and store but do not iterate (wrong results)
     int cus;                     // compute units of the device
     int sor_deep;                // levels with few tiles take all solver iterations in one launch (sor_plan)
+    int sor_wide;                // levels of at least this many pixels per side use the 128 x 64 tile (0: none)
     int coarse_stagger;          // test knob: the pairs of a k_coarse launch start one after the other
     int coarse_max;              // levels up to this many px per side run inside k_coarse: 0 (none), 32 or 64
     std::vector<Geo> geo;
@@ -320,7 +332,7 @@ extern "C" int hm_brox_create(int device, int W, int H, int max_batch, float alp
     h->device = device; h->W = W; h->H = H; h->B = max_batch;
     h->alpha = alpha; h->gamma = gamma; h->scale = scale; h->omega = 1.99f;
     h->inner = inner; h->outer = outer; h->solver = solver; h->fuse = 0; h->sor_threads = 0; h->sor_dry = 0;
-    h->coarse_max = 32; h->sor_deep = 1; h->cus = 0; h->coarse_stagger = 0;
+    h->coarse_max = 32; h->sor_deep = 1; h->cus = 0; h->coarse_stagger = 0; h->sor_wide = 0;
     if (hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) h->cus = 0;
     h->arena = nullptr; h->d_f0 = h->d_f1 = nullptr; h->d_ox = h->d_oy = nullptr; h->stream = nullptr;
     h->prof = false; h->ev_used = 0; h->prof_ms = 0; h->prof_pxit = 0; h->prof_px = 0; h->prof_launches = 0;
@@ -428,6 +440,9 @@ extern "C" int hm_brox_tune(hm_brox_t h, const char *key, int value)
             HM_HIP(hipStreamSynchronize(h->stream));
             h->stream = to;
         }
+    } else if (!strcmp(key, "sor_wide")) {           // same bits either way
+        HM_ARG(value >= 0 && value <= 8192, "hm_brox_tune: sor_wide must be 0 (never) or the smallest level side that uses the 128 x 64 tile");
+        h->sor_wide = value;
     } else if (!strcmp(key, "sor_deep")) {
         HM_ARG(value >= 0 && value <= 8, "hm_brox_tune: sor_deep must be 0 .. 8");
         h->sor_deep = value;
@@ -613,7 +628,7 @@ static int brox_run(hm_brox *h, int n, const uint8_t *d_f0, const uint8_t *d_f1,
         // times over is bound by how many tiles are resident -- 512 threads, two workgroups per CU (measured, one /
         // eight 1024^2 pairs: 4.31 / 12.3 ms of SOR per series with 1024 threads, 4.71 / 10.4 with 512, 6.65 / 13.7 with 256)
         const int threads = h->sor_threads ? h->sor_threads : (n <= 2 ? 1024 : 512);
-        SorPlan plan = sor_plan(g, h->solver, h->fuse, threads, n, (long long)h->sor_deep * h->cus);
+        SorPlan plan = sor_plan(g, h->solver, h->fuse, threads, n, (long long)h->sor_deep * h->cus, n > 2 ? h->sor_wide : 0);
         const int launches_per_inner = h->solver / plan.K;
         Coef co = {h->nu, h->nv, h->a12, h->idu, h->idv, h->sx, h->sy};
         for (int it = 0; it < h->inner; it++) {

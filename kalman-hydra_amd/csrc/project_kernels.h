@@ -64,6 +64,7 @@ __global__ __launch_bounds__(OUTLINE_NT) void k_outline(const uint8_t *__restric
 //                  object pixels join their W / NW / N / NE neighbours (8-connected), background pixels their W / N
 //                  neighbours (4-connected) -- both kinds in the same pass, a pixel belongs to one of the two;
 //   k_ccl_border   the same unions across tile borders, on the labels in memory;
+//   k_ccl_roots    the first pixels of the tile-local components find their roots;
 //   k_ccl_flatten  every pixel points to its root; background components that reach the frame edge are marked
 //                  (findContours treats the frame as surrounded by background: they are outside, not holes);
 //   k_ccl_stats    nesting comes from the roots: the pixel ABOVE a component's first pixel belongs to the component
@@ -178,14 +179,21 @@ __global__ __launch_bounds__(CCL_NT) void k_ccl_local(const uint8_t *__restrict_
         const int root = d_ccl_find_lds(sl, r * CCL_TW + lane);
         const size_t p = (size_t)y * W + x;
         c.L[p] = (y0 + root / CCL_TW) * W + x0 + (root % CCL_TW);
-        c.cnt[p] = 0;
+        c.cnt[p] = root == r * CCL_TW + lane ? 1 : 0;      // marks the first pixel of a tile-local component (k_ccl_roots)
         c.bnd[p] = 0;
         c.edge[p] = 0;
     }
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) c.best[0] = 0ull;
 }
 
-// the unions across tile borders: grid (ceil(W / 64), ceil(H / 4)), a wave per 64-pixel row segment
+// the unions across tile borders: grid (ceil(W / 64), ceil(H / 4)), a wave per 64-pixel row segment.  Along a border
+// most neighbouring pixels ask for the same union (the same two tile-local components meet along a whole edge): a lane
+// whose pair of labels is the pair of the lane before it -- or, down a tile's side, of the row above it -- leaves the
+// union to that one (100 000 -> a few thousand unions at 1024^2, all of which would otherwise fight over one root).
+__device__ __forceinline__ void d_ccl_unite_once(int *L, int p, int q, bool dup)
+{
+    if (!dup) d_ccl_unite(L, p, q);
+}
 __global__ __launch_bounds__(CCL_NT) void k_ccl_border(const uint8_t *__restrict__ ym, Ccl c)
 {
     const int lane = threadIdx.x & 63;
@@ -196,19 +204,43 @@ __global__ __launch_bounds__(CCL_NT) void k_ccl_border(const uint8_t *__restrict
     const int W = c.W, p = y * W + x;
     const uint8_t *row = ym + (size_t)y * W;
     const bool fg = row[x] > 0;
-    if (left && x > 0 && (row[x - 1] > 0) == fg) d_ccl_unite(c.L, p, p - 1);
+    const int lp = c.L[p];                           // tile-local labels (k_ccl_local): what "the same union" is judged by
+    // W: down the left side of a tile the pair (label of p, label of p - 1) usually repeats row after row
+    if (left && x > 0 && (row[x - 1] > 0) == fg) {
+        const bool dup = !top && c.L[p - W] == lp && c.L[p - W - 1] == c.L[p - 1];
+        d_ccl_unite_once(c.L, p, p - 1, dup);
+    }
     if (y == 0) return;
     const uint8_t *up = row - W;
     const bool n = up[x] > 0;
     if (fg) {
-        if (n) { if (top) d_ccl_unite(c.L, p, p - W); }
-        else {
+        if (n) {
+            if (top) {
+                // along the top row: the lane before asked for the same union when both its labels are the same
+                const bool dup = lane > 0 && c.L[p - 1] == lp && c.L[p - W - 1] == c.L[p - W] && row[x - 1] > 0 && up[x - 1] > 0;
+                d_ccl_unite_once(c.L, p, p - W, dup);
+            }
+        } else {
             if ((top || left) && x > 0 && up[x - 1] > 0) d_ccl_unite(c.L, p, p - W - 1);
             if ((top || right) && x + 1 < W && up[x + 1] > 0) d_ccl_unite(c.L, p, p - W + 1);
         }
     } else if (!n && top) {
-        d_ccl_unite(c.L, p, p - W);
+        const bool dup = lane > 0 && c.L[p - 1] == lp && c.L[p - W - 1] == c.L[p - W] && !(row[x - 1] > 0) && !(up[x - 1] > 0);
+        d_ccl_unite_once(c.L, p, p - W, dup);
     }
+}
+
+// the first pixels of the tile-local components (a few thousand) walk to their roots and point at them: every other pixel
+// is then two hops from its root
+__global__ __launch_bounds__(CCL_NT) void k_ccl_roots(Ccl c)
+{
+    const int lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 64 + lane, y = blockIdx.y * (CCL_NT / 64) + (threadIdx.x >> 6);
+    if (x >= c.W || y >= c.H) return;
+    const int p = y * c.W + x;
+    if (!c.cnt[p]) return;
+    c.cnt[p] = 0;
+    (void)d_ccl_find(c.L, p);
 }
 
 __global__ __launch_bounds__(CCL_NT) void k_ccl_flatten(const uint8_t *__restrict__ ym, Ccl c)
@@ -217,7 +249,10 @@ __global__ __launch_bounds__(CCL_NT) void k_ccl_flatten(const uint8_t *__restric
     const int x = blockIdx.x * 64 + lane, y = blockIdx.y * (CCL_NT / 64) + (threadIdx.x >> 6);
     if (x >= c.W || y >= c.H) return;
     const int p = y * c.W + x;
-    const int r = d_ccl_find(c.L, p);
+    // p -> its tile's first pixel of the component -> the root (k_ccl_roots has shortened that hop; a pixel that lost a
+    // race there walks on): without the compressing atomics of d_ccl_find, a million of which took 45 us
+    int r = c.L[p];
+    for (int q = c.L[r]; q != r; q = c.L[r]) r = q;
     c.L[p] = r;
     if (!(ym[p] > 0) && (x == 0 || y == 0 || x == c.W - 1 || y == c.H - 1)) c.edge[r] = 1;
 }

@@ -41,6 +41,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "dry":        # where a SOR launch spends its time: loads + stores only
         run(1024, 8, 3, [dict(sor_fuse=0, sor_threads=512, sor_dry=0), dict(sor_fuse=0, sor_threads=512, sor_dry=1)])
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "wide":       # the 128 x 64 SOR tile from which level size on
+        wt = [dict(sor_wide=0), dict(sor_wide=1024), dict(sor_wide=640), dict(sor_wide=400), dict(sor_wide=256), dict(sor_wide=128), dict(sor_wide=0)]
+        run(1024, 8, 5, wt)
+        run(1024, 4, 5, [dict(sor_wide=0), dict(sor_wide=400)])
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "coarse":     # the coarse end of the pyramid: one launch against launch per operator
         ct = [dict(coarse_max=32, sor_deep=0), dict(sor_deep=1), dict(sor_deep=2), dict(sor_deep=3), dict(sor_deep=4), dict(sor_deep=8)]
         run(64, 1, 20, ct)
