@@ -577,6 +577,34 @@ def test_bench_flowbatch_two_ranks_gloo_stub_flow(hm):
     assert "seeds 0..5" in out["config"]["workload"] and out["value"] > 0
 
 
+def test_bench_starts_its_own_ranks_or_refuses(hm):
+    """`python bench.py --gpus N` with no launcher around it (no WORLD_SIZE in the environment) must not print a
+    one-rank line labelled as N were asked for: it starts torch.distributed.run --nproc-per-node N itself, as a child
+    process, before it has imported anything that touches the GPU, and leaves with the child's exit code; under a
+    launcher whose WORLD_SIZE is not N it refuses to run."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "flowbatch",
+           "--backend", "gloo", "--stub-flow", "--size", "32", "--pairs-per-gpu", "2"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "launching" in res.stderr and "torch.distributed.run" in res.stderr
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["distributed"]["world"] == 2
+    # a launcher with another world size: refused, with the command to run in the message
+    bad = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
+    assert bad.returncode != 0 and "does not match WORLD_SIZE 3" in (bad.stderr + bad.stdout)
+    # one rank asked for, one rank run: no launcher needed
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--workload",
+                          "flowbatch", "--backend", "gloo", "--stub-flow", "--size", "32", "--pairs-per-gpu", "2"],
+                         capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert one.returncode == 0 and json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
+
+
 def test_newton_worker_equals_synchronous_call(hm):
     """hm_ms_newton_start / _finish (the next frame's state prediction on a host thread, include/hydra_mi.h) give
     the numbers and the iteration count of hm_ms_newton; a worker takes one job at a time and can be reused."""
