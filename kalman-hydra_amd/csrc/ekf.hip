@@ -542,7 +542,7 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
         if (e == hipSuccess) e = hm_malloc((void **)&h->d_out, (size_t)h->njobs * MEAS_VSPLIT_MAX * MEAS_OUT * sizeof(double));
         if (e == hipSuccess) e = hm_malloc((void **)&h->d_partial, (size_t)h->red_blocks * 4 * sizeof(double));
         h->ntiles = hm_cdiv(W, RI_W) * hm_cdiv(H, 8);           // most strips of k_render_iter (render_rows 8)
-        if (e == hipSuccess) e = hm_malloc((void **)&h->d_tpart, (size_t)h->ntiles * 4 * sizeof(double));
+        if (e == hipSuccess) e = hm_malloc((void **)&h->d_tpart, (size_t)h->ntiles * RI_NV * sizeof(double));
         if (e == hipSuccess) e = hm_malloc((void **)&h->d_im8, n);
         if (e == hipSuccess) e = hm_malloc((void **)&h->d_m8, n);
         const size_t n4 = (size_t)4 * N, nn = n4 * n4 * sizeof(double);

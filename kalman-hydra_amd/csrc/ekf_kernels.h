@@ -120,6 +120,20 @@ __device__ __forceinline__ bool d_tri_cover(const TriSetup &s, double dc, double
     const double e2 = fma(s.ea[2], dc, fma(s.eb[2], dr, s.ecb[2]));
     return (e0 > 0.0) & (e1 > 0.0) & (e2 > 0.0);
 }
+// the same, handing back the values of edges 1 and 2 (with the top-left bias in: ecb): the barycentrics of a covered pixel
+// follow from them by taking the bias out again -- whole numbers below 2^53, so e - bias IS ea c + eb r + ec, exactly
+__device__ __forceinline__ bool d_tri_cover2(const TriSetup &s, double dc, double dr, double &e1, double &e2)
+{
+    const double e0 = fma(s.ea[0], dc, fma(s.eb[0], dr, s.ecb[0]));
+    e1 = fma(s.ea[1], dc, fma(s.eb[1], dr, s.ecb[1]));
+    e2 = fma(s.ea[2], dc, fma(s.eb[2], dr, s.ecb[2]));
+    return (e0 > 0.0) & (e1 > 0.0) & (e2 > 0.0);
+}
+__device__ __forceinline__ void d_tri_bary2(const TriSetup &s, double e1, double e2, float &l1, float &l2)
+{
+    l1 = (float)(e1 - (s.tl[1] ? 1.0 : 0.0)) * s.inv;
+    l2 = (float)(e2 - (s.tl[2] ? 1.0 : 0.0)) * s.inv;
+}
 __device__ __forceinline__ void d_tri_bary(const TriSetup &s, double dc, double dr, float &l1, float &l2)
 {
     l1 = (float)fma(s.ea[1], dc, fma(s.eb[1], dr, s.ec[1])) * s.inv;
@@ -455,9 +469,9 @@ __device__ __forceinline__ StarVal d_star_eval(const TriSetup *__restrict__ cfg,
     q.t0 = -1; q.t1 = -1;
     if (VEL) { vel.fxp = 0.0f; vel.fxm = 0.0f; vel.fyp = 0.0f; vel.fym = 0.0f; }
     const double dc = (double)c, dr = (double)r;
-    auto add = [&](const TriSetup &t) {
+    auto add = [&](const TriSetup &t, double e1, double e2) {
         float l1, l2;
-        d_tri_bary(t, dc, dr, l1, l2);
+        d_tri_bary2(t, e1, e2, l1, l2);            // (round 4: not evaluated a second time -- 319 -> 315.5 us per iteration)
         const int at = d_texel_at(t, l1, l2, m.W, m.H);
         if (s.cnt == 0) q.t0 = at;
         else if (s.cnt == 1) q.t1 = at;
@@ -477,7 +491,8 @@ __device__ __forceinline__ StarVal d_star_eval(const TriSetup *__restrict__ cfg,
     };
     for (unsigned mm = mask; mm != 0; mm &= mm - 1) {
         const TriSetup &t = cfg[__builtin_ctz(mm)];
-        if (d_tri_cover(t, dc, dr)) add(t);
+        double e1, e2;
+        if (d_tri_cover2(t, dc, dr, e1, e2)) add(t, e1, e2);
     }
     return s;
 }

@@ -211,6 +211,27 @@ def test_dense_mesh_grows_the_difference_image_pool(hm):
     assert np.array_equal(first[2][0], outs[0][1])
 
 
+def test_render_strip_height_changes_no_integer_term(hm):
+    """hm_ctx_tune "render_rows": the strips of k_render_iter 8 instead of 16 rows high (twice as many partial sums: the
+    buffer is sized for them) -- the same render, the same whole-number error terms, the flow terms to rounding."""
+    n = 96
+    outs = []
+    for rows in (16, 8):
+        dm, N, tex, R, meas = _setup(hm, n, 9.0, seed=3)
+        R.tune("render_rows", rows)
+        rng = np.random.default_rng(5)
+        X = _state(dm, rng, pos_sigma=0.8)
+        y_im, flow, y_m = _observation(dm, meas, rng, n)
+        st = _Flow()
+        st.X = X.reshape(-1, 1)
+        R.update_frame(y_im, flow, y_m)
+        outs.append(R.error(st, y_im, flow, y_m))
+    a, b = outs
+    assert a[0] == b[0] and a[3] == b[3]
+    assert abs(a[1] - b[1]) <= 1e-12 * a[1] and abs(a[2] - b[2]) <= 1e-12 * a[2]
+    assert np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+
+
 @pytest.mark.parametrize("case", ["outside", "folded", "blank", "saturated"])
 def test_measure_edge_cases_match_oracle(hm, case):
     """The fused measurement where the rasteriser's corner cases matter: a mesh partly outside the
