@@ -204,7 +204,7 @@ struct hm_ctx {
     // need none of its buffers.  tail_on_stream4: it may still be running; `stream` waits for ev_tail (on the device)
     // before anything there touches the dense buffers (ctx_join; hm_update_run itself only before its first solve).
     hipStream_t stream4 = nullptr;
-    hipEvent_t ev_tail = nullptr, ev_post = nullptr;
+    hipEvent_t ev_tail = nullptr;
     bool tail_on_stream4 = false;
     int tail_split = 1;              // hm_ctx_tune "tail_split": 0 keeps the tail on `stream` (same results either way)
     int *d_nbars, *d_nvoff, *d_nvbar, *d_ninfo;     // its spring topology (bars, CSR of the bars of every vertex), result words
@@ -409,7 +409,6 @@ static int ctx_free(hm_ctx *h)
     if (h->ev_outline) (void)hipEventDestroy(h->ev_outline);
     if (h->ev_m0) (void)hipEventDestroy(h->ev_m0);
     if (h->ev_tail) (void)hipEventDestroy(h->ev_tail);
-    if (h->ev_post) (void)hipEventDestroy(h->ev_post);
     if (h->stream4) (void)hipStreamDestroy(h->stream4);
     if (h->stream3) (void)hipStreamDestroy(h->stream3);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
