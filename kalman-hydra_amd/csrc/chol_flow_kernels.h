@@ -84,6 +84,9 @@ __device__ __forceinline__ void flow_fill_row(const FlowArgs &a, int row, int t,
         for (int j = t; j < upto; j += nt) a.Tinv[(size_t)row * a.n + j] = s;
     }
 }
+// (thread t of nt, over all the workgroups that share the fill: FLOW_FILL_WGS of them -- one workgroup alone took ~10 us
+// for the 850 KB of Lt and P at n = 804 and was what k_solve_prep's 17 us hung on)
+#define FLOW_FILL_WGS 32
 __device__ __forceinline__ void flow_fill_blocks(const FlowArgs &a, int t, int nt)
 {
     const double s = __longlong_as_double((long long)FLOW_SENTINEL);
@@ -94,7 +97,7 @@ __device__ __forceinline__ void flow_fill_blocks(const FlowArgs &a, int t, int n
 // ... or a launch of its own (the inverse of the prior has no assembly pass): one workgroup per row, one more for Lt / P
 __global__ __launch_bounds__(256) void k_flow_fill(FlowArgs a)
 {
-    if ((int)blockIdx.x == a.nrows) flow_fill_blocks(a, threadIdx.x, 256);
+    if ((int)blockIdx.x >= a.nrows) flow_fill_blocks(a, ((int)blockIdx.x - a.nrows) * 256 + threadIdx.x, 256 * FLOW_FILL_WGS);
     else flow_fill_row(a, blockIdx.x, threadIdx.x, 256);
 }
 
@@ -433,7 +436,10 @@ __global__ __launch_bounds__(256) void k_assemble_flow(const double *__restrict_
 {
     __shared__ double s[4];
     const int row = blockIdx.x;
-    if (row == (int)gridDim.x - 1) { flow_fill_blocks(f, threadIdx.x, 256); return; }
+    if (row >= (int)gridDim.x - FLOW_FILL_WGS) {
+        flow_fill_blocks(f, (row - ((int)gridDim.x - FLOW_FILL_WGS)) * 256 + threadIdx.x, 256 * FLOW_FILL_WGS);
+        return;
+    }
     flow_fill_row(f, row, threadIdx.x, 256);
     if (row >= n) {
         if (row != rhs_row)
@@ -485,7 +491,10 @@ __global__ __launch_bounds__(256) void k_solve_prep(PrepArgs p)
     __shared__ double s_term[PREP_MAX_ENTRIES];
     __shared__ double s_hz;
     const int row = blockIdx.x, t = threadIdx.x, n = p.n;
-    if (row == (int)gridDim.x - 1) { flow_fill_blocks(p.f, t, 256); return; }
+    if (row >= (int)gridDim.x - FLOW_FILL_WGS) {
+        flow_fill_blocks(p.f, (row - ((int)gridDim.x - FLOW_FILL_WGS)) * 256 + t, 256 * FLOW_FILL_WGS);
+        return;
+    }
     flow_fill_row(p.f, row, t, 256);
     if (row >= n) {
         if (row != p.rhs_row)

@@ -1220,7 +1220,7 @@ static void chol_factor(hm_ctx *h, double *A, double *L, double *Lt, double *T, 
         // (chol_flow_kernels.h); the same bits as the launch-per-step form.  first_done: the caller's assembly pass
         // (k_assemble_flow) has pre-filled the outputs
         FlowArgs a = {A, L, Lt, T, h->d_flowP, n, nrows, nb, nbr, h->d_flowctl, h->flow_stall};
-        if (!first_done) hipLaunchKernelGGL(k_flow_fill, dim3(nrows + 1), dim3(256), 0, st, a);
+        if (!first_done) hipLaunchKernelGGL(k_flow_fill, dim3(nrows + FLOW_FILL_WGS), dim3(256), 0, st, a);
         hipLaunchKernelGGL(k_chol_flow, dim3(h->flow_wgs), dim3(FLOW_NT), 0, st, a);
         return;
     }
@@ -1271,7 +1271,7 @@ static double *solve_step(hm_ctx *h, int slot, double deltaX)
         p.invW0 = h->d_invW0; p.X0 = h->d_X0; p.X = h->d_X;
         p.A = A; p.Hz = h->d_Hz; p.Hzc = h->d_Hzc; p.n = n4; p.rhs_row = rhs_index;
         p.f = FlowArgs{A, h->d_Af[slot], h->d_Lt[slot], h->d_T[slot], h->d_flowP, n4, nrows, nb, hm_cdiv(nrows, DNB), h->d_flowctl, 0};
-        hipLaunchKernelGGL(k_solve_prep, dim3(nrows + 1), dim3(256), 0, h->stream, p);
+        hipLaunchKernelGGL(k_solve_prep, dim3(nrows + FLOW_FILL_WGS), dim3(256), 0, h->stream, p);
     }
     if (h->d_Wres == h->d_Wtmp) h->d_Wres = nullptr;          // a covariance predicted since hm_update_begin is lost
     chol_factor(h, A, h->d_Af[slot], h->d_Lt[slot], h->d_T[slot], h->d_Wtmp, n4, true, h->chol_flow != 0);
