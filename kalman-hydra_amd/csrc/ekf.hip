@@ -484,7 +484,10 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->red_blocks = 512;
     h->run_ticket = 0;
     h->vsplit = 5;
-    h->esplit = 2;
+    // one workgroup per edge job: 556 workgroups at 201 vertices are ONE round of the chip (122 VGPRs: four per CU, 1 024
+    // slots); two per edge are 1 112 -- 88 of them wait for a slot and the launch takes a second round (308.6 -> 305.1 us per
+    // iteration with one; the sums are added in another order than with two: rounding-level differences)
+    h->esplit = 1;
     const size_t n = (size_t)W * H;
     int rc = HM_OK;
     auto step = [&](int r) { if (rc == HM_OK) rc = r; };
