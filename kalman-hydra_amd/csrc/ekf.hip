@@ -470,7 +470,10 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->d_Wprior = h->d_gain = h->d_Awork = h->d_Lt[0] = h->d_Lt[1] = nullptr; h->d_Wres = nullptr; h->pin = nullptr; h->pin_n = 0;
     h->tri.assign(tri, tri + (size_t)3 * T);
     h->d_outline = nullptr; h->d_outline_cnt = nullptr; h->d_pm_mask = nullptr;
-    h->chol_flow = 1; h->flow_wgs = 256; h->d_flowP = nullptr; h->d_flowctl = nullptr;
+    // (192 workgroups of the factorisation launch: 304.9 -> 306.9 us per iteration with the filter alone, but 260.5 -> 264.2 and
+    // 318.6 -> 324.1 frames/s in the two benches -- the workgroups that poll for blocks take issue slots from the flow's
+    // kernels on every compute unit they sit on; 160 and 128 starve the chain: profiles/r04_ab_tunes.txt)
+    h->chol_flow = 1; h->flow_wgs = 192; h->d_flowP = nullptr; h->d_flowctl = nullptr;
     h->stream2 = nullptr; h->d_nbars = h->d_nvoff = h->d_nvbar = h->d_ninfo = nullptr; h->d_nl0 = h->d_nX = nullptr; h->ncap = 0;
     h->d_ids[0] = h->d_ids[1] = h->d_ids[2] = nullptr; h->d_labels = nullptr; h->d_lbox = nullptr; h->d_lout = nullptr; h->lcap = 0;
     h->worker_active = false; h->worker_rc = HM_OK; h->worker_err[0] = 0;
