@@ -1716,14 +1716,11 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
             // stream) start when this frame's first measurement has run -- beside the first factorisation, which leaves
             // the chip idle -- not beside the first render and measurement, and not in the window between two frames,
             // where they slowed the state prediction's one workgroup down (0.33 instead of 0.27 ms)
+            // (the event now; the launches when this iteration's own launches are queued and the host has nothing to do
+            // but wait: eight launches here kept the first system of the frame waiting for the host, ~17 us per iteration
+            // on average in the kernel trace)
             if (!h->ev_m0) HM_HIP(hipEventCreateWithFlags(&h->ev_m0, hipEventDisableTiming));
             HM_HIP(hipEventRecord(h->ev_m0, h->stream));
-            rc = ensure_stream2(h);
-            if (rc) return rc;
-            HM_HIP(hipStreamWaitEvent(h->stream2, h->ev_m0, 0));
-            rc = prepare_mask(h, next_mask);
-            if (rc) return rc;
-            next_mask = nullptr;
         }
         if (collected) h->X0 = Xcur;               // the state of the reference render (hm_jz / hm_j)
         h->have_ref = true;
@@ -1749,6 +1746,12 @@ extern "C" int hm_update_run(hm_ctx_t h, const double *W_prior, double *X, doubl
             if (rc) { unspec(); return rc; }
         }
         const auto dbg_t0 = std::chrono::steady_clock::now();
+        if (next_mask && it == 0) {
+            rc = ensure_stream2(h);
+            if (rc == HM_OK) { HM_HIP(hipStreamWaitEvent(h->stream2, h->ev_m0, 0)); rc = prepare_mask(h, next_mask); }
+            if (rc) { unspec(); return rc; }
+            next_mask = nullptr;
+        }
         if (!collected) {
             rc = chain_collect();
             if (rc) { unspec(); (void)hipStreamSynchronize(h->stream); return rc; }
