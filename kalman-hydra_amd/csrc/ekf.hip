@@ -487,10 +487,11 @@ extern "C" int hm_ctx_create(int device, int W, int H, int N, int T, const int32
     h->red_blocks = 512;
     h->run_ticket = 0;
     h->vsplit = 5;
-    // one workgroup per edge job: 556 workgroups at 201 vertices are ONE round of the chip (122 VGPRs: four per CU, 1 024
-    // slots); two per edge are 1 112 -- 88 of them wait for a slot and the launch takes a second round (308.6 -> 305.1 us per
-    // iteration with one; the sums are added in another order than with two: rounding-level differences)
-    h->esplit = 1;
+    // two workgroups per edge job as long as they are ONE round of the chip (122 VGPRs: four workgroups per CU, 1 024 slots),
+    // else one: at 201 vertices 556 edges x 2 = 1 112 workgroups had 88 of them wait for a slot and the launch take a second
+    // round (308.6 -> 305.1 us per iteration with one; the sums of an edge are then added in another order: rounding-level
+    // differences); small meshes keep the parallelism of two
+    h->esplit = 2 * h->E > 1024 ? 1 : 2;
     const size_t n = (size_t)W * H;
     int rc = HM_OK;
     auto step = [&](int r) { if (rc == HM_OK) rc = r; };
