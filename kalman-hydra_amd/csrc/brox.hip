@@ -276,6 +276,16 @@ struct hm_brox {
     Taps taps;
     hipStream_t stream;                 // the stream launches go to: `whole` or `masked`
     hipStream_t whole = nullptr, masked = nullptr;
+    // lanes = 2 (experiment, off): a call of four or more pairs on the CU-masked stream runs as two halves side by side,
+    // the second on a twin of that stream.  The launches of a series alternate between kernels bound by HBM (k_prepare,
+    // the fill of a SOR tile) and by the CU (the sweeps); two halves at different places of that sequence fill each
+    // other's gaps -- two handles with 4 pairs each: 14.1 instead of 15.5 ms per 8 x 1024^2 pairs, the two lanes of one
+    // call, which end together: 15.0.  Beside the filter it costs more than it gives (the filter's workgroups find
+    // fewer free places between two queues of flow launches): 229 against 261 frames/s at 20 frames, 241 against 323
+    // at 64.  Same bits: a pair's flow does not depend on what it shares a launch with.
+    int lanes = 1;
+    hipStream_t masked2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float *arena;
     size_t arena_floats;
     std::vector<float *> pyr0, pyr1;
@@ -313,6 +323,9 @@ static int brox_free(hm_brox *h)
     if (h->d_oy) hipFree(h->d_oy);
     if (h->whole) hipStreamDestroy(h->whole);
     if (h->masked) hipStreamDestroy(h->masked);
+    if (h->masked2) hipStreamDestroy(h->masked2);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
     delete h;
     return HM_OK;
 }
@@ -422,11 +435,13 @@ extern "C" int hm_brox_tune(hm_brox_t h, const char *key, int value)
         HM_HIP(hipSetDevice(h->device));
         HM_HIP(hipStreamSynchronize(h->stream));
         if (h->masked) { HM_HIP(hipStreamDestroy(h->masked)); h->masked = nullptr; }
+        if (h->masked2) { HM_HIP(hipStreamDestroy(h->masked2)); h->masked2 = nullptr; }
         if (value > 0) {
             const int words = (h->cus + 31) / 32;
             std::vector<uint32_t> mask(words, 0u);
             for (int i = 0; i < h->cus - value; i++) mask[i / 32] |= 1u << (i % 32);
             HM_HIP(hipExtStreamCreateWithCUMask(&h->masked, (uint32_t)words, mask.data()));
+            if (h->lanes >= 2) HM_HIP(hipExtStreamCreateWithCUMask(&h->masked2, (uint32_t)words, mask.data()));
         }
         h->stream = h->masked ? h->masked : h->whole;
     } else if (!strcmp(key, "whole_chip")) {
@@ -440,6 +455,20 @@ extern "C" int hm_brox_tune(hm_brox_t h, const char *key, int value)
             HM_HIP(hipStreamSynchronize(h->stream));
             h->stream = to;
         }
+    } else if (!strcmp(key, "lanes")) {              // same bits either way
+        // (before "cu_reserve": the second lane's stream gets the mask the first one has.  It exists only in a handle
+        // that asked for it, and only as a CU-masked stream, which has a hardware queue of its own: a plain stream takes
+        // one of the FOUR queues the runtime spreads all plain streams of a priority over (GPU_MAX_HW_QUEUES), and this
+        // process has four already -- the null stream, the copy stream of hm_dev_upload, the frame ring's, the handle's.
+        // A fifth, even idle, made the ring's uploads share a queue: 173 instead of 261 frames/s)
+        HM_ARG(value == 1 || value == 2, "hm_brox_tune: lanes must be 1 or 2");
+        HM_ARG(value == 1 || h->masked == nullptr, "hm_brox_tune: lanes must be set before cu_reserve");
+        HM_HIP(hipSetDevice(h->device));
+        if (value == 2 && !h->ev_fork) {
+            HM_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            HM_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        }
+        h->lanes = value;
     } else if (!strcmp(key, "sor_wide")) {           // same bits either way
         HM_ARG(value >= 0 && value <= 8192, "hm_brox_tune: sor_wide must be 0 (never) or the smallest level side that uses the 128 x 64 tile");
         h->sor_wide = value;
@@ -539,12 +568,29 @@ extern "C" int hm_brox_profile_read(hm_brox_t h, double *ms, long long *launches
 }
 
 // ---- the pipeline ---------------------------------------------------------------------------
-static int brox_run(hm_brox *h, int n, const uint8_t *d_f0, const uint8_t *d_f1, float *d_ox, float *d_oy)
+// Pairs z0 .. z0 + n - 1 of a call, queued on stream s.  Every working plane holds max_batch pairs, pair z of a level
+// at z x (that level's plane): a lane that starts at pair z0 works in the same buffers from z0 x (plane of level 0) on
+// -- room for its n pairs at every level, and clear of the lane in front of it, which has at most z0 pairs.
+static int brox_run(hm_brox *h, int z0, int n, hipStream_t s, const uint8_t *d_f0, const uint8_t *d_f1, float *d_ox, float *d_oy)
 {
-    hipStream_t s = h->stream;
+    const size_t fo = (size_t)z0 * h->geo[0].plane;
+    auto P0 = [&](int k) { return h->pyr0[k] + (size_t)z0 * h->geo[k].plane; };
+    auto P1 = [&](int k) { return h->pyr1[k] + (size_t)z0 * h->geo[k].plane; };
+    float *const tmpA = h->tmpA + fo, *const tmpB = h->tmpB + fo;
+    float *const Ix0 = h->Ix0 + fo, *const Iy0 = h->Iy0 + fo, *const I1x = h->I1x + fo, *const I1y = h->I1y + fo;
+    float *const I1xx = h->I1xx + fo, *const I1xy = h->I1xy + fo, *const I1yy = h->I1yy + fo;
+    float *const Iz = h->Iz + fo, *const Ix = h->Ix + fo, *const Iy = h->Iy + fo, *const Ixz = h->Ixz + fo, *const Iyz = h->Iyz + fo;
+    float *const Ixx = h->Ixx + fo, *const Ixy = h->Ixy + fo, *const Iyy = h->Iyy + fo;
+    float *const c_nu = h->nu + fo, *const c_nv = h->nv + fo, *const c_a12 = h->a12 + fo, *const c_idu = h->idu + fo;
+    float *const c_idv = h->idv + fo, *const c_sx = h->sx + fo, *const c_sy = h->sy + fo;
+    float *const b_u = h->u + fo, *const b_v = h->v + fo, *const b_u2 = h->u2 + fo, *const b_v2 = h->v2 + fo;
+    float *const b_du[2] = {h->du[0] + fo, h->du[1] + fo}, *const b_dv[2] = {h->dv[0] + fo, h->dv[1] + fo};
+    const float *const zero = h->zero + fo;
+    d_f0 += (size_t)z0 * h->W * h->H; d_f1 += (size_t)z0 * h->W * h->H;
+    d_ox += (size_t)z0 * h->W * h->H; d_oy += (size_t)z0 * h->W * h->H;
     const int L = (int)h->geo.size();
     const Geo &g0 = h->geo[0];
-    hipLaunchKernelGGL(k_u8_to_f32, grid2d(g0, 2 * n), kBlock2d, 0, s, d_f0, d_f1, h->W, h->W * h->H, h->pyr0[0], h->pyr1[0], g0, n);
+    hipLaunchKernelGGL(k_u8_to_f32, grid2d(g0, 2 * n), kBlock2d, 0, s, d_f0, d_f1, h->W, h->W * h->H, P0(0), P1(0), g0, n);
     // Small levels are launch-latency bound: one fused launch per level (k_pyr_down, k_deriv_all recompute
     // their taps instead of storing intermediate images -- ~100 / ~56 cached reads per pixel).  Large levels
     // are bandwidth bound and keep the separate streaming kernels, which read every pixel once per pass
@@ -553,20 +599,20 @@ static int brox_run(hm_brox *h, int n, const uint8_t *d_f0, const uint8_t *d_f1,
     for (int k = 1; k < L; k++) {
         const Geo &gs = h->geo[k - 1], &gd = h->geo[k];
         if ((long long)gd.w * gd.h * n <= fuse_below) {
-            hipLaunchKernelGGL(k_pyr_down, grid2d(gd, 2 * n), kBlock2d, 0, s, h->pyr0[k - 1], h->pyr1[k - 1], gs, h->pyr0[k],
-                               h->pyr1[k], gd, h->taps, n);
+            hipLaunchKernelGGL(k_pyr_down, grid2d(gd, 2 * n), kBlock2d, 0, s, P0(k - 1), P1(k - 1), gs, P0(k),
+                               P1(k), gd, h->taps, n);
             continue;
         }
         // both frames per launch; the second one's intermediates borrow two planes the pyramid does not use yet
-        hipLaunchKernelGGL((k_blur<false>), grid2d(gs, 2 * n), kBlock2d, 0, s, h->pyr0[k - 1], h->tmpA, h->pyr1[k - 1], h->Ix0, gs,
+        hipLaunchKernelGGL((k_blur<false>), grid2d(gs, 2 * n), kBlock2d, 0, s, P0(k - 1), tmpA, P1(k - 1), Ix0, gs,
                            h->taps, n);
-        hipLaunchKernelGGL((k_blur<true>), grid2d(gs, 2 * n), kBlock2d, 0, s, h->tmpA, h->tmpB, h->Ix0, h->Iy0, gs, h->taps, n);
-        hipLaunchKernelGGL(k_resample, grid2d(gd, 2 * n), kBlock2d, 0, s, h->tmpB, h->pyr0[k], h->Iy0, h->pyr1[k], gs, gd, 1.0f, n);
+        hipLaunchKernelGGL((k_blur<true>), grid2d(gs, 2 * n), kBlock2d, 0, s, tmpA, tmpB, Ix0, Iy0, gs, h->taps, n);
+        hipLaunchKernelGGL(k_resample, grid2d(gd, 2 * n), kBlock2d, 0, s, tmpB, P0(k), Iy0, P1(k), gs, gd, 1.0f, n);
     }
     // u = v = 0 at the coarsest level and du = dv = 0 at the start of every level: a plane of zeros that is
     // only ever read (no memsets); u / v of a level are written by the level above it, never in place
-    const float *u = h->zero, *v = h->zero;
-    float *un = h->u, *vn = h->v, *uo = h->u2, *vo = h->v2;      // next level's u, v; the pair after that
+    const float *u = zero, *v = zero;
+    float *un = b_u, *vn = b_v, *uo = b_u2, *vo = b_v2;      // next level's u, v; the pair after that
     // The coarse end of the pyramid -- the levels of at most coarse_max x coarse_max px, each a single SOR tile --
     // in one launch per tile size (k_coarse<32> for levels up to 32 x 32 px, then k_coarse<64>) and per COARSE_MAX
     // levels (more only when the scale factor is close to 1).
@@ -581,13 +627,13 @@ static int brox_run(hm_brox *h, int n, const uint8_t *d_f0, const uint8_t *d_f1,
         ca.nlev = hi - lo + 1;
         for (int k = hi; k >= lo; k--) {
             ca.g[hi - k] = h->geo[k];
-            ca.I0[hi - k] = h->pyr0[k];
-            ca.I1[hi - k] = h->pyr1[k];
+            ca.I0[hi - k] = P0(k);
+            ca.I1[hi - k] = P1(k);
         }
         ca.u_in = u; ca.v_in = v;
         ca.scratch_plane = h->geo[lo].plane;            // the finest level of the launch
         ca.stagger = h->coarse_stagger;
-        ca.Ix0 = h->Ix0; ca.Iy0 = h->Iy0; ca.I1x = h->I1x; ca.I1y = h->I1y; ca.I1xx = h->I1xx; ca.I1xy = h->I1xy; ca.I1yy = h->I1yy;
+        ca.Ix0 = Ix0; ca.Iy0 = Iy0; ca.I1x = I1x; ca.I1y = I1y; ca.I1xx = I1xx; ca.I1xy = I1xy; ca.I1yy = I1yy;
         if (lo > 0) {
             ca.gout = h->geo[lo - 1];
             ca.u_out = un; ca.v_out = vn;
@@ -610,18 +656,18 @@ static int brox_run(hm_brox *h, int n, const uint8_t *d_f0, const uint8_t *d_f1,
         const Geo &g = h->geo[k];
         const dim3 gr = grid2d(g, n);
         if ((long long)g.w * g.h * n <= fuse_below) {
-            DerivOut dout = {h->Ix0, h->Iy0, h->I1x, h->I1y, h->I1xx, h->I1xy, h->I1yy};
-            hipLaunchKernelGGL(k_deriv_all, gr, kBlock2d, 0, s, h->pyr0[k], h->pyr1[k], dout, g);
+            DerivOut dout = {Ix0, Iy0, I1x, I1y, I1xx, I1xy, I1yy};
+            hipLaunchKernelGGL(k_deriv_all, gr, kBlock2d, 0, s, P0(k), P1(k), dout, g);
         } else {
             const dim3 gr2 = grid2d(g, 2 * n);           // two images per launch
-            hipLaunchKernelGGL(k_deriv, gr2, kBlock2d, 0, s, h->pyr0[k], h->Ix0, h->Iy0, h->pyr1[k], h->I1x, h->I1y, g, n);
-            hipLaunchKernelGGL(k_deriv, gr2, kBlock2d, 0, s, h->I1x, h->I1xx, h->I1xy, h->I1y, (float *)nullptr, h->I1yy, g, n);
+            hipLaunchKernelGGL(k_deriv, gr2, kBlock2d, 0, s, P0(k), Ix0, Iy0, P1(k), I1x, I1y, g, n);
+            hipLaunchKernelGGL(k_deriv, gr2, kBlock2d, 0, s, I1x, I1xx, I1xy, I1y, (float *)nullptr, I1yy, g, n);
         }
-        WarpIn wi = {h->pyr0[k], h->Ix0, h->Iy0, h->pyr1[k], h->I1x, h->I1y, h->I1xx, h->I1xy, h->I1yy, u, v};
-        WarpOut wo = {h->Iz, h->Ix, h->Iy, h->Ixz, h->Iyz, h->Ixx, h->Ixy, h->Iyy};
+        WarpIn wi = {P0(k), Ix0, Iy0, P1(k), I1x, I1y, I1xx, I1xy, I1yy, u, v};
+        WarpOut wo = {Iz, Ix, Iy, Ixz, Iyz, Ixx, Ixy, Iyy};
         if (h->warp_window) hipLaunchKernelGGL((k_warp<true>), gr, kBlock2d, 0, s, wi, wo, g);
         else hipLaunchKernelGGL((k_warp<false>), gr, kBlock2d, 0, s, wi, wo, g);
-        const float *du = h->zero, *dv = h->zero;
+        const float *du = zero, *dv = zero;
         int nxt = 0;
         // workgroup size: with few pairs a launch is bound by the latency of one workgroup (its ten half-sweeps in
         // sequence) -- 1024 threads, two rows per thread, finish a tile soonest; a launch that fills the chip several
@@ -630,17 +676,17 @@ static int brox_run(hm_brox *h, int n, const uint8_t *d_f0, const uint8_t *d_f1,
         const int threads = h->sor_threads ? h->sor_threads : (n <= 2 ? 1024 : 512);
         SorPlan plan = sor_plan(g, h->solver, h->fuse, threads, n, (long long)h->sor_deep * h->cus, n > 2 ? h->sor_wide : 0);
         const int launches_per_inner = h->solver / plan.K;
-        Coef co = {h->nu, h->nv, h->a12, h->idu, h->idv, h->sx, h->sy};
+        Coef co = {c_nu, c_nv, c_a12, c_idu, c_idv, c_sx, c_sy};
         for (int it = 0; it < h->inner; it++) {
-            PrepIn pi = {u, v, du, dv, h->Iz, h->Ix, h->Iy, h->Ixz, h->Iyz, h->Ixx, h->Ixy, h->Iyy};
+            PrepIn pi = {u, v, du, dv, Iz, Ix, Iy, Ixz, Iyz, Ixx, Ixy, Iyy};
             hipLaunchKernelGGL(k_prepare, dim3(hm_cdiv(g.w, PREP_BX), hm_cdiv(g.h, PREP_BY), n), dim3(PREP_BX, PREP_BY), 0, s,
                                pi, co, g, h->alpha, h->gamma);
             for (int pass = 0; pass < launches_per_inner; pass++) {
                 SorArgs a;
                 a.du_in = du; a.dv_in = dv;
-                a.du_out = h->du[nxt]; a.dv_out = h->dv[nxt];
-                a.nu = h->nu; a.nv = h->nv; a.a12 = h->a12; a.idu = h->idu; a.idv = h->idv;
-                a.sx = h->sx; a.sy = h->sy;
+                a.du_out = b_du[nxt]; a.dv_out = b_dv[nxt];
+                a.nu = c_nu; a.nv = c_nv; a.a12 = c_a12; a.idu = c_idu; a.idv = c_idv;
+                a.sx = c_sx; a.sy = c_sy;
                 a.g = g;
                 a.om = h->omega; a.om1 = 1.0f - h->omega;
                 bool rec = h->prof;
@@ -663,7 +709,7 @@ static int brox_run(hm_brox *h, int n, const uint8_t *d_f0, const uint8_t *d_f1,
                     h->ev_px.push_back((double)g.w * g.h * n);
                     h->ev_level.push_back(k);
                 }
-                du = h->du[nxt]; dv = h->dv[nxt];
+                du = b_du[nxt]; dv = b_dv[nxt];
                 nxt ^= 1;
             }
         }
@@ -689,7 +735,20 @@ extern "C" int hm_brox_calc_dev(hm_brox_t h, int n, const uint8_t *d_f0, const u
     HM_ARG(n >= 1 && n <= h->B, "hm_brox_calc_dev: n=%d outside 1..max_batch=%d", n, h->B);
     HM_ARG(d_f0 && d_f1 && d_ox && d_oy, "hm_brox_calc_dev: NULL pointer");
     HM_HIP(hipSetDevice(h->device));
-    return brox_run(h, n, d_f0, d_f1, d_ox, d_oy);
+    // (the second lane exists beside the CU-masked stream only: a masked stream has a hardware queue of its own, a plain
+    // one takes a place in the runtime's pool of four -- see the note at "lanes" in hm_brox_tune)
+    hipStream_t s2 = h->stream == h->masked ? h->masked2 : nullptr;
+    if (h->lanes < 2 || n < 4 || h->prof || !s2) return brox_run(h, 0, n, h->stream, d_f0, d_f1, d_ox, d_oy);
+    // two lanes: the second starts behind everything queued on the handle's stream so far, and the handle's stream
+    // ends behind the second -- to the caller the call is still one piece of work on hm_brox_stream()
+    const int n0 = (n + 1) / 2;
+    HM_HIP(hipEventRecord(h->ev_fork, h->stream));
+    HM_HIP(hipStreamWaitEvent(s2, h->ev_fork, 0));
+    int rc = brox_run(h, 0, n0, h->stream, d_f0, d_f1, d_ox, d_oy);
+    if (rc == HM_OK) rc = brox_run(h, n0, n - n0, s2, d_f0, d_f1, d_ox, d_oy);
+    HM_HIP(hipEventRecord(h->ev_join, s2));
+    HM_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    return rc;
 }
 
 extern "C" int hm_brox_calc_batch(hm_brox_t h, int n, const uint8_t *f0, const uint8_t *f1, float *ox, float *oy)

@@ -444,20 +444,39 @@ __global__ __launch_bounds__(PREP_BX * PREP_BY) void k_prepare(PrepIn in, Coef c
     const size_t off = (size_t)blockIdx.z * g.plane;
     const int bx0 = blockIdx.x * PREP_BX, by0 = blockIdx.y * PREP_BY;
     const int tid = threadIdx.y * PREP_BX + threadIdx.x;
-    for (int i = tid; i < (PREP_BY + 2) * (PREP_BX + 2); i += PREP_BX * PREP_BY) {
-        int ly = i / (PREP_BX + 2), lx = i - ly * (PREP_BX + 2);
-        int gx = d_clampi(bx0 + lx - 1, 0, w - 1), gy = d_clampi(by0 + ly - 1, 0, h - 1);
-        size_t p = off + gy * pitch + gx;
-        const float uu = in.u[p], vv = in.v[p];
-        su0[ly][lx] = uu;
-        sv0[ly][lx] = vv;
-        sU[ly][lx] = uu + in.du[p];
-        sV[ly][lx] = vv + in.dv[p];
+    // Every load of the workgroup is issued before the first wait: the staged ring first (two rounds of the 256 threads
+    // over its 6 x 66 pixels), then the ten fields and du, dv of the thread's own pixel, which are only needed after
+    // the diffusivities -- one round trip to memory per workgroup instead of three (a clamped address keeps the loads
+    // of a thread outside the image unconditional; nothing of theirs is used).
+    constexpr int NS = (PREP_BY + 2) * (PREP_BX + 2), NTH = PREP_BX * PREP_BY, NR = (NS + NTH - 1) / NTH;
+    float r_u[NR], r_v[NR], r_du[NR], r_dv[NR];
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+        const int i = min(tid + k * NTH, NS - 1);
+        const int ly = i / (PREP_BX + 2), lx = i - ly * (PREP_BX + 2);
+        const int gx = d_clampi(bx0 + lx - 1, 0, w - 1), gy = d_clampi(by0 + ly - 1, 0, h - 1);
+        const size_t p = off + gy * pitch + gx;
+        r_u[k] = in.u[p]; r_v[k] = in.v[p]; r_du[k] = in.du[p]; r_dv[k] = in.dv[p];
+    }
+    const int x = bx0 + threadIdx.x, y = by0 + threadIdx.y;
+    const bool inside = x < w && y < h;
+    const size_t p = off + min(y, h - 1) * pitch + min(x, w - 1);
+    const float ddu = in.du[p], ddv = in.dv[p];
+    const float ix = in.Ix[p], iy = in.Iy[p], iz = in.Iz[p];
+    const float ixx = in.Ixx[p], ixy = in.Ixy[p], iyy = in.Iyy[p], ixz = in.Ixz[p], iyz = in.Iyz[p];
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+        const int i = tid + k * NTH;
+        if (i < NS) {
+            const int ly = i / (PREP_BX + 2), lx = i - ly * (PREP_BX + 2);
+            su0[ly][lx] = r_u[k];
+            sv0[ly][lx] = r_v[k];
+            sU[ly][lx] = r_u[k] + r_du[k];
+            sV[ly][lx] = r_v[k] + r_dv[k];
+        }
     }
     __syncthreads();
-    const int x = bx0 + threadIdx.x, y = by0 + threadIdx.y;
     const int lx = threadIdx.x + 1, ly = threadIdx.y + 1;
-    const bool inside = x < w && y < h;
     // diffusivities of the own right / lower edge (zero across the image border) ...
     float rsx = 0.0f, rsy = 0.0f;
     if (inside) {
@@ -479,12 +498,8 @@ __global__ __launch_bounds__(PREP_BX * PREP_BY) void k_prepare(PrepIn in, Coef c
     }
     __syncthreads();
     if (!inside) return;
-    const size_t p = off + y * pitch + x;
     c.sx[p] = rsx;
     c.sy[p] = rsy;
-    float ddu = in.du[p], ddv = in.dv[p];
-    float ix = in.Ix[p], iy = in.Iy[p], iz = in.Iz[p];
-    float ixx = in.Ixx[p], ixy = in.Ixy[p], iyy = in.Iyy[p], ixz = in.Ixz[p], iyz = in.Iyz[p];
     float q0 = (iz + ix * ddu) + iy * ddv;
     float pd = d_psi(q0 * q0);
     float q1 = (ixz + ixx * ddu) + ixy * ddv;

@@ -192,6 +192,32 @@ def test_calc_batch_and_tuning_do_not_change_results(hm, oracle_brox):
         assert np.array_equal(U, U2) and np.array_equal(V, V2), (key, val)
 
 
+def test_two_lanes_give_the_bits_of_one(hm, oracle_brox):
+    """hm_brox_tune "lanes" = 2: a series of four or more pairs on the CU-masked stream runs as two halves side by side,
+    in disjoint parts of the handle's planes -- every pair the oracle's flow, whatever half it was in."""
+    from hydra_mi import brox, synth
+    n = 112
+    names = ["warp", "rotate", "translate_leftup", "translate_leftup_stretch", "warp", "rotate", "translate_leftup"]
+    pairs = [synth.warp_pair(n, name, seed) for seed, name in enumerate(names)]
+    F0 = np.stack([p[0] for p in pairs])
+    F1 = np.stack([p[1] for p in pairs])
+    bf = brox.BroxOpticalFlow(n, n, max_batch=7)
+    U, V = bf.calc_batch(F0, F1)
+    for i in (0, 3, 4, 6):                        # the first and last pair of either half (4 + 3)
+        ru, rv = oracle_brox.calc(F0[i], F1[i])
+        assert np.array_equal(U[i], ru) and np.array_equal(V[i], rv), i
+    bf.tune("lanes", 2)
+    bf.tune("cu_reserve", 32)
+    for count in (7, 4, 5, 3):                    # 3: below four pairs one lane
+        U2, V2 = bf.calc_batch(F0[:count], F1[:count])
+        assert np.array_equal(U[:count], U2) and np.array_equal(V[:count], V2), count
+    bf.tune("whole_chip", 1)                      # the plain stream has no twin: one lane
+    U2, V2 = bf.calc_batch(F0, F1)
+    assert np.array_equal(U, U2) and np.array_equal(V, V2)
+    with pytest.raises(RuntimeError):
+        bf.tune("lanes", 2)                       # after cu_reserve: refused (the twin stream takes its mask there)
+
+
 @pytest.mark.parametrize("w,h,kw,okw", [
     (64, 64, {}, {}),                                                        # the whole pyramid inside k_coarse
     (57, 33, dict(inner_iterations=3, solver_iterations=4), dict(inner=3, solver=4)),

@@ -41,6 +41,16 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "dry":        # where a SOR launch spends its time: loads + stores only
         run(1024, 8, 3, [dict(sor_fuse=0, sor_threads=512, sor_dry=0), dict(sor_fuse=0, sor_threads=512, sor_dry=1)])
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "series":     # the product's configuration: a series of 8 pairs, 2 pairs, one pair
+        run(1024, 8, 5, [dict()])
+        run(1024, 2, 5, [dict()])
+        run(1024, 1, 5, [dict()])
+        run(512, 1, 5, [dict()])
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "series8":    # series of 8, 6, 5, 4 pairs as the product runs them
+        for b in (8, 6, 5, 4):
+            run(1024, b, 5, [dict()])
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "wide":       # the 128 x 64 SOR tile from which level size on
         wt = [dict(sor_wide=0), dict(sor_wide=1024), dict(sor_wide=640), dict(sor_wide=400), dict(sor_wide=256), dict(sor_wide=128), dict(sor_wide=0)]
         run(1024, 8, 5, wt)
