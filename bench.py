@@ -326,7 +326,7 @@ def main():
     ap.add_argument("--h0", type=float, default=0.047, help="mesh edge length as a fraction of the frame size")
     ap.add_argument("--flow-batch", type=int, default=8, help="consecutive frame pairs per Brox launch series")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--two-flow-handles", action="store_true", help="two flow series in flight (default: one at a time)")
+    ap.add_argument("--one-flow-handle", action="store_true", help="experiment: one flow series in flight at a time (default: two, on two handles)")
     ap.add_argument("--split-start", action="store_true", help="experiment: a phase starts with two flow series side by side (pipeline.split_start)")
     ap.add_argument("--first-series", type=int, default=0, help="experiment: fixed size of the first flow series of a phase (default: sized from measurements)")
     ap.add_argument("--cu-reserve", type=int, default=None,
@@ -417,8 +417,8 @@ def main():
             self.dm = mesh.disk_mesh(centre[0], centre[1], radius - 1.0, args.h0 * n)
             self.kf = kalman.IteratedMSKalmanFilter(self.dm, self.video[0], np.zeros((n, n, 2), np.float32), True, device=dev)
             extra = {} if args.cu_reserve is None else {"cu_reserve": args.cu_reserve}
-            if args.two_flow_handles:
-                extra["concurrent_series"] = True
+            if args.one_flow_handle:
+                extra["concurrent_series"] = False
             self.pipe = FlowEKFPipeline(self.kf, self.video, self.masks, flow_batch=B, device=dev, resident=args.resident, **extra)
             self.bf = self.pipe.bf
             if args.split_start:

@@ -5,6 +5,7 @@
 #include "hm_common.h"
 #include <hip/hip_ext.h>
 #include "brox_kernels.h"
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -368,6 +369,9 @@ extern "C" int hm_brox_create(int device, int W, int H, int max_batch, float alp
     // padding columns are read (never used) by float2 loads: keep them finite.  The fill
     // goes on the handle's own stream: that stream is non-blocking, so a fill issued on the
     // null stream could still be running when the first calc starts.
+    // (Tried and taken back: this stream as a CU-masked one with every CU in its mask, which has a hardware queue of its
+    // own instead of a place among the runtime's four -- the benches ran as before, the native flow tool, which has no
+    // other stream in its process, hung in its first series.)
     e = hipStreamCreateWithFlags(&h->whole, hipStreamNonBlocking);
     h->stream = h->whole;
     if (e == hipSuccess) e = hipMemsetAsync(h->arena, 0, h->arena_floats * sizeof(float), h->stream);

@@ -319,7 +319,7 @@ class FlowEKFPipeline:
     """
 
     def __init__(self, kf, video, masks=None, flow_batch=8, device=0, brox_params=None, sor_threads=0, maskflow=True,
-                 observed=None, return_flow=False, cu_reserve=32, concurrent_series=False, resident=False):
+                 observed=None, return_flow=False, cu_reserve=32, concurrent_series=True, resident=False):
         """return_flow: whether step() brings the rendered flow planes of every frame to the host, as
         KalmanFilter.compute does for the reference's callers (8 MB per 1024^2 frame); a frame loop that
         looks at the error sums and the state only (reference run_kalmanfilter.py:78-89 ignores the return
@@ -354,10 +354,15 @@ class FlowEKFPipeline:
         _lib.register(self, 0)
         self.d_u = DeviceBuffer(3 * self.B * n * 4, device)          # flow planes: one buffer in use, two being filled
         self.d_v = DeviceBuffer(3 * self.B * n * 4, device)
-        # concurrent_series: two flow handles (streams), two series in flight at a time.  Measured at 1024^2 / 201
-        # vertices, 20 frames: 182 frames/s against 214 with one series at a time -- the filter's frames take 5.3 to
-        # 13 ms beside two series (4.2 to 5.6 beside one) and the first pair of a phase is no sooner there (7.4 ms).
-        # Off by default; the results are the same bits either way (tools/determinism_check.py).
+        # concurrent_series: two flow handles (streams), two series in flight at a time -- while the filter works through
+        # the pairs of one series the next TWO run beside it, each on a handle of its own.  A phase starts with one pair
+        # (the whole chip) and a second series beside it, and the series grow as _next_concurrent sizes them (1, 2, 2, 3,
+        # 5, 8 at 1024^2 / 201 vertices): the filter waits ~7 ms for its first pair instead of ~13 for a first series of
+        # five, and once the series are full it does not wait at their boundaries any more (one series at a time: 0.3 to
+        # 2.7 ms at every boundary, profiles/r04_frame_trace_64.txt).  Driver's bench, 20 frames: 267-270 against
+        # 261-264 frames/s, 64 frames: 331-333 against 322-325.  (Round 2 measured this mode at 182 against 214 frames/s:
+        # before the filter's streams had their priority and the flow's its CU mask.)  The results are the same bits
+        # either way (tools/determinism_check.py).
         def make_handle():
             bf = _brox.BroxOpticalFlow(self.W, self.H, max_batch=self.B, device=device, **(brox_params or {}))
             bf.tune("sor_threads", sor_threads)         # 0: chosen per series (1024 for one or two pairs, else 512)
@@ -445,10 +450,11 @@ class FlowEKFPipeline:
         first = not self._flying and self._ready[0] == self._ready[1]       # the first series of a phase: nothing runs beside it
         if alone is not None:
             first = alone
+        measured = first and not self.concurrent_series      # (with two handles the second series starts beside the first)
         t = threading.Thread(target=work)
         t0 = time.perf_counter()
         t.start()
-        self._flying.append({"lo": k, "hi": k + nb, "buf": buf, "handle": h, "thread": t, "t0": t0, "alone": first})
+        self._flying.append({"lo": k, "hi": k + nb, "buf": buf, "handle": h, "thread": t, "t0": t0, "alone": measured})
 
     def _next_series(self, last):
         """Pairs of the series that follows one of `last` pairs.  A phase starts with two pairs and grows 2, 3, 5, 8: a
@@ -467,6 +473,44 @@ class FlowEKFPipeline:
         room = last * self._frame_s / 1.3
         n = int(n_a + (room - a) / b) if b > 0 else self.B
         return min(self.B, max(last + 1, min(n, 2 * last)))
+
+    def _next_concurrent(self):
+        """Pairs of the next series with two handles (concurrent_series): the largest series that is done by the time the
+        filter needs its first pair.  That moment follows from what is queued in front of it -- the pairs that are ready
+        and not yet used, and the series in flight, each ready at (its launch + what a series of its size takes beside
+        the filter and another series, 1.6 x what it takes alone) and then used up at one frame of the filter per pair.
+        None without measurements (calibrate / earlier frames): the fixed ramp of _next_series."""
+        # (a ramp sized this way is 1, 2, 2, 4, 7, 8 at 1024^2 / 201 vertices: 7 ms of waiting at the start of a phase
+        # instead of the 11 of the fixed ramp 1, 2, 3, 4, 5 ... and the 13 of one series at a time)
+        model = self._series_model()
+        if model is None or not self.adaptive_first or not self.model_ramp:
+            return None
+        a, b, n_a = model
+        F, slow = max(self._frame_s, 1e-4), 1.6
+        now = time.perf_counter()
+        t = now + max(0, self._ready[1] - self._cursor) * F
+        last, overdue = 1, False
+        for f in self._flying:
+            n = f["hi"] - f["lo"]
+            done = f["t0"] + slow * (a + b * (n - n_a))
+            overdue = overdue or done < now
+            t = max(t, done) + n * F
+            last = n
+        best = 1
+        for n in range(1, self.B + 1):
+            if now + slow * (a + b * (n - n_a)) <= t:
+                best = n
+        # never smaller than the series in front of it; and when a series in flight should have been done already the
+        # flow is what the frames wait for: then larger series, which cost less per pair, not smaller ones
+        fit = best
+        best = max(best, last)
+        if overdue:
+            best = max(best, last + 1, int(1.7 * last))
+        if self.trace:
+            self.trace("next series: %.1f ms until it is needed, a series of n takes %.2f + %.2f (n - %d) ms alone, a frame %.2f ms: "
+                       "%d pairs fit, last %d%s -> %d" % (1e3 * (t - now), 1e3 * a, 1e3 * b, n_a, 1e3 * F, fit, last,
+                                                          ", overdue" if overdue else "", min(self.B, best)))
+        return min(self.B, best)
 
     def _series_model(self):
         """(a, b, n_a): a series of n pairs alone takes about a + b (n - n_a) seconds, from the first series of earlier
@@ -540,7 +584,7 @@ class FlowEKFPipeline:
         pairs look like 9.7 instead of 6.8 ms, and every series after it was sized from that).  ~30 ms at 1024^2, once
         per pipeline, at the start of its first phase."""
         nb = min(self.B, self.F - 1 - first)
-        if nb < 2 or self.concurrent_series:
+        if nb < 2:
             return
         n, B = self._px, self.B
         self.ring.ensure(first + nb + 1, first)
@@ -588,7 +632,10 @@ class FlowEKFPipeline:
             if nxt >= self._end:
                 return
             size = (last["hi"] - last["lo"]) if last else (self._ready[1] - self._ready[0])
-            self._launch(nxt, self._end, self._next_series(size) if size else self._first_series())
+            most = self._next_series(size) if size else self._first_series()
+            if self.concurrent_series and size:
+                most = self._next_concurrent() or most
+            self._launch(nxt, self._end, most)
 
     def flow_ready(self, k):
         """Make the flow of pair (k, k+1) available -> (device pointer of u, of v)."""

@@ -165,7 +165,7 @@ def test_streaming_frame_ring_equals_resident_video(hm):
     # with split_start a phase that follows a measured one starts with two series side by side on two handles (a short
     # one so that the filter starts soon, the one sized from the measurements behind it): the same bits
     kf3 = new_filter()
-    p3 = FlowEKFPipeline(kf3, video, masks, observed=video * masks, flow_batch=4)
+    p3 = FlowEKFPipeline(kf3, video, masks, observed=video * masks, flow_batch=4, concurrent_series=False)
     p3.split_start = True                                     # (off by default: measured slower, pipeline.py)
     got3 = []
     p3.run(0, 2, on_frame=lambda k, e: got3.append((kf3.state.X.copy(), e[:4], kf3.niter)))
@@ -175,7 +175,12 @@ def test_streaming_frame_ring_equals_resident_video(hm):
     assert len(got3) == F - 1
     for k in range(F - 1):
         assert np.array_equal(got3[k][0], ref[k][0]) and got3[k][1] == ref[k][1] and got3[k][2] == ref[k][2], k
-    for p in (pr, ps, pv, p2, p3):
+    # one series in flight at a time (the default is two, on two handles): the same bits
+    p4, kf4, got4 = track(lambda kf: FlowEKFPipeline(kf, video, masks, observed=video * masks, flow_batch=3, concurrent_series=False))
+    assert len(p4.bfs) == 1 and len(ps.bfs) == 2
+    for k in range(F - 1):
+        assert np.array_equal(got4[k][0], ref[k][0]) and got4[k][1] == ref[k][1] and got4[k][2] == ref[k][2], k
+    for p in (pr, ps, pv, p2, p3, p4):
         p.close()
 
 

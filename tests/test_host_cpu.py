@@ -667,3 +667,34 @@ def test_flow_series_are_sized_from_the_measured_model(hm):
     assert [p._next_series(n) for n in (8, 10, 14)] == [10, 14, 16]
     p.model_ramp = False                                     # the fixed rule again
     assert p._next_series(4) == 6
+
+
+def test_concurrent_series_are_sized_from_what_is_queued_in_front_of_them(hm):
+    """FlowEKFPipeline._next_concurrent (host logic, no GPU): with two handles the next series is the largest one that is done
+    (1.6 x its time alone) when the filter has used up the pairs that are ready and the series in flight; never smaller
+    than the series in front of it, larger when that one is overdue, None without measurements."""
+    import time
+    from hydra_mi.pipeline import FlowEKFPipeline
+    p = object.__new__(FlowEKFPipeline)
+    p.B, p.concurrent_series, p.first_series, p.adaptive_first, p.model_ramp, p.trace = 8, True, 0, True, True, None
+    p._series_s, p._frame_s, p._flying, p._ready, p._cursor = {}, None, [], (0, 0), 0
+    assert p._next_concurrent() is None and p._first_series() == 1
+    p._series_s, p._frame_s = {2: 6.82e-3, 8: 15.58e-3}, 3.7e-3          # a series of n pairs alone: 6.82 + 1.46 (n - 2) ms
+    now = time.perf_counter()
+    # the start of a phase: one pair in flight since just now -- needed in 1.6 x 5.36 + 3.7 = 12.3 ms: 1.6 x T(2) = 10.9 fits
+    p._flying = [{"lo": 0, "hi": 1, "t0": now}]
+    assert p._next_concurrent() == 2
+    # two pairs ready and unused, a series of two launched 7 ms ago: needed in max(7.4, 3.9) + 7.4 = 14.8 ms: T(3) = 8.28 -> 13.2 fits
+    p._ready, p._cursor = (1, 3), 1
+    p._flying = [{"lo": 3, "hi": 5, "t0": now - 7e-3}]
+    assert p._next_concurrent() == 3
+    # full series: 8 ready, 8 in flight: a series of 8 fits many times over
+    p._ready, p._cursor = (10, 18), 10
+    p._flying = [{"lo": 18, "hi": 26, "t0": now - 5e-3}]
+    assert p._next_concurrent() == 8
+    # nothing ready, and the series in flight (3 pairs) should have been done long ago: the flow is late -- a larger series
+    p._ready, p._cursor = (5, 5), 5
+    p._flying = [{"lo": 5, "hi": 8, "t0": now - 1.0}]
+    assert p._next_concurrent() == 5
+    p._flying = [{"lo": 5, "hi": 6, "t0": now - 1.0}]
+    assert p._next_concurrent() == 2
