@@ -478,9 +478,10 @@ def run_video(args, tracks, rank, world, dev, coll_dev, info, V, K, Wm, B, n):
     # the flow series of the timed region start small and grow to B pairs (pipeline.py: sized from what series and
     # frames have taken so far); the first one of B pairs is profiled (kernel start/stop events for every SOR launch)
     tracks[0].pipe.profile_full = True
-    # (with series sized from measurements a timed region of 20 frames has series of 4, 5 and 6 pairs: the first one of
-    # at least 5 that runs beside the filter is the one profiled; the PMC traffic per launch scales with the pairs)
-    tracks[0].pipe.profile_min_pairs = min(B, 5) if K < 40 else B      # (a full series only comes after ~30 frames)
+    # (with two series in flight, each sized from measurements, a timed region of 20 frames has series of 1, 2, 2, 3, 3, 5
+    # and 8 pairs: the first one of at least 3 that runs beside the filter is the one profiled; the PMC traffic per
+    # launch scales with the pairs)
+    tracks[0].pipe.profile_min_pairs = min(B, 3) if K < 40 else B      # (a full series only comes after ~30 frames)
 
     if world > 1:
         dist.barrier()
