@@ -417,7 +417,7 @@ def main():
             self.dm = mesh.disk_mesh(centre[0], centre[1], radius - 1.0, args.h0 * n)
             self.kf = kalman.IteratedMSKalmanFilter(self.dm, self.video[0], np.zeros((n, n, 2), np.float32), True, device=dev)
             extra = {} if args.cu_reserve is None else {"cu_reserve": args.cu_reserve}
-            if args.one_flow_handle:
+            if args.one_flow_handle or args.split_start:     # (split_start is an experiment of the one-series mode)
                 extra["concurrent_series"] = False
             self.pipe = FlowEKFPipeline(self.kf, self.video, self.masks, flow_batch=B, device=dev, resident=args.resident, **extra)
             self.bf = self.pipe.bf
