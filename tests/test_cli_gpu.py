@@ -115,6 +115,43 @@ def test_pipeline_equals_sequential_calls(hm):
     pipe.close()
 
 
+def test_two_series_in_flight_at_the_edges(hm):
+    """The default mode (two flow series in flight on two handles) where there is hardly room for it: series of one pair,
+    a video of two and of three frames, several phases through one pipeline with the series sized from the measurements
+    of the earlier ones, random access in between -- the flow of every pair the bits of a single call, nothing hangs."""
+    from hydra_mi import brox, kalman, mesh, synth
+    from hydra_mi.pipeline import FlowEKFPipeline
+    n, F = 64, 9
+    video, masks, c, r = synth.disk_video(n, F, "rotate", 2)
+    zero = np.zeros((n, n, 2), np.float32)
+    bf = brox.BroxOpticalFlow(n, n)
+    flows = [bf.calc(video[k], video[k + 1]) for k in range(F - 1)]
+
+    def new_filter():
+        return kalman.IteratedMSKalmanFilter(mesh.disk_mesh(c[0], c[1], r - 1.0, 12.0), video[0], zero, True, nI=2)
+
+    def same(pipe, k):
+        f = pipe.flow_host(k)
+        return np.array_equal(f[:, :, 0], flows[k][0]) and np.array_equal(f[:, :, 1], flows[k][1])
+
+    for B in (1, 2, 3):
+        for frames in (2, 3, F):
+            with FlowEKFPipeline(new_filter(), video[:frames], masks[:frames], flow_batch=B) as pipe:
+                assert pipe.concurrent_series and len(pipe.bfs) == 2
+                seen = []
+                pipe.run(on_frame=lambda k, e: seen.append(k))
+                assert seen == list(range(frames - 1)), (B, frames)
+                assert all(same(pipe, k) for k in range(frames - 1)), (B, frames)
+    with FlowEKFPipeline(new_filter(), video, masks, flow_batch=3) as pipe:
+        pipe.run(0, 2)                                  # a first phase: calibrates, measures a frame of the filter
+        assert pipe._series_s and pipe._frame_s is not None
+        pipe.run(2, 5)                                  # the second one sizes its series from that (_next_concurrent)
+        assert same(pipe, 7) and same(pipe, 1)          # random access, backwards too
+        pipe.run(5, F - 1)
+        assert pipe.kf.state.X.shape[0] > 0
+        assert all(same(pipe, k) for k in range(F - 1))
+
+
 def test_streaming_frame_ring_equals_resident_video(hm):
     """the frame loop reads one frame per iteration (reference run_kalmanfilter.py:78-89).  The
     pipeline's default -- frames and masks read from the source one by one and uploaded over a copy stream into a ring
