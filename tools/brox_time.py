@@ -47,6 +47,12 @@ if __name__ == "__main__":
         run(1024, 1, 5, [dict()])
         run(512, 1, 5, [dict()])
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "coarse64":   # levels up to 64 px inside k_coarse<64> against launch per operator
+        ct = [dict(coarse_max=32), dict(coarse_max=64), dict(coarse_max=32), dict(coarse_max=64)]
+        for b in (1, 2, 4, 8):
+            run(1024, b, 5, ct)
+        run(512, 1, 5, ct)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "series8":    # series of 8, 6, 5, 4 pairs as the product runs them
         for b in (8, 6, 5, 4):
             run(1024, b, 5, [dict()])
