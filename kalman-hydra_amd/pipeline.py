@@ -401,6 +401,7 @@ class FlowEKFPipeline:
         self._frame_s = None             # seconds per frame of the filter (median of the last frames)
         self._frame_hist = []
         self._calibrated = False
+        self._flow_late = False
         self.adaptive_first = True       # size the first series of a phase from those measurements
         self.first_series = 0            # > 0: fixed size of the first series of every phase
         self.profiled_handle = None
@@ -489,7 +490,7 @@ class FlowEKFPipeline:
         F, slow = max(self._frame_s, 1e-4), 1.6
         now = time.perf_counter()
         t = now + max(0, self._ready[1] - self._cursor) * F
-        last, overdue = 1, False
+        last, overdue = max(1, self._ready[1] - self._ready[0]), bool(self._flow_late)
         for f in self._flying:
             n = f["hi"] - f["lo"]
             done = f["t0"] + slow * (a + b * (n - n_a))
@@ -500,8 +501,10 @@ class FlowEKFPipeline:
         for n in range(1, self.B + 1):
             if now + slow * (a + b * (n - n_a)) <= t:
                 best = n
-        # never smaller than the series in front of it; and when a series in flight should have been done already the
-        # flow is what the frames wait for: then larger series, which cost less per pair, not smaller ones
+        # never smaller than the series in front of it (the one in flight, or the one the filter is working through); and
+        # when the filter has just waited for a series (flow_ready) or one in flight should have been done already, the flow
+        # is what the frames wait for: then larger series, which cost less per pair, not smaller ones -- a filter that
+        # converges in one or two iterations per frame (0.9 ms) is fed by series of B pairs, not of two
         fit = best
         best = max(best, last)
         if overdue:
@@ -649,8 +652,10 @@ class FlowEKFPipeline:
             self._cursor = k
             self._top_up()
             f = self._flying.pop(0)
+            t_w = time.perf_counter()
             if f["thread"] is not _Done:
                 self._wait(f)
+            self._flow_late = time.perf_counter() - t_w > 5e-4      # the filter waited for this series (_next_concurrent)
             self._ready, self._buf = (f["lo"], f["hi"]), f["buf"]
             self._top_up()
         self._cursor = k

@@ -677,7 +677,7 @@ def test_concurrent_series_are_sized_from_what_is_queued_in_front_of_them(hm):
     from hydra_mi.pipeline import FlowEKFPipeline
     p = object.__new__(FlowEKFPipeline)
     p.B, p.concurrent_series, p.first_series, p.adaptive_first, p.model_ramp, p.trace = 8, True, 0, True, True, None
-    p._series_s, p._frame_s, p._flying, p._ready, p._cursor = {}, None, [], (0, 0), 0
+    p._series_s, p._frame_s, p._flying, p._ready, p._cursor, p._flow_late = {}, None, [], (0, 0), 0, False
     assert p._next_concurrent() is None and p._first_series() == 1
     p._series_s, p._frame_s = {2: 6.82e-3, 8: 15.58e-3}, 3.7e-3          # a series of n pairs alone: 6.82 + 1.46 (n - 2) ms
     now = time.perf_counter()
@@ -698,3 +698,13 @@ def test_concurrent_series_are_sized_from_what_is_queued_in_front_of_them(hm):
     assert p._next_concurrent() == 5
     p._flying = [{"lo": 5, "hi": 6, "t0": now - 1.0}]
     assert p._next_concurrent() == 2
+    # a filter that converges in an iteration per frame (0.9 ms): nothing "fits", the series stay as large as the last one,
+    # also when both handles are free (nothing in flight: the series the filter works through counts) ...
+    p._frame_s = 0.9e-3
+    p._ready, p._cursor, p._flying = (40, 48), 47, []
+    assert p._next_concurrent() == 8
+    p._ready, p._cursor, p._flying = (40, 43), 42, []
+    assert p._next_concurrent() == 3
+    # ... and grow when the filter has just waited for the flow
+    p._flow_late = True
+    assert p._next_concurrent() == 5
