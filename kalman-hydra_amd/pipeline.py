@@ -610,6 +610,7 @@ class FlowEKFPipeline:
         self._end = self.F - 1 if end is None else min(int(end), self.F - 1)
         self._ready = (first, first)
         self._cursor = first
+        self._flow_late = False
         if not self.resident:
             self.ring.reset(first)               # nothing of an earlier phase is assumed to be in the ring
         if self.model_ramp and self.adaptive_first and not self._calibrated:
