@@ -573,11 +573,22 @@ struct SorRegs {
 
 // K red-black iterations of a tile held in s_uv (checkerboard-compressed rows: the pixels of colour 0 first,
 // then colour 1; (du, dv) side by side) by NT threads, thread (grp, i) owning rows grp * RPT .. and the pixel
-// pair 2i, 2i + 1 of each.  (gx0, gy0) = image coordinates of the tile's first pixel.  BORDER = false drops
-// the image-border selects (a tile that does not touch the border never takes them).
-template <int TW, int TH, int NT, bool BORDER>
+// pair 2i, 2i + 1 of each.  (gx0, gy0) = image coordinates of the tile's first pixel.  BORDER (uniform over the
+// workgroup; BORDER_T its default) = false skips the image-border selects: a tile that does not touch the border never
+// takes them.
+//
+// `own`: the thread's own pixels, [row][pixel of the pair], the values s_uv holds for them on entry and on exit.  A
+// relaxed pixel's own value, its neighbour in the same pair (one of left / right is always the other pixel of the
+// pair) and its neighbours in the thread's other rows come from these registers; LDS is read for the pixels of OTHER
+// threads only -- per half-sweep and thread RPT reads to the side and two up / down instead of 5 RPT -- and written
+// for every relaxed pixel as before.  (The sweeps of a tile are bound by what the workgroup puts through the CU's LDS
+// pipe and the barrier behind it: 24 LDS operations per thread and half-sweep at four rows per thread, now 10.)  Same
+// values, same arithmetic: at the edge of a tile the clamped LDS slots the reads fell back on are this thread's own
+// pixels too, so they are read as before.
+template <int TW, int TH, int NT, bool BORDER_T>
 __device__ __forceinline__ void d_sor_sweeps(const SorRegs<TH / (NT / (TW / 2))> &R, float2 *s_uv, int K, int w, int h,
-                                             int gx0, int gy0, float om, float om1)
+                                             int gx0, int gy0, float om, float om1, float2 (&own)[TH / (NT / (TW / 2))][2],
+                                             const bool BORDER = BORDER_T)
 {
     constexpr int HALF = TW / 2, NG = NT / HALF, RPT = TH / NG;
     const int grp = threadIdx.x / HALF, i = threadIdx.x - grp * HALF;
@@ -586,20 +597,31 @@ __device__ __forceinline__ void d_sor_sweeps(const SorRegs<TH / (NT / (TW / 2))>
     for (int it = 0; it < K; it++) {
 #pragma unroll
         for (int c = 0; c < 2; c++) {
+            // the reads of other threads' pixels first (all of a half-sweep's in flight together), then the arithmetic
+            float2 side[RPT], up, down;
+#pragma unroll
+            for (int j = 0; j < RPT; j++) {
+                const int q = (j + c) & 1;
+                const int r = r0 + j, oc = (1 - c) * HALF;
+                int is = q ? i + 1 : i - 1;              // the neighbour outside the pair: right of the odd, left of the even pixel
+                is = is < 0 ? 0 : (is > HALF - 1 ? HALF - 1 : is);
+                side[j] = s_uv[r * TW + oc + is];
+            }
+            {
+                const int oc = (1 - c) * HALF;
+                const int ru = r0 > 0 ? r0 - 1 : 0, rd = r0 + RPT - 1 < TH - 1 ? r0 + RPT : TH - 1;
+                up = s_uv[ru * TW + oc + i];
+                down = s_uv[rd * TW + oc + i];
+            }
 #pragma unroll
             for (int j = 0; j < RPT; j++) {
                 // colour c in row r: pixel x = 2i + q with q = (r + c) & 1 = (j + c) & 1
                 const int q = (j + c) & 1;
                 const int r = r0 + j, gy = gy0 + r, gx = gxa + q;
-                const int oc = (1 - c) * HALF;           // neighbours have the other colour
-                // slots of the left / right neighbours inside their row
-                int il = q ? i : i - 1, ir = q ? i + 1 : i;
-                il = il < 0 ? 0 : il;
-                ir = ir > HALF - 1 ? HALF - 1 : ir;
-                const int ru = r > 0 ? r - 1 : 0, rd = r < TH - 1 ? r + 1 : TH - 1;
-                const float2 pc = s_uv[r * TW + c * HALF + i];
-                const float2 pl = s_uv[r * TW + oc + il], pr = s_uv[r * TW + oc + ir];
-                const float2 pt = s_uv[ru * TW + oc + i], pb = s_uv[rd * TW + oc + i];
+                const float2 pc = own[j][q];
+                const float2 pl = q ? own[j][0] : side[j], pr = q ? side[j] : own[j][1];
+                const float2 pt = j > 0 ? own[j > 0 ? j - 1 : 0][q] : up;
+                const float2 pb = j < RPT - 1 ? own[j < RPT - 1 ? j + 1 : 0][q] : down;
                 const float cu = pc.x, cv = pc.y;
                 float ul = pl.x, ur = pr.x, ut = pt.x, ub = pb.x;
                 float vl = pl.y, vr = pr.y, vt = pt.y, vb = pb.y;
@@ -616,6 +638,7 @@ __device__ __forceinline__ void d_sor_sweeps(const SorRegs<TH / (NT / (TW / 2))>
                 const float sv = ((wl * vl + R.sr[j][q] * vr) + wt * vt) + R.sb[j][q] * vb;
                 const float dun = om1 * cu + om * (((R.nu[j][q] - R.a12[j][q] * cv) + su) * R.idu[j][q]);
                 const float dvn = om1 * cv + om * (((R.nv[j][q] - R.a12[j][q] * dun) + sv) * R.idv[j][q]);
+                own[j][q] = make_float2(dun, dvn);
                 s_uv[r * TW + c * HALF + i] = make_float2(dun, dvn);
             }
             __syncthreads();
@@ -643,6 +666,7 @@ __device__ __forceinline__ void d_sor_tile(const SorArgs &a, int K, int bid, int
 
     SorRegs<RPT> R;
     R.st0[0] = 0.0f; R.st0[1] = 0.0f;
+    float2 own[RPT][2];                            // (du, dv) of the thread's pixels: d_sor_sweeps
 
 #pragma unroll
     for (int j = 0; j < RPT; j++) {
@@ -679,41 +703,46 @@ __device__ __forceinline__ void d_sor_tile(const SorArgs &a, int K, int bid, int
         R.sr[j][1] = ok1 ? f_sx.y : 0.0f; R.sb[j][1] = ok1 ? f_sy.y : 0.0f;
         // checkerboard-compressed LDS row: colour of the even pixel is (r & 1) == (j & 1)
         const int c0 = j & 1;
-        s_uv[r * TW + c0 * HALF + i] = make_float2(f_du.x, f_dv.x);
-        s_uv[r * TW + (1 - c0) * HALF + i] = ok1 ? make_float2(f_du.y, f_dv.y) : make_float2(0.0f, 0.0f);
+        own[j][0] = make_float2(f_du.x, f_dv.x);
+        own[j][1] = ok1 ? make_float2(f_du.y, f_dv.y) : make_float2(0.0f, 0.0f);
+        s_uv[r * TW + c0 * HALF + i] = own[j][0];
+        s_uv[r * TW + (1 - c0) * HALF + i] = own[j][1];
     }
     __syncthreads();
 
-    // A tile that does not touch the image border needs none of the border selects (they never fire):
-    // the loop is compiled twice and the workgroup takes its variant -- a quarter fewer vector instructions
-    // for all but the outermost ring of tiles.
+    // A tile that does not touch the image border needs none of the border selects (they never fire).
     const bool touches = gx0 <= 0 || gy0 <= 0 || gx0 + TW >= w || gy0 + TH >= h;
-    if (touches) d_sor_sweeps<TW, TH, NT, true>(R, s_uv, K, w, h, gx0, gy0, a.om, a.om1);
-    else d_sor_sweeps<TW, TH, NT, false>(R, s_uv, K, w, h, gx0, gy0, a.om, a.om1);
-
-    // write back the interior
+    // write back the interior (from the registers the sweeps leave the thread's pixels in)
     const int lx = 2 * i;
     const bool colin = lx >= a.halo_x && lx < a.halo_x + a.step_x;
+    auto write_back = [&]() {
 #pragma unroll
-    for (int j = 0; j < RPT; j++) {
-        const int r = r0 + j, gy = gy0 + r;
-        if (!colin || r < a.halo_y || r >= a.halo_y + a.step_y || gy >= h || gxa >= w) continue;
-        const size_t p = off + (size_t)gy * pitch + gxa;
-        const int c0 = j & 1;
-        const float2 q0 = s_uv[r * TW + c0 * HALF + i], q1 = s_uv[r * TW + (1 - c0) * HALF + i];
-        const float u0 = q0.x, u1 = q1.x, v0 = q0.y, v1 = q1.y;
-        if (gxa + 1 < w) {
-            *(float2 *)(a.du_out + p) = make_float2(u0, u1);
-            *(float2 *)(a.dv_out + p) = make_float2(v0, v1);
-        } else {
-            a.du_out[p] = u0;
-            a.dv_out[p] = v0;
+        for (int j = 0; j < RPT; j++) {
+            const int r = r0 + j, gy = gy0 + r;
+            if (!colin || r < a.halo_y || r >= a.halo_y + a.step_y || gy >= h || gxa >= w) continue;
+            const size_t p = off + (size_t)gy * pitch + gxa;
+            const float2 q0 = own[j][0], q1 = own[j][1];
+            const float u0 = q0.x, u1 = q1.x, v0 = q0.y, v1 = q1.y;
+            if (gxa + 1 < w) {
+                *(float2 *)(a.du_out + p) = make_float2(u0, u1);
+                *(float2 *)(a.dv_out + p) = make_float2(v0, v1);
+            } else {
+                a.du_out[p] = u0;
+                a.dv_out[p] = v0;
+            }
         }
-    }
+    };
+    // ONE loop, the border selects behind a branch that is uniform over the workgroup (an interior tile skips them: a
+    // quarter fewer vector instructions).  As two instantiations of the loop, one per kind of tile, the kernel needed 210
+    // registers once the thread's pixels were carried through them (what either loop keeps invariant is hoisted above the
+    // branch between them) -- 52 to 80 spills at the 128 of two workgroups per CU; this form takes 114.
+    d_sor_sweeps<TW, TH, NT, true>(R, s_uv, K, w, h, gx0, gy0, a.om, a.om1, own, __builtin_amdgcn_readfirstlane(touches));
+    write_back();
 }
 
+// (the 1 024-thread form of the 64 x 64 tile is held to the 64 registers of two workgroups per CU: 66 -> 64, two spills)
 template <int TW, int TH, int NT>
-__global__ __launch_bounds__(NT) void k_sor(SorArgs a, int K)
+__global__ __launch_bounds__(NT, (NT == 1024 && TW == 64) ? 8 : 1) void k_sor(SorArgs a, int K)
 {
     __shared__ float2 s_uv[TH * TW];          // (du, dv) of a pixel side by side: one 8-byte LDS access each
     // XCD-aware tile order: consecutive workgroup ids land on different XCDs, so
@@ -954,7 +983,12 @@ __global__ __launch_bounds__(T * T / 4) void k_coarse(CoarseArgs a)
                     R.idv[j][q] = 1.0f / (A22 + ssum);
                 }
             }
-            d_sor_sweeps<T, T, NT, true>(R, s_uv, a.solver, w, h, 0, 0, a.om, a.om1);   // ends on a barrier
+            float2 own[RPT][2];                    // the thread's pixels as the planes hold them (all threads are past the
+#pragma unroll                                     // barrier behind the last writes of s_uv)
+            for (int j = 0; j < RPT; j++)
+#pragma unroll
+                for (int q = 0; q < 2; q++) own[j][q] = s_uv[d_cb<T>(xa + q, ya + j)];
+            d_sor_sweeps<T, T, NT, true>(R, s_uv, a.solver, w, h, 0, 0, a.om, a.om1, own);   // ends on a barrier
         }
         // u + du, v + dv carried to the next finer level (k_add_prolong) or out (k_add_out)
         if (lv + 1 < a.nlev) {
