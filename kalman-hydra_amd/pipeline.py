@@ -481,8 +481,8 @@ class FlowEKFPipeline:
         and not yet used, and the series in flight, each ready at (its launch + what a series of its size takes beside
         the filter and another series, 1.6 x what it takes alone) and then used up at one frame of the filter per pair.
         None without measurements (calibrate / earlier frames): the fixed ramp of _next_series."""
-        # (a ramp sized this way is 1, 2, 2, 4, 7, 8 at 1024^2 / 201 vertices: 7 ms of waiting at the start of a phase
-        # instead of the 11 of the fixed ramp 1, 2, 3, 4, 5 ... and the 13 of one series at a time)
+        # (a ramp sized this way is 1, 2, 2, 2, 3, 4, 6 at 1024^2 / 201 vertices: 11 ms of waiting over the driver's 20 frames,
+        # 7 of them for the opening pair, instead of the 13 + 2 of one series at a time)
         model = self._series_model()
         if model is None or not self.adaptive_first or not self.model_ramp:
             return None
@@ -506,7 +506,7 @@ class FlowEKFPipeline:
         # is what the frames wait for: then larger series, which cost less per pair, not smaller ones -- a filter that
         # converges in one or two iterations per frame (0.9 ms) is fed by series of B pairs, not of two
         fit = best
-        best = max(best, last)
+        best = max(best, last, min(self.B, 2))      # (a series of one pair costs 5.3 ms a pair, one of two 3.4: only the opening one)
         if overdue:
             best = max(best, last + 1, int(1.7 * last))
         if self.trace:
@@ -654,9 +654,11 @@ class FlowEKFPipeline:
             self._top_up()
             f = self._flying.pop(0)
             t_w = time.perf_counter()
+            opening = self._ready[0] == self._ready[1]             # the first series of a phase is always waited for
             if f["thread"] is not _Done:
                 self._wait(f)
-            self._flow_late = time.perf_counter() - t_w > 5e-4      # the filter waited for this series (_next_concurrent)
+            # the filter waited for this series although it had others to work through before (_next_concurrent)
+            self._flow_late = (not opening) and time.perf_counter() - t_w > 5e-4
             self._ready, self._buf = (f["lo"], f["hi"]), f["buf"]
             self._top_up()
         self._cursor = k

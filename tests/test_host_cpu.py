@@ -698,6 +698,10 @@ def test_concurrent_series_are_sized_from_what_is_queued_in_front_of_them(hm):
     assert p._next_concurrent() == 5
     p._flying = [{"lo": 5, "hi": 6, "t0": now - 1.0}]
     assert p._next_concurrent() == 2
+    # never a series of one pair behind the opening one, whatever fits (a slow calibration, a fast filter)
+    p._ready, p._cursor, p._flying, p._frame_s = (5, 6), 5, [{"lo": 6, "hi": 7, "t0": now}], 0.5e-3
+    assert p._next_concurrent() == 2
+    p._frame_s = 3.7e-3
     # a filter that converges in an iteration per frame (0.9 ms): nothing "fits", the series stay as large as the last one,
     # also when both handles are free (nothing in flight: the series the filter works through counts) ...
     p._frame_s = 0.9e-3
