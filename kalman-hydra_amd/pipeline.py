@@ -402,6 +402,10 @@ class FlowEKFPipeline:
         self._frame_hist = []
         self._calibrated = False
         self._flow_late = False
+        # the series beside a phase's opening pair starts this fraction of (a series of two pairs alone) later: 0.3 x 7 ms.
+        # Three runs each, 20 frames: 263-264 frames/s with 0 (opening wait 7.0-7.7 ms), 263-274 with 0.2, 266-268 with 0.35
+        # (6.1-6.4 ms), 262-266 with 0.5 (the second series is late instead)
+        self.second_delay = 0.3
         self.adaptive_first = True       # size the first series of a phase from those measurements
         self.first_series = 0            # > 0: fixed size of the first series of every phase
         self.profiled_handle = None
@@ -415,8 +419,9 @@ class FlowEKFPipeline:
         self.model_ramp = True
 
     # -- flow series ---------------------------------------------------------------------------------
-    def _launch(self, k, end, most, alone=None, whole=None):
-        """Queue the series of pairs k .. k + nb - 1 on a handle and a buffer that are free."""
+    def _launch(self, k, end, most, alone=None, whole=None, delay=0.0):
+        """Queue the series of pairs k .. k + nb - 1 on a handle and a buffer that are free (`delay`: seconds the helper
+        thread waits before it queues the launches)."""
         nb = min(most, end - k)
         n, B = self._px, self.B
         busy_h = {f["handle"] for f in self._flying}
@@ -427,6 +432,8 @@ class FlowEKFPipeline:
 
         def work():
             try:
+                if delay > 0:
+                    time.sleep(delay)
                 if self.profile_full and self.profiled_pairs == 0 and nb >= (self.profile_min_pairs or self.B) and not first:
                     bf.profile(True)                    # hm_brox_profile around the first series of flow_batch pairs
                     self.profiled_pairs, self.profiled_handle, self.profile_full = nb, bf, False
@@ -637,9 +644,19 @@ class FlowEKFPipeline:
                 return
             size = (last["hi"] - last["lo"]) if last else (self._ready[1] - self._ready[0])
             most = self._next_series(size) if size else self._first_series()
+            delay = 0.0
             if self.concurrent_series and size:
                 most = self._next_concurrent() or most
-            self._launch(nxt, self._end, most)
+                if last is not None and self._ready[0] == self._ready[1] and last.get("opening") and self.second_delay:
+                    # the series beside the opening one: the opening pair -- what the filter is waiting for, a chain of
+                    # ~450 short launches -- has the chip to itself for a while first (the second series is needed a frame
+                    # of the filter after that pair, and the two slow each other down)
+                    model = self._series_model()
+                    if model is not None:
+                        delay = float(self.second_delay) * model[0]
+            self._launch(nxt, self._end, most, delay=delay)
+            if not last and self._ready[0] == self._ready[1]:
+                self._flying[-1]["opening"] = True
 
     def flow_ready(self, k):
         """Make the flow of pair (k, k+1) available -> (device pointer of u, of v)."""
