@@ -485,11 +485,12 @@ class FlowEKFPipeline:
     def _next_concurrent(self):
         """Pairs of the next series with two handles (concurrent_series): the largest series that is done by the time the
         filter needs its first pair.  That moment follows from what is queued in front of it -- the pairs that are ready
-        and not yet used, and the series in flight, each ready at (its launch + what a series of its size takes beside
-        the filter and another series, 1.6 x what it takes alone) and then used up at one frame of the filter per pair.
+        and not yet used, and the series in flight, each ready when the work of the series in front of it and its own are
+        done (they share the chip; 1.6 x what the work takes alone: beside the filter) and then used up at one frame of
+        the filter per pair.
         None without measurements (calibrate / earlier frames): the fixed ramp of _next_series."""
-        # (a ramp sized this way is 1, 2, 2, 2, 3, 4, 6 at 1024^2 / 201 vertices: 11 ms of waiting over the driver's 20 frames,
-        # 7 of them for the opening pair, instead of the 13 + 2 of one series at a time)
+        # (a ramp sized this way is 1, 2, 2, 3, 3, 3, 4 at 1024^2 / 201 vertices: 9.5 ms of waiting over the driver's 20 frames,
+        # 6.4 of them for the opening pair, instead of the 13 + 2 of one series at a time)
         model = self._series_model()
         if model is None or not self.adaptive_first or not self.model_ramp:
             return None
@@ -498,20 +499,19 @@ class FlowEKFPipeline:
         now = time.perf_counter()
         t = now + max(0, self._ready[1] - self._cursor) * F
         last, overdue = max(1, self._ready[1] - self._ready[0]), bool(self._flow_late)
+        ahead = 0.0                                # what the series in flight still have to do, in time alone
         for f in self._flying:
             n = f["hi"] - f["lo"]
-            done = f["t0"] + slow * (a + b * (n - n_a))
-            overdue = overdue or done < now
-            t = max(t, done) + n * F
+            alone = a + b * (n - n_a)
+            overdue = overdue or f["t0"] + slow * alone < now
+            # (the series in flight share the chip: one is done when the work in front of it and its own are)
+            ahead += max(0.0, alone - (now - f["t0"]) / slow)
+            t = max(t, now + slow * ahead) + n * F
             last = n
         best = 1
         for n in range(1, self.B + 1):
-            if now + slow * (a + b * (n - n_a)) <= t:
+            if now + slow * (ahead + a + b * (n - n_a)) <= t:
                 best = n
-        # never smaller than the series in front of it (the one in flight, or the one the filter is working through); and
-        # when the filter has just waited for a series (flow_ready) or one in flight should have been done already, the flow
-        # is what the frames wait for: then larger series, which cost less per pair, not smaller ones -- a filter that
-        # converges in one or two iterations per frame (0.9 ms) is fed by series of B pairs, not of two
         fit = best
         best = max(best, last, min(self.B, 2))      # (a series of one pair costs 5.3 ms a pair, one of two 3.4: only the opening one)
         if overdue:

@@ -671,7 +671,8 @@ def test_flow_series_are_sized_from_the_measured_model(hm):
 
 def test_concurrent_series_are_sized_from_what_is_queued_in_front_of_them(hm):
     """FlowEKFPipeline._next_concurrent (host logic, no GPU): with two handles the next series is the largest one that is done
-    (1.6 x its time alone) when the filter has used up the pairs that are ready and the series in flight; never smaller
+    (1.6 x its time alone and what the series in flight still have to do: they share the chip) when the filter has used up
+    the pairs that are ready and the series in flight; never smaller
     than the series in front of it, larger when that one is overdue, None without measurements."""
     import time
     from hydra_mi.pipeline import FlowEKFPipeline
@@ -684,9 +685,12 @@ def test_concurrent_series_are_sized_from_what_is_queued_in_front_of_them(hm):
     # the start of a phase: one pair in flight since just now -- needed in 1.6 x 5.36 + 3.7 = 12.3 ms: 1.6 x T(2) = 10.9 fits
     p._flying = [{"lo": 0, "hi": 1, "t0": now}]
     assert p._next_concurrent() == 2
-    # two pairs ready and unused, a series of two launched 7 ms ago: needed in max(7.4, 3.9) + 7.4 = 14.8 ms: T(3) = 8.28 -> 13.2 fits
+    # two pairs ready and unused, a series of two launched 7 ms ago (2.4 ms of its work left): needed in 14.8 ms, and the
+    # chip is shared with what that series still has to do: 1.6 x (2.4 + T(2)) = 14.8 does not quite fit -- as large as the last
     p._ready, p._cursor = (1, 3), 1
     p._flying = [{"lo": 3, "hi": 5, "t0": now - 7e-3}]
+    assert p._next_concurrent() == 2
+    p._flying = [{"lo": 3, "hi": 5, "t0": now - 11e-3}]      # ... launched 11 ms ago it is done: 1.6 x T(3) = 13.2 fits
     assert p._next_concurrent() == 3
     # full series: 8 ready, 8 in flight: a series of 8 fits many times over
     p._ready, p._cursor = (10, 18), 10
